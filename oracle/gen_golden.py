@@ -1,0 +1,257 @@
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF (imported from
+/root/reference, CPU, fp32) on seeded inputs.  Runs only in the build
+container; the fixtures it writes are committed and travel to the GPU box.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+Inputs are drawn from numpy's legacy ``RandomState`` (MT19937: stable across
+numpy versions) and are NOT stored - tests regenerate them with
+``tests/golden/inputs.py``; outputs are stored in full when small and as a
+strided subsample + sums when large.
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get('HAWKEYE_REFERENCE', '/root/reference')
+sys.path.insert(0, os.path.join(HERE, '_stubs'))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+from inputs import rs_randn, rs_relu_randn, sub  # noqa: E402  (tests/golden/inputs.py)
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+import model  # noqa: E402  (reference package; registers all methods)
+from model.registry import MODEL  # noqa: E402
+
+M_BCNN = sys.modules['model.methods.BCNN']
+M_CBCNN = sys.modules['model.methods.CBCNN']
+M_MPN = sys.modules['model.methods.MPNCOV']
+M_AP = sys.modules['model.methods.APCNN']
+M_OSME = sys.modules['model.methods.OSME']
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name + '.npz'),
+                        **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                           for k, v in arrs.items()})
+    print('wrote', name, {k: tuple(np.asarray(v.detach() if torch.is_tensor(v) else v).shape)
+                          for k, v in arrs.items()})
+
+
+# ---------------------------------------------------------------- BCNN pool
+def gen_bcnn():
+    pool = M_BCNN.BilinearPooling()
+    # small ragged case, stored in full
+    x = t(rs_relu_randn(11, (3, 32, 5, 7))).requires_grad_(True)
+    y = pool(x)
+    w = t(rs_randn(12, tuple(y.shape)))
+    (y * w).sum().backward()
+    save('bcnn_small', y=y, dx=x.grad)
+    # headline shape C=512, HW=196, subsampled
+    x = t(rs_relu_randn(1234, (2, 512, 14, 14))).requires_grad_(True)
+    y = pool(x)
+    w = t(rs_randn(1235, tuple(y.shape)))
+    (y * w).sum().backward()
+    save('bcnn_512', y_sub=sub(y), y_sum=y.double().sum(), y_argmax=y.argmax(dim=1),
+         y_rownorm=y.norm(dim=1), dx_sub=sub(x.grad), dx_sum=x.grad.double().sum(),
+         dx_abs=x.grad.double().abs().sum())
+
+
+# ---------------------------------------------------------------- CBP
+def gen_cbp():
+    cbp = M_CBCNN.CompactBilinearPooling(16, 16, 64)
+    x = t(rs_relu_randn(21, (2, 16, 3, 5))).requires_grad_(True)
+    y = cbp(x)
+    w = t(rs_randn(22, tuple(y.shape)))
+    (y * w).sum().backward()
+    save('cbp_small', y=y, dx=x.grad)
+    cbp = M_CBCNN.CompactBilinearPooling(512, 512, 6000)
+    x = t(rs_relu_randn(1234, (2, 512, 14, 14))).requires_grad_(True)
+    y = cbp(x)
+    w = t(rs_randn(1236, tuple(y.shape)))
+    (y * w).sum().backward()
+    s1 = cbp.sparse_sketch_matrix1
+    s2 = cbp.sparse_sketch_matrix2
+    h1 = s1.abs().argmax(dim=1)
+    h2 = s2.abs().argmax(dim=1)
+    save('cbp_512', y=y, dx_sub=sub(x.grad), dx_sum=x.grad.double().sum(),
+         dx_abs=x.grad.double().abs().sum(),
+         h1=h1, sgn1=s1[torch.arange(512), h1], h2=h2, sgn2=s2[torch.arange(512), h2])
+
+
+# ---------------------------------------------------------------- MPN-COV
+def gen_mpn():
+    for tag, shape, iters in (('mpn_small', (2, 16, 4, 5), (5, 3, 2, 1)),
+                              ('mpn_256', (2, 256, 14, 14), (5,))):
+        out = {}
+        for it in iters:
+            x = t(rs_relu_randn(31, shape)).requires_grad_(True)
+            cov = M_MPN.Covpool.apply(x)
+            cov.retain_grad()
+            sq = M_MPN.Sqrtm.apply(cov, it)
+            sq.retain_grad()
+            tv = M_MPN.Triuvec.apply(sq)
+            w = t(rs_randn(32, tuple(tv.shape)))
+            (tv * w).sum().backward()
+            big = shape[1] > 64
+            f = sub if big else (lambda a: a)
+            out.update({f'cov_it{it}': f(cov), f'sqrtm_it{it}': f(sq), f'triu_it{it}': f(tv),
+                        f'dcov_it{it}': f(cov.grad), f'dsq_it{it}': f(sq.grad), f'dx_it{it}': f(x.grad),
+                        f'triu_sum_it{it}': tv.double().sum(), f'dx_abs_it{it}': x.grad.double().abs().sum(),
+                        f'trace0_it{it}': cov[0].trace()})
+        out['triu_shape'] = np.array(tv.shape)
+        save(tag, **out)
+
+
+# ---------------------------------------------------------------- AP-CNN
+class _Dummy:
+    pass
+
+
+def gen_apcnn():
+    # pyramid attention with a small channel count (weights stored: tiny)
+    apn = M_AP.PyramidAttentions(channel_size=32)
+    sd = {k: v.clone() for k, v in apn.state_dict().items()}
+    feats = [t(rs_randn(41 + i, (2, 32, s, s))).requires_grad_(True) for i, s in enumerate((28, 14, 7))]
+    a3, a4, a5, s3, s4, s5 = apn(feats)
+    pooled = [a.mean(dim=(2, 3)) for a in (a3, a4, a5)]
+    w = [t(rs_randn(44 + i, tuple(p.shape))) for i, p in enumerate(pooled)]
+    sum((p * wi).sum() for p, wi in zip(pooled, w)).backward()
+    save('apcnn_apn', **{'w_' + k.replace('.', '__'): v for k, v in sd.items()},
+         pooled3=pooled[0], pooled4=pooled[1], pooled5=pooled[2],
+         s3=s3, s4=s4, s5=s5, df3=sub(feats[0].grad), df4=sub(feats[1].grad), df5=feats[2].grad,
+         df3_abs=feats[0].grad.double().abs().sum(), df4_abs=feats[1].grad.double().abs().sum())
+
+    # ROI selection: reference get_att_roi on random sigmoid-like masks (no ties)
+    out = {}
+    for ncls in (200, 8142):
+        d = _Dummy()
+        d.num_classes = ncls
+        for lvl, (hw, stride, size, topk) in enumerate(((56, 8, 64, 5), (28, 16, 128, 3), (14, 32, 256, 1))):
+            m = t(1.0 / (1.0 + np.exp(-2.0 * rs_randn(50 + lvl, (3, 1, hw, hw))))).float()
+            roi = M_AP.ResNet.get_att_roi(d, m, stride, size, 448, 448, iou_thred=0.05, topk=topk)
+            out[f'roi_c{ncls}_l{lvl + 3}'] = roi
+    save('apcnn_roi', **out)
+
+    # ROI crop / drop / resize (training uses python `random`; seed recorded)
+    d = _Dummy()
+    d.num_classes = 200
+    masks = [t(1.0 / (1.0 + np.exp(-2.0 * rs_randn(50 + l, (3, 1, hw, hw))))).float()
+             for l, hw in enumerate((56, 28, 14))]
+    rois = [M_AP.ResNet.get_att_roi(d, m, s, a, 448, 448, iou_thred=0.05, topk=k)
+            for m, (s, a, k) in zip(masks, ((8, 64, 5), (16, 128, 3), (32, 256, 1)))]
+    res = {}
+    for mode in ('train', 'eval'):
+        d.training = mode == 'train'
+        x2 = t(rs_randn(60, (3, 8, 56, 56))).requires_grad_(True)
+        random.seed(7)
+        # record the reference's own draw sequence so tests can inject it
+        state = random.getstate()
+        y, _ = M_AP.ResNet.get_roi_crop_feat(d, x2, rois, 8)
+        w = t(rs_randn(61, tuple(y.shape)))
+        (y * w).sum().backward()
+        res[f'y_{mode}'] = sub(y, 61)
+        res[f'y_abs_{mode}'] = y.double().abs().sum()
+        res[f'dx_{mode}'] = sub(x2.grad, 61)
+        res[f'dx_abs_{mode}'] = x2.grad.double().abs().sum()
+        if mode == 'train':
+            random.setstate(state)
+            picks = []
+            for i in range(3):
+                n3 = int((rois[0][:, 0] == i).sum())
+                n4 = int((rois[1][:, 0] == i).sum())
+                pr = random.random()
+                if pr < 0.3:
+                    picks.append((3, random.randint(0, n3 - 1)))
+                elif pr < 0.6:
+                    picks.append((4, random.randint(0, n4 - 1)))
+                else:
+                    picks.append((0, -1))
+            res['drops'] = np.array(picks)
+    save('apcnn_crop', roi3=rois[0], roi4=rois[1], roi5=rois[2], **res)
+
+
+# ---------------------------------------------------------------- OSME
+def gen_osme():
+    osme = M_OSME.OSME(32, 8, feature_shape=7, num_attention=2)
+    sd = {k: v.clone() for k, v in osme.state_dict().items()}
+    x = t(rs_relu_randn(71, (3, 32, 7, 7))).requires_grad_(True)
+    f, parts = osme(x)
+    w = t(rs_randn(72, tuple(parts.shape)))
+    ((parts * w).sum() + f.sum()).backward()
+    save('osme_small', **{'w_' + k.replace('.', '__'): v for k, v in sd.items()},
+         f=f, parts=parts, dx=x.grad)
+
+
+# ---------------------------------------------------------------- key contracts
+def gen_keys():
+    from yacs.config import CfgNode as CN
+    real_vgg16 = M_BCNN.vgg16
+    M_BCNN.vgg16 = lambda pretrained=True: real_vgg16(pretrained=False)
+    M_CBCNN.vgg16 = lambda pretrained=True: real_vgg16(pretrained=False)
+    real_r50 = M_MPN.resnet50
+    M_MPN.resnet50 = lambda pretrained=True: real_r50(pretrained=False)
+    real_r101 = M_OSME.resnet101
+    M_OSME.resnet101 = lambda pretrained=True: real_r101(pretrained=False)
+    models = {
+        'BCNN': MODEL.get('BCNN')(CN(dict(stage=2, num_classes=200))),
+        'CBCNN': MODEL.get('CBCNN')(CN(dict(stage=2, num_classes=200, input_channel=512, output_channel=6000))),
+        'MPN': MODEL.get('MPN')(CN(dict(iter_num=5, is_sqrt=True, is_vec=True, input_dim=2048,
+                                        dimension_reduction=256, num_classes=200))),
+        'APCNN': M_AP.resnet50(200),
+        'APCNN_8142': M_AP.resnet50(8142),
+        'OSMENet': MODEL.get('OSMENet')(CN(dict(num_attention=2, num_classes=200))),
+    }
+    keys = {}
+    for name, m in models.items():
+        keys[name] = {
+            'state_dict': [[k, list(v.shape)] for k, v in m.state_dict().items()],
+            'children': [n for n, _ in m.named_children()],
+            'n_params': sum(p.numel() for p in m.parameters()),
+        }
+    with open(os.path.join(OUT, 'state_dict_keys.json'), 'w') as f:
+        json.dump(keys, f)
+    print('wrote state_dict_keys.json', {k: len(v['state_dict']) for k, v in keys.items()})
+    return models
+
+
+# ---------------------------------------------------------------- whole-model logits
+def gen_models(models):
+    """Tiny end-to-end pins: 64x64 images through the reference BCNN / CBCNN / MPN with
+    a seeded re-initialisation that tests/golden/inputs.py:seeded_init reproduces."""
+    from inputs import seeded_init
+    res = {}
+    for name in ('BCNN', 'CBCNN', 'MPN'):
+        m = models[name]
+        seeded_init(m, 900)
+        m.eval()
+        x = t(rs_randn(901, (2, 3, 64, 64)))
+        with torch.no_grad():
+            res[name] = m(x)
+    save('model_logits', **res)
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    gen_bcnn()
+    gen_cbp()
+    gen_mpn()
+    gen_apcnn()
+    gen_osme()
+    ms = gen_keys()
+    gen_models(ms)

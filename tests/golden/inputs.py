@@ -1,0 +1,41 @@
+"""Deterministic inputs shared by oracle/gen_golden.py (which stores the
+reference's outputs) and the tests (which regenerate the same inputs).
+numpy's legacy RandomState (MT19937) is stable across numpy versions."""
+import numpy as np
+import torch
+
+
+def rs_randn(seed, shape):
+    return np.random.RandomState(seed).randn(*shape).astype(np.float32)
+
+
+def rs_relu_randn(seed, shape):
+    return np.maximum(rs_randn(seed, shape), 0.0)
+
+
+def sub(a, stride=1009):
+    """Strided subsample of a flattened tensor (stride prime, offset 0)."""
+    if torch.is_tensor(a):
+        return a.detach().reshape(-1)[::stride].clone()
+    return np.asarray(a).reshape(-1)[::stride].copy()
+
+
+def seeded_init(module, seed):
+    """Overwrite every parameter/buffer with small seeded values, in state_dict
+    order, so that two independently constructed copies of a model agree."""
+    rs = np.random.RandomState(seed)
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue
+            a = rs.randn(*v.shape).astype(np.float32) if v.dim() else np.float32(rs.randn())
+            if k.endswith('running_var'):
+                a = np.abs(a) + 0.5
+            elif v.dim() >= 2:
+                fan_in = int(np.prod(v.shape[1:]))
+                a = a * np.float32(np.sqrt(2.0 / fan_in))
+            elif k.endswith('weight'):
+                a = 1.0 + 0.1 * a
+            else:
+                a = 0.1 * a
+            v.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)))
