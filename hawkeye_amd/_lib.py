@@ -1,0 +1,97 @@
+"""ctypes binding of libhawkeye_hip.so (C ABI declared in include/hawkeye_hip.h).
+
+The library is loaded AFTER torch so that its NEEDED libamdhip64.so.7 resolves to
+the HIP runtime torch already mapped (one runtime => torch's stream handles are
+valid inside the kernels' launches).  There is no CPU fallback: if the library
+is missing or a tensor is not on a HIP device, the op raises.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported before the .so is dlopen'ed)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libhawkeye_hip.so')
+
+c_f = ctypes.c_void_p       # device float*
+c_i = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_ll = ctypes.c_longlong
+c_fl = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/hawkeye_hip.h one to one
+SIGNATURES = {
+    'hk_version': (ctypes.c_char_p, []),
+    'hk_bcnn_pool_ws_bytes': (c_sz, [c_i, c_i, c_i]),
+    'hk_bcnn_pool_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_bcnn_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_cov_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    'hk_cov_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    'hk_ns_sqrtm_ws_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
+    'hk_ns_sqrtm_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_ns_sqrtm_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_triu_vec_fwd': (c_i, [c_f, c_f, c_i, c_i, c_f]),
+    'hk_triu_vec_bwd': (c_i, [c_f, c_f, c_i, c_i, c_f]),
+    'hk_cbp_plan_bytes': (c_sz, [c_i, c_i]),
+    'hk_cbp_plan_build': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f]),
+    'hk_cbp_ws_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
+    'hk_cbp_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_cbp_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_att_pool_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    'hk_att_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    'hk_att_roi_select': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
+    'hk_roi_crop_resize_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    'hk_roi_crop_resize_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    'hk_roi_boxes': (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_fl, c_f, c_f, c_i, c_f]),
+    'hk_osme_gap': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
+    'hk_osme_scale_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'hk_osme_scale_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'hk_bgemm_f32': (c_i, [c_f, c_i, c_ll, c_i, c_f, c_i, c_ll, c_i, c_f, c_i, c_ll, c_i, c_i, c_i, c_i,
+                           c_fl, c_fl, c_fl, c_f]),
+}
+
+_lib = None
+
+
+class HawkeyeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library and attach prototypes.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HawkeyeHipError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C hawkeye_amd/csrc` (there is no CPU fallback for the HIP ops)')
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError => header/library drifted apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HawkeyeHipError(f'{what} failed with code {rc} '
+                              f'({"HK_ERR" if rc < 0 else "hipError_t"})')
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int32 HIP tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HawkeyeHipError('hawkeye_amd ops run on MI355X only: got a CPU tensor (no CPU fallback; '
+                              'the CPU reference lives in oracle/ and is test infrastructure)')
+    if not t.is_contiguous():
+        raise HawkeyeHipError('internal error: non-contiguous tensor handed to the C ABI')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,397 @@
+// AP-CNN attention-pooling head (replaces pieces of model/methods/APCNN.py):
+//   K8  attention pooling (gap / a_s-weighted gap in one pass)         :256-266,:377-405,:533-538
+//   K9  attention -> ROI selection with on-device greedy NMS            :444-476 + nms.py:4-93
+//   K10 ROI union/drop boxes + crop / drop / rescale / bilinear resize  :478-531
+// All HBM-bound streaming or tiny latency-bound kernels: wave64 shuffles for the
+// reductions, 16 B per-lane loads where the layout allows, fixed reduction
+// orders (bit-reproducible), no host synchronisation anywhere.
+#include "hk_common.h"
+#include "../../include/hawkeye_hip.h"
+
+namespace hk {
+
+// ---------------------------------------------------------------------- K8
+// one wave per (b,c) row of F; 4 rows per workgroup
+template <bool VEC>
+__global__ __launch_bounds__(256) void att_pool_fwd_kernel(const float* __restrict__ f, const float* __restrict__ a_s,
+                                                           float* __restrict__ gap, float* __restrict__ sgap,
+                                                           long long rows, int C, int HW) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(row / C);
+    const float* fp = f + row * HW;
+    const float* ap = a_s ? a_s + (long long)b * HW : nullptr;
+    float s0 = 0.f, s1 = 0.f;
+    if (VEC) {
+        const int n4 = HW >> 2;
+        for (int i = lane; i < n4; i += 64) {
+            const float4 v = reinterpret_cast<const float4*>(fp)[i];
+            s0 += (v.x + v.y) + (v.z + v.w);
+            if (ap) {
+                const float4 a = reinterpret_cast<const float4*>(ap)[i];
+                s1 += (v.x * a.x + v.y * a.y) + (v.z * a.z + v.w * a.w);
+            }
+        }
+    } else {
+        for (int i = lane; i < HW; i += 64) {
+            const float v = fp[i];
+            s0 += v;
+            if (ap) s1 += v * ap[i];
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+        gap[row] = s0 / (float)HW;
+        if (sgap) sgap[row] = s1 / (float)HW;
+    }
+}
+
+// thread owns one hw column of image b and walks the channels:
+//   df[b,c,hw] = (dsgap[b,c] a_s[b,hw] + dgap[b,c]) / HW ;  da_s[b,hw] = sum_c dsgap[b,c] F[b,c,hw] / HW
+__global__ __launch_bounds__(256) void att_pool_bwd_kernel(const float* __restrict__ f, const float* __restrict__ a_s,
+                                                           const float* __restrict__ dgap,
+                                                           const float* __restrict__ dsgap, float* __restrict__ df,
+                                                           float* __restrict__ da_s, int C, int HW) {
+    extern __shared__ float sm[];  // dgap[C], dsgap[C] of this image
+    const int b = blockIdx.y;
+    float* sg = sm;
+    float* ss = sm + C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        sg[c] = dgap ? dgap[(long long)b * C + c] : 0.f;
+        ss[c] = dsgap ? dsgap[(long long)b * C + c] : 0.f;
+    }
+    __syncthreads();
+    const int hw = blockIdx.x * 256 + threadIdx.x;
+    if (hw >= HW) return;
+    const float inv = 1.0f / (float)HW;
+    const float a = a_s ? a_s[(long long)b * HW + hw] : 0.f;
+    const float* fp = f + (long long)b * C * HW + hw;
+    float* dp = df + (long long)b * C * HW + hw;
+    float acc = 0.f;
+    if (a_s && da_s) {
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            acc += ss[c] * fp[(long long)c * HW];
+            dp[(long long)c * HW] = (ss[c] * a + sg[c]) * inv;
+        }
+        da_s[(long long)b * HW + hw] = acc * inv;
+    } else {
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) dp[(long long)c * HW] = (ss[c] * a + sg[c]) * inv;
+    }
+}
+
+// ---------------------------------------------------------------------- K9
+struct Cand {
+    float s;
+    int i;
+};
+__device__ __forceinline__ Cand better(Cand a, Cand b) {  // higher score; ties: higher index
+    return (b.s > a.s || (b.s == a.s && b.i > a.i)) ? b : a;
+}
+
+// one 256-thread workgroup per image; scores + alive flags in LDS
+__global__ __launch_bounds__(256) void att_roi_select_kernel(const float* __restrict__ att, float* __restrict__ rois,
+                                                             int* __restrict__ count, int h, int w, int stride,
+                                                             float anchor, int img_h, int img_w, int r0, int r1, int c0,
+                                                             int c1, float thr, int topk) {
+    extern __shared__ float sm[];  // score[h*w] ; alive flags packed as floats (>0 alive)
+    __shared__ float red[4];
+    __shared__ Cand wbest[4];
+    __shared__ Cand winner;
+    const int b = blockIdx.x, n = h * w, tid = threadIdx.x;
+    float* score = sm;
+    float* alive = sm + n;
+    const float* ap = att + (long long)b * n;
+    float part = 0.f;
+    for (int p = tid; p < n; p += 256) {
+        const int y = p / w, x = p % w;
+        const float keep = (y >= r0 && y < r1 && x >= c0 && x < c1) ? 1.f : 0.f;
+        const float s = ap[p] * keep;   // att_mask * att_corner_unmask   (APCNN.py:455)
+        score[p] = s;
+        part += s;
+    }
+    const float mean = block_sum<4>(part, red) / (float)n;      // scores.mean() over ALL cells (:460)
+    for (int p = tid; p < n; p += 256) alive[p] = (score[p] > mean) ? 1.f : 0.f;   // :461
+    __syncthreads();
+
+    const float half = 0.5f * anchor;
+    const float area = (2.f * half) * (2.f * half);              // (x2-x1)*(y2-y1), identical for all anchors
+    float* out = rois + (long long)b * topk * 5;
+    int found = 0;
+    for (int t = 0; t < topk; ++t) {
+        Cand best;
+        best.s = -1.f; best.i = -1;
+        for (int p = tid; p < n; p += 256)
+            if (alive[p] > 0.f) {
+                Cand c; c.s = score[p]; c.i = p;
+                best = better(best, c);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            Cand oth;
+            oth.s = __shfl_xor(best.s, o, 64);
+            oth.i = __shfl_xor(best.i, o, 64);
+            best = better(best, oth);
+        }
+        if ((tid & 63) == 0) wbest[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            Cand r = wbest[0];
+            for (int k = 1; k < 4; ++k) r = better(r, wbest[k]);
+            winner = r;
+        }
+        __syncthreads();
+        const Cand wv = winner;
+        if (wv.i < 0) break;   // uniform: nothing left (reference loop ends, nms.py:38)
+        const float wx = (float)((wv.i % w) * stride), wy = (float)((wv.i / w) * stride);
+        const float wx1 = wx - half, wy1 = wy - half, wx2 = wx + half, wy2 = wy + half;
+        if (tid == 0) {
+            out[t * 5 + 0] = fmaxf(wx1, 0.f);                     // clamp after NMS (:469-472)
+            out[t * 5 + 1] = fmaxf(wy1, 0.f);
+            out[t * 5 + 2] = fminf(wx2, (float)(img_w - 1));
+            out[t * 5 + 3] = fminf(wy2, (float)(img_h - 1));
+            out[t * 5 + 4] = wv.s;
+        }
+        ++found;
+        for (int p = tid; p < n; p += 256) {                      // suppress IoU >= thr  (nms.py:56-91)
+            if (alive[p] <= 0.f) continue;
+            if (p == wv.i) { alive[p] = 0.f; continue; }
+            const float px = (float)((p % w) * stride), py = (float)((p / w) * stride);
+            const float xx1 = fmaxf(px - half, wx1), yy1 = fmaxf(py - half, wy1);
+            const float xx2 = fminf(px + half, wx2), yy2 = fminf(py + half, wy2);
+            const float iw = fmaxf(xx2 - xx1, 0.f), ih = fmaxf(yy2 - yy1, 0.f);
+            const float inter = iw * ih;
+            const float uni = (area - inter) + area;
+            if (!(inter / uni < thr)) alive[p] = 0.f;
+        }
+        __syncthreads();
+    }
+    for (int e = found * 5 + tid; e < topk * 5; e += 256) out[e] = 0.f;
+    if (tid == 0) count[b] = found;
+}
+
+// ---------------------------------------------------------------------- K10 boxes
+__global__ void roi_boxes_kernel(const float* __restrict__ r3, const int* __restrict__ n3, int k3,
+                                 const float* __restrict__ r4, const int* __restrict__ n4, int k4,
+                                 const float* __restrict__ r5, const int* __restrict__ n5, int k5,
+                                 const float* __restrict__ u01, float scale, float* __restrict__ box,
+                                 float* __restrict__ drop, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float x1 = 3.0e38f, y1 = 3.0e38f, x2 = -3.0e38f, y2 = -3.0e38f;
+    const float* tabs[3] = {r3 + (long long)b * k3 * 5, r4 + (long long)b * k4 * 5, r5 + (long long)b * k5 * 5};
+    const int cnts[3] = {n3[b], n4[b], n5[b]};
+    for (int l = 0; l < 3; ++l)
+        for (int i = 0; i < cnts[l]; ++i) {
+            const float* r = tabs[l] + i * 5;
+            x1 = fminf(x1, r[0] / scale); y1 = fminf(y1, r[1] / scale);    // :487-489
+            x2 = fmaxf(x2, r[2] / scale); y2 = fmaxf(y2, r[3] / scale);
+        }
+    box[b * 4 + 0] = x1; box[b * 4 + 1] = y1; box[b * 4 + 2] = x2; box[b * 4 + 3] = y2;
+    float d[4] = {0.f, 0.f, -1.f, -1.f};
+    if (u01) {
+        const float pr = u01[b * 2], ui = u01[b * 2 + 1];
+        const int lvl = pr < 0.3f ? 0 : (pr < 0.6f ? 1 : -1);               // :494-504
+        if (lvl >= 0 && cnts[lvl] > 0) {
+            int idx = (int)(ui * (float)cnts[lvl]);
+            if (idx > cnts[lvl] - 1) idx = cnts[lvl] - 1;
+            const float* r = tabs[lvl] + idx * 5;
+            d[0] = r[0] / scale; d[1] = r[1] / scale; d[2] = r[2] / scale; d[3] = r[3] / scale;
+        }
+    }
+    drop[b * 4 + 0] = d[0]; drop[b * 4 + 1] = d[1]; drop[b * 4 + 2] = d[2]; drop[b * 4 + 3] = d[3];
+}
+
+// ---------------------------------------------------------------------- K10 crop/resize
+struct CropGeom {
+    int x1, y1, cw, ch;        // integer crop (python .long() truncation + slice clipping)
+    int dx1, dy1, dx2, dy2;    // integer drop rectangle (empty if dx2 <= dx1)
+    float rate;                // c*h*w / sum(mask) (1 in eval)
+    float sh, sw;              // source scales in / out
+};
+
+__device__ __forceinline__ int clipi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ CropGeom crop_geom(const float* box, const float* drop, int C, int H, int W, int training) {
+    CropGeom g;
+    const float fx1 = box[0], fy1 = box[1], fx2 = box[2], fy2 = box[3];
+    const int x1 = clipi((int)fx1, 0, W), x2 = clipi((int)fx2, 0, W);
+    const int y1 = clipi((int)fy1, 0, H), y2 = clipi((int)fy2, 0, H);
+    g.x1 = x1; g.y1 = y1;
+    g.cw = x2 > x1 ? x2 - x1 : 0;
+    g.ch = y2 > y1 ? y2 - y1 : 0;
+    g.dx1 = g.dy1 = 0; g.dx2 = g.dy2 = 0;
+    g.rate = 1.f;
+    if (training) {
+        if (drop[2] > drop[0] || drop[3] > drop[1]) {
+            g.dx1 = clipi((int)drop[0], 0, W); g.dx2 = clipi((int)drop[2], 0, W);
+            g.dy1 = clipi((int)drop[1], 0, H); g.dy2 = clipi((int)drop[3], 0, H);
+        }
+        int ox = min(g.dx2, x2) - max(g.dx1, x1); if (ox < 0) ox = 0;
+        int oy = min(g.dy2, y2) - max(g.dy1, y1); if (oy < 0) oy = 0;
+        const float msum = (float)C * (float)(g.cw * g.ch - ox * oy);       // torch.sum(mask_un[crop])
+        g.rate = ((float)C * (fy2 - fy1)) * (fx2 - fx1) / msum;             // :509-511 (float box, not the ints)
+    }
+    g.sh = (float)g.ch / (float)H;
+    g.sw = (float)g.cw / (float)W;
+    return g;
+}
+
+// torch upsample_bilinear2d source index (align_corners = False)
+__device__ __forceinline__ void src_index(float scale, int dst, int in, int& i0, int& i1, float& l0, float& l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void roi_crop_fwd_kernel(const float* __restrict__ x, const float* __restrict__ box,
+                                                           const float* __restrict__ drop, float* __restrict__ y,
+                                                           int C, int H, int W, int training) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const CropGeom g = crop_geom(box + b * 4, drop + b * 4, C, H, W, training);
+    const float* xp = x + ((long long)b * C + c) * H * W;
+    float* yp = y + ((long long)b * C + c) * H * W;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < H * W; o += gridDim.x * 256) {
+        if (g.cw <= 0 || g.ch <= 0) { yp[o] = 0.f; continue; }
+        const int oy = o / W, ox = o % W;
+        int a0, a1, b0, b1;
+        float la0, la1, lb0, lb1;
+        src_index(g.sh, oy, g.ch, a0, a1, la0, la1);
+        src_index(g.sw, ox, g.cw, b0, b1, lb0, lb1);
+        float v[2][2];
+        const int ys[2] = {g.y1 + a0, g.y1 + a1}, xs[2] = {g.x1 + b0, g.x1 + b1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float t = xp[ys[i] * W + xs[j]];
+                if (training) {
+                    const bool dropped = ys[i] >= g.dy1 && ys[i] < g.dy2 && xs[j] >= g.dx1 && xs[j] < g.dx2;
+                    t = (dropped ? 0.f : t) * g.rate;
+                }
+                v[i][j] = t;
+            }
+        yp[o] = la0 * (lb0 * v[0][0] + lb1 * v[0][1]) + la1 * (lb0 * v[1][0] + lb1 * v[1][1]);
+    }
+}
+
+// gather form of the transpose: every input pixel sums the output pixels that sampled it
+__global__ __launch_bounds__(256) void roi_crop_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ box,
+                                                           const float* __restrict__ drop, float* __restrict__ dx,
+                                                           int C, int H, int W, int training) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const CropGeom g = crop_geom(box + b * 4, drop + b * 4, C, H, W, training);
+    const float* gp = dy + ((long long)b * C + c) * H * W;
+    float* dp = dx + ((long long)b * C + c) * H * W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < H * W; p += gridDim.x * 256) {
+        const int iy = p / W, ix = p % W;
+        const int ry = iy - g.y1, rx = ix - g.x1;
+        float acc = 0.f;
+        if (g.cw > 0 && g.ch > 0 && ry >= 0 && ry < g.ch && rx >= 0 && rx < g.cw) {
+            const bool dropped = training && iy >= g.dy1 && iy < g.dy2 && ix >= g.dx1 && ix < g.dx2;
+            if (!dropped) {
+                // output rows/cols whose source interval touches ry / rx (conservative bounds, exact weights)
+                int oy0 = (int)floorf(((float)ry - 0.5f) / g.sh - 0.5f) - 1, oy1 = (int)ceilf(((float)ry + 1.5f) / g.sh - 0.5f) + 1;
+                int ox0 = (int)floorf(((float)rx - 0.5f) / g.sw - 0.5f) - 1, ox1 = (int)ceilf(((float)rx + 1.5f) / g.sw - 0.5f) + 1;
+                oy0 = clipi(oy0, 0, H - 1); oy1 = clipi(oy1, 0, H - 1);
+                ox0 = clipi(ox0, 0, W - 1); ox1 = clipi(ox1, 0, W - 1);
+                for (int oy = oy0; oy <= oy1; ++oy) {
+                    int a0, a1; float la0, la1;
+                    src_index(g.sh, oy, g.ch, a0, a1, la0, la1);
+                    const float wy = (a0 == ry ? la0 : 0.f) + (a1 == ry ? la1 : 0.f);
+                    if (wy == 0.f) continue;
+                    float rowacc = 0.f;
+                    for (int ox = ox0; ox <= ox1; ++ox) {
+                        int b0, b1; float lb0, lb1;
+                        src_index(g.sw, ox, g.cw, b0, b1, lb0, lb1);
+                        const float wx = (b0 == rx ? lb0 : 0.f) + (b1 == rx ? lb1 : 0.f);
+                        rowacc += wx * gp[oy * W + ox];
+                    }
+                    acc += wy * rowacc;
+                }
+                acc *= g.rate;
+            }
+        }
+        dp[p] = acc;
+    }
+}
+
+}  // namespace hk
+
+using namespace hk;
+
+extern "C" int hk_att_pool_fwd(const float* f, const float* a_s, float* gap, float* sgap, int B, int C, int HW,
+                               hk_stream_t stream) {
+    if (!f || !gap || B <= 0 || C <= 0 || HW <= 0 || (a_s && !sgap)) return HK_ERR_BAD_ARG;
+    const long long rows = (long long)B * C;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const bool vec = (HW % 4 == 0) && aligned16(f) && (!a_s || aligned16(a_s));
+    if (vec)
+        hipLaunchKernelGGL(att_pool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, f, a_s, gap, sgap, rows, C, HW);
+    else
+        hipLaunchKernelGGL(att_pool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, f, a_s, gap, sgap, rows, C, HW);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_att_pool_bwd(const float* f, const float* a_s, const float* dgap, const float* dsgap, float* df,
+                               float* da_s, int B, int C, int HW, hk_stream_t stream) {
+    if (!f || !df || B <= 0 || C <= 0 || HW <= 0 || (!dgap && !dsgap)) return HK_ERR_BAD_ARG;
+    if ((size_t)2 * C * sizeof(float) > 64 * 1024) return HK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(att_pool_bwd_kernel, dim3((HW + 255) / 256, B), dim3(256), 2 * C * sizeof(float),
+                       (hipStream_t)stream, f, a_s, dgap, dsgap, df, da_s, C, HW);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_att_roi_select(const float* att, float* rois, int32_t* count, int B, int h, int w, int feature_stride,
+                                 float anchor_size, int img_h, int img_w, int keep_r0, int keep_r1, int keep_c0,
+                                 int keep_c1, float iou_thr, int topk, hk_stream_t stream) {
+    if (!att || !rois || !count || B <= 0 || h <= 0 || w <= 0 || topk <= 0) return HK_ERR_BAD_ARG;
+    const size_t sm = (size_t)2 * h * w * sizeof(float);
+    if (sm > 150 * 1024) return HK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(att_roi_select_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, att, rois, (int*)count, h, w,
+                       feature_stride, anchor_size, img_h, img_w, keep_r0, keep_r1, keep_c0, keep_c1, iou_thr, topk);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_roi_boxes(const float* rois3, const int32_t* cnt3, int k3, const float* rois4, const int32_t* cnt4,
+                            int k4, const float* rois5, const int32_t* cnt5, int k5, const float* u01, float scale,
+                            float* box, float* drop, int B, hk_stream_t stream) {
+    if (!rois3 || !cnt3 || !rois4 || !cnt4 || !rois5 || !cnt5 || !box || !drop || B <= 0 || scale <= 0.f)
+        return HK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(roi_boxes_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rois3, (const int*)cnt3,
+                       k3, rois4, (const int*)cnt4, k4, rois5, (const int*)cnt5, k5, u01, scale, box, drop, B);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_roi_crop_resize_fwd(const float* x, const float* box, const float* drop, float* y, int B, int C, int H,
+                                      int W, int training, hk_stream_t stream) {
+    if (!x || !box || !drop || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return HK_ERR_BAD_ARG;
+    int gx = (H * W + 255) / 256;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(roi_crop_fwd_kernel, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, x, box, drop, y, C, H, W,
+                       training);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_roi_crop_resize_bwd(const float* dy, const float* box, const float* drop, float* dx, int B, int C,
+                                      int H, int W, int training, hk_stream_t stream) {
+    if (!dy || !box || !drop || !dx || B <= 0 || C <= 0 || H <= 0 || W <= 0) return HK_ERR_BAD_ARG;
+    int gx = (H * W + 255) / 256;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(roi_crop_bwd_kernel, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, dy, box, drop, dx, C, H, W,
+                       training);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}

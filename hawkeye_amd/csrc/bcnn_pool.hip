@@ -1,0 +1,192 @@
+// BCNN bilinear pooling, forward + backward (replaces model/methods/BCNN.py:13-27).
+//
+//   G = X X^T / M ; z = sqrt(G + 1e-5) ; n = max(|z|_2, 1e-12) ; y = z / n
+//
+// Forward: the l2 norm does not need z:  |z|^2 = sum_ij (G_ij + 1e-5)
+//   = (1/M) sum_hw (sum_c x[c,hw])^2 + C^2 * 1e-5   (exact identity), so a small
+// column-sum kernel produces 1/n BEFORE the Gram kernel, whose epilogue writes
+// the final y in one pass: X is read once, y written once, nothing else touches HBM.
+//
+// Backward (Appendix A of SURVEY.md):  t = <y,dy>,
+//   dG = (dy - y t) / (2 n^2 y M),   dX = (dG + dG^T) X.
+// With P_ij = (dy_ij + dy_ji) / (2 n^2 M y_ij):  dG + dG^T = P - (t / (n^2 M)) 11^T, so
+//   dX = P X - (t / (n^2 M)) 1 colsum(X)^T.
+// P is formed on the fly by the GEMM's A-operand loader from y / dy tiles (never
+// materialised); t is accumulated by the same loader (each (y,dy) element exactly
+// once, fixed order) and the rank-1 term is applied by a small second kernel.
+#include "hk_bgemm.h"
+#include "../../include/hawkeye_hip.h"
+
+namespace hk {
+
+// colsum[b,hw] = sum_c x[b,c,hw];  inv_norm[b] = 1 / max(sqrt(sum_hw colsum^2 / M + C*C*1e-5), 1e-12)
+// One workgroup (1024 threads) per sample; threads stride over channel rows with
+// a fixed hw column each, LDS tree over the row groups: deterministic.
+__global__ __launch_bounds__(1024) void bcnn_colsum_norm_kernel(const float* __restrict__ x,
+                                                                float* __restrict__ colsum,
+                                                                float* __restrict__ inv_norm, int C, int HW) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [groups][HW] + 16
+    const int b = blockIdx.x;
+    const float* xb = x + (long long)b * C * HW;
+    const int tid = threadIdx.x;
+    // column-major assignment: thread handles column (tid % ncol) for rows tid/ncol, +groups, ...
+    const int ncol = HW < 1024 ? HW : 1024;
+    const int groups = 1024 / ncol;  // >= 1
+    const int col = tid % ncol, grp = tid / ncol;
+    float* part = sm;                // [groups][HW]
+    float* red = sm + groups * HW;   // 16 floats
+    for (int c0 = 0; c0 < HW; c0 += ncol) {
+        const int hw = c0 + col;
+        float s = 0.f;
+        if (grp < groups && hw < HW)
+            for (int c = grp; c < C; c += groups) s += xb[(long long)c * HW + hw];
+        if (grp < groups && hw < HW) part[grp * HW + hw] = s;
+    }
+    __syncthreads();
+    float ssq = 0.f;
+    for (int hw = tid; hw < HW; hw += 1024) {
+        float s = 0.f;
+        for (int g = 0; g < groups; ++g) s += part[g * HW + hw];
+        colsum[(long long)b * HW + hw] = s;
+        ssq += s * s;
+    }
+    const float tot = block_sum<16>(ssq, red);
+    if (tid == 0) {
+        const float n2 = tot / (float)HW + (float)C * (float)C * 1e-5f;
+        inv_norm[b] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    }
+}
+
+// Gram epilogue: y = sqrt(acc / M + 1e-5) * inv_norm[b]
+struct EpBcnn {
+    float* y;
+    const float* inv_norm;
+    int C;
+    float m;  // HW as float
+    __device__ __forceinline__ void operator()(int b, int i, int j, float v) const {
+        y[(long long)b * C * C + (long long)i * C + j] = sqrtf(v / m + 1e-5f) * inv_norm[b];
+    }
+};
+
+// A-operand loader of the backward GEMM:  P[i][k] = (dy[i][k] + dy[k][i]) / y[i][k] * coef[b],
+// coef = inv_norm^2 / (2 M).  Also accumulates t-partials sum y*dy for the tile
+// column tn == 0 (each row-block of y/dy is then visited exactly once).
+struct LdBcnnP {
+    const float* y;
+    const float* dy;
+    const float* inv_norm;
+    float* tpart;  // [B][tilesM]
+    int C;
+    float inv2m;   // 1 / (2 M)
+    int vec;
+    float coef;
+    float tacc;
+    int active;
+    __device__ __forceinline__ void begin(int b, int, int tn) {
+        const float in = inv_norm[b];
+        coef = in * in * inv2m;
+        tacc = 0.f;
+        active = (tn == 0);
+    }
+    __device__ __forceinline__ float4 ld4(int b, int r, int c) {
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < C && c < C) {
+            const long long base = (long long)b * C * C;
+            const float* yq = y + base + (long long)r * C + c;
+            const float* dq = dy + base + (long long)r * C + c;
+            float yv[4] = {1.f, 1.f, 1.f, 1.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vec && c + 3 < C) {
+                const float4 a = *reinterpret_cast<const float4*>(yq);
+                const float4 d = *reinterpret_cast<const float4*>(dq);
+                yv[0] = a.x; yv[1] = a.y; yv[2] = a.z; yv[3] = a.w;
+                dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (c + t < C) { yv[t] = yq[t]; dv[t] = dq[t]; }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (c + t < C) {
+                    const float dt = dy[base + (long long)(c + t) * C + r];
+                    p[t] = (dv[t] + dt) / yv[t] * coef;
+                    if (active) tacc += yv[t] * dv[t];
+                }
+            }
+        }
+        return make_float4(p[0], p[1], p[2], p[3]);
+    }
+    __device__ __forceinline__ void finish(int b, int tm, int tn, int tilesM, float* red) {
+        if (tn != 0) return;  // uniform per workgroup
+        const float s = block_sum<4>(tacc, red);
+        if (threadIdx.x == 0) tpart[(long long)b * tilesM + tm] = s;
+    }
+};
+
+// dx[b,c,hw] -= (t[b] * inv_norm[b]^2 / M) * colsum[b,hw],  t[b] = sum of the partials (fixed order)
+__global__ __launch_bounds__(256) void bcnn_rank1_fix_kernel(float* __restrict__ dx, const float* __restrict__ tpart,
+                                                             const float* __restrict__ inv_norm,
+                                                             const float* __restrict__ colsum, int C, int HW,
+                                                             int tilesM, long long per_sample) {
+    const int b = blockIdx.y;
+    float t = 0.f;
+    for (int i = 0; i < tilesM; ++i) t += tpart[(long long)b * tilesM + i];
+    const float in = inv_norm[b];
+    const float k = t * in * in / (float)HW;
+    float* d = dx + (long long)b * per_sample;
+    const float* cs = colsum + (long long)b * HW;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < per_sample; e += (long long)gridDim.x * 256)
+        d[e] -= k * cs[e % HW];
+}
+
+}  // namespace hk
+
+using namespace hk;
+
+extern "C" size_t hk_bcnn_pool_ws_bytes(int B, int C, int HW) {
+    (void)HW;
+    const size_t tiles = (size_t)((C + 63) / 64);
+    return (size_t)B * tiles * sizeof(float) + 256;
+}
+
+extern "C" int hk_bcnn_pool_fwd(const float* x, float* y, float* inv_norm, float* colsum, int B, int C, int HW,
+                                void* ws, size_t ws_bytes, hk_stream_t stream) {
+    (void)ws; (void)ws_bytes;
+    if (!x || !y || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int ncol = HW < 1024 ? HW : 1024;
+    const int groups = 1024 / ncol;
+    const size_t sm = ((size_t)groups * HW + 16) * sizeof(float);
+    if (sm > 150 * 1024) return HK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bcnn_colsum_norm_kernel, dim3(B), dim3(1024), sm, st, x, colsum, inv_norm, C, HW);
+    HK_LAUNCH_CHECK();
+    const LdPlain xa = make_plain(x, (long long)C * HW, HW, C, HW);
+    EpBcnn ep;
+    ep.y = y; ep.inv_norm = inv_norm; ep.C = C; ep.m = (float)HW;
+    return bgemm_launch<true, true>(xa, xa, ep, C, C, HW, B, st);
+}
+
+extern "C" int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm,
+                                const float* colsum, float* dx, int B, int C, int HW, void* ws, size_t ws_bytes,
+                                hk_stream_t stream) {
+    if (!x || !y || !dy || !inv_norm || !colsum || !dx || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    if (!ws || ws_bytes < hk_bcnn_pool_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int tilesM = (C + 63) / 64;
+    LdBcnnP pa;
+    pa.y = y; pa.dy = dy; pa.inv_norm = inv_norm; pa.tpart = (float*)ws; pa.C = C;
+    pa.inv2m = 1.0f / (2.0f * (float)HW);
+    pa.vec = (aligned16(y) && aligned16(dy) && (C % 4 == 0)) ? 1 : 0;
+    pa.coef = 0.f; pa.tacc = 0.f; pa.active = 0;
+    const LdPlain xb = make_plain(x, (long long)C * HW, HW, C, HW);  // K x N, N contiguous
+    const EpAffine ep = make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f);
+    int rc = bgemm_launch<true, false>(pa, xb, ep, C, HW, C, B, st);
+    if (rc != HK_OK) return rc;
+    const long long per = (long long)C * HW;
+    int gx = (int)((per + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bcnn_rank1_fix_kernel, dim3(gx, B), dim3(256), 0, st, dx, (const float*)ws, inv_norm, colsum,
+                       C, HW, tilesM, per);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}

@@ -1,0 +1,75 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define HK_OK 0
+#define HK_ERR_BAD_ARG (-1)
+#define HK_ERR_WORKSPACE (-2)
+#define HK_ERR_UNSUPPORTED (-3)
+
+#define HK_LAUNCH_CHECK()                                 \
+    do {                                                  \
+        hipError_t e__ = hipGetLastError();               \
+        if (e__ != hipSuccess) return (int)e__;           \
+    } while (0)
+
+namespace hk {
+
+constexpr int WAVE = 64;
+constexpr int NXCD = 8;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x = NW*64 threads; `red` is NW floats of LDS.
+// Fixed reduction order -> bit-reproducible.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += red[i];
+    return s;
+}
+
+// Work-item -> (sample, tile) map that keeps every tile of one batch sample on
+// one XCD (blocks are dispatched round-robin, block b -> XCD b % 8; each XCD has
+// a private 4 MiB L2, so a sample's operand panels are fetched into ONE L2).
+// Speed only: correctness never depends on the placement.
+// grid size = hk_xcd_grid(nb, tiles).
+__host__ __device__ __forceinline__ int xcd_grid(int nb, int tiles) {
+    return (nb >= NXCD) ? NXCD * ((nb + NXCD - 1) / NXCD) * tiles : nb * tiles;
+}
+__device__ __forceinline__ bool xcd_map(int bid, int nb, int tiles, int& sample, int& tile) {
+    if (nb >= NXCD) {
+        const int xcd = bid % NXCD, slot = bid / NXCD;
+        sample = xcd + NXCD * (slot / tiles);
+        tile = slot % tiles;
+    } else {
+        sample = bid / tiles;
+        tile = bid % tiles;
+    }
+    return sample < nb;
+}
+
+__host__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace hk

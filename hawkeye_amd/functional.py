@@ -1,0 +1,425 @@
+"""torch.autograd.Function wrappers over the C ABI (include/hawkeye_hip.h).
+
+Same pattern the reference already uses for MPN-COV (model/methods/MPNCOV.py:105-230:
+hand-written forward/backward `Function`s), applied to every op on the hot path.
+Outputs and workspaces are allocated through torch's caching allocator; kernels
+are enqueued on torch's current HIP stream; nothing synchronises the host.
+fp32 only, HIP tensors only - there is no CPU fallback (see hawkeye_amd/_lib.py).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise _lib.HawkeyeHipError(f'hawkeye_amd ops are fp32 (reference parity target); got {t.dtype}')
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------- BCNN
+class _BilinearPool(torch.autograd.Function):
+    """replaces BilinearPooling.forward, model/methods/BCNN.py:13-27."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x)
+        b, c, h, w = x.shape
+        hw = h * w
+        y = torch.empty(b, c * c, dtype=torch.float32, device=x.device)
+        inv_norm = torch.empty(b, dtype=torch.float32, device=x.device)
+        colsum = torch.empty(b, hw, dtype=torch.float32, device=x.device)
+        check(lib.hk_bcnn_pool_fwd(ptr(x), ptr(y), ptr(inv_norm), ptr(colsum), b, c, hw, None, 0, stream()),
+              'hk_bcnn_pool_fwd')
+        ctx.save_for_backward(x, y, inv_norm, colsum)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, inv_norm, colsum = ctx.saved_tensors
+        b, c, h, w = x.shape
+        hw = h * w
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        nws = lib.hk_bcnn_pool_ws_bytes(b, c, hw)
+        ws = _ws(nws, x.device)
+        check(lib.hk_bcnn_pool_bwd(ptr(x), ptr(y), ptr(dy), ptr(inv_norm), ptr(colsum), ptr(dx), b, c, hw,
+                                   ptr(ws), nws, stream()), 'hk_bcnn_pool_bwd')
+        return dx
+
+
+def bilinear_pool(x):
+    """[B,C,H,W] -> [B,C*C]:  sqrt(X X^T / HW + 1e-5), l2-normalised."""
+    return _BilinearPool.apply(x)
+
+
+# --------------------------------------------------------------------- MPN-COV
+class _Covpool(torch.autograd.Function):
+    """replaces Covpool, model/methods/MPNCOV.py:105-134."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x)
+        b, c, h, w = x.shape
+        m = h * w
+        cov = torch.empty(b, c, c, dtype=torch.float32, device=x.device)
+        mu = torch.empty(b, c, dtype=torch.float32, device=x.device)
+        check(lib.hk_cov_pool_fwd(ptr(x), ptr(cov), ptr(mu), b, c, m, stream()), 'hk_cov_pool_fwd')
+        ctx.save_for_backward(x, mu)
+        return cov
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, mu = ctx.saved_tensors
+        b, c, h, w = x.shape
+        g = _f32c(g)
+        dx = torch.empty_like(x)
+        check(lib.hk_cov_pool_bwd(ptr(x), ptr(mu), ptr(g), ptr(dx), b, c, h * w, stream()), 'hk_cov_pool_bwd')
+        return dx
+
+
+class _Sqrtm(torch.autograd.Function):
+    """replaces Sqrtm, model/methods/MPNCOV.py:137-202."""
+
+    @staticmethod
+    def forward(ctx, a, iter_n):
+        lib = _lib.load()
+        a = _f32c(a)
+        b, d, _ = a.shape
+        out = torch.empty_like(a)
+        norm_a = torch.empty(b, dtype=torch.float32, device=a.device)
+        slots = max(iter_n - 1, 1)
+        ysave = torch.empty(b, slots, d, d, dtype=torch.float32, device=a.device)
+        zsave = torch.empty(b, slots, d, d, dtype=torch.float32, device=a.device)
+        nws = lib.hk_ns_sqrtm_ws_bytes(b, d, iter_n, 0)
+        ws = _ws(nws, a.device)
+        check(lib.hk_ns_sqrtm_fwd(ptr(a), ptr(out), ptr(norm_a), ptr(ysave), ptr(zsave), b, d, iter_n,
+                                  ptr(ws), nws, stream()), 'hk_ns_sqrtm_fwd')
+        ctx.iter_n = iter_n
+        ctx.save_for_backward(a, out, norm_a, ysave, zsave)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, out, norm_a, ysave, zsave = ctx.saved_tensors
+        b, d, _ = a.shape
+        g = _f32c(g)
+        da = torch.empty_like(a)
+        nws = lib.hk_ns_sqrtm_ws_bytes(b, d, ctx.iter_n, 1)
+        ws = _ws(nws, a.device)
+        check(lib.hk_ns_sqrtm_bwd(ptr(a), ptr(out), ptr(norm_a), ptr(ysave), ptr(zsave), ptr(g), ptr(da),
+                                  b, d, ctx.iter_n, ptr(ws), nws, stream()), 'hk_ns_sqrtm_bwd')
+        return da, None
+
+
+class _Triuvec(torch.autograd.Function):
+    """replaces Triuvec, model/methods/MPNCOV.py:205-230 (keeps its [B, L, 1] output shape)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x)
+        b, d, _ = x.shape
+        y = torch.empty(b, d * (d + 1) // 2, 1, dtype=torch.float32, device=x.device)
+        check(lib.hk_triu_vec_fwd(ptr(x), ptr(y), b, d, stream()), 'hk_triu_vec_fwd')
+        ctx.dims = (b, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        b, d = ctx.dims
+        g = _f32c(g)
+        dx = torch.empty(b, d, d, dtype=torch.float32, device=g.device)
+        check(lib.hk_triu_vec_bwd(ptr(g), ptr(dx), b, d, stream()), 'hk_triu_vec_bwd')
+        return dx
+
+
+def covpool(x):
+    return _Covpool.apply(x)
+
+
+def sqrtm(x, iter_n):
+    return _Sqrtm.apply(x, int(iter_n))
+
+
+def triuvec(x):
+    return _Triuvec.apply(x)
+
+
+# --------------------------------------------------------------------- CBP
+def sketch_hashes(input_dim1, input_dim2, output_dim):
+    """The reference's fixed count-sketch hashes (CBCNN.py:76-91): legacy numpy
+    RandomState seeds 1/3 (h1/s1) and 5/7 (h2/s2).  Saves and restores the
+    global numpy RNG state so constructing a model does not disturb user code."""
+    state = np.random.get_state()
+    try:
+        np.random.seed(1)
+        h1 = np.random.randint(output_dim, size=input_dim1)
+        np.random.seed(3)
+        s1 = 2 * np.random.randint(2, size=input_dim1) - 1
+        np.random.seed(5)
+        h2 = np.random.randint(output_dim, size=input_dim2)
+        np.random.seed(7)
+        s2 = 2 * np.random.randint(2, size=input_dim2) - 1
+    finally:
+        np.random.set_state(state)
+    return h1.astype(np.int32), s1.astype(np.float32), h2.astype(np.int32), s2.astype(np.float32)
+
+
+class CbpPlan:
+    """Device-side CSR plan (bin -> signed Gram entries) built once per device."""
+
+    def __init__(self, h1, s1, h2, s2, output_dim, device):
+        lib = _lib.load()
+        assert h1.ndim == 1 and s1.ndim == 1 and len(h1) == len(s1)            # CBCNN.py:151-152
+        assert len(h1) == len(h2), 'the Gram route needs input_dim1 == input_dim2'
+        assert np.all(h1 >= 0) and np.all(h1 < output_dim)                      # CBCNN.py:153
+        assert np.all(h2 >= 0) and np.all(h2 < output_dim)
+        self.C, self.D, self.device = len(h1), int(output_dim), device
+        h1 = np.ascontiguousarray(h1, dtype=np.int32)
+        h2 = np.ascontiguousarray(h2, dtype=np.int32)
+        s1 = np.ascontiguousarray(s1, dtype=np.float32)
+        s2 = np.ascontiguousarray(s2, dtype=np.float32)
+        self.blob = torch.empty(lib.hk_cbp_plan_bytes(self.C, self.D), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            check(lib.hk_cbp_plan_build(h1.ctypes.data, s1.ctypes.data, h2.ctypes.data, s2.ctypes.data,
+                                        self.C, self.D, ptr(self.blob), stream()), 'hk_cbp_plan_build')
+
+
+class _CompactBilinearPool(torch.autograd.Function):
+    """replaces CompactBilinearPooling.forward, model/methods/CBCNN.py:96-135."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        lib = _lib.load()
+        x = _f32c(x)
+        b, c, h, w = x.shape
+        hw, d = h * w, plan.D
+        y = torch.empty(b, d, dtype=torch.float32, device=x.device)
+        c_raw = torch.empty(b, d, dtype=torch.float32, device=x.device)
+        inv_norm = torch.empty(b, dtype=torch.float32, device=x.device)
+        nws = lib.hk_cbp_ws_bytes(b, c, hw, d)
+        ws = _ws(nws, x.device)
+        check(lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(c_raw), ptr(inv_norm), b, c, hw, d,
+                             ptr(ws), nws, stream()), 'hk_cbp_fwd')
+        ctx.plan = plan
+        ctx.save_for_backward(x, y, c_raw, inv_norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, c_raw, inv_norm = ctx.saved_tensors
+        plan = ctx.plan
+        b, c, h, w = x.shape
+        hw, d = h * w, plan.D
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        nws = lib.hk_cbp_ws_bytes(b, c, hw, d)
+        ws = _ws(nws, x.device)
+        check(lib.hk_cbp_bwd(ptr(x), ptr(plan.blob), ptr(y), ptr(c_raw), ptr(inv_norm), ptr(dy), ptr(dx),
+                             b, c, hw, d, ptr(ws), nws, stream()), 'hk_cbp_bwd')
+        return dx, None
+
+
+def compact_bilinear_pool(x, plan):
+    return _CompactBilinearPool.apply(x, plan)
+
+
+# --------------------------------------------------------------------- AP-CNN
+class _AttPool(torch.autograd.Function):
+    """gap = mean_hw F ; sgap = mean_hw a_s F  (one pass over F).
+    replaces APCNN.py:256-266 + the AdaptiveAvgPool2d(1) heads :377-405,:533-538."""
+
+    @staticmethod
+    def forward(ctx, f, a_s):
+        lib = _lib.load()
+        f = _f32c(f)
+        b, c, h, w = f.shape
+        gap = torch.empty(b, c, dtype=torch.float32, device=f.device)
+        if a_s is None:
+            check(lib.hk_att_pool_fwd(ptr(f), None, ptr(gap), None, b, c, h * w, stream()), 'hk_att_pool_fwd')
+            ctx.save_for_backward(f)
+            ctx.has_att = False
+            return gap, None
+        a_s = _f32c(a_s)
+        sgap = torch.empty(b, c, dtype=torch.float32, device=f.device)
+        check(lib.hk_att_pool_fwd(ptr(f), ptr(a_s), ptr(gap), ptr(sgap), b, c, h * w, stream()), 'hk_att_pool_fwd')
+        ctx.save_for_backward(f, a_s)
+        ctx.has_att = True
+        return gap, sgap
+
+    @staticmethod
+    def backward(ctx, dgap, dsgap):
+        lib = _lib.load()
+        f = ctx.saved_tensors[0]
+        b, c, h, w = f.shape
+        df = torch.empty_like(f)
+        if dgap is None:
+            dgap = torch.zeros(b, c, dtype=torch.float32, device=f.device)
+        dgap = _f32c(dgap)
+        if not ctx.has_att:
+            check(lib.hk_att_pool_bwd(ptr(f), None, ptr(dgap), None, ptr(df), None, b, c, h * w, stream()),
+                  'hk_att_pool_bwd')
+            return df, None
+        a_s = ctx.saved_tensors[1]
+        if dsgap is None:
+            dsgap = torch.zeros(b, c, dtype=torch.float32, device=f.device)
+        dsgap = _f32c(dsgap)
+        da = torch.empty_like(a_s)
+        check(lib.hk_att_pool_bwd(ptr(f), ptr(a_s), ptr(dgap), ptr(dsgap), ptr(df), ptr(da), b, c, h * w,
+                                  stream()), 'hk_att_pool_bwd')
+        return df, da
+
+
+def att_pool(f, a_s=None):
+    """-> (gap [B,C], sgap [B,C] or None)"""
+    return _AttPool.apply(f, a_s)
+
+
+def att_roi_select(att_mask, feature_stride, anchor_size, img_h, img_w, num_classes, iou_thred, topk):
+    """Device-side get_att_roi (APCNN.py:444-476).  -> (rois [B,topk,5], count [B] int32),
+    rows beyond count are zero.  No gradient (reference: torch.no_grad, :447)."""
+    lib = _lib.load()
+    with torch.no_grad():
+        a = _f32c(att_mask.detach())
+        n, _, h, w = a.shape
+        lo, hi = (0.2, 0.8) if num_classes == 200 else (0.1, 0.9)     # APCNN.py:451-455
+        r0, r1, c0, c1 = int(lo * h), int(hi * h), int(lo * w), int(hi * w)
+        rois = torch.empty(n, topk, 5, dtype=torch.float32, device=a.device)
+        cnt = torch.empty(n, dtype=torch.int32, device=a.device)
+        check(lib.hk_att_roi_select(ptr(a), ptr(rois), ptr(cnt), n, h, w, int(feature_stride), float(anchor_size),
+                                    int(img_h), int(img_w), r0, r1, c0, c1, float(iou_thred), int(topk), stream()),
+              'hk_att_roi_select')
+    return rois, cnt
+
+
+def roi_boxes(tables, u01, scale):
+    """Union / drop boxes on device from three (rois, count) tables.  -> box [B,4], drop [B,4]"""
+    lib = _lib.load()
+    (r3, n3), (r4, n4), (r5, n5) = tables
+    b = r3.shape[0]
+    box = torch.empty(b, 4, dtype=torch.float32, device=r3.device)
+    drop = torch.empty(b, 4, dtype=torch.float32, device=r3.device)
+    check(lib.hk_roi_boxes(ptr(r3), ptr(n3), r3.shape[1], ptr(r4), ptr(n4), r4.shape[1], ptr(r5), ptr(n5),
+                           r5.shape[1], ptr(u01) if u01 is not None else None, float(scale), ptr(box), ptr(drop),
+                           b, stream()), 'hk_roi_boxes')
+    return box, drop
+
+
+class _RoiCropResize(torch.autograd.Function):
+    """replaces get_roi_crop_feat's per-image python loop, APCNN.py:478-531."""
+
+    @staticmethod
+    def forward(ctx, x, box, drop, training):
+        lib = _lib.load()
+        x = _f32c(x)
+        b, c, h, w = x.shape
+        box, drop = _f32c(box), _f32c(drop)
+        y = torch.empty_like(x)
+        check(lib.hk_roi_crop_resize_fwd(ptr(x), ptr(box), ptr(drop), ptr(y), b, c, h, w, int(training), stream()),
+              'hk_roi_crop_resize_fwd')
+        ctx.save_for_backward(box, drop)
+        ctx.training = int(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        box, drop = ctx.saved_tensors
+        dy = _f32c(dy)
+        b, c, h, w = dy.shape
+        dx = torch.empty_like(dy)
+        check(lib.hk_roi_crop_resize_bwd(ptr(dy), ptr(box), ptr(drop), ptr(dx), b, c, h, w, ctx.training, stream()),
+              'hk_roi_crop_resize_bwd')
+        return dx, None, None, None
+
+
+def roi_crop_resize(x, box, drop, training):
+    return _RoiCropResize.apply(x, box, drop, training)
+
+
+# --------------------------------------------------------------------- OSME
+class _OsmeGap(torch.autograd.Function):
+    """z = GAP(x).  replaces OSME.py:21 (avg_pool + squeeze)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x)
+        n, c, h, w = x.shape
+        z = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        check(lib.hk_osme_gap(ptr(x), ptr(z), n, c, h * w, stream()), 'hk_osme_gap')
+        ctx.shape = x.shape
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        n, c, h, w = ctx.shape
+        return (dz / float(h * w)).view(n, c, 1, 1).expand(n, c, h, w).contiguous()
+
+
+class _OsmeScale(torch.autograd.Function):
+    """s[p] = m[p] (.) x for all P gates in one pass.  replaces OSME.py:23."""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        lib = _lib.load()
+        x, m = _f32c(x), _f32c(m)
+        n, c, h, w = x.shape
+        p = m.shape[0]
+        s = torch.empty(p, n, c, h, w, dtype=torch.float32, device=x.device)
+        check(lib.hk_osme_scale_fwd(ptr(x), ptr(m), ptr(s), p, n, c, h * w, stream()), 'hk_osme_scale_fwd')
+        ctx.save_for_backward(x, m)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        lib = _lib.load()
+        x, m = ctx.saved_tensors
+        n, c, h, w = x.shape
+        p = m.shape[0]
+        ds = _f32c(ds)
+        dx = torch.empty_like(x)
+        dm = torch.empty_like(m)
+        check(lib.hk_osme_scale_bwd(ptr(x), ptr(m), ptr(ds), None, ptr(dx), ptr(dm), p, n, c, h * w, stream()),
+              'hk_osme_scale_bwd')
+        return dx, dm
+
+
+def osme_gap(x):
+    return _OsmeGap.apply(x)
+
+
+def osme_scale(x, m):
+    """x [N,C,H,W], m [P,N,C] -> s [P,N,C,H,W]"""
+    return _OsmeScale.apply(x, m)
+
+
+# --------------------------------------------------------------------- generic
+def bgemm(a, b, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, diag=0.0, out=None):
+    """Batched fp32 MFMA GEMM (test / composition helper).  a [B,M,K] (or [B,K,M]), b [B,K,N] (or [B,N,K])."""
+    lib = _lib.load()
+    a, b = _f32c(a), _f32c(b)
+    nb = a.shape[0]
+    m, k = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
+    n = b.shape[1] if trans_b else b.shape[2]
+    if out is None:
+        out = torch.zeros(nb, m, n, dtype=torch.float32, device=a.device)
+    check(lib.hk_bgemm_f32(ptr(a), a.shape[2], a.shape[1] * a.shape[2], int(trans_a),
+                           ptr(b), b.shape[2], b.shape[1] * b.shape[2], int(trans_b),
+                           ptr(out), n, m * n, m, n, k, nb, float(alpha), float(beta), float(diag), stream()),
+          'hk_bgemm_f32')
+    return out

@@ -1,0 +1,198 @@
+/* hawkeye_hip.h - C ABI of libhawkeye_hip.so (MI355X / gfx950 kernels for the
+ * Hawkeye high-order pooling + attention-pooling hot path).
+ *
+ * The reference (Hawkeye-FineGrained/Hawkeye) is pure Python/PyTorch: it has no
+ * FFI of its own.  Each entry point below therefore replaces a *sequence of ATen
+ * calls* issued by one reference function; the function is cited as
+ * "replaces <file>:<lines>" (paths relative to the reference checkout).  The
+ * Python binding a maintainer adds on the reference side is a ctypes stub inside
+ * a torch.autograd.Function - see INTEGRATION.md.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers to contiguous fp32 (or int32 where said)
+ *    buffers owned by the caller; nothing is allocated or freed by the library;
+ *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream);
+ *    every call only enqueues kernels on it: no host synchronisation, no
+ *    global mutable state, safe to call from one thread per device;
+ *  - scratch memory is passed in (`ws`, `ws_bytes`); the matching
+ *    hk_*_ws_bytes() tells how much is needed; contents need not be preserved
+ *    between calls unless stated ("saved for backward" buffers are explicit
+ *    arguments);
+ *  - return value: 0 on success, a negative HK_ERR_* for bad arguments, or a
+ *    positive hipError_t from the launch;
+ *  - reductions use fixed orders (no float atomics): reruns are bit-identical.
+ */
+#ifndef HAWKEYE_HIP_H
+#define HAWKEYE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hk_stream_t; /* hipStream_t */
+
+#define HK_OK 0
+#define HK_ERR_BAD_ARG (-1)
+#define HK_ERR_WORKSPACE (-2)
+#define HK_ERR_UNSUPPORTED (-3)
+
+/* library / build identification: returns e.g. "hawkeye_hip 0.1 gfx950" */
+const char* hk_version(void);
+
+/* ---------------------------------------------------------------- BCNN ----
+ * Bilinear pooling: G = X X^T / HW ; z = sqrt(G + 1e-5) ; y = z / max(|z|_2, 1e-12).
+ * replaces model/methods/BCNN.py:13-27 (BilinearPooling.forward: view, transpose,
+ * bmm, div, add, sqrt, F.normalize) and its autograd backward.
+ *   x        [B, C, HW]   input feature map (NCHW contiguous, HW = H*W)
+ *   y        [B, C*C]     output
+ *   inv_norm [B]          1/max(|z|_2,1e-12)            (saved for backward)
+ *   colsum   [B, HW]      sum_c x[b,c,hw]               (saved for backward)
+ */
+size_t hk_bcnn_pool_ws_bytes(int B, int C, int HW);
+int hk_bcnn_pool_fwd(const float* x, float* y, float* inv_norm, float* colsum, int B, int C, int HW,
+                     void* ws, size_t ws_bytes, hk_stream_t stream);
+/* dx [B, C, HW] = d loss / d x given dy [B, C*C] */
+int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm,
+                     const float* colsum, float* dx, int B, int C, int HW, void* ws, size_t ws_bytes,
+                     hk_stream_t stream);
+
+/* ------------------------------------------------------------ Fast MPN-COV ----
+ * Covariance pooling  cov = (1/M) (X - mu 1^T) X^T.
+ * replaces model/methods/MPNCOV.py:105-119 (Covpool.forward) / :121-134 (backward).
+ *   x [B, C, M] ; cov [B, C, C] ; mu [B, C] channel means (saved for backward)
+ */
+int hk_cov_pool_fwd(const float* x, float* cov, float* mu, int B, int C, int M, hk_stream_t stream);
+int hk_cov_pool_bwd(const float* x, const float* mu, const float* dcov, float* dx, int B, int C, int M,
+                    hk_stream_t stream);
+
+/* Newton-Schulz matrix square root, iter_n coupled iterations with trace
+ * pre-normalisation and sqrt(trace) post-compensation.
+ * replaces model/methods/MPNCOV.py:137-164 (Sqrtm.forward) / :166-202 (backward,
+ * including its per-sample python loop :198-201).
+ *   a      [B, d, d]  input (covariance)
+ *   out    [B, d, d]  sqrtm
+ *   norm_a [B]        trace(a)                                  (saved)
+ *   ysave, zsave [B, max(iter_n-1,1), d, d]  Y_i / Z_i iterates (saved; unused when iter_n < 2)
+ */
+size_t hk_ns_sqrtm_ws_bytes(int B, int d, int iter_n, int backward);
+int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
+                    int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream);
+int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* norm_a, const float* ysave,
+                    const float* zsave, const float* dout, float* da, int B, int d, int iter_n, void* ws,
+                    size_t ws_bytes, hk_stream_t stream);
+
+/* Row-major upper-triangle (incl. diagonal) vectorisation, index in closed form.
+ * replaces model/methods/MPNCOV.py:205-218 (Triuvec.forward; index built on the
+ * CPU every call :213-214) / :220-230 (backward).
+ *   x [B, d, d] -> y [B, d(d+1)/2]
+ */
+int hk_triu_vec_fwd(const float* x, float* y, int B, int d, hk_stream_t stream);
+int hk_triu_vec_bwd(const float* dy, float* dx, int B, int d, hk_stream_t stream);
+
+/* ------------------------------------------------------- Compact bilinear ----
+ * Tensor-sketch compact bilinear pooling, evaluated through the exact identity
+ *   c[b,k] = sum_{i,j : (h1[i]+h2[j]) mod D = k} s1[i] s2[j] (X X^T)[b,i,j]
+ * (= ifft(fft(S1^T x) * fft(S2^T x)) summed over positions), then
+ *   u = sign(c) sqrt(|c| + 1e-10) ; y = u / max(|u|_2, 1e-12).
+ * replaces model/methods/CBCNN.py:96-135 (CompactBilinearPooling.forward) and its
+ * autograd backward.
+ * hk_cbp_plan_build: host+device one-time setup from the count-sketch hashes
+ * (CBCNN.py:76-91): writes a CSR "bin -> (i*C+j, sign)" table into `plan`
+ * (device memory, hk_cbp_plan_bytes(C, D) bytes).  h1,h2 int32 [C] in [0,D);
+ * s1,s2 fp32 [C] of +-1; all four are HOST pointers.
+ */
+size_t hk_cbp_plan_bytes(int C, int D);
+int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32_t* h2, const float* s2, int C, int D,
+                      void* plan, hk_stream_t stream);
+size_t hk_cbp_ws_bytes(int B, int C, int HW, int D);
+/* x [B,C,HW] -> y [B,D]; c_raw [B,D] pre-normalisation sums and inv_norm [B] saved for backward */
+int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_raw, float* inv_norm, int B, int C, int HW,
+               int D, void* ws, size_t ws_bytes, hk_stream_t stream);
+int hk_cbp_bwd(const float* x, const void* plan, const float* y, const float* c_raw, const float* inv_norm,
+               const float* dy, float* dx, int B, int C, int HW, int D, void* ws, size_t ws_bytes,
+               hk_stream_t stream);
+
+/* ------------------------------------------------------------------ AP-CNN ----
+ * Attention pooling.  The reference materialises A = a_s*F + a_c*F and only ever
+ * consumes its global average (cls3/4/5 start with AdaptiveAvgPool2d(1)), so
+ *   gap [b,c] = mean_hw F[b,c,hw]              (also ChannelGate / Concate input)
+ *   sgap[b,c] = mean_hw a_s[b,hw] F[b,c,hw]
+ * and pooled = sgap + a_c * gap.  One pass over F.
+ * replaces model/methods/APCNN.py:256,261,266 + :377-405 first layer + :533-538.
+ *   f [B,C,HW] ; a_s [B,HW] (nullable: gap only) ; gap, sgap [B,C]
+ */
+int hk_att_pool_fwd(const float* f, const float* a_s, float* gap, float* sgap, int B, int C, int HW,
+                    hk_stream_t stream);
+/* df [B,C,HW] = (dsgap*a_s + dgap)/HW ; da_s [B,HW] = sum_c dsgap*F / HW (nullable with a_s) */
+int hk_att_pool_bwd(const float* f, const float* a_s, const float* dgap, const float* dsgap, float* df,
+                    float* da_s, int B, int C, int HW, hk_stream_t stream);
+
+/* Attention -> ROI: border mask, one square anchor per cell, keep score > mean,
+ * greedy NMS (IoU < thr keeps, area without +1, highest score first; ties:
+ * highest cell index first), top-k, clamp to the image.  One workgroup per image,
+ * no host synchronisation.
+ * replaces model/methods/APCNN.py:444-476 (get_att_roi) + model/methods/nms.py:4-93.
+ *   att   [B, h*w]      spatial attention (sigmoid output)
+ *   rois  [B, topk, 5]  x1,y1,x2,y2,score (rows >= count are zero)
+ *   count [B] int32     number of valid rows
+ *   keep_r0..keep_c1: rows [r0,r1) x cols [c0,c1) that survive the border mask
+ *       (= int(0.2*h), int(0.8*h), ... for 200 classes, 0.1/0.9 otherwise; the
+ *       caller evaluates the reference's python expression, APCNN.py:451-455)
+ */
+int hk_att_roi_select(const float* att, float* rois, int32_t* count, int B, int h, int w,
+                      int feature_stride, float anchor_size, int img_h, int img_w, int keep_r0, int keep_r1,
+                      int keep_c0, int keep_c1, float iou_thr, int topk, hk_stream_t stream);
+
+/* ROI-guided zoom-in (+ drop block): crop the union box of an image's ROIs,
+ * zero one dropped ROI (training), rescale by c*h*w/sum(mask), bilinear resize
+ * (align_corners=False) back to H x W.
+ * replaces model/methods/APCNN.py:478-531 (get_roi_crop_feat).
+ *   x    [B, C, H, W]
+ *   box  [B, 4] fp32   x1,y1,x2,y2 of the union box in feature coordinates (already /scale)
+ *   drop [B, 4] fp32   box to zero, or x2<=x1 for "no drop" (ignored when training == 0)
+ *   y    [B, C, H, W]
+ * Integer truncation of the box corners and the scale-rate rule follow the reference.
+ */
+int hk_roi_crop_resize_fwd(const float* x, const float* box, const float* drop, float* y, int B, int C, int H,
+                           int W, int training, hk_stream_t stream);
+int hk_roi_crop_resize_bwd(const float* dy, const float* box, const float* drop, float* dx, int B, int C, int H,
+                           int W, int training, hk_stream_t stream);
+/* Union / drop boxes from the fixed-layout ROI tables of hk_att_roi_select, on
+ * device (no host read of the counts).
+ *   rois_l [B,k_l,5], cnt_l [B] for the three pyramid levels; scale = 8 (coordinates are divided by it);
+ *   u01 [B,2] uniforms in [0,1): u[.,0] picks the branch (<0.3 level-3 drop,
+ *   <0.6 level-4 drop, else none), u[.,1] the ROI index floor(u*n).
+ */
+int hk_roi_boxes(const float* rois3, const int32_t* cnt3, int k3, const float* rois4, const int32_t* cnt4, int k4,
+                 const float* rois5, const int32_t* cnt5, int k5, const float* u01, float scale, float* box,
+                 float* drop, int B, hk_stream_t stream);
+
+/* -------------------------------------------------------------------- OSME ----
+ * One-squeeze multi-excitation: z = GAP(x) (one pass), and per attention p the
+ * channel re-scaling s_p = m_p (.) x written for the following FC.
+ * replaces model/methods/OSME.py:19-24 (avg_pool / broadcast mul).
+ *   x [N,C,HW] ; z [N,C] ; m [P,N,C] sigmoid gates ; s [P,N,C,HW]
+ */
+int hk_osme_gap(const float* x, float* z, int N, int C, int HW, hk_stream_t stream);
+int hk_osme_scale_fwd(const float* x, const float* m, float* s, int P, int N, int C, int HW, hk_stream_t stream);
+/* dx [N,C,HW] = sum_p m_p * ds_p (+ dz/HW if dz != NULL) ; dm [P,N,C] = sum_hw ds_p * x */
+int hk_osme_scale_bwd(const float* x, const float* m, const float* ds, const float* dz, float* dx, float* dm,
+                      int P, int N, int C, int HW, hk_stream_t stream);
+
+/* ------------------------------------------------------- generic primitive ----
+ * Batched fp32 GEMM on the f32 MFMA path (exact fp32 fma chain):
+ *   C[b] = alpha * op(A[b]) op(B[b]) + beta * C[b] + diag * I
+ * row-major operands; trans_a: A stored K x M; trans_b: B stored N x K.
+ * Exposed for the tests and for composing the Newton-Schulz chain.
+ */
+int hk_bgemm_f32(const float* a, int lda, long long stride_a, int trans_a, const float* b, int ldb,
+                 long long stride_b, int trans_b, float* c, int ldc, long long stride_c, int M, int N, int K,
+                 int batch, float alpha, float beta, float diag, hk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAWKEYE_HIP_H */

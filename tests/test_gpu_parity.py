@@ -1,0 +1,340 @@
+"""GPU parity: HIP kernels (through the C ABI / hawkeye_amd.functional) vs the CPU
+oracle on identical seeded inputs, and vs the committed reference goldens.
+
+Tolerances (north_star: <= 1e-4 relative fp32, exact argmax):
+  * norm-wise relative error  |a-b|_2 / |b|_2  <= 1e-5 .. 1e-4 depending on chain length
+  * element-wise where the function is well conditioned
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import hawkeye_oracle as O
+from inputs import rs_randn, rs_relu_randn, sub
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(G, name + '.npz'))
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().reshape(-1)
+    b = (b.detach() if torch.is_tensor(b) else torch.from_numpy(np.asarray(b))).double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope='module')
+def F():
+    import hawkeye_amd.functional as F_
+    from hawkeye_amd import _lib
+    lib = _lib.load()
+    assert b'gfx950' in lib.hk_version()
+    return F_
+
+
+DEV = 'cuda'
+
+
+# ------------------------------------------------------------------ generic GEMM
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('m,n,k', [(64, 64, 32), (70, 45, 33), (256, 256, 256), (1, 1, 1), (130, 196, 512)])
+def test_bgemm_layouts(F, ta, tb, m, n, k):
+    nb = 3
+    a = t(rs_randn(1, (nb, k, m) if ta else (nb, m, k)))
+    b = t(rs_randn(2, (nb, n, k) if tb else (nb, k, n)))   # asymmetric B: catches transposed C writes
+    ref = torch.bmm(a.transpose(1, 2).double() if ta else a.double(), b.transpose(1, 2).double() if tb else b.double())
+    out = F.bgemm(a.to(DEV), b.to(DEV), ta, tb)
+    assert rel(out, ref) < 2e-6
+
+
+def test_bgemm_epilogue_and_batch9(F):
+    nb, d = 9, 40            # nb >= 8 exercises the XCD-affine block map with a ragged last group
+    a, b = t(rs_randn(3, (nb, d, d))), t(rs_randn(4, (nb, d, d)))
+    c0 = t(rs_randn(5, (nb, d, d)))
+    ref = -0.5 * torch.bmm(a.double(), b.double()) + 0.25 * c0.double() + 1.5 * torch.eye(d).double()
+    out = F.bgemm(a.to(DEV), b.to(DEV), alpha=-0.5, beta=0.25, diag=1.5, out=c0.to(DEV).clone())
+    assert rel(out, ref) < 2e-6
+
+
+# ------------------------------------------------------------------ BCNN
+def _bcnn_case(F, x_np, w_np):
+    x = t(x_np).requires_grad_(True)
+    y = O.bilinear_pool(x)
+    (y * t(w_np)).sum().backward()
+    xg = t(x_np).to(DEV).requires_grad_(True)
+    yg = F.bilinear_pool(xg)
+    (yg * t(w_np).to(DEV)).sum().backward()
+    return x, y, xg, yg
+
+
+def test_bcnn_small_ragged_vs_oracle_and_golden(F):
+    g = load('bcnn_small')
+    x, y, xg, yg = _bcnn_case(F, rs_relu_randn(11, (3, 32, 5, 7)), rs_randn(12, (3, 1024)))
+    assert rel(yg, y) < 1e-6 and rel(yg, g['y']) < 1e-6
+    assert rel(xg.grad, x.grad) < 1e-5 and rel(xg.grad, g['dx']) < 1e-5
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), g['y'], rtol=1e-5, atol=1e-8)
+
+
+def test_bcnn_512_vs_golden(F):
+    g = load('bcnn_512')
+    x, y, xg, yg = _bcnn_case(F, rs_relu_randn(1234, (2, 512, 14, 14)), rs_randn(1235, (2, 512 * 512)))
+    assert rel(yg, y) < 1e-6
+    np.testing.assert_allclose(sub(yg.detach().cpu()).numpy(), g['y_sub'], rtol=1e-5, atol=1e-9)
+    assert yg.argmax(dim=1).cpu().tolist() == g['y_argmax'].tolist()          # bit-exact class-style argmax
+    np.testing.assert_allclose(yg.detach().norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
+    assert rel(xg.grad, x.grad) < 1e-5
+    np.testing.assert_allclose(sub(xg.grad.cpu()).numpy(), g['dx_sub'], rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('shape', [(1, 8, 1, 1), (2, 13, 3, 3), (5, 64, 7, 7), (9, 100, 4, 6)])
+def test_bcnn_edge_shapes(F, shape):
+    c = shape[1]
+    x, y, xg, yg = _bcnn_case(F, rs_relu_randn(5, shape), rs_randn(6, (shape[0], c * c)))
+    assert rel(yg, y) < 1e-6
+    assert rel(xg.grad, x.grad) < 2e-5
+
+
+def test_bcnn_full_size_properties(F):
+    """B=64, C=512, 14x14 (BASELINE config 2): size-independent properties."""
+    x = torch.relu(torch.randn(64, 512, 14, 14, generator=torch.Generator().manual_seed(0))).to(DEV)
+    y = F.bilinear_pool(x)
+    assert torch.isfinite(y).all()
+    np.testing.assert_allclose(y.norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)       # unit l2 norm
+    ym = y.view(64, 512, 512)
+    assert torch.equal(ym, ym.transpose(1, 2))                                     # exact symmetry
+    y2 = F.bilinear_pool(x)
+    assert torch.equal(y, y2)                                                      # deterministic
+    # scaling law: pool(a x) for large a -> same direction as sqrt(G) (eps negligible)
+    yo = O.bilinear_pool(x[:2].cpu())
+    assert rel(y[:2], yo) < 1e-6
+    assert y[:2].argmax(dim=1).cpu().tolist() == yo.argmax(dim=1).tolist()
+
+
+# ------------------------------------------------------------------ MPN-COV
+@pytest.mark.parametrize('it', [5, 3, 2, 1])
+def test_mpn_small_vs_oracle_and_golden(F, it):
+    g = load('mpn_small')
+    xn, wn = rs_relu_randn(31, (2, 16, 4, 5)), rs_randn(32, (2, 136, 1))
+    x = t(xn).requires_grad_(True)
+    cov = O.covpool(x); cov.retain_grad()
+    sq = O.sqrtm(cov, it); sq.retain_grad()
+    tv = O.triuvec(sq)
+    (tv * t(wn)).sum().backward()
+    xg = t(xn).to(DEV).requires_grad_(True)
+    covg = F.covpool(xg); covg.retain_grad()
+    sqg = F.sqrtm(covg, it); sqg.retain_grad()
+    tvg = F.triuvec(sqg)
+    assert list(tvg.shape) == g['triu_shape'].tolist()
+    (tvg * t(wn).to(DEV)).sum().backward()
+    assert rel(covg, cov) < 2e-6 and rel(covg, g[f'cov_it{it}']) < 2e-6
+    assert rel(sqg, sq) < 1e-5 and rel(tvg, g[f'triu_it{it}']) < 1e-5
+    assert rel(sqg.grad, sq.grad) < 1e-6
+    assert rel(covg.grad, cov.grad) < 1e-4
+    assert rel(xg.grad, x.grad) < 1e-4 and rel(xg.grad, g[f'dx_it{it}']) < 1e-4
+
+
+def test_mpn_256_vs_golden(F):
+    g = load('mpn_256')
+    xn, wn = rs_relu_randn(31, (2, 256, 14, 14)), rs_randn(32, (2, 32896, 1))
+    x = t(xn).requires_grad_(True)
+    tv = O.mpncov_pool(x)
+    (tv * t(wn)).sum().backward()
+    xg = t(xn).to(DEV).requires_grad_(True)
+    covg = F.covpool(xg)
+    sqg = F.sqrtm(covg, 5)
+    tvg = F.triuvec(sqg)
+    (tvg * t(wn).to(DEV)).sum().backward()
+    np.testing.assert_allclose(sub(covg.detach().cpu()).numpy(), g['cov_it5'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sub(sqg.detach().cpu()).numpy(), g['sqrtm_it5'], rtol=1e-4, atol=1e-6)
+    assert rel(tvg, tv) < 1e-5
+    assert rel(xg.grad, x.grad) < 1e-4
+    assert abs(float(tvg.detach().double().sum()) / float(g['triu_sum_it5']) - 1) < 1e-5
+
+
+def test_mpn_49_and_properties(F):
+    """HW = 49 (the yaml's 224^2 input): not a multiple of 4 -> scalar operand loads."""
+    xn = rs_relu_randn(77, (3, 64, 7, 7))
+    x = t(xn).requires_grad_(True)
+    tv = O.mpncov_pool(x)
+    tv.sum().backward()
+    xg = t(xn).to(DEV).requires_grad_(True)
+    covg = F.covpool(xg)
+    assert torch.allclose(covg, covg.transpose(1, 2), atol=1e-6)
+    tvg = F.triuvec(F.sqrtm(covg, 5))
+    tvg.sum().backward()
+    assert rel(tvg, tv) < 1e-5 and rel(xg.grad, x.grad) < 1e-4
+
+
+def test_triuvec_roundtrip(F):
+    x = t(rs_randn(8, (4, 37, 37))).to(DEV).requires_grad_(True)
+    y = F.triuvec(x)
+    idx = O.triu_index(37).squeeze(1)
+    assert torch.equal(y.detach().squeeze(2).cpu(), x.detach().cpu().reshape(4, -1)[:, idx])
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad.cpu(), torch.ones(37, 37).triu().expand(4, 37, 37))
+
+
+# ------------------------------------------------------------------ CBP
+def _plan(F, c, d):
+    return F.CbpPlan(*F.sketch_hashes(c, c, d), d, torch.device('cuda', torch.cuda.current_device()))
+
+
+def test_cbp_hashes_match_golden(F):
+    g = load('cbp_512')
+    h1, s1, h2, s2 = F.sketch_hashes(512, 512, 6000)
+    assert (h1 == g['h1']).all() and (h2 == g['h2']).all() and (s1 == g['sgn1']).all() and (s2 == g['sgn2']).all()
+
+
+def test_cbp_small_and_512(F):
+    for tag, shape, d, seeds in (('cbp_small', (2, 16, 3, 5), 64, (21, 22)), ('cbp_512', (2, 512, 14, 14), 6000, (1234, 1236))):
+        g = load(tag)
+        xn, wn = rs_relu_randn(seeds[0], shape), rs_randn(seeds[1], (shape[0], d))
+        x = t(xn).requires_grad_(True)
+        y = O.compact_bilinear_pool(x, d)               # FFT-literal route on the CPU
+        (y * t(wn)).sum().backward()
+        xg = t(xn).to(DEV).requires_grad_(True)
+        yg = F.compact_bilinear_pool(xg, _plan(F, shape[1], d))
+        (yg * t(wn).to(DEV)).sum().backward()
+        # sign(c) sqrt(|c| + 1e-10) is ill-conditioned at c ~ 0 (slope up to 5e4): the reference's fp32 FFT
+        # route leaves ~1e-8 round-off in bins whose true value is 0 and the Gram route does not.  The
+        # yardstick is the same formula evaluated in fp64; the HIP result must be at least as close to it
+        # as the reference's own fp32 path is, and within 1e-4 of the reference (north_star tolerance).
+        y64 = O.compact_bilinear_pool(t(xn).double(), d)
+        assert rel(yg, y64) <= max(2.0 * rel(y, y64), 2e-6)
+        assert rel(yg, g['y']) < 1e-4 and rel(yg, y) < 1e-4
+        np.testing.assert_allclose(yg.detach().norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
+        assert rel(xg.grad, x.grad) < 1e-4
+        assert yg.argmax(dim=1).cpu().tolist() == y.argmax(dim=1).tolist()
+
+
+# ------------------------------------------------------------------ AP-CNN
+def test_att_pool(F):
+    for hw in ((28, 28), (7, 7), (5, 3)):
+        fn, an = rs_randn(41, (3, 32) + hw), 1 / (1 + np.exp(-rs_randn(42, (3, 1) + hw)))
+        f = t(fn).requires_grad_(True)
+        a = t(an.astype(np.float32)).requires_grad_(True)
+        gap_o = f.mean(dim=(2, 3))
+        sgap_o = (a * f).mean(dim=(2, 3))
+        w1, w2 = t(rs_randn(43, (3, 32))), t(rs_randn(44, (3, 32)))
+        ((gap_o * w1).sum() + (sgap_o * w2).sum()).backward()
+        fg = t(fn).to(DEV).requires_grad_(True)
+        ag = t(an.astype(np.float32)).to(DEV).requires_grad_(True)
+        gap, sgap = F.att_pool(fg, ag)
+        ((gap * w1.to(DEV)).sum() + (sgap * w2.to(DEV)).sum()).backward()
+        assert rel(gap, gap_o) < 1e-6 and rel(sgap, sgap_o) < 1e-6
+        assert rel(fg.grad, f.grad) < 1e-6 and rel(ag.grad, a.grad) < 1e-5
+        gap2, none = F.att_pool(fg.detach(), None)
+        assert none is None and rel(gap2, gap_o) < 1e-6
+
+
+def _masks():
+    return [t(1.0 / (1.0 + np.exp(-2.0 * rs_randn(50 + l, (3, 1, hw, hw))))).float()
+            for l, hw in enumerate((56, 28, 14))]
+
+
+LEVELS = ((8, 64, 5), (16, 128, 3), (32, 256, 1))
+
+
+def _compact(rois, cnt):
+    rows = []
+    for i in range(rois.shape[0]):
+        k = int(cnt[i])
+        rows.append(torch.cat([torch.full((k, 1), float(i)), rois[i, :k].cpu()], 1))
+    return torch.cat(rows, 0)
+
+
+@pytest.mark.parametrize('ncls', [200, 8142])
+def test_att_roi_select_bit_exact(F, ncls):
+    g = load('apcnn_roi')
+    for lvl, (m, (s, a, k)) in enumerate(zip(_masks(), LEVELS)):
+        rois, cnt = F.att_roi_select(m.to(DEV), s, a, 448, 448, ncls, 0.05, k)
+        got = _compact(rois, cnt)
+        np.testing.assert_array_equal(got.numpy(), g[f'roi_c{ncls}_l{lvl + 3}'])   # boxes AND scores bit-exact
+        np.testing.assert_array_equal(got.numpy(), O.att_roi(m, s, a, 448, 448, ncls, 0.05, k).numpy())
+
+
+def test_att_roi_select_exhausts_candidates(F):
+    m = torch.zeros(2, 1, 14, 14)
+    m[0, 0, 6, 6] = 0.9                    # single candidate above the mean -> 1 ROI although topk = 3
+    m[1, 0, 3, 3] = 0.7
+    m[1, 0, 10, 10] = 0.8
+    rois, cnt = F.att_roi_select(m.to(DEV), 32, 64, 448, 448, 200, 0.05, 3)
+    assert cnt.cpu().tolist() == [1, 2]
+    ref = O.att_roi(m, 32, 64, 448, 448, 200, 0.05, 3)
+    np.testing.assert_array_equal(_compact(rois, cnt).numpy(), ref.numpy())
+    assert float(rois[0, 1:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_roi_crop_resize(F, mode):
+    g = load('apcnn_crop')
+    rois = [t(g['roi3']), t(g['roi4']), t(g['roi5'])]
+    drops = [None if l == 0 else (int(l), int(i)) for l, i in g['drops']]
+    xn, wn = rs_randn(60, (3, 8, 56, 56)), rs_randn(61, (3, 8, 56, 56))
+    x = t(xn).requires_grad_(True)
+    y = O.roi_crop_feat(x, rois, 8, training=(mode == 'train'), drops=drops)
+    (y * t(wn)).sum().backward()
+    box = torch.zeros(3, 4)
+    drop = torch.tensor([[0., 0., -1., -1.]] * 3)
+    allr = torch.cat(rois, 0)
+    for i in range(3):
+        r = allr[allr[:, 0] == i] / 8
+        box[i] = torch.cat([r[:, 1:3].min(0)[0], r[:, 3:5].max(0)[0]])
+        if mode == 'train' and drops[i] is not None:
+            src = rois[0] if drops[i][0] == 3 else rois[1]
+            drop[i] = (src[src[:, 0] == i] / 8)[drops[i][1], 1:5]
+    xg = t(xn).to(DEV).requires_grad_(True)
+    yg = F.roi_crop_resize(xg, box.to(DEV), drop.to(DEV), mode == 'train')
+    (yg * t(wn).to(DEV)).sum().backward()
+    assert rel(yg, y) < 1e-6
+    np.testing.assert_allclose(sub(yg.detach().cpu(), 61).numpy(), g[f'y_{mode}'], rtol=1e-5, atol=1e-6)
+    assert rel(xg.grad, x.grad) < 1e-6
+    np.testing.assert_allclose(sub(xg.grad.cpu(), 61).numpy(), g[f'dx_{mode}'], rtol=1e-5, atol=1e-6)
+
+
+def test_roi_boxes_device(F):
+    tabs = []
+    for m, (s, a, k) in zip(_masks(), LEVELS):
+        tabs.append(F.att_roi_select(m.to(DEV), s, a, 448, 448, 200, 0.05, k))
+    u = torch.tensor([[0.1, 0.5], [0.45, 0.99], [0.9, 0.2]])
+    box, drop = F.roi_boxes(tabs, u.to(DEV), 8.0)
+    g = load('apcnn_crop')
+    allr = torch.cat([t(g['roi3']), t(g['roi4']), t(g['roi5'])], 0)
+    for i in range(3):
+        r = allr[allr[:, 0] == i] / 8
+        assert torch.equal(box[i].cpu(), torch.cat([r[:, 1:3].min(0)[0], r[:, 3:5].max(0)[0]]))
+    r3 = t(g['roi3']); r4 = t(g['roi4'])
+    assert torch.equal(drop[0].cpu(), (r3[r3[:, 0] == 0] / 8)[2, 1:5])     # floor(0.5*5) = 2
+    assert torch.equal(drop[1].cpu(), (r4[r4[:, 0] == 1] / 8)[2, 1:5])     # floor(0.99*3) = 2
+    assert drop[2].cpu().tolist() == [0., 0., -1., -1.]
+
+
+# ------------------------------------------------------------------ OSME
+def test_osme_gate(F):
+    g = load('osme_small')
+    w = {k[2:].replace('__', '.'): t(g[k]) for k in g.files if k.startswith('w_')}
+    xn = rs_relu_randn(71, (3, 32, 7, 7))
+    wd = {k: v.to(DEV) for k, v in w.items()}
+    xg = t(xn).to(DEV).requires_grad_(True)
+    z = F.osme_gap(xg)
+    ms = []
+    for p in range(2):
+        hdn = torch.relu(torch.nn.functional.linear(z, wd[f'blocks.{p}.block.0.weight'], wd[f'blocks.{p}.block.0.bias']))
+        ms.append(torch.sigmoid(torch.nn.functional.linear(hdn, wd[f'blocks.{p}.block.2.weight'], wd[f'blocks.{p}.block.2.bias'])))
+    s = F.osme_scale(xg, torch.stack(ms, 0))
+    feats = [torch.nn.functional.linear(s[p].reshape(3, -1), wd[f'fcs.{p}.weight'], wd[f'fcs.{p}.bias']) for p in range(2)]
+    f, parts = sum(feats), torch.stack(feats, dim=1)
+    ((parts * t(rs_randn(72, (3, 2, 8))).to(DEV)).sum() + f.sum()).backward()
+    assert rel(f, g['f']) < 1e-5 and rel(parts, g['parts']) < 1e-5
+    assert rel(xg.grad, g['dx']) < 1e-4
