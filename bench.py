@@ -1,0 +1,254 @@
+"""Headline benchmark: training images/sec (fwd + bwd + SGD step) of BCNN
+(VGG-16, 448x448, C=512, 200 classes, batch 64 per GPU) - BASELINE.json's metric on
+BASELINE.json configs[1] (`BCNN_S2.yaml on 1xMI355X`).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one minibatch already resident in HBM -> model forward (VGG-16 on
+MIOpen, bilinear pooling on the gfx950 kernels) -> CrossEntropy(label_smoothing
+0.1) -> backward -> SGD(momentum 0.9) step.  fp32
+throughout (the reference's dtype; parity target 1e-4).  Weak scaling: every
+rank trains batch 64; `value` = all images of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  At N=1 it also carries
+  roofline     - the dominant hand-written kernel: algorithmic FLOPs / HIP-event time
+  kernels      - the same for every stage of the pooling head
+  cpu_baseline - the oracle's BCNN (reference algorithm on the torch CPU path) timed on the host cores
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from hawkeye_amd.miopen_cache import use_in_tree_cache  # noqa: E402
+
+use_in_tree_cache()       # MIOpen JIT cache inside the repo (no gfx950 kernel db in the image): see miopen_cache.py
+
+PEAK_MFMA_F32_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (metric: 64)')
+    ap.add_argument('--image', type=int, default=448)
+    ap.add_argument('--classes', type=int, default=200)
+    ap.add_argument('--model', default='BCNN', choices=['BCNN', 'CBCNN', 'MPN', 'APCNN'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernels', action='store_true')
+    ap.add_argument('--channels-last', type=int, default=0)
+    ap.add_argument('--miopen-find', type=int, default=0)
+    ap.add_argument('--verbose', action='store_true')
+    return ap.parse_args()
+
+
+def build_model(name, classes):
+    import hawkeye_amd.model  # noqa: F401
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.registry import MODEL
+    cfgs = {
+        'BCNN': dict(name='BCNN', stage=2, num_classes=classes),
+        'CBCNN': dict(name='CBCNN', stage=2, num_classes=classes, input_channel=512, output_channel=6000),
+        'MPN': dict(name='MPN', iter_num=5, is_sqrt=True, is_vec=True, input_dim=2048, dimension_reduction=256,
+                    num_classes=classes),
+        'APCNN': dict(name='APCNN', num_classes=classes),
+    }
+    cfg = CfgNode(cfgs[name])
+    cfg.freeze()
+    return MODEL.get(name)(cfg)
+
+
+def time_events(fn, iters, warm=3):
+    """Average duration (ms) of fn() measured with HIP events on torch's current stream - the stream the
+    C ABI launches on (functional.stream())."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_rooflines(B, C, HW, dev):
+    """Per-stage timing of the bilinear-pooling head at the metric's shape.  Algorithmic work:
+    gram_norm  FLOPs 2*B*C*C*HW ; bytes 4*B*C*HW (x) + 4*B*C*C (y)
+    bwd_gemm   FLOPs 2*B*C*C*HW ; bytes 2*4*B*C*C (y, dy) + 2*4*B*C*HW (x, dx)
+    colsum     bytes 4*B*C*HW ;  rank1 bytes 2*4*B*C*HW"""
+    from hawkeye_amd import _lib
+    from hawkeye_amd._lib import ptr, stream
+    lib = _lib.load()
+    x = torch.relu(torch.randn(B, C, HW, device=dev))
+    y = torch.empty(B, C * C, device=dev)
+    dy = torch.randn(B, C * C, device=dev)
+    dx = torch.empty_like(x)
+    inv = torch.empty(B, device=dev)
+    cs = torch.empty(B, HW, device=dev)
+    tp = torch.empty(B, (C + 63) // 64, device=dev)
+    lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, stream())
+    lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream())
+    flops = 2.0 * B * C * C * HW
+    stages = [
+        ('bcnn_colsum_norm_kernel', lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, stream()),
+         0.0, 4.0 * B * C * HW),
+        ('bgemm_kernel<gram,EpBcnn>', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
+         flops, 4.0 * B * C * HW + 4.0 * B * C * C),
+        ('bgemm_kernel<LdBcnnP,bwd>', lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp),
+                                                                   B, C, HW, stream()),
+         flops, 8.0 * B * C * C + 8.0 * B * C * HW),
+        ('bcnn_rank1_fix_kernel', lambda: lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream()),
+         0.0, 8.0 * B * C * HW),
+    ]
+    out = []
+    for name, fn, fl, by in stages:
+        ms = time_events(fn, 50)
+        tf, gbs = fl / ms / 1e9, by / ms / 1e6
+        bound = 'mfma' if fl > 0 and fl / by > PEAK_MFMA_F32_TF * 1e3 / PEAK_HBM_GBS else 'hbm'
+        out.append({'kernel': name, 'us': round(ms * 1e3, 2), 'bound': bound,
+                    'achieved': round(tf if bound == 'mfma' else gbs, 2),
+                    'peak': PEAK_MFMA_F32_TF if bound == 'mfma' else PEAK_HBM_GBS,
+                    'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+                    'frac': round((tf / PEAK_MFMA_F32_TF) if bound == 'mfma' else (gbs / PEAK_HBM_GBS), 4),
+                    'traffic': None})
+    return out
+
+
+def cpu_baseline(image, classes):
+    """Reference algorithm on the host: the oracle's BCNN (VGG-16 + BilinearPooling on the torch CPU path, i.e. what
+    the reference executes with `experiment.cuda: []`) training step at batch 4 (BASELINE.json configs[0]).
+    Bounded: 1 warm-up + at most 3 timed steps or ~25 s.  Threads: min(host cores, 32) - oneDNN convolutions at
+    batch 4 stop scaling (and on a 256-core host get much slower) beyond that; `cores` reports what was used."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import hawkeye_oracle as O
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    bs = 4
+    m = O.BCNNOracle(classes, stage=2)
+    opt = torch.optim.SGD(m.parameters(), lr=0.005, momentum=0.9, weight_decay=1e-5)
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+    x = torch.randn(bs, 3, image, image)
+    y = torch.randint(0, classes, (bs,))
+    times = []
+    for it in range(4):
+        t0 = time.time()
+        loss = crit(m(x), y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if it > 0 and sum(times) > 25:
+            break
+    best = min(times)
+    return {'value': round(bs / best, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'BCNN stage-2 train step, batch {bs}, {image}x{image}, best of {len(times)} after 1 warm-up, '
+                      f'torch CPU fp32, {threads} threads of {os.cpu_count()} host cores'}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    from hawkeye_amd import ddp
+    rank, world, local = ddp.init_from_env('nccl' if world > 1 else None)
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)   # MIOpen find mode: pick the fastest conv algorithm once
+    torch.manual_seed(0)
+
+    model = build_model(a.model, a.classes).to(dev)
+    if a.channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.005, momentum=0.9, weight_decay=1e-5)   # configs/BCNN_S2
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+    reducer = ddp.GradientAllReducer(model) if world > 1 else None
+
+    g = torch.Generator(device=dev).manual_seed(rank)
+    images = torch.randn(a.batch, 3, a.image, a.image, device=dev, generator=g)
+    if a.channels_last:
+        images = images.contiguous(memory_format=torch.channels_last)
+    labels = torch.randint(0, a.classes, (a.batch,), device=dev, generator=g)
+
+    def step():
+        out = model(images, labels) if a.model == 'APCNN' else model(images)
+        loss = sum(crit(o, labels) for o in out[1]) if a.model == 'APCNN' else crit(out, labels)
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    for i in range(a.warmup):
+        tw = time.perf_counter()
+        step()
+        if a.verbose:
+            torch.cuda.synchronize()
+            print(f'[bench] warmup step {i}: {time.perf_counter() - tw:.2f}s', file=sys.stderr, flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(loss).item(), 'loss is not finite'
+
+    if rank == 0:
+        res = {
+            'metric': f'images/sec (train fwd+bwd) {a.model} VGG-16 448^2 bs64' if a.model in ('BCNN', 'CBCNN')
+                      else f'images/sec (train fwd+bwd) {a.model}',
+            'value': round(a.batch * world * a.steps / dt, 2), 'unit': 'images/sec',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{a.model}_S2: VGG-16 {a.image}x{a.image}, per-GPU batch {a.batch}, {a.classes} classes, '
+                                   f'SGD momentum 0.9, CE label_smoothing 0.1, full train step'
+                                   if a.model in ('BCNN', 'CBCNN') else f'{a.model} {a.image}x{a.image} batch {a.batch}',
+                       'global_batch': a.batch * world, 'parallelism': f'dp{world}',
+                       'memory_format': 'channels_last' if a.channels_last else 'contiguous'},
+        }
+        if world == 1 and not a.no_kernels:
+            ks = kernel_rooflines(a.batch, 512, (a.image // 32) ** 2, dev)
+            dom = max(ks, key=lambda k: k['us'])
+            res['roofline'] = {k: dom[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
+            res['roofline']['kernel'] = dom['kernel']
+            res['roofline']['us'] = dom['us']
+            res['kernels'] = ks
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(a.image, a.classes)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -149,21 +149,60 @@ extern "C" size_t hk_bcnn_pool_ws_bytes(int B, int C, int HW) {
     return (size_t)B * tiles * sizeof(float) + 256;
 }
 
-extern "C" int hk_bcnn_pool_fwd(const float* x, float* y, float* inv_norm, float* colsum, int B, int C, int HW,
-                                void* ws, size_t ws_bytes, hk_stream_t stream) {
-    (void)ws; (void)ws_bytes;
-    if (!x || !y || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
+extern "C" int hk_bcnn_colsum_norm(const float* x, float* colsum, float* inv_norm, int B, int C, int HW,
+                                  hk_stream_t stream) {
+    if (!x || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
     const int ncol = HW < 1024 ? HW : 1024;
     const int groups = 1024 / ncol;
     const size_t sm = ((size_t)groups * HW + 16) * sizeof(float);
     if (sm > 150 * 1024) return HK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bcnn_colsum_norm_kernel, dim3(B), dim3(1024), sm, st, x, colsum, inv_norm, C, HW);
+    hipLaunchKernelGGL(bcnn_colsum_norm_kernel, dim3(B), dim3(1024), sm, (hipStream_t)stream, x, colsum, inv_norm, C, HW);
     HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_bcnn_gram_norm(const float* x, const float* inv_norm, float* y, int B, int C, int HW,
+                                 hk_stream_t stream) {
+    if (!x || !y || !inv_norm || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
     const LdPlain xa = make_plain(x, (long long)C * HW, HW, C, HW);
     EpBcnn ep;
     ep.y = y; ep.inv_norm = inv_norm; ep.C = C; ep.m = (float)HW;
-    return bgemm_launch<true, true>(xa, xa, ep, C, C, HW, B, st);
+    return bgemm_launch<true, true>(xa, xa, ep, C, C, HW, B, (hipStream_t)stream);
+}
+
+extern "C" int hk_bcnn_pool_fwd(const float* x, float* y, float* inv_norm, float* colsum, int B, int C, int HW,
+                                void* ws, size_t ws_bytes, hk_stream_t stream) {
+    (void)ws; (void)ws_bytes;
+    if (!x || !y || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    int rc = hk_bcnn_colsum_norm(x, colsum, inv_norm, B, C, HW, stream);
+    if (rc != HK_OK) return rc;
+    return hk_bcnn_gram_norm(x, inv_norm, y, B, C, HW, stream);
+}
+
+extern "C" int hk_bcnn_bwd_gemm(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx,
+                                float* tpart, int B, int C, int HW, hk_stream_t stream) {
+    if (!x || !y || !dy || !inv_norm || !dx || !tpart || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    LdBcnnP pa;
+    pa.y = y; pa.dy = dy; pa.inv_norm = inv_norm; pa.tpart = tpart; pa.C = C;
+    pa.inv2m = 1.0f / (2.0f * (float)HW);
+    pa.vec = (aligned16(y) && aligned16(dy) && (C % 4 == 0)) ? 1 : 0;
+    pa.coef = 0.f; pa.tacc = 0.f; pa.active = 0;
+    const LdPlain xb = make_plain(x, (long long)C * HW, HW, C, HW);  // K x N, N contiguous
+    const EpAffine ep = make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f);
+    return bgemm_launch<true, false>(pa, xb, ep, C, HW, C, B, (hipStream_t)stream);
+}
+
+extern "C" int hk_bcnn_bwd_rank1(float* dx, const float* tpart, const float* inv_norm, const float* colsum, int B, int C,
+                                 int HW, hk_stream_t stream) {
+    if (!dx || !tpart || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    const int tilesM = (C + 63) / 64;
+    const long long per = (long long)C * HW;
+    int gx = (int)((per + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bcnn_rank1_fix_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dx, tpart, inv_norm, colsum,
+                       C, HW, tilesM, per);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
 }
 
 extern "C" int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm,
@@ -171,22 +210,7 @@ extern "C" int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy,
                                 hk_stream_t stream) {
     if (!x || !y || !dy || !inv_norm || !colsum || !dx || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_bcnn_pool_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const int tilesM = (C + 63) / 64;
-    LdBcnnP pa;
-    pa.y = y; pa.dy = dy; pa.inv_norm = inv_norm; pa.tpart = (float*)ws; pa.C = C;
-    pa.inv2m = 1.0f / (2.0f * (float)HW);
-    pa.vec = (aligned16(y) && aligned16(dy) && (C % 4 == 0)) ? 1 : 0;
-    pa.coef = 0.f; pa.tacc = 0.f; pa.active = 0;
-    const LdPlain xb = make_plain(x, (long long)C * HW, HW, C, HW);  // K x N, N contiguous
-    const EpAffine ep = make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f);
-    int rc = bgemm_launch<true, false>(pa, xb, ep, C, HW, C, B, st);
+    int rc = hk_bcnn_bwd_gemm(x, y, dy, inv_norm, dx, (float*)ws, B, C, HW, stream);
     if (rc != HK_OK) return rc;
-    const long long per = (long long)C * HW;
-    int gx = (int)((per + 255) / 256);
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(bcnn_rank1_fix_kernel, dim3(gx, B), dim3(256), 0, st, dx, (const float*)ws, inv_norm, colsum,
-                       C, HW, tilesM, per);
-    HK_LAUNCH_CHECK();
-    return HK_OK;
+    return hk_bcnn_bwd_rank1(dx, (const float*)ws, inv_norm, colsum, B, C, HW, stream);
 }

@@ -1,0 +1,44 @@
+"""MIOpen cold-start control.  The image ships NO gfx950 kernel database or find-db
+(torch/share/miopen/db has gfx942/gfx90a only), so every new convolution shape is
+JIT-compiled on first use: measured on a fresh MI355X box, the first BCNN step at
+batch 64 / 448x448 costs 20 s (forward) + 253 s (backward) before a single image is
+trained; with the kernels cached the same step starts in ~2 s.  MIOpen keeps what it
+compiled in $MIOPEN_CUSTOM_CACHE_DIR (kernel binaries, *.ukdb) and
+$MIOPEN_USER_DB_PATH (find db).  hawkeye_amd/miopen_db/ holds a ~200 KB cache
+populated by `tools/warm_miopen.sh` on a GPU box for the shapes bench.py / smoke()
+use; it is copied to a scratch directory (MIOpen writes into it) and the two
+variables are pointed there.  Pure plumbing: no effect on numerics or on the HIP kernels;
+if the seed is missing or stale MIOpen simply compiles again.
+"""
+import os
+import shutil
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SEED = os.path.join(HERE, 'miopen_db')
+
+
+def use_in_tree_cache(base=None):
+    """Call before the first convolution runs.  Respects variables the user already set.
+    HAWKEYE_MIOPEN_DIR=<dir> uses <dir> directly (how the seed is (re)populated)."""
+    if 'MIOPEN_CUSTOM_CACHE_DIR' in os.environ and 'MIOPEN_USER_DB_PATH' in os.environ:
+        return os.environ['MIOPEN_CUSTOM_CACHE_DIR']
+    base = base or os.environ.get('HAWKEYE_MIOPEN_DIR')
+    try:
+        if base is None:
+            base = os.path.join(tempfile.gettempdir(), f'hawkeye_miopen_{os.getuid()}')
+            for sub in ('cache', 'db'):
+                dst, src = os.path.join(base, sub), os.path.join(SEED, sub)
+                os.makedirs(dst, exist_ok=True)
+                if os.path.isdir(src):
+                    for f in os.listdir(src):
+                        if not os.path.exists(os.path.join(dst, f)):
+                            shutil.copy2(os.path.join(src, f), os.path.join(dst, f))
+        else:
+            os.makedirs(os.path.join(base, 'cache'), exist_ok=True)
+            os.makedirs(os.path.join(base, 'db'), exist_ok=True)
+    except OSError:
+        return None
+    os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(base, 'cache'))
+    os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(base, 'db'))
+    return base

@@ -244,6 +244,21 @@ def gen_models(models):
         with torch.no_grad():
             res[name] = m(x)
     save('model_logits', **res)
+    # AP-CNN (eval mode: no python-random drop) and OSMENet at 224x224
+    m = models['APCNN']
+    seeded_init(m, 910)
+    m.eval()
+    x = t(rs_randn(911, (2, 3, 224, 224)))
+    with torch.no_grad():
+        out_mean, out_list, mask_cat, roi_list = m(x, None)
+    save('model_apcnn', out_mean=out_mean, out_list=torch.stack(out_list), mask_cat=sub(mask_cat, 13),
+         roi3=roi_list[0], roi4=roi_list[1], roi5=roi_list[2])
+    m = models['OSMENet']
+    seeded_init(m, 920)
+    m.eval()
+    with torch.no_grad():
+        logits, parts = m(t(rs_randn(921, (2, 3, 224, 224))))
+    save('model_osme', logits=logits, parts=parts)
 
 
 if __name__ == '__main__':

@@ -9,6 +9,11 @@ for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests', 'golde
         sys.path.insert(0, p)
 
 
+from hawkeye_amd.miopen_cache import use_in_tree_cache  # noqa: E402
+
+use_in_tree_cache()
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -34,8 +34,14 @@ def seeded_init(module, seed):
             elif v.dim() >= 2:
                 fan_in = int(np.prod(v.shape[1:]))
                 a = a * np.float32(np.sqrt(2.0 / fan_in))
+                if '_1.conv.weight' in k and v.shape[1] == 1:
+                    # AP-CNN SpatialGate ConvTranspose2d [C,1,3,3]: true fan-in is C*9; keep sigmoid unsaturated
+                    # (the reference itself crashes in nms.py:93 when a saturated map leaves no score > mean)
+                    a = a * np.float32(0.1 / v.shape[0] ** 0.5)
             elif k.endswith('weight'):
                 a = 1.0 + 0.1 * a
+                if k.endswith('bn3.weight'):
+                    a = 0.25 * a          # damp the residual branches so deep trunks keep O(1) activations
             else:
                 a = 0.1 * a
             v.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)))
