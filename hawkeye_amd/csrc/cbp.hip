@@ -96,9 +96,11 @@ __global__ __launch_bounds__(256) void cbp_dc_kernel(const float* __restrict__ y
     for (int k = threadIdx.x; k < D; k += 256) {
         const float c = c_raw[o + k];
         const float du = (dy[o + k] - y[o + k] * t) * in;
-        // No special case at c == 0: the reference's FFT route never produces an exact 0 (round-off leaves
-        // ~1e-8), so its autograd always takes the finite slope 1/(2 sqrt(|c|+1e-10)); the limit c -> 0 is used.
-        dc[o + k] = du / (2.0f * sqrtf(fabsf(c) + 1e-10f));
+        // c == 0 exactly (a bin whose Gram entries are all exactly 0): torch's autograd of sign(c)*sqrt(|c|+1e-10)
+        // gives 0 there (sign' = 0, abs'(0) = 0).  The reference's FFT route turns such a bin into round-off noise
+        // and differentiates THAT (slope 1/(2 sqrt(|noise|)): 5e2 in fp32, 5e4 in fp64) - not reproducible by any
+        // deterministic algorithm; see DESIGN.md "CBP zero bins".
+        dc[o + k] = (c != 0.f) ? du / (2.0f * sqrtf(fabsf(c) + 1e-10f)) : 0.f;
     }
 }
 

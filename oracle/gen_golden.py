@@ -80,6 +80,13 @@ def gen_cbp():
     w = t(rs_randn(22, tuple(y.shape)))
     (y * w).sum().backward()
     save('cbp_small', y=y, dx=x.grad)
+    # dense strictly positive input: no bin is exactly 0, so the backward is well defined
+    cbp = M_CBCNN.CompactBilinearPooling(16, 16, 64)
+    x = t(np.abs(rs_randn(23, (2, 16, 3, 5))) + 0.1).requires_grad_(True)
+    y = cbp(x)
+    w = t(rs_randn(24, tuple(y.shape)))
+    (y * w).sum().backward()
+    save('cbp_small_dense', y=y, dx=x.grad)
     cbp = M_CBCNN.CompactBilinearPooling(512, 512, 6000)
     x = t(rs_relu_randn(1234, (2, 512, 14, 14))).requires_grad_(True)
     y = cbp(x)

@@ -81,6 +81,28 @@ def compact_bilinear_pool(x, output_dim, hashes=None):
     return F.normalize(cbp)                                      # :133
 
 
+def compact_bilinear_pool_gram(x, output_dim, hashes=None):
+    """The same function through the count-sketch identity
+        c[b,k] = sum_{(i,j): (h1[i]+h2[j]) mod D = k} s1[i] s2[j] (X X^T)[b,i,j]
+    (circular convolution of two count sketches = count sketch of the outer product;
+    the sum over positions commutes).  Not what the reference executes - it is the
+    algebraic form the HIP path uses - kept here so that tests can (a) verify the
+    identity against the FFT route on the CPU and (b) pin autograd semantics at bins
+    that are exactly 0 (torch: sign'(c) = 0, abs'(0) = 0 -> zero gradient), where the
+    FFT route differentiates its own round-off noise."""
+    b, c, h, w = x.shape
+    if hashes is None:
+        hashes = sketch_hashes(c, c, output_dim)
+    h1, s1, h2, s2 = hashes
+    xm = x.reshape(b, c, h * w)
+    gram = torch.bmm(xm, xm.transpose(1, 2))
+    bins = ((torch.from_numpy(h1)[:, None] + torch.from_numpy(h2)[None, :]) % output_dim).reshape(-1)
+    sign = (torch.from_numpy(s1)[:, None] * torch.from_numpy(s2)[None, :]).to(x.dtype).reshape(-1)
+    cbp = torch.zeros(b, output_dim, dtype=x.dtype).index_add(1, bins, gram.reshape(b, -1) * sign)
+    cbp = torch.sign(cbp) * torch.sqrt(torch.abs(cbp) + 1e-10)
+    return F.normalize(cbp)
+
+
 # ----------------------------------------------------------------------------
 # Fast MPN-COV  (model/methods/MPNCOV.py:105-230)
 # ----------------------------------------------------------------------------

@@ -74,6 +74,28 @@ def test_cbp():
     assert abs(float(x.grad.double().abs().sum()) / float(g['dx_abs']) - 1) < 1e-5
 
 
+def test_cbp_gram_identity_equals_fft_route():
+    """The count-sketch identity the HIP path relies on, checked on the CPU against the reference's FFT route
+    (goldens from /root/reference) for inputs without exactly-zero bins: forward and input gradient."""
+    g = load('cbp_small_dense')
+    xn = (np.abs(rs_randn(23, (2, 16, 3, 5))) + 0.1).astype(np.float32)
+    x = t(xn).requires_grad_(True)
+    y = O.compact_bilinear_pool_gram(x, 64)
+    (y * t(rs_randn(24, (2, 64)))).sum().backward()
+    close(y, g['y'], rtol=1e-4, atol=1e-6)
+    close(x.grad, g['dx'], rtol=1e-3, atol=1e-5)
+    x2 = t(xn).requires_grad_(True)
+    y2 = O.compact_bilinear_pool(x2, 64)
+    (y2 * t(rs_randn(24, (2, 64)))).sum().backward()
+    close(y2, g['y'], rtol=1e-5, atol=1e-7)
+    g = load('cbp_512')
+    x = t(rs_relu_randn(1234, (2, 512, 14, 14))).requires_grad_(True)
+    y = O.compact_bilinear_pool_gram(x, 6000)
+    (y * t(rs_randn(1236, (2, 6000)))).sum().backward()
+    assert float((y.detach() - t(g['y'])).norm() / t(g['y']).norm()) < 2e-6
+    assert abs(float(x.grad.double().abs().sum()) / float(g['dx_abs']) - 1) < 1e-4
+
+
 @pytest.mark.parametrize('it', [5, 3, 2, 1])
 def test_mpn_small(it):
     g = load('mpn_small')
