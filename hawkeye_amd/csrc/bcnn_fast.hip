@@ -1,0 +1,344 @@
+// Specialised BCNN bilinear-pooling kernels for the shapes the configs use
+// (C % 64 == 0, HW in {196, 144, 100, 64}: VGG/ResNet 14x14 .. 8x8 maps).  Anything
+// else takes the generic hk::bgemm_kernel path in bcnn_pool.hip.
+//
+// Forward  (bcnn_gram_panel_kernel): G is symmetric, so only the 64x64 tiles (I,J),
+//   J >= I, are computed and each is written twice (direct + mirrored).  A workgroup
+//   owns a row-block I (or the balanced pair {p, nb-1-p}: nb+1 tiles each, so that
+//   B=64 x C=512 is exactly 256 equal workgroups = one per CU), keeps the 64 x HW
+//   A-panel resident in LDS (50 KB, full K) and streams the J-panels through two more
+//   LDS buffers: the next panel is fetched into registers before the MFMA loop and
+//   written after it, one barrier per tile.  X[b] row-panels are contiguous in HBM and
+//   HW = 196 = 4 * 49 floats per row gives a conflict-free ds_read_b128 pitch with no
+//   padding.  4 waves = 2x2 sub-tiles of 32x32 on v_mfma_f32_32x32x2_f32; the
+//   sqrt / normalise / store epilogue of tile t is interleaved, register by register,
+//   with the MFMAs of tile t+1 so the matrix pipe does not drain between tiles.
+//
+// Backward (bcnn_bwd_panel_kernel): dX[I-rows] = sum_K P(I,K) X(K) with
+//   P = (dy + dy^T) / (2 n^2 M y) built per 64x64 tile in LDS from coalesced reads of
+//   y(I,K), dy(I,K) and dy(K,I) (transposed through LDS).  N = HW = 196 is covered by
+//   13 tiles of 16 columns (v_mfma_f32_16x16x4_f32: 94 % useful instead of 77 % with
+//   64-wide tiles); each of the 4 waves owns 16 rows x 208 columns (13 accumulators).
+//   The next K-block's operands are prefetched into registers during the MFMA loop;
+//   68 KB of LDS per workgroup -> 2 workgroups per CU overlap each other's phases.
+#include "hk_common.h"
+
+namespace hk {
+
+// ----------------------------------------------------------------------------- forward
+struct GramEpi {
+    float* yb;       // y + b*C*C
+    int C;
+    int i0, j0;      // top-left of this wave's 32x32 sub-tile
+    float inv, inv_m;
+    int offdiag;
+    int l31, lh;
+    __device__ __forceinline__ float direct(float v, int r) {
+        const float z = sqrtf(fmaf(v, inv_m, 1e-5f)) * inv;
+        const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        yb[(long long)i * C + j0 + l31] = z;
+        return z;
+    }
+    __device__ __forceinline__ void mirror(const f32x16& p, int g) {   // rows 8g+4lh .. +3 of column l31 -> y[j][i..i+3]
+        if (!offdiag) return;
+        const float4 q = make_float4(p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]);
+        *reinterpret_cast<float4*>(&yb[(long long)(j0 + l31) * C + i0 + 8 * g + 4 * lh]) = q;
+    }
+};
+
+template <int HW, bool HASPREV>
+__device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x16& acc, f32x16& prev, GramEpi& ep,
+                                          int lh) {
+    constexpr int KS = HW / 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(Ap + 8 * s);
+        const float4 q = *reinterpret_cast<const float4*>(Bp + 8 * s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q.w, acc, 0, 0, 0);
+        if (HASPREV) {
+            if (s < 16) prev[s] = ep.direct(prev[s], s);
+            else if (s < 20) ep.mirror(prev, s - 16);
+        }
+    }
+    if (HW % 8 == 4) {   // k = 8*KS .. +3: lanes 0-31 take the first two, lanes 32-63 the last two
+        const float2 a = *reinterpret_cast<const float2*>(Ap + 8 * KS - 2 * lh);
+        const float2 q = *reinterpret_cast<const float2*>(Bp + 8 * KS - 2 * lh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, acc, 0, 0, 0);
+    }
+    if (HASPREV) {
+#pragma unroll
+        for (int s = KS; s < 20; ++s) {
+            if (s < 16) prev[s] = ep.direct(prev[s], s);
+            else ep.mirror(prev, s - 16);
+        }
+    }
+}
+
+template <int HW>
+__global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ inv_norm,
+                                                                 float* __restrict__ y, int C, int nb, int B,
+                                                                 int pair_mode) {
+    constexpr int PANEL = 64 * HW;
+    constexpr int N4 = PANEL / 4;
+    constexpr int NST = (N4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds[3 * PANEL];
+
+    int b, w;
+    const int per = pair_mode ? (nb + 1) / 2 : nb;
+    if (!xcd_map(blockIdx.x, B, per, b, w)) return;
+    const int rb0 = w;
+    int rb1 = pair_mode ? nb - 1 - w : -1;
+    if (rb1 == rb0) rb1 = -1;
+    const int nrb = rb1 >= 0 ? 2 : 1;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    const float* xb = x + (long long)b * C * HW;
+
+    GramEpi ep;
+    ep.yb = y + (long long)b * C * C;
+    ep.C = C;
+    ep.inv = inv_norm[b];
+    ep.inv_m = 1.0f / (float)HW;
+    ep.l31 = l31;
+    ep.lh = lh;
+    ep.i0 = ep.j0 = ep.offdiag = 0;
+
+    {   // first A panel: plain copy
+        const float4* src = reinterpret_cast<const float4*>(xb + (long long)rb0 * PANEL);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int f = tid; f < N4; f += 256) dst[f] = src[f];
+    }
+    __syncthreads();
+
+    int a_idx = 0, b_idx = 0;
+    f32x16 prev;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) prev[i] = 0.f;
+    bool has_prev = false;
+
+    for (int ri = 0; ri < nrb; ++ri) {
+        const int I = ri == 0 ? rb0 : rb1;
+        for (int J = I; J < nb; ++J) {
+            int next_blk = -1;
+            bool newrow = false;
+            if (J + 1 < nb) next_blk = J + 1;
+            else if (ri + 1 < nrb) { next_blk = rb1; newrow = true; }
+            const int n_idx = (a_idx == b_idx) ? (a_idx + 1) % 3 : 3 - a_idx - b_idx;
+
+            float4 st[NST];
+            {   // unconditional (index-clamped) loads keep st[] in registers; on the last tile they re-read a panel
+                const int lb = next_blk >= 0 ? next_blk : J;
+                const float4* src = reinterpret_cast<const float4*>(xb + (long long)lb * PANEL);
+#pragma unroll
+                for (int u = 0; u < NST; ++u) {
+                    const int f = tid + 256 * u;
+                    st[u] = src[f < N4 ? f : N4 - 1];
+                }
+            }
+
+            const float* Ap = lds + a_idx * PANEL + (wm * 32 + l31) * HW + 4 * lh;
+            const float* Bp = lds + b_idx * PANEL + (wn * 32 + l31) * HW + 4 * lh;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            if (has_prev) gram_tile<HW, true>(Ap, Bp, acc, prev, ep, lh);
+            else gram_tile<HW, false>(Ap, Bp, acc, prev, ep, lh);
+
+            if (next_blk >= 0) {
+                float4* dst = reinterpret_cast<float4*>(lds + n_idx * PANEL);
+#pragma unroll
+                for (int u = 0; u < NST; ++u) {
+                    const int f = tid + 256 * u;
+                    if (f < N4) dst[f] = st[u];
+                }
+            }
+            prev = acc;
+            ep.i0 = I * 64 + wm * 32;
+            ep.j0 = J * 64 + wn * 32;
+            ep.offdiag = (I != J);
+            has_prev = true;
+            __syncthreads();
+            if (next_blk >= 0) {
+                if (newrow) { a_idx = n_idx; b_idx = n_idx; }
+                else b_idx = n_idx;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) prev[r] = ep.direct(prev[r], r);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ep.mirror(prev, g);
+}
+
+// ----------------------------------------------------------------------------- backward
+// this thread's 4 float4 of the 64x64 tiles (I,kb) of y, dy and (kb,I) of dy (row = f >> 4, col4 = (f & 15) * 4,
+// f = tid + 256 u) and its share of the 64 x HW block kb of X
+template <int HW, int NSX>
+__device__ __forceinline__ void bwd_load(f32x4 (&ry)[4], f32x4 (&rd)[4], f32x4 (&rt)[4], f32x4 (&rx)[NSX],
+                                         const float* __restrict__ y, const float* __restrict__ dy,
+                                         const float* __restrict__ xb, long long cc, int C, int I, int kb, int tid) {
+    constexpr int XN4 = 64 * HW / 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
+        const long long o1 = cc + (long long)(I * 64 + r) * C + kb * 64 + c4;
+        const long long o2 = cc + (long long)(kb * 64 + r) * C + I * 64 + c4;
+        ry[u] = *reinterpret_cast<const f32x4*>(y + o1);
+        rd[u] = *reinterpret_cast<const f32x4*>(dy + o1);
+        rt[u] = *reinterpret_cast<const f32x4*>(dy + o2);
+    }
+    const f32x4* xs = reinterpret_cast<const f32x4*>(xb + (long long)kb * 64 * HW);
+#pragma unroll
+    for (int u = 0; u < NSX; ++u) {
+        const int f = tid + 256 * u;
+        rx[u] = xs[f < XN4 ? f : XN4 - 1];
+    }
+}
+
+template <int HW>
+__global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ dy,
+                                                                const float* __restrict__ inv_norm,
+                                                                float* __restrict__ dx, float* __restrict__ tpart,
+                                                                int C, int nb, int B) {
+    constexpr int NT = (HW + 15) / 16;          // 16-column output tiles
+    constexpr int XN4 = 64 * HW / 4;
+    constexpr int NSX = (XN4 + 255) / 256;
+    constexpr int PP = 68;                      // P tile pitch
+    constexpr int TP = 65;                      // dy^T scratch pitch
+    constexpr int XREG = (64 * HW + 16) > (64 * TP) ? (64 * HW + 16) : (64 * TP);
+    __shared__ __attribute__((aligned(16))) float lds[64 * PP + XREG];
+    float* sP = lds;
+    float* sX = lds + 64 * PP;
+
+    int b, I;
+    if (!xcd_map(blockIdx.x, B, nb, b, I)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const long long cc = (long long)b * C * C;
+    const float* xb = x + (long long)b * C * HW;
+    const float in = inv_norm[b];
+    const float coef = in * in / (2.0f * (float)HW);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float tacc = 0.f;
+
+    f32x4 ry[4], rd[4], rt[4], rx[NSX];
+    bwd_load<HW, NSX>(ry, rd, rt, rx, y, dy, xb, cc, C, I, 0, tid);
+    for (int kb = 0; kb < nb; ++kb) {
+        __syncthreads();                                   // previous MFMA phase finished with sP / sX
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                      // dy(K,I) transposed into the scratch: T[i][k] = dy[k][i]
+            const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
+            sX[(c4 + 0) * TP + r] = rt[u][0];
+            sX[(c4 + 1) * TP + r] = rt[u][1];
+            sX[(c4 + 2) * TP + r] = rt[u][2];
+            sX[(c4 + 3) * TP + r] = rt[u][3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                      // P tile
+            const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
+            const float* tp = sX + r * TP + c4;
+            f32x4 p;
+            p[0] = (rd[u][0] + tp[0]) / ry[u][0] * coef;
+            p[1] = (rd[u][1] + tp[1]) / ry[u][1] * coef;
+            p[2] = (rd[u][2] + tp[2]) / ry[u][2] * coef;
+            p[3] = (rd[u][3] + tp[3]) / ry[u][3] * coef;
+            tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
+            *reinterpret_cast<f32x4*>(&sP[r * PP + c4]) = p;
+        }
+        __syncthreads();                                   // scratch reads done: X block may overwrite it
+#pragma unroll
+        for (int u = 0; u < NSX; ++u) {
+            const int f = tid + 256 * u;
+            if (f < XN4) reinterpret_cast<f32x4*>(sX)[f] = rx[u];
+        }
+        __syncthreads();
+        // next K-block's operands: in flight during the MFMA phase (last iteration: harmless re-read)
+        bwd_load<HW, NSX>(ry, rd, rt, rx, y, dy, xb, cc, C, I, (kb + 1 < nb ? kb + 1 : kb), tid);
+
+        const float* ap = sP + (wave * 16 + l15) * PP + 4 * lq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * s);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float* bp = sX + (16 * s + 4 * lq + t) * HW + l15;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bp[16 * n], acc[n], 0, 0, 0);
+            }
+        }
+    }
+
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+    float* dxb = dx + (long long)b * C * HW + (long long)(I * 64 + wave * 16 + lq * 4) * HW;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = 16 * n + l15;
+        if (col < HW) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dxb[(long long)r * HW + col] = acc[n][r];
+        }
+    }
+    __syncthreads();
+    const float tsum = block_sum<4>(tacc, lds);
+    if (tid == 0) tpart[(long long)b * nb + I] = tsum;
+}
+
+// ----------------------------------------------------------------------------- dispatch
+template <int HW>
+static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, hipStream_t st) {
+    const int nb = C / 64;
+    const int pair_mode = ((long long)B * nb > 256) ? 1 : 0;
+    const int per = pair_mode ? (nb + 1) / 2 : nb;
+    hipLaunchKernelGGL((bcnn_gram_panel_kernel<HW>), dim3(xcd_grid(B, per)), dim3(256), 0, st, x, inv_norm, y, C, nb, B,
+                       pair_mode);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+template <int HW>
+static int bwd_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
+                      int B, int C, hipStream_t st) {
+    const int nb = C / 64;
+    hipLaunchKernelGGL((bcnn_bwd_panel_kernel<HW>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx, tpart,
+                       C, nb, B);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+// returns HK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the generic GEMM)
+int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(y)) return HK_ERR_UNSUPPORTED;
+    switch (HW) {
+        case 196: return gram_launch<196>(x, inv_norm, y, B, C, st);
+        case 144: return gram_launch<144>(x, inv_norm, y, B, C, st);
+        case 100: return gram_launch<100>(x, inv_norm, y, B, C, st);
+        case 64: return gram_launch<64>(x, inv_norm, y, B, C, st);
+        default: return HK_ERR_UNSUPPORTED;
+    }
+}
+
+int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart, int B,
+                  int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(y) || !aligned16(dy) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+    switch (HW) {
+        case 196: return bwd_launch<196>(x, y, dy, inv_norm, dx, tpart, B, C, st);
+        case 144: return bwd_launch<144>(x, y, dy, inv_norm, dx, tpart, B, C, st);
+        case 100: return bwd_launch<100>(x, y, dy, inv_norm, dx, tpart, B, C, st);
+        case 64: return bwd_launch<64>(x, y, dy, inv_norm, dx, tpart, B, C, st);
+        default: return HK_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace hk

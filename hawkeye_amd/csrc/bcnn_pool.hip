@@ -14,10 +14,20 @@
 // P is formed on the fly by the GEMM's A-operand loader from y / dy tiles (never
 // materialised); t is accumulated by the same loader (each (y,dy) element exactly
 // once, fixed order) and the rank-1 term is applied by a small second kernel.
+#include <cstdlib>
 #include "hk_bgemm.h"
 #include "../../include/hawkeye_hip.h"
 
 namespace hk {
+
+// bcnn_fast.hip: panel-resident kernels for C % 64 == 0 and HW in {196,144,100,64}; HK_ERR_UNSUPPORTED otherwise
+int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C, int HW, hipStream_t st);
+int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart, int B,
+                  int C, int HW, hipStream_t st);
+static inline bool force_generic() {   // HK_BCNN_GENERIC=1: A/B switch used by the tests and bench
+    const char* e = getenv("HK_BCNN_GENERIC");
+    return e && e[0] == '1';
+}
 
 // colsum[b,hw] = sum_c x[b,c,hw];  inv_norm[b] = 1 / max(sqrt(sum_hw colsum^2 / M + C*C*1e-5), 1e-12)
 // One workgroup (1024 threads) per sample; threads stride over channel rows with
@@ -164,6 +174,10 @@ extern "C" int hk_bcnn_colsum_norm(const float* x, float* colsum, float* inv_nor
 extern "C" int hk_bcnn_gram_norm(const float* x, const float* inv_norm, float* y, int B, int C, int HW,
                                  hk_stream_t stream) {
     if (!x || !y || !inv_norm || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    if (!force_generic()) {
+        const int rc = bcnn_fast_gram(x, inv_norm, y, B, C, HW, (hipStream_t)stream);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
     const LdPlain xa = make_plain(x, (long long)C * HW, HW, C, HW);
     EpBcnn ep;
     ep.y = y; ep.inv_norm = inv_norm; ep.C = C; ep.m = (float)HW;
@@ -182,6 +196,10 @@ extern "C" int hk_bcnn_pool_fwd(const float* x, float* y, float* inv_norm, float
 extern "C" int hk_bcnn_bwd_gemm(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx,
                                 float* tpart, int B, int C, int HW, hk_stream_t stream) {
     if (!x || !y || !dy || !inv_norm || !dx || !tpart || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    if (!force_generic()) {
+        const int rc = bcnn_fast_bwd(x, y, dy, inv_norm, dx, tpart, B, C, HW, (hipStream_t)stream);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
     LdBcnnP pa;
     pa.y = y; pa.dy = dy; pa.inv_norm = inv_norm; pa.tpart = tpart; pa.C = C;
     pa.inv2m = 1.0f / (2.0f * (float)HW);

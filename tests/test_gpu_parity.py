@@ -121,6 +121,48 @@ def test_bcnn_full_size_properties(F):
     assert y[:2].argmax(dim=1).cpu().tolist() == yo.argmax(dim=1).tolist()
 
 
+@pytest.mark.parametrize('b,c,hw', [(1, 64, 14), (9, 128, 14), (3, 192, 12), (2, 64, 10), (5, 128, 8), (90, 192, 8)])
+def test_bcnn_panel_kernels_vs_oracle_and_generic(F, b, c, hw):
+    """Shapes served by the panel-resident kernels (C % 64 == 0, HW in {196,144,100,64}); (90,192,8) takes the
+    balanced row-block-pair schedule with an odd number of row blocks.  Checked against the oracle and against
+    the generic GEMM path (HK_BCNN_GENERIC=1)."""
+    xn, wn = rs_relu_randn(91, (b, c, hw, hw)), rs_randn(92, (b, c * c))
+    x, y, xg, yg = _bcnn_case(F, xn, wn)
+    assert rel(yg, y) < 1e-6 and rel(xg.grad, x.grad) < 2e-5
+    ym = yg.detach().view(b, c, c)
+    assert torch.equal(ym, ym.transpose(1, 2))
+    os.environ['HK_BCNN_GENERIC'] = '1'
+    try:
+        xg2 = t(xn).to(DEV).requires_grad_(True)
+        yg2 = F.bilinear_pool(xg2)
+        (yg2 * t(wn).to(DEV)).sum().backward()
+    finally:
+        del os.environ['HK_BCNN_GENERIC']
+    assert rel(yg, yg2) < 1e-6 and rel(xg.grad, xg2.grad) < 1e-5
+
+
+def test_bcnn_full_size_backward_vs_generic(F):
+    """B=64, C=512, 14x14: pair-scheduled forward + row-block backward vs the generic path and the oracle (2 samples)."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.relu(torch.randn(64, 512, 14, 14, generator=g))
+    w = torch.randn(64, 512 * 512, generator=g)
+    outs = []
+    for generic in ('0', '1'):
+        os.environ['HK_BCNN_GENERIC'] = generic
+        try:
+            xg = x.to(DEV).requires_grad_(True)
+            yg = F.bilinear_pool(xg)
+            (yg * w.to(DEV)).sum().backward()
+            outs.append((yg.detach(), xg.grad))
+        finally:
+            del os.environ['HK_BCNN_GENERIC']
+    assert rel(outs[0][0], outs[1][0]) < 1e-6 and rel(outs[0][1], outs[1][1]) < 1e-5
+    xc = x[62:].clone().requires_grad_(True)
+    yo = O.bilinear_pool(xc)
+    (yo * w[62:]).sum().backward()
+    assert rel(outs[0][0][62:], yo) < 1e-6 and rel(outs[0][1][62:], xc.grad) < 2e-5
+
+
 # ------------------------------------------------------------------ MPN-COV
 @pytest.mark.parametrize('it', [5, 3, 2, 1])
 def test_mpn_small_vs_oracle_and_golden(F, it):
