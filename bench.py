@@ -106,9 +106,9 @@ def kernel_rooflines(B, C, HW, dev):
     stages = [
         ('bcnn_colsum_norm_kernel', lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, stream()),
          0.0, 4.0 * B * C * HW),
-        ('bgemm_kernel<gram,EpBcnn>', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
+        ('bcnn_gram_panel_kernel<196>', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
          flops, 4.0 * B * C * HW + 4.0 * B * C * C),
-        ('bgemm_kernel<LdBcnnP,bwd>', lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp),
+        ('bcnn_bwd_panel_kernel<196>', lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp),
                                                                    B, C, HW, stream()),
          flops, 8.0 * B * C * C + 8.0 * B * C * HW),
         ('bcnn_rank1_fix_kernel', lambda: lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream()),

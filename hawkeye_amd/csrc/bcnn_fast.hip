@@ -46,18 +46,22 @@ struct GramEpi {
     }
 };
 
+// One 64x64 tile step for this wave's 32x32 sub-tile.  K is split over TWO independent accumulator chains (the two
+// k-pairs of every 8-wide step alternate between them): a dependent f32 MFMA chain tolerates no issue slot between
+// its links (MI355X_MICROARCH.md: +43 cycles for the first extra state), and the epilogue of the previous tile is
+// interleaved here; with two chains the matrix pipe always has the other chain's instruction to run.
 template <int HW, bool HASPREV>
-__device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x16& acc, f32x16& prev, GramEpi& ep,
-                                          int lh) {
+__device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x16& acc0, f32x16& acc1, f32x16& prev,
+                                          GramEpi& ep, int lh) {
     constexpr int KS = HW / 8;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const float4 a = *reinterpret_cast<const float4*>(Ap + 8 * s);
-        const float4 q = *reinterpret_cast<const float4*>(Bp + 8 * s);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q.w, acc, 0, 0, 0);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Ap + 8 * s);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(Bp + 8 * s);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], q[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], q[2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], q[3], acc1, 0, 0, 0);
         if (HASPREV) {
             if (s < 16) prev[s] = ep.direct(prev[s], s);
             else if (s < 20) ep.mirror(prev, s - 16);
@@ -66,8 +70,8 @@ __device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x
     if (HW % 8 == 4) {   // k = 8*KS .. +3: lanes 0-31 take the first two, lanes 32-63 the last two
         const float2 a = *reinterpret_cast<const float2*>(Ap + 8 * KS - 2 * lh);
         const float2 q = *reinterpret_cast<const float2*>(Bp + 8 * KS - 2 * lh);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, acc, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, acc1, 0, 0, 0);
     }
     if (HASPREV) {
 #pragma unroll
@@ -109,10 +113,20 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     ep.lh = lh;
     ep.i0 = ep.j0 = ep.offdiag = 0;
 
-    {   // first A panel: plain copy
-        const float4* src = reinterpret_cast<const float4*>(xb + (long long)rb0 * PANEL);
-        float4* dst = reinterpret_cast<float4*>(lds);
-        for (int f = tid; f < N4; f += 256) dst[f] = src[f];
+    {   // first A panel: all loads in flight at once, then the LDS writes
+        const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)rb0 * PANEL);
+        f32x4 st0[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int f = tid + 256 * u;
+            st0[u] = src[f < N4 ? f : N4 - 1];
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int f = tid + 256 * u;
+            if (f < N4) dst[f] = st0[u];
+        }
     }
     __syncthreads();
 
@@ -131,10 +145,10 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
             else if (ri + 1 < nrb) { next_blk = rb1; newrow = true; }
             const int n_idx = (a_idx == b_idx) ? (a_idx + 1) % 3 : 3 - a_idx - b_idx;
 
-            float4 st[NST];
+            f32x4 st[NST];
             {   // unconditional (index-clamped) loads keep st[] in registers; on the last tile they re-read a panel
                 const int lb = next_blk >= 0 ? next_blk : J;
-                const float4* src = reinterpret_cast<const float4*>(xb + (long long)lb * PANEL);
+                const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)lb * PANEL);
 #pragma unroll
                 for (int u = 0; u < NST; ++u) {
                     const int f = tid + 256 * u;
@@ -144,21 +158,21 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
 
             const float* Ap = lds + a_idx * PANEL + (wm * 32 + l31) * HW + 4 * lh;
             const float* Bp = lds + b_idx * PANEL + (wn * 32 + l31) * HW + 4 * lh;
-            f32x16 acc;
+            f32x16 acc0, acc1;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            if (has_prev) gram_tile<HW, true>(Ap, Bp, acc, prev, ep, lh);
-            else gram_tile<HW, false>(Ap, Bp, acc, prev, ep, lh);
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+            if (has_prev) gram_tile<HW, true>(Ap, Bp, acc0, acc1, prev, ep, lh);
+            else gram_tile<HW, false>(Ap, Bp, acc0, acc1, prev, ep, lh);
 
             if (next_blk >= 0) {
-                float4* dst = reinterpret_cast<float4*>(lds + n_idx * PANEL);
+                f32x4* dst = reinterpret_cast<f32x4*>(lds + n_idx * PANEL);
 #pragma unroll
                 for (int u = 0; u < NST; ++u) {
                     const int f = tid + 256 * u;
                     if (f < N4) dst[f] = st[u];
                 }
             }
-            prev = acc;
+            prev = acc0 + acc1;
             ep.i0 = I * 64 + wm * 32;
             ep.j0 = J * 64 + wn * 32;
             ep.offdiag = (I != J);
@@ -249,10 +263,12 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
             const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
             const float* tp = sX + r * TP + c4;
             f32x4 p;
-            p[0] = (rd[u][0] + tp[0]) / ry[u][0] * coef;
-            p[1] = (rd[u][1] + tp[1]) / ry[u][1] * coef;
-            p[2] = (rd[u][2] + tp[2]) / ry[u][2] * coef;
-            p[3] = (rd[u][3] + tp[3]) / ry[u][3] * coef;
+            // v_rcp_f32 (1 ulp) instead of an IEEE division: 16 of them per thread per K-block sit on the
+            // critical path between two MFMA phases; the parity budget is 1e-4
+            p[0] = (rd[u][0] + tp[0]) * (__builtin_amdgcn_rcpf(ry[u][0]) * coef);
+            p[1] = (rd[u][1] + tp[1]) * (__builtin_amdgcn_rcpf(ry[u][1]) * coef);
+            p[2] = (rd[u][2] + tp[2]) * (__builtin_amdgcn_rcpf(ry[u][2]) * coef);
+            p[3] = (rd[u][3] + tp[3]) * (__builtin_amdgcn_rcpf(ry[u][3]) * coef);
             tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
             *reinterpret_cast<f32x4*>(&sP[r * PP + c4]) = p;
         }
