@@ -156,3 +156,24 @@ def test_reducer_on_gpu_single_rank_matches_plain_sgd():
         if use:
             red.finish()
     torch.testing.assert_close(m1.classifier.weight.grad, m2.classifier.weight.grad)
+
+
+def test_trainer_runs_one_synthetic_epoch(tmp_path):
+    """The reference's Trainer flow (build from yaml -> train -> validate -> checkpoint) on the MI355X heads."""
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.examples.BCNN import BCNNTrainer
+    cfg = CfgNode.load_cfg(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), 'configs',
+                                             'BCNN_S2_synthetic.yaml')))
+    cfg.experiment.log_dir = str(tmp_path)
+    cfg.dataset.samples = 8
+    cfg.dataset.batch_size = 4
+    cfg.dataset.num_workers = 0
+    cfg.dataset.transformer.image_size = 64
+    cfg.train.save_frequence = 1
+    cfg.freeze()
+    tr = BCNNTrainer(cfg)
+    tr.train()
+    assert len(tr.performance_meters['train']['loss'].values) == 1
+    assert os.path.isfile(os.path.join(tr.log_root, 'BCNN_epoch_1.pth'))
+    sd = torch.load(os.path.join(tr.log_root, 'BCNN_epoch_1.pth'), map_location='cpu')
+    assert 'classifier.weight' in sd and not any(k.startswith('module.') for k in sd)

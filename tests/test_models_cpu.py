@@ -106,3 +106,39 @@ def test_forward_on_cpu_fails_loudly():
     m = MODEL.get('BCNN')(CfgNode(dict(num_classes=3)))
     with pytest.raises(HawkeyeHipError):
         m(torch.randn(1, 3, 64, 64))
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/configs'), reason='reference checkout not present')
+def test_reference_yaml_configs_load_unchanged():
+    """Every yaml of the reference loads through the yacs-compatible CfgNode (config.py:13-17 semantics)."""
+    import glob
+    from hawkeye_amd.config import load_config
+    files = sorted(glob.glob('/root/reference/configs/*.yaml'))
+    assert len(files) >= 20
+    for f in files:
+        cfg = load_config(f)
+        assert cfg.is_frozen() and 'name' in cfg.model and 'experiment' in cfg
+    cfg = load_config('/root/reference/configs/BCNN_S2.yaml')
+    assert cfg.model.stage == 2 and cfg.dataset.transformer.image_size == 448 and cfg.experiment.cuda == [0]
+
+
+def test_example_trainers_keep_the_reference_optimizer_groups():
+    """Optimiser param-group logic of the per-method trainers, without running them (no GPU here)."""
+    import hawkeye_amd.examples.APCNN as EA
+    import hawkeye_amd.examples.MPN as EM
+
+    class Shell:           # minimal stand-in for a constructed Trainer
+        pass
+
+    m = MODEL.get('APCNN')(CfgNode(CONFIGS['APCNN']))
+    sh = Shell()
+    sh.model = m
+    sh.get_model_module = lambda model=None: m
+    opt = EA.APCNNTrainer.get_optimizer(sh, CfgNode(dict(lr=0.0005, weight_decay=0.0005)))
+    n_head = sum(p.numel() for k in list(m.children())[7:] for p in k.parameters())
+    assert sum(p.numel() for p in opt.param_groups[0]['params']) == n_head
+    assert opt.param_groups[1]['lr'] == pytest.approx(0.00005)
+    m = MODEL.get('MPN')(CfgNode(CONFIGS['MPN']))
+    sh.model = m
+    opt = EM.MPNTrainer.get_optimizer(sh, CfgNode(dict(lr=8e-5, weight_decay=2e-5)))
+    assert [g['lr'] for g in opt.param_groups] == [8e-5, 8e-5, pytest.approx(1.6e-5)]
