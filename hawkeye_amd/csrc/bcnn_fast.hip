@@ -34,7 +34,8 @@ struct GramEpi {
     int offdiag;
     int l31, lh;
     __device__ __forceinline__ float direct(float v, int r) {
-        const float z = sqrtf(fmaf(v, inv_m, 1e-5f)) * inv;
+        // v_sqrt_f32 (1 ulp, argument >= 1e-5: no denormal/negative handling needed) - parity budget is 1e-4
+        const float z = __builtin_amdgcn_sqrtf(fmaf(v, inv_m, 1e-5f)) * inv;
         const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         yb[(long long)i * C + j0 + l31] = z;
         return z;
@@ -50,14 +51,31 @@ struct GramEpi {
 // k-pairs of every 8-wide step alternate between them): a dependent f32 MFMA chain tolerates no issue slot between
 // its links (MI355X_MICROARCH.md: +43 cycles for the first extra state), and the epilogue of the previous tile is
 // interleaved here; with two chains the matrix pipe always has the other chain's instruction to run.
-template <int HW, bool HASPREV>
+// The staged next panel (st[], fetched before the loop) is written into its free LDS buffer from INSIDE the k loop,
+// one 16-B store per step in the second half of the tile, so that neither the wait for the global loads nor the LDS
+// write pass sits between two tiles: the tile boundary is a bare barrier.
+template <int HW, bool HASPREV, int NST>
 __device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x16& acc0, f32x16& acc1, f32x16& prev,
-                                          GramEpi& ep, int lh) {
+                                          GramEpi& ep, int lh, const f32x4 (&st)[NST], f32x4* dst, bool do_write,
+                                          int tid) {
     constexpr int KS = HW / 8;
+    constexpr int N4 = 16 * HW;
+    constexpr int WS = (KS - NST - 1) > 0 ? (KS - NST - 1) : 0;   // first step that writes
+    // operand fragments are fetched one step ahead: the 4 MFMAs of a step block the wave's issue for ~130 cycles
+    // (dependent pairs), so reads issued after them would land too late for the next step
+    f32x4 a = *reinterpret_cast<const f32x4*>(Ap);
+    f32x4 q = *reinterpret_cast<const f32x4*>(Bp);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(Ap + 8 * s);
-        const f32x4 q = *reinterpret_cast<const f32x4*>(Bp + 8 * s);
+        f32x4 an = a, qn = q;
+        if (s + 1 < KS) {
+            an = *reinterpret_cast<const f32x4*>(Ap + 8 * (s + 1));
+            qn = *reinterpret_cast<const f32x4*>(Bp + 8 * (s + 1));
+        }
+        if (s >= WS && s - WS < NST) {
+            const int f = tid + 256 * (s - WS);
+            if (do_write && f < N4) dst[f] = st[s - WS];
+        }
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], q[0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], q[2], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[1], acc0, 0, 0, 0);
@@ -66,6 +84,8 @@ __device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x
             if (s < 16) prev[s] = ep.direct(prev[s], s);
             else if (s < 20) ep.mirror(prev, s - 16);
         }
+        a = an;
+        q = qn;
     }
     if (HW % 8 == 4) {   // k = 8*KS .. +3: lanes 0-31 take the first two, lanes 32-63 the last two
         const float2 a = *reinterpret_cast<const float2*>(Ap + 8 * KS - 2 * lh);
@@ -161,23 +181,18 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-            if (has_prev) gram_tile<HW, true>(Ap, Bp, acc0, acc1, prev, ep, lh);
-            else gram_tile<HW, false>(Ap, Bp, acc0, acc1, prev, ep, lh);
-
-            if (next_blk >= 0) {
-                f32x4* dst = reinterpret_cast<f32x4*>(lds + n_idx * PANEL);
-#pragma unroll
-                for (int u = 0; u < NST; ++u) {
-                    const int f = tid + 256 * u;
-                    if (f < N4) dst[f] = st[u];
-                }
-            }
+            f32x4* dst = reinterpret_cast<f32x4*>(lds + n_idx * PANEL);
+            if (has_prev) gram_tile<HW, true, NST>(Ap, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
+            else gram_tile<HW, false, NST>(Ap, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
             prev = acc0 + acc1;
             ep.i0 = I * 64 + wm * 32;
             ep.j0 = J * 64 + wn * 32;
             ep.offdiag = (I != J);
             has_prev = true;
-            __syncthreads();
+            // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for every epilogue store of this tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             if (next_blk >= 0) {
                 if (newrow) { a_idx = n_idx; b_idx = n_idx; }
                 else b_idx = n_idx;
