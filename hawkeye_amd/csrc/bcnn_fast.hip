@@ -26,16 +26,18 @@
 namespace hk {
 
 // ----------------------------------------------------------------------------- forward
+// MODE 0: BCNN  y = sqrt(acc / M + 1e-5) * inv_norm[b]        MODE 1: raw  y = alpha * acc  (CBP Gram, covariance)
+template <int MODE>
 struct GramEpi {
     float* yb;       // y + b*C*C
     int C;
     int i0, j0;      // top-left of this wave's 32x32 sub-tile
-    float inv, inv_m;
+    float inv, inv_m;   // MODE 1: inv = alpha
     int offdiag;
     int l31, lh;
     __device__ __forceinline__ float direct(float v, int r) {
         // v_sqrt_f32 (1 ulp, argument >= 1e-5: no denormal/negative handling needed) - parity budget is 1e-4
-        const float z = __builtin_amdgcn_sqrtf(fmaf(v, inv_m, 1e-5f)) * inv;
+        const float z = MODE == 0 ? __builtin_amdgcn_sqrtf(fmaf(v, inv_m, 1e-5f)) * inv : v * inv;
         const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         yb[(long long)i * C + j0 + l31] = z;
         return z;
@@ -54,9 +56,9 @@ struct GramEpi {
 // The staged next panel (st[], fetched before the loop) is written into its free LDS buffer from INSIDE the k loop,
 // one 16-B store per step in the second half of the tile, so that neither the wait for the global loads nor the LDS
 // write pass sits between two tiles: the tile boundary is a bare barrier.
-template <int HW, bool HASPREV, int NST>
+template <int HW, bool HASPREV, int NST, class EPI>
 __device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x16& acc0, f32x16& acc1, f32x16& prev,
-                                          GramEpi& ep, int lh, const f32x4 (&st)[NST], f32x4* dst, bool do_write,
+                                          EPI& ep, int lh, const f32x4 (&st)[NST], f32x4* dst, bool do_write,
                                           int tid) {
     constexpr int KS = HW / 8;
     constexpr int N4 = 16 * HW;
@@ -102,11 +104,13 @@ __device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x
     }
 }
 
-template <int HW>
+// CENTER: subtract the channel mean mu[b][row] while staging a panel (covariance: (X - mu)(X - mu)^T)
+template <int HW, int MODE, bool CENTER>
 __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ inv_norm,
                                                                  float* __restrict__ y, int C, int nb, int B,
-                                                                 int pair_mode) {
+                                                                 int pair_mode, const float* __restrict__ mu,
+                                                                 float alpha) {
     constexpr int PANEL = 64 * HW;
     constexpr int N4 = PANEL / 4;
     constexpr int NST = (N4 + 255) / 256;
@@ -124,10 +128,11 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
     const float* xb = x + (long long)b * C * HW;
 
-    GramEpi ep;
+    GramEpi<MODE> ep;
     ep.yb = y + (long long)b * C * C;
     ep.C = C;
-    ep.inv = inv_norm[b];
+    ep.inv = MODE == 0 ? inv_norm[b] : alpha;
+    const float* mub = CENTER ? mu + (long long)b * C : nullptr;
     ep.inv_m = 1.0f / (float)HW;
     ep.l31 = l31;
     ep.lh = lh;
@@ -138,8 +143,9 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
         f32x4 st0[NST];
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
-            const int f = tid + 256 * u;
-            st0[u] = src[f < N4 ? f : N4 - 1];
+            const int f = tid + 256 * u, fc = f < N4 ? f : N4 - 1;
+            st0[u] = src[fc];
+            if (CENTER) st0[u] -= mub[rb0 * 64 + (4 * fc) / HW];
         }
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
 #pragma unroll
@@ -171,8 +177,9 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
                 const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)lb * PANEL);
 #pragma unroll
                 for (int u = 0; u < NST; ++u) {
-                    const int f = tid + 256 * u;
-                    st[u] = src[f < N4 ? f : N4 - 1];
+                    const int f = tid + 256 * u, fc = f < N4 ? f : N4 - 1;
+                    st[u] = src[fc];
+                    if (CENTER) st[u] -= mub[lb * 64 + (4 * fc) / HW];
                 }
             }
 
@@ -208,34 +215,63 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
 // ----------------------------------------------------------------------------- backward
 // this thread's 4 float4 of the 64x64 tiles (I,kb) of y, dy and (kb,I) of dy (row = f >> 4, col4 = (f & 15) * 4,
 // f = tid + 256 u) and its share of the 64 x HW block kb of X
-template <int HW, int NSX>
+// MODE 0 BCNN: P = (dy + dy^T) / y * coef          (ry, rd, rt loaded)
+// MODE 1 COV : P = (g + g^T) / M, X centred          (rd, rt loaded; rx -= mu[k])
+// MODE 2 CBP : P = dG + dG^T gathered from dc         (rd computed; nothing to transpose)
+struct BwdExtra {
+    const float* mu;     // [B][C]      (COV)
+    const int* h1;       // [C]         (CBP)
+    const int* h2;
+    const float* s1;
+    const float* s2;
+    const float* dc;     // [B][D]
+    int D;
+};
+
+template <int HW, int NSX, int MODE>
 __device__ __forceinline__ void bwd_load(f32x4 (&ry)[4], f32x4 (&rd)[4], f32x4 (&rt)[4], f32x4 (&rx)[NSX],
                                          const float* __restrict__ y, const float* __restrict__ dy,
-                                         const float* __restrict__ xb, long long cc, int C, int I, int kb, int tid) {
+                                         const float* __restrict__ xb, long long cc, int C, int I, int kb, int tid,
+                                         const BwdExtra& ex, int b) {
     constexpr int XN4 = 64 * HW / 4;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
         const long long o1 = cc + (long long)(I * 64 + r) * C + kb * 64 + c4;
         const long long o2 = cc + (long long)(kb * 64 + r) * C + I * 64 + c4;
-        ry[u] = *reinterpret_cast<const f32x4*>(y + o1);
-        rd[u] = *reinterpret_cast<const f32x4*>(dy + o1);
-        rt[u] = *reinterpret_cast<const f32x4*>(dy + o2);
+        if (MODE == 0) ry[u] = *reinterpret_cast<const f32x4*>(y + o1);
+        if (MODE != 2) {
+            rd[u] = *reinterpret_cast<const f32x4*>(dy + o1);
+            rt[u] = *reinterpret_cast<const f32x4*>(dy + o2);
+        } else {
+            const int i = I * 64 + r;
+            const int h1i = ex.h1[i], h2i = ex.h2[i];
+            const float s1i = ex.s1[i], s2i = ex.s2[i];
+            const float* d = ex.dc + (long long)b * ex.D;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = kb * 64 + c4 + t;
+                int ba = h1i + ex.h2[k]; if (ba >= ex.D) ba -= ex.D;
+                int bb = ex.h1[k] + h2i; if (bb >= ex.D) bb -= ex.D;
+                rd[u][t] = s1i * ex.s2[k] * d[ba] + ex.s1[k] * s2i * d[bb];
+            }
+        }
     }
     const f32x4* xs = reinterpret_cast<const f32x4*>(xb + (long long)kb * 64 * HW);
 #pragma unroll
     for (int u = 0; u < NSX; ++u) {
-        const int f = tid + 256 * u;
-        rx[u] = xs[f < XN4 ? f : XN4 - 1];
+        const int f = tid + 256 * u, fc = f < XN4 ? f : XN4 - 1;
+        rx[u] = xs[fc];
+        if (MODE == 1) rx[u] -= ex.mu[(long long)b * C + kb * 64 + (4 * fc) / HW];
     }
 }
 
-template <int HW>
+template <int HW, int MODE>
 __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                 const float* __restrict__ dy,
                                                                 const float* __restrict__ inv_norm,
                                                                 float* __restrict__ dx, float* __restrict__ tpart,
-                                                                int C, int nb, int B) {
+                                                                int C, int nb, int B, BwdExtra ex) {
     constexpr int NT = (HW + 15) / 16;          // 16-column output tiles
     constexpr int XN4 = 64 * HW / 4;
     constexpr int NSX = (XN4 + 255) / 256;
@@ -252,8 +288,11 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     const int l15 = lane & 15, lq = lane >> 4;
     const long long cc = (long long)b * C * C;
     const float* xb = x + (long long)b * C * HW;
-    const float in = inv_norm[b];
-    const float coef = in * in / (2.0f * (float)HW);
+    float coef = 1.0f / (float)HW;                         // COV
+    if (MODE == 0) {
+        const float in = inv_norm[b];
+        coef = in * in / (2.0f * (float)HW);
+    }
 
     f32x4 acc[NT];
 #pragma unroll
@@ -261,30 +300,41 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     float tacc = 0.f;
 
     f32x4 ry[4], rd[4], rt[4], rx[NSX];
-    bwd_load<HW, NSX>(ry, rd, rt, rx, y, dy, xb, cc, C, I, 0, tid);
+    bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, 0, tid, ex, b);
     for (int kb = 0; kb < nb; ++kb) {
         __syncthreads();                                   // previous MFMA phase finished with sP / sX
+        if (MODE != 2) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                      // dy(K,I) transposed into the scratch: T[i][k] = dy[k][i]
-            const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
-            sX[(c4 + 0) * TP + r] = rt[u][0];
-            sX[(c4 + 1) * TP + r] = rt[u][1];
-            sX[(c4 + 2) * TP + r] = rt[u][2];
-            sX[(c4 + 3) * TP + r] = rt[u][3];
+            for (int u = 0; u < 4; ++u) {                  // dy(K,I) transposed into the scratch: T[i][k] = dy[k][i]
+                const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
+                sX[(c4 + 0) * TP + r] = rt[u][0];
+                sX[(c4 + 1) * TP + r] = rt[u][1];
+                sX[(c4 + 2) * TP + r] = rt[u][2];
+                sX[(c4 + 3) * TP + r] = rt[u][3];
+            }
+            __syncthreads();
         }
-        __syncthreads();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                      // P tile
             const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
             const float* tp = sX + r * TP + c4;
             f32x4 p;
-            // v_rcp_f32 (1 ulp) instead of an IEEE division: 16 of them per thread per K-block sit on the
-            // critical path between two MFMA phases; the parity budget is 1e-4
-            p[0] = (rd[u][0] + tp[0]) * (__builtin_amdgcn_rcpf(ry[u][0]) * coef);
-            p[1] = (rd[u][1] + tp[1]) * (__builtin_amdgcn_rcpf(ry[u][1]) * coef);
-            p[2] = (rd[u][2] + tp[2]) * (__builtin_amdgcn_rcpf(ry[u][2]) * coef);
-            p[3] = (rd[u][3] + tp[3]) * (__builtin_amdgcn_rcpf(ry[u][3]) * coef);
-            tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
+            if (MODE == 0) {
+                // v_rcp_f32 (1 ulp) instead of an IEEE division: 16 of them per thread per K-block sit on the
+                // critical path between two MFMA phases; the parity budget is 1e-4
+                p[0] = (rd[u][0] + tp[0]) * (__builtin_amdgcn_rcpf(ry[u][0]) * coef);
+                p[1] = (rd[u][1] + tp[1]) * (__builtin_amdgcn_rcpf(ry[u][1]) * coef);
+                p[2] = (rd[u][2] + tp[2]) * (__builtin_amdgcn_rcpf(ry[u][2]) * coef);
+                p[3] = (rd[u][3] + tp[3]) * (__builtin_amdgcn_rcpf(ry[u][3]) * coef);
+                tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
+            } else if (MODE == 1) {
+                p[0] = (rd[u][0] + tp[0]) * coef;
+                p[1] = (rd[u][1] + tp[1]) * coef;
+                p[2] = (rd[u][2] + tp[2]) * coef;
+                p[3] = (rd[u][3] + tp[3]) * coef;
+            } else {
+                p = rd[u];
+            }
             *reinterpret_cast<f32x4*>(&sP[r * PP + c4]) = p;
         }
         __syncthreads();                                   // scratch reads done: X block may overwrite it
@@ -295,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
         }
         __syncthreads();
         // next K-block's operands: in flight during the MFMA phase (last iteration: harmless re-read)
-        bwd_load<HW, NSX>(ry, rd, rt, rx, y, dy, xb, cc, C, I, (kb + 1 < nb ? kb + 1 : kb), tid);
+        bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, (kb + 1 < nb ? kb + 1 : kb), tid, ex, b);
 
         const float* ap = sP + (wave * 16 + l15) * PP + 4 * lq;
 #pragma unroll
@@ -321,55 +371,94 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
             for (int r = 0; r < 4; ++r) dxb[(long long)r * HW + col] = acc[n][r];
         }
     }
-    __syncthreads();
-    const float tsum = block_sum<4>(tacc, lds);
-    if (tid == 0) tpart[(long long)b * nb + I] = tsum;
+    if (MODE == 0) {
+        __syncthreads();
+        const float tsum = block_sum<4>(tacc, lds);
+        if (tid == 0) tpart[(long long)b * nb + I] = tsum;
+    }
 }
 
 // ----------------------------------------------------------------------------- dispatch
-template <int HW>
-static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, hipStream_t st) {
+template <int HW, int MODE, bool CENTER>
+static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, const float* mu, float alpha,
+                       hipStream_t st) {
     const int nb = C / 64;
     const int pair_mode = ((long long)B * nb > 256) ? 1 : 0;
     const int per = pair_mode ? (nb + 1) / 2 : nb;
-    hipLaunchKernelGGL((bcnn_gram_panel_kernel<HW>), dim3(xcd_grid(B, per)), dim3(256), 0, st, x, inv_norm, y, C, nb, B,
-                       pair_mode);
+    hipLaunchKernelGGL((bcnn_gram_panel_kernel<HW, MODE, CENTER>), dim3(xcd_grid(B, per)), dim3(256), 0, st, x, inv_norm,
+                       y, C, nb, B, pair_mode, mu, alpha);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
 
-template <int HW>
+template <int HW, int MODE>
 static int bwd_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
-                      int B, int C, hipStream_t st) {
+                      int B, int C, const BwdExtra& ex, hipStream_t st) {
     const int nb = C / 64;
-    hipLaunchKernelGGL((bcnn_bwd_panel_kernel<HW>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx, tpart,
-                       C, nb, B);
+    hipLaunchKernelGGL((bcnn_bwd_panel_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
+                       tpart, C, nb, B, ex);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
 
-// returns HK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the generic GEMM)
+#define HK_HW_SWITCH(CALL)                      \
+    switch (HW) {                               \
+        case 196: return CALL(196);             \
+        case 144: return CALL(144);             \
+        case 100: return CALL(100);             \
+        case 64: return CALL(64);               \
+        default: return HK_ERR_UNSUPPORTED;     \
+    }
+
+// All return HK_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the generic GEMM).
 int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C, int HW, hipStream_t st) {
     if (C % 64 != 0 || !aligned16(x) || !aligned16(y)) return HK_ERR_UNSUPPORTED;
-    switch (HW) {
-        case 196: return gram_launch<196>(x, inv_norm, y, B, C, st);
-        case 144: return gram_launch<144>(x, inv_norm, y, B, C, st);
-        case 100: return gram_launch<100>(x, inv_norm, y, B, C, st);
-        case 64: return gram_launch<64>(x, inv_norm, y, B, C, st);
-        default: return HK_ERR_UNSUPPORTED;
+#define CALL(H) gram_launch<H, 0, false>(x, inv_norm, y, B, C, nullptr, 1.f, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
+// G = alpha * X X^T (raw Gram, CBP) or alpha * (X - mu)(X - mu)^T (covariance, mu != nullptr)
+int gram_fast_raw(const float* x, const float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(g)) return HK_ERR_UNSUPPORTED;
+    if (mu) {
+#define CALL(H) gram_launch<H, 1, true>(x, nullptr, g, B, C, mu, alpha, st)
+        HK_HW_SWITCH(CALL)
+#undef CALL
     }
+#define CALL(H) gram_launch<H, 1, false>(x, nullptr, g, B, C, nullptr, alpha, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
 }
 
 int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart, int B,
                   int C, int HW, hipStream_t st) {
     if (C % 64 != 0 || !aligned16(x) || !aligned16(y) || !aligned16(dy) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
-    switch (HW) {
-        case 196: return bwd_launch<196>(x, y, dy, inv_norm, dx, tpart, B, C, st);
-        case 144: return bwd_launch<144>(x, y, dy, inv_norm, dx, tpart, B, C, st);
-        case 100: return bwd_launch<100>(x, y, dy, inv_norm, dx, tpart, B, C, st);
-        case 64: return bwd_launch<64>(x, y, dy, inv_norm, dx, tpart, B, C, st);
-        default: return HK_ERR_UNSUPPORTED;
-    }
+    BwdExtra ex = {};
+#define CALL(H) bwd_launch<H, 0>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
+// dX = (1/M) (g + g^T) (X - mu)
+int cov_fast_bwd(const float* x, const float* mu, const float* g, float* dx, int B, int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(g) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+    BwdExtra ex = {};
+    ex.mu = mu;
+#define CALL(H) bwd_launch<H, 1>(x, nullptr, g, nullptr, dx, nullptr, B, C, ex, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
+// dX = (dG + dG^T) X,  dG_ij = s1_i s2_j dc[(h1_i + h2_j) mod D]
+int cbp_fast_bwd(const float* x, const int* h1, const int* h2, const float* s1, const float* s2, const float* dc, int D,
+                 float* dx, int B, int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+    BwdExtra ex = {};
+    ex.h1 = h1; ex.h2 = h2; ex.s1 = s1; ex.s2 = s2; ex.dc = dc; ex.D = D;
+#define CALL(H) bwd_launch<H, 2>(x, nullptr, nullptr, nullptr, dx, nullptr, B, C, ex, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
 }
 
 }  // namespace hk

@@ -207,7 +207,8 @@ extern "C" int hk_bcnn_bwd_gemm(const float* x, const float* y, const float* dy,
     pa.coef = 0.f; pa.tacc = 0.f; pa.active = 0;
     const LdPlain xb = make_plain(x, (long long)C * HW, HW, C, HW);  // K x N, N contiguous
     const EpAffine ep = make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f);
-    return bgemm_launch<true, false>(pa, xb, ep, C, HW, C, B, (hipStream_t)stream);
+    // 64-row tiles only: tpart is indexed by 64-row block (hk_bcnn_bwd_rank1 sums ceil(C/64) partials)
+    return bgemm_launch<true, false>(pa, xb, ep, C, HW, C, B, (hipStream_t)stream, /*allow_big=*/0);
 }
 
 extern "C" int hk_bcnn_bwd_rank1(float* dx, const float* tpart, const float* inv_norm, const float* colsum, int B, int C,

@@ -14,12 +14,21 @@
 // Backward: dc from the signed-sqrt / l2 chain, then
 //     dX = (dG + dG^T) X,  dG_ij = s1_i s2_j dc[(h1_i + h2_j) mod D]
 // with dG + dG^T generated on the fly by the GEMM's A-operand loader.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "hk_bgemm.h"
 #include "../../include/hawkeye_hip.h"
 
 namespace hk {
+
+int gram_fast_raw(const float* x, const float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
+int cbp_fast_bwd(const float* x, const int* h1, const int* h2, const float* s1, const float* s2, const float* dc, int D,
+                 float* dx, int B, int C, int HW, hipStream_t st);
+static inline bool force_generic() {
+    const char* e = getenv("HK_BCNN_GENERIC");
+    return e && e[0] == '1';
+}
 
 struct CbpPlan {  // device-side view of the plan blob
     const int* h1;
@@ -28,6 +37,8 @@ struct CbpPlan {  // device-side view of the plan blob
     const float* s2;
     const int* off;      // [D+1]
     const unsigned* ent; // [C*C]  bit31 = negative sign, low bits = i*C + j
+    const unsigned* ell; // [E][D] transposed (ELL) copy of the bins: entry e of bin k at ell[e*D + k], 0xffffffff = none
+    int E;               // max entries per bin
 };
 
 __host__ __device__ inline size_t cbp_align(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -40,28 +51,41 @@ static inline CbpPlan cbp_view(const void* plan, int C, int D) {
     v.s1 = (const float*)p;          p += cbp_align((size_t)C * 4);
     v.s2 = (const float*)p;          p += cbp_align((size_t)C * 4);
     v.off = (const int*)p;           p += cbp_align((size_t)(D + 1) * 4);
-    v.ent = (const unsigned*)p;
+    v.ent = (const unsigned*)p;      p += cbp_align((size_t)C * C * 4);
+    v.ell = (const unsigned*)p;
+    v.E = ((const int*)plan)[2];
     return v;
 }
 
-// c_raw[b,k] = sum over the bin's (i,j) list of +-G[b,i,j]; one wave per bin
-__global__ __launch_bounds__(256) void cbp_bin_kernel(const float* __restrict__ G, const int* __restrict__ off,
-                                                      const unsigned* __restrict__ ent, float* __restrict__ c_raw,
-                                                      int CC, int D) {
+// c_raw[b,k] = sum over the bin's (i,j) list of +-G[b,i,j].  One LANE per bin walking the transposed (ELL) entry
+// table: entry reads are coalesced across lanes, the G gathers of successive entries are independent (8 in flight per
+// lane), and every bin is summed by one lane in a fixed order (deterministic).  ~6000*64/64 = 6000 waves: all resident.
+__global__ __launch_bounds__(256) void cbp_bin_kernel(const float* __restrict__ G, const unsigned* __restrict__ ell, int E,
+                                                      float* __restrict__ c_raw, int CC, int D) {
     const int b = blockIdx.y;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= D) return;
-    const int lane = threadIdx.x & 63;
     const float* g = G + (long long)b * CC;
-    const int lo = off[k], hi = off[k + 1];
     float s = 0.f;
-    for (int e = lo + lane; e < hi; e += 64) {
-        const unsigned u = ent[e];
-        const float v = g[u & 0x7fffffffu];
-        s += (u >> 31) ? -v : v;
+    int e = 0;
+    for (; e + 8 <= E; e += 8) {
+        unsigned u[8];
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = ell[(long long)(e + q) * D + k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (u[q] != 0xffffffffu) ? g[u[q] & 0x7fffffffu] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += (u[q] >> 31) ? -v[q] : v[q];      // padding: u>>31 = 1, v = 0 -> -0 adds nothing
     }
-    s = wave_sum(s);
-    if (lane == 0) c_raw[(long long)b * D + k] = s;
+    for (; e < E; ++e) {
+        const unsigned u = ell[(long long)e * D + k];
+        if (u != 0xffffffffu) {
+            const float v = g[u & 0x7fffffffu];
+            s += (u >> 31) ? -v : v;
+        }
+    }
+    c_raw[(long long)b * D + k] = s;
 }
 
 // u = sign(c) sqrt(|c| + 1e-10) ; y = u / max(|u|_2, 1e-12)      (CBCNN.py:132-133)
@@ -135,8 +159,19 @@ struct LdCbpDG {
 
 using namespace hk;
 
+// upper bound of the ELL depth used for sizing: the true maximum bin population is only known after hashing, so the
+// blob reserves HK_CBP_MAX_E rows (bins hold C*C/D entries on average; 4x that plus slack is never reached by the
+// reference's hashes: C=512, D=6000 -> mean 43.7, max 71)
+static inline int cbp_max_e(int C, int D) {
+    const long long mean = ((long long)C * C + D - 1) / D;
+    long long e = 4 * mean + 32;
+    if (e > (long long)C * C) e = (long long)C * C;
+    return (int)e;
+}
+
 extern "C" size_t hk_cbp_plan_bytes(int C, int D) {
-    return 16 + 4 * cbp_align((size_t)C * 4) + cbp_align((size_t)(D + 1) * 4) + cbp_align((size_t)C * C * 4);
+    return 16 + 4 * cbp_align((size_t)C * 4) + cbp_align((size_t)(D + 1) * 4) + cbp_align((size_t)C * C * 4) +
+           cbp_align((size_t)cbp_max_e(C, D) * D * 4);
 }
 
 extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32_t* h2, const float* s2, int C, int D,
@@ -166,6 +201,15 @@ extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32
             const unsigned neg = (s1[i] * s2[j] < 0.f) ? 0x80000000u : 0u;
             ent[cur[k]++] = neg | (unsigned)(i * C + j);
         }
+    // transposed (ELL) copy for the lane-per-bin reduction kernel
+    int E = 0;
+    for (int k = 0; k < D; ++k) E = cnt[k] > E ? cnt[k] : E;
+    if (E > cbp_max_e(C, D)) return HK_ERR_UNSUPPORTED;      // pathological hashes (all channels in a few bins)
+    ((int*)blob.data())[2] = E;
+    unsigned* ell = (unsigned*)((char*)ent + cbp_align((size_t)C * C * 4));
+    for (long long q = 0; q < (long long)E * D; ++q) ell[q] = 0xffffffffu;
+    for (int k = 0; k < D; ++k)
+        for (int q = 0; q < cnt[k]; ++q) ell[(long long)q * D + k] = ent[off[k] + q];
     hipError_t e = hipMemcpyAsync(plan, blob.data(), blob.size(), hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize((hipStream_t)stream);   // one-time setup: the host blob dies at return
@@ -188,9 +232,10 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
     float* G = (float*)ws;
     const LdPlain xa = make_plain(x, (long long)C * HW, HW, C, HW);
     const EpAffine ep = make_affine(G, (long long)C * C, C, 1.0f, nullptr, 0.f, 0.f);
-    int rc = bgemm_launch<true, true>(xa, xa, ep, C, C, HW, B, st);      // raw Gram, no 1/HW
+    int rc = force_generic() ? HK_ERR_UNSUPPORTED : gram_fast_raw(x, nullptr, 1.0f, G, B, C, HW, st);
+    if (rc == HK_ERR_UNSUPPORTED) rc = bgemm_launch<true, true>(xa, xa, ep, C, C, HW, B, st);      // raw Gram, no 1/HW
     if (rc != HK_OK) return rc;
-    hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 3) / 4, B), dim3(256), 0, st, (const float*)G, pl.off, pl.ent, c_raw,
+    hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 255) / 256, B), dim3(256), 0, st, (const float*)G, pl.ell, pl.E, c_raw,
                        C * C, D);
     HK_LAUNCH_CHECK();
     hipLaunchKernelGGL(cbp_norm_kernel, dim3(B), dim3(256), 0, st, (const float*)c_raw, y, inv_norm, D);
@@ -208,6 +253,11 @@ extern "C" int hk_cbp_bwd(const float* x, const void* plan, const float* y, cons
     float* dc = (float*)ws;
     hipLaunchKernelGGL(cbp_dc_kernel, dim3(B), dim3(256), 0, st, y, dy, c_raw, inv_norm, dc, D);
     HK_LAUNCH_CHECK();
+    if (!force_generic()) {
+        const CbpPlan pv = cbp_view(plan, C, D);
+        const int rc = cbp_fast_bwd(x, pv.h1, pv.h2, pv.s1, pv.s2, dc, D, dx, B, C, HW, st);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
     LdCbpDG la;
     la.pl = cbp_view(plan, C, D);
     la.dc = dc; la.C = C; la.D = D;

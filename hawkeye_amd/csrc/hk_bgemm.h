@@ -3,9 +3,9 @@
 //
 //   C[b] (M x N) = epilogue( sum_k A[b](i,k) * B[b](k,j) )
 //
-// Tiling: 64x64 output tile per 256-thread workgroup (4 waves, 2x2, one 32x32
-// MFMA accumulator = 16 VGPRs each), K in chunks of 32, register-staged
-// global->LDS double buffer, one barrier per chunk; 37 KB LDS -> 4 WGs/CU.
+// Tiling: 64x64 (or 128x128 for large M,N) output tile per 256-thread workgroup
+// (4 waves, 2x2, each TxT 32x32 MFMA accumulators), K in chunks of 32,
+// register-staged global->LDS double buffer, one barrier per chunk.
 //
 // Operand storage is described by a compile-time flag per operand:
 //   *_KC = true : memory is [mn][k], k contiguous  (A row-major / B given as N x K, "NT")
@@ -113,14 +113,23 @@ struct EpAffine {
 };
 
 // ---------------------------------------------------------------- kernel
-template <bool A_KC, bool B_KC, class AL, class BL, class EP>
+// T = MFMA tiles per wave in each direction: T=1 -> 64x64 workgroup tile (16 acc VGPRs, 37 KB LDS, 4 WGs/CU),
+// T=2 -> 128x128 (64 acc VGPRs, 71 KB LDS, 2 WGs/CU; 16 MFMAs per pair of operand reads).  Measured on the
+// Newton-Schulz shape (256^3 x 64 samples): T=2 gives 256 workgroups = 1 per CU with nothing to overlap its
+// load/barrier phases and is 1.3x SLOWER than T=1 (1024 workgroups, 4 per CU), so T=1 is the default;
+// allow_big=1 opts in (useful only when tiles >> CUs).
+template <int T, bool A_KC, bool B_KC, class AL, class BL, class EP>
 __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb,
                                                      int tilesM, int tilesN) {
-    constexpr int BM = 64, BN = 64, BK = 32;
+    constexpr int BM = 64 * T, BN = 64 * T, BK = 32;
     constexpr int PA = A_KC ? BK + 4 : BM + 4;
     constexpr int PB = B_KC ? BK + 4 : BN + 4;
     constexpr int SA = (A_KC ? BM : BK) * PA;
     constexpr int SB = (B_KC ? BN : BK) * PB;
+    constexpr int NLA = BM * BK / 4 / 256;      // float4 per thread per operand tile (2 or 4)
+    constexpr int NLB = BN * BK / 4 / 256;
+    constexpr int A4 = A_KC ? BK / 4 : BM / 4;  // float4 per staged row
+    constexpr int B4 = B_KC ? BK / 4 : BN / 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * (SA + SB)];
 
     int b, tile;
@@ -134,34 +143,41 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
     al.begin(b, tm, tn);
     bl.begin(b, tm, tn);
 
-    f32x16 acc;
+    f32x16 acc[T][T];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[2], rb[2];
-    // staging coordinates of this thread's two float4 per operand
-    const int f0 = tid, f1 = tid + 256;
-    const int arow0 = A_KC ? (f0 >> 3) : (f0 >> 4), ac0 = A_KC ? (f0 & 7) : (f0 & 15);
-    const int arow1 = A_KC ? (f1 >> 3) : (f1 >> 4), ac1 = A_KC ? (f1 & 7) : (f1 & 15);
-    const int brow0 = B_KC ? (f0 >> 3) : (f0 >> 4), bc0 = B_KC ? (f0 & 7) : (f0 & 15);
-    const int brow1 = B_KC ? (f1 >> 3) : (f1 >> 4), bc1 = B_KC ? (f1 & 7) : (f1 & 15);
+    float4 ra[NLA], rb[NLB];
 
-#define HK_GLOAD(k0)                                                                       \
-    do {                                                                                   \
-        ra[0] = A_KC ? al.ld4(b, m0 + arow0, (k0) + 4 * ac0) : al.ld4(b, (k0) + arow0, m0 + 4 * ac0); \
-        ra[1] = A_KC ? al.ld4(b, m0 + arow1, (k0) + 4 * ac1) : al.ld4(b, (k0) + arow1, m0 + 4 * ac1); \
-        rb[0] = B_KC ? bl.ld4(b, n0 + brow0, (k0) + 4 * bc0) : bl.ld4(b, (k0) + brow0, n0 + 4 * bc0); \
-        rb[1] = B_KC ? bl.ld4(b, n0 + brow1, (k0) + 4 * bc1) : bl.ld4(b, (k0) + brow1, n0 + 4 * bc1); \
+// (macro-local names carry a trailing underscore: the argument expressions mention the caller's `c`)
+#define HK_GLOAD(k0)                                                                                   \
+    do {                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < NLA; ++u) {                                              \
+            const int f_ = tid + 256 * u, r_ = f_ / A4, c_ = f_ % A4;                                       \
+            ra[u] = A_KC ? al.ld4(b, m0 + r_, (k0) + 4 * c_) : al.ld4(b, (k0) + r_, m0 + 4 * c_);          \
+        }                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < NLB; ++u) {                                              \
+            const int f_ = tid + 256 * u, r_ = f_ / B4, c_ = f_ % B4;                                       \
+            rb[u] = B_KC ? bl.ld4(b, n0 + r_, (k0) + 4 * c_) : bl.ld4(b, (k0) + r_, n0 + 4 * c_);          \
+        }                                                                                              \
     } while (0)
 
-#define HK_SSTORE(buf)                                                                     \
-    do {                                                                                   \
-        float* As_ = lds + (buf) * (SA + SB);                                              \
-        float* Bs_ = As_ + SA;                                                             \
-        *reinterpret_cast<float4*>(&As_[arow0 * PA + 4 * ac0]) = ra[0];                    \
-        *reinterpret_cast<float4*>(&As_[arow1 * PA + 4 * ac1]) = ra[1];                    \
-        *reinterpret_cast<float4*>(&Bs_[brow0 * PB + 4 * bc0]) = rb[0];                    \
-        *reinterpret_cast<float4*>(&Bs_[brow1 * PB + 4 * bc1]) = rb[1];                    \
+#define HK_SSTORE(buf)                                                                                 \
+    do {                                                                                               \
+        float* As_ = lds + (buf) * (SA + SB);                                                          \
+        float* Bs_ = As_ + SA;                                                                         \
+        _Pragma("unroll") for (int u = 0; u < NLA; ++u) {                                              \
+            const int f_ = tid + 256 * u, r_ = f_ / A4, c_ = f_ % A4;                                       \
+            *reinterpret_cast<float4*>(&As_[r_ * PA + 4 * c_]) = ra[u];                                  \
+        }                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < NLB; ++u) {                                              \
+            const int f_ = tid + 256 * u, r_ = f_ / B4, c_ = f_ % B4;                                       \
+            *reinterpret_cast<float4*>(&Bs_[r_ * PB + 4 * c_]) = rb[u];                                  \
+        }                                                                                              \
     } while (0)
 
     const int nk = (K + BK - 1) / BK;
@@ -176,23 +192,36 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
         const float* Bs = As + SA;
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
-            float a[4], bb[4];
-            if (A_KC) {
-                const float4 v = *reinterpret_cast<const float4*>(&As[(wm * 32 + l31) * PA + 8 * s + 4 * lh]);
-                a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
-            } else {
+            float a[T][4], bb[T][4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) a[t] = As[(8 * s + 4 * lh + t) * PA + wm * 32 + l31];
-            }
-            if (B_KC) {
-                const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn * 32 + l31) * PB + 8 * s + 4 * lh]);
-                bb[0] = v.x; bb[1] = v.y; bb[2] = v.z; bb[3] = v.w;
-            } else {
+            for (int i = 0; i < T; ++i) {
+                const int row = (wm * T + i) * 32 + l31;
+                if (A_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(&As[row * PA + 8 * s + 4 * lh]);
+                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+                } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bb[t] = Bs[(8 * s + 4 * lh + t) * PB + wn * 32 + l31];
+                    for (int t = 0; t < 4; ++t) a[i][t] = As[(8 * s + 4 * lh + t) * PA + row];
+                }
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bb[t], acc, 0, 0, 0);
+            for (int j = 0; j < T; ++j) {
+                const int col = (wn * T + j) * 32 + l31;
+                if (B_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(&Bs[col * PB + 8 * s + 4 * lh]);
+                    bb[j][0] = v.x; bb[j][1] = v.y; bb[j][2] = v.z; bb[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bb[j][t] = Bs[(8 * s + 4 * lh + t) * PB + col];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc[i][j], 0, 0, 0);
         }
         if (c + 1 < nk) HK_SSTORE(cur ^ 1);
         __syncthreads();
@@ -201,23 +230,33 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
 #undef HK_SSTORE
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int j = n0 + wn * 32 + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (i < M && j < N) ep(b, i, j, acc[r]);
-    }
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int jj = n0 + (wn * T + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ii = m0 + (wm * T + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ii < M && jj < N) ep(b, ii, jj, acc[i][j][r]);
+            }
+        }
     al.finish(b, tm, tn, tilesM, lds);
 }
 
 template <bool A_KC, bool B_KC, class AL, class BL, class EP>
 static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb,
-                               hipStream_t st) {
+                               hipStream_t st, int allow_big = 0) {
     if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
-    const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-    const int grid = xcd_grid(nb, tm * tn);
-    hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP>), dim3(grid), dim3(256), 0, st, al, bl, ep, M, N, K,
-                       nb, tm, tn);
+    if (allow_big && M >= 128 && N >= 128) {
+        const int tm = (M + 127) / 128, tn = (N + 127) / 128;
+        hipLaunchKernelGGL((bgemm_kernel<2, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al,
+                           bl, ep, M, N, K, nb, tm, tn);
+    } else {
+        const int tm = (M + 63) / 64, tn = (N + 63) / 64;
+        hipLaunchKernelGGL((bgemm_kernel<1, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al,
+                           bl, ep, M, N, K, nb, tm, tn);
+    }
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

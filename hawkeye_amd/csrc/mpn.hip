@@ -6,10 +6,19 @@
 // reference spends ~25 small kernels on per direction is folded into those
 // epilogues or into four small kernels below.  No host loop over the batch
 // (reference: MPNCOV.py:198-201), no CPU-side index rebuild (:213-214).
+#include <cstdlib>
 #include "hk_bgemm.h"
 #include "../../include/hawkeye_hip.h"
 
 namespace hk {
+
+// bcnn_fast.hip (panel-resident kernels; HK_ERR_UNSUPPORTED when the shape is not covered)
+int gram_fast_raw(const float* x, const float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
+int cov_fast_bwd(const float* x, const float* mu, const float* g, float* dx, int B, int C, int HW, hipStream_t st);
+static inline bool force_generic() {
+    const char* e = getenv("HK_BCNN_GENERIC");
+    return e && e[0] == '1';
+}
 
 // ----------------------------------------------------------------- covariance
 // mu[b,c] = mean_m x[b,c,m] : one wave per row, 4 rows per workgroup
@@ -167,6 +176,10 @@ extern "C" int hk_cov_pool_fwd(const float* x, float* cov, float* mu, int B, int
     const long long rows = (long long)B * C;
     hipLaunchKernelGGL(row_mean_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, mu, rows, M);
     HK_LAUNCH_CHECK();
+    if (!force_generic()) {
+        const int rc = gram_fast_raw(x, mu, 1.0f / (float)M, cov, B, C, M, st);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
     LdRowSub l;
     l.base = make_plain(x, (long long)C * M, M, C, M);
     l.mu = mu; l.mubs = C;
@@ -178,6 +191,10 @@ extern "C" int hk_cov_pool_bwd(const float* x, const float* mu, const float* dco
                                hk_stream_t stream) {
     if (!x || !mu || !dcov || !dx || B <= 0 || C <= 0 || M <= 0) return HK_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (!force_generic()) {
+        const int rc = cov_fast_bwd(x, mu, dcov, dx, B, C, M, st);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
     LdSym ls;
     ls.p = dcov; ls.bs = (long long)C * C; ls.d = C;
     LdRowSub lx;  // B operand: K x N = C x M, rows are channels

@@ -218,6 +218,35 @@ def test_mpn_49_and_properties(F):
     assert rel(tvg, tv) < 1e-5 and rel(xg.grad, x.grad) < 1e-4
 
 
+@pytest.mark.parametrize('b,c,hw', [(2, 64, 14), (9, 128, 10), (70, 256, 8)])
+def test_cov_and_cbp_panel_kernels_vs_generic(F, b, c, hw):
+    """Covariance (centred Gram) and CBP (raw Gram + gathered dG) reuse the panel-resident kernels for
+    C % 64 == 0, HW in {196,144,100,64}: check them against the generic GEMM path and the oracle."""
+    xn = rs_relu_randn(93, (b, c, hw, hw))
+    d = 96
+    plan = _plan(F, c, d)
+    res = []
+    for generic in ('0', '1'):
+        os.environ['HK_BCNN_GENERIC'] = generic
+        try:
+            xg = t(xn).to(DEV).requires_grad_(True)
+            cov = F.covpool(xg)
+            cov.backward(t(rs_randn(94, (b, c, c))).to(DEV))
+            xg2 = t(xn).to(DEV).requires_grad_(True)
+            yc = F.compact_bilinear_pool(xg2, plan)
+            yc.backward(t(rs_randn(95, (b, d))).to(DEV))
+            res.append((cov.detach(), xg.grad, yc.detach(), xg2.grad))
+        finally:
+            del os.environ['HK_BCNN_GENERIC']
+    for a, g, tol in zip(res[0], res[1], (1e-5, 1e-5, 1e-5, 1e-4)):   # CBP gradient: sqrt slope amplifies rounding
+        assert rel(a, g) < tol
+    xo = t(xn[:2]).requires_grad_(True)
+    co = O.covpool(xo)
+    co.backward(t(rs_randn(94, (b, c, c))[:2]))
+    assert rel(res[0][0][:2], co) < 2e-6 and rel(res[0][1][:2], xo.grad) < 1e-5
+    assert torch.equal(res[0][0], res[0][0].transpose(1, 2))
+
+
 def test_triuvec_roundtrip(F):
     x = t(rs_randn(8, (4, 37, 37))).to(DEV).requires_grad_(True)
     y = F.triuvec(x)
