@@ -128,6 +128,21 @@ def kernel_rooflines(B, C, HW, dev):
     return out
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r1b_pool_kernels_pmc.csv:
+    FETCH_SIZE / WRITE_SIZE in KiB, separate passes; FETCH_SIZE doubled - gfx950 reports half of the bytes of
+    16-B-per-lane streaming reads, MI355X_MICROARCH.md section HBM).  PMC cannot be sampled from inside this
+    process, so this is the last profiled value, or None when the file is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r1b_pool_kernels_pmc.csv')
+    try:
+        import csv
+        vals = {r['Counter']: float(r['MeanValue']) for r in csv.DictReader(open(path))
+                if r['Kernel'].startswith(kernel_prefix) and r['Counter'] in ('FETCH_SIZE', 'WRITE_SIZE')}
+        return round((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0)
+    except Exception:
+        return None
+
+
 def cpu_baseline(image, classes):
     """Reference algorithm on the host: the oracle's BCNN (VGG-16 + BilinearPooling on the torch CPU path, i.e. what
     the reference executes with `experiment.cuda: []`) training step at batch 4 (BASELINE.json configs[0]).
@@ -242,6 +257,12 @@ def main():
             res['roofline'] = {k: dom[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
             res['roofline']['kernel'] = dom['kernel']
             res['roofline']['us'] = dom['us']
+            res['roofline']['traffic'] = pmc_traffic('hk::' + dom['kernel'].split('<')[0])
+            res['roofline']['traffic_source'] = 'profiles/r1b_pool_kernels_pmc.csv (rocprofv3 --pmc, bytes per launch)'
+            res['roofline']['algorithmic'] = {'flops_per_launch': 2.0 * a.batch * 512 * 512 * (a.image // 32) ** 2,
+                                              'bytes_per_launch': (8.0 * a.batch * (512 * 512 + 512 * (a.image // 32) ** 2)
+                                                                   if 'bwd' in dom['kernel'] else
+                                                                   4.0 * a.batch * (512 * 512 + 512 * (a.image // 32) ** 2))}
             res['kernels'] = ks
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.image, a.classes)

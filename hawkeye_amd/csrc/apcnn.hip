@@ -323,6 +323,115 @@ __global__ __launch_bounds__(256) void roi_crop_bwd_kernel(const float* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------- K10 table-driven variants (H, W <= 64)
+// One workgroup per (image, channel) map.  The crop geometry and the per-row / per-column bilinear tables depend only
+// on the image, so they are built once per workgroup in LDS (the kernels above recompute them per thread: ~100 VALU
+// instructions per output element, measured 118 us forward / 338 us backward at B=16, C=512, 56x56).
+struct AxisTab {         // source taps of one output coordinate
+    int i0, i1;
+    float l0, l1;
+};
+
+__global__ __launch_bounds__(256) void roi_crop_fwd_tab_kernel(const float* __restrict__ x, const float* __restrict__ box,
+                                                               const float* __restrict__ drop, float* __restrict__ y,
+                                                               int C, int H, int W, int training) {
+    __shared__ CropGeom g;
+    __shared__ AxisTab ty[64], tx[64];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) g = crop_geom(box + b * 4, drop + b * 4, C, H, W, training);
+    __syncthreads();
+    if (tid < H && g.ch > 0) src_index(g.sh, tid, g.ch, ty[tid].i0, ty[tid].i1, ty[tid].l0, ty[tid].l1);
+    if (tid >= 64 && tid - 64 < W && g.cw > 0)
+        src_index(g.sw, tid - 64, g.cw, tx[tid - 64].i0, tx[tid - 64].i1, tx[tid - 64].l0, tx[tid - 64].l1);
+    __syncthreads();
+    const float* xp = x + ((long long)b * C + c) * H * W;
+    float* yp = y + ((long long)b * C + c) * H * W;
+    const bool empty = g.cw <= 0 || g.ch <= 0;
+    for (int o = tid; o < H * W; o += 256) {
+        if (empty) { yp[o] = 0.f; continue; }
+        const int oy = o / W, ox = o % W;
+        const AxisTab a = ty[oy], q = tx[ox];
+        const int ys[2] = {g.y1 + a.i0, g.y1 + a.i1}, xs[2] = {g.x1 + q.i0, g.x1 + q.i1};
+        float v[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float t = xp[ys[i] * W + xs[j]];
+                if (training) {
+                    const bool dropped = ys[i] >= g.dy1 && ys[i] < g.dy2 && xs[j] >= g.dx1 && xs[j] < g.dx2;
+                    t = (dropped ? 0.f : t) * g.rate;
+                }
+                v[i][j] = t;
+            }
+        yp[o] = a.l0 * (q.l0 * v[0][0] + q.l1 * v[0][1]) + a.l1 * (q.l0 * v[1][0] + q.l1 * v[1][1]);
+    }
+}
+
+// dX = rate * mask * (Wy^T dY Wx) restricted to the crop.  Wy [ch][H] / Wx [cw][W] are built dense in LDS (each
+// output coordinate owns its column: two adds, no race) together with the non-zero range of every row, so the gather
+// of an input pixel is a short doubly-bounded loop over table entries.  Deterministic, no atomics.
+__global__ __launch_bounds__(256) void roi_crop_bwd_tab_kernel(const float* __restrict__ dy, const float* __restrict__ box,
+                                                               const float* __restrict__ drop, float* __restrict__ dx,
+                                                               int C, int H, int W, int training) {
+    __shared__ CropGeom g;
+    __shared__ float wy[64 * 65], wx[64 * 65];
+    __shared__ int ylo[64], yhi[64], xlo[64], xhi[64];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) g = crop_geom(box + b * 4, drop + b * 4, C, H, W, training);
+    for (int e = tid; e < 64 * 65; e += 256) { wy[e] = 0.f; wx[e] = 0.f; }
+    __syncthreads();
+    if (g.ch > 0 && g.cw > 0) {
+        if (tid < H) {                                   // output row tid contributes to source rows i0, i1
+            int i0, i1; float l0, l1;
+            src_index(g.sh, tid, g.ch, i0, i1, l0, l1);
+            wy[i0 * 65 + tid] += l0;
+            wy[i1 * 65 + tid] += l1;
+        } else if (tid >= 64 && tid - 64 < W) {
+            const int ox = tid - 64;
+            int i0, i1; float l0, l1;
+            src_index(g.sw, ox, g.cw, i0, i1, l0, l1);
+            wx[i0 * 65 + ox] += l0;
+            wx[i1 * 65 + ox] += l1;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {                                       // non-zero range of each table row
+        int lo = H, hi = -1;
+        for (int o = 0; o < H; ++o)
+            if (wy[tid * 65 + o] != 0.f) { lo = o < lo ? o : lo; hi = o; }
+        ylo[tid] = lo; yhi[tid] = hi;
+    } else if (tid < 128) {
+        const int r = tid - 64;
+        int lo = W, hi = -1;
+        for (int o = 0; o < W; ++o)
+            if (wx[r * 65 + o] != 0.f) { lo = o < lo ? o : lo; hi = o; }
+        xlo[r] = lo; xhi[r] = hi;
+    }
+    __syncthreads();
+    const float* gp = dy + ((long long)b * C + c) * H * W;
+    float* dp = dx + ((long long)b * C + c) * H * W;
+    for (int p = tid; p < H * W; p += 256) {
+        const int iy = p / W, ix = p % W;
+        const int ry = iy - g.y1, rx = ix - g.x1;
+        float acc = 0.f;
+        if (g.cw > 0 && g.ch > 0 && ry >= 0 && ry < g.ch && rx >= 0 && rx < g.cw) {
+            const bool dropped = training && iy >= g.dy1 && iy < g.dy2 && ix >= g.dx1 && ix < g.dx2;
+            if (!dropped) {
+                const int oy0 = ylo[ry], oy1 = yhi[ry], ox0 = xlo[rx], ox1 = xhi[rx];
+                for (int oy = oy0; oy <= oy1; ++oy) {
+                    float rowacc = 0.f;
+                    for (int ox = ox0; ox <= ox1; ++ox) rowacc += wx[rx * 65 + ox] * gp[oy * W + ox];
+                    acc += wy[ry * 65 + oy] * rowacc;
+                }
+                acc *= g.rate;
+            }
+        }
+        dp[p] = acc;
+    }
+}
+
 }  // namespace hk
 
 using namespace hk;
@@ -377,6 +486,12 @@ extern "C" int hk_roi_boxes(const float* rois3, const int32_t* cnt3, int k3, con
 extern "C" int hk_roi_crop_resize_fwd(const float* x, const float* box, const float* drop, float* y, int B, int C, int H,
                                       int W, int training, hk_stream_t stream) {
     if (!x || !box || !drop || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return HK_ERR_BAD_ARG;
+    if (H <= 64 && W <= 64) {
+        hipLaunchKernelGGL(roi_crop_fwd_tab_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, box, drop, y, C, H, W,
+                           training);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     int gx = (H * W + 255) / 256;
     if (gx > 16) gx = 16;
     hipLaunchKernelGGL(roi_crop_fwd_kernel, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, x, box, drop, y, C, H, W,
@@ -388,6 +503,12 @@ extern "C" int hk_roi_crop_resize_fwd(const float* x, const float* box, const fl
 extern "C" int hk_roi_crop_resize_bwd(const float* dy, const float* box, const float* drop, float* dx, int B, int C,
                                       int H, int W, int training, hk_stream_t stream) {
     if (!dy || !box || !drop || !dx || B <= 0 || C <= 0 || H <= 0 || W <= 0) return HK_ERR_BAD_ARG;
+    if (H <= 64 && W <= 64) {
+        hipLaunchKernelGGL(roi_crop_bwd_tab_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, box, drop, dx, C, H, W,
+                           training);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     int gx = (H * W + 255) / 256;
     if (gx > 16) gx = 16;
     hipLaunchKernelGGL(roi_crop_bwd_kernel, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, dy, box, drop, dx, C, H, W,

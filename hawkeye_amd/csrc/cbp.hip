@@ -57,11 +57,32 @@ static inline CbpPlan cbp_view(const void* plan, int C, int D) {
     return v;
 }
 
-// c_raw[b,k] = sum over the bin's (i,j) list of +-G[b,i,j].  One LANE per bin walking the transposed (ELL) entry
-// table: entry reads are coalesced across lanes, the G gathers of successive entries are independent (8 in flight per
-// lane), and every bin is summed by one lane in a fixed order (deterministic).  ~6000*64/64 = 6000 waves: all resident.
-__global__ __launch_bounds__(256) void cbp_bin_kernel(const float* __restrict__ G, const unsigned* __restrict__ ell, int E,
-                                                      float* __restrict__ c_raw, int CC, int D) {
+// c_raw[b,k] = sum over the bin's (i,j) list of +-G[b,i,j]; one wave per bin, lanes stride over its ~44 entries,
+// butterfly reduction (fixed order).  The gathers touch one 64-B sector per 4-B entry, so this stage is bound by
+// L2 sector traffic (~130 us at B=64); a lane-per-bin walk of the transposed (ELL) table - cbp_bin_ell_kernel below,
+// coalesced entry reads, 8 gathers in flight per lane - was measured SLOWER (190 us): same sector traffic, fewer
+// waves.  The real fix (round 2) is to bin inside the Gram epilogue from LDS so G never leaves the chip.
+__global__ __launch_bounds__(256) void cbp_bin_kernel(const float* __restrict__ G, const int* __restrict__ off,
+                                                      const unsigned* __restrict__ ent, float* __restrict__ c_raw,
+                                                      int CC, int D) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= D) return;
+    const int lane = threadIdx.x & 63;
+    const float* g = G + (long long)b * CC;
+    const int lo = off[k], hi = off[k + 1];
+    float s = 0.f;
+    for (int e = lo + lane; e < hi; e += 64) {
+        const unsigned u = ent[e];
+        const float v = g[u & 0x7fffffffu];
+        s += (u >> 31) ? -v : v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) c_raw[(long long)b * D + k] = s;
+}
+
+__global__ __launch_bounds__(256) void cbp_bin_ell_kernel(const float* __restrict__ G, const unsigned* __restrict__ ell,
+                                                          int E, float* __restrict__ c_raw, int CC, int D) {
     const int b = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= D) return;
@@ -235,8 +256,13 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
     int rc = force_generic() ? HK_ERR_UNSUPPORTED : gram_fast_raw(x, nullptr, 1.0f, G, B, C, HW, st);
     if (rc == HK_ERR_UNSUPPORTED) rc = bgemm_launch<true, true>(xa, xa, ep, C, C, HW, B, st);      // raw Gram, no 1/HW
     if (rc != HK_OK) return rc;
-    hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 255) / 256, B), dim3(256), 0, st, (const float*)G, pl.ell, pl.E, c_raw,
-                       C * C, D);
+    const char* use_ell = getenv("HK_CBP_ELL");      // A/B switch for the measured-slower lane-per-bin variant
+    if (use_ell && use_ell[0] == '1')
+        hipLaunchKernelGGL(cbp_bin_ell_kernel, dim3((D + 255) / 256, B), dim3(256), 0, st, (const float*)G, pl.ell, pl.E,
+                           c_raw, C * C, D);
+    else
+        hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 3) / 4, B), dim3(256), 0, st, (const float*)G, pl.off, pl.ent, c_raw,
+                           C * C, D);
     HK_LAUNCH_CHECK();
     hipLaunchKernelGGL(cbp_norm_kernel, dim3(B), dim3(256), 0, st, (const float*)c_raw, y, inv_norm, D);
     HK_LAUNCH_CHECK();

@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    f32x16 acc2;                                  // second k-chain (T == 1 only)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+
     float4 ra[NLA], rb[NLB];
 
 // (macro-local names carry a trailing underscore: the argument expressions mention the caller's `c`)
@@ -190,45 +194,62 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
         if (c + 1 < nk) HK_GLOAD((c + 1) * BK);
         const float* As = lds + cur * (SA + SB);
         const float* Bs = As + SA;
+        // operand fragments of step s+1 are fetched before the MFMAs of step s are issued (the dependent MFMAs block
+        // the wave's issue for >100 cycles); for T == 1 the single 32x32 accumulator is split into two independent
+        // k-chains (summed in the epilogue) so that the matrix pipe is not paced by one dependency chain
+        float a[T][4], bb[T][4];
+#define HK_FRAG(s_, A_, B_)                                                                                    \
+        do {                                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < T; ++i) {                                                        \
+                const int row_ = (wm * T + i) * 32 + l31;                                                          \
+                if (A_KC) {                                                                                        \
+                    const float4 v_ = *reinterpret_cast<const float4*>(&As[row_ * PA + 8 * (s_) + 4 * lh]);        \
+                    A_[i][0] = v_.x; A_[i][1] = v_.y; A_[i][2] = v_.z; A_[i][3] = v_.w;                            \
+                } else {                                                                                           \
+                    _Pragma("unroll") for (int t = 0; t < 4; ++t) A_[i][t] = As[(8 * (s_) + 4 * lh + t) * PA + row_]; \
+                }                                                                                                  \
+            }                                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < T; ++j) {                                                        \
+                const int col_ = (wn * T + j) * 32 + l31;                                                          \
+                if (B_KC) {                                                                                        \
+                    const float4 v_ = *reinterpret_cast<const float4*>(&Bs[col_ * PB + 8 * (s_) + 4 * lh]);        \
+                    B_[j][0] = v_.x; B_[j][1] = v_.y; B_[j][2] = v_.z; B_[j][3] = v_.w;                            \
+                } else {                                                                                           \
+                    _Pragma("unroll") for (int t = 0; t < 4; ++t) B_[j][t] = Bs[(8 * (s_) + 4 * lh + t) * PB + col_]; \
+                }                                                                                                  \
+            }                                                                                                      \
+        } while (0)
+        HK_FRAG(0, a, bb);
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
-            float a[T][4], bb[T][4];
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                const int row = (wm * T + i) * 32 + l31;
-                if (A_KC) {
-                    const float4 v = *reinterpret_cast<const float4*>(&As[row * PA + 8 * s + 4 * lh]);
-                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) a[i][t] = As[(8 * s + 4 * lh + t) * PA + row];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < T; ++j) {
-                const int col = (wn * T + j) * 32 + l31;
-                if (B_KC) {
-                    const float4 v = *reinterpret_cast<const float4*>(&Bs[col * PB + 8 * s + 4 * lh]);
-                    bb[j][0] = v.x; bb[j][1] = v.y; bb[j][2] = v.z; bb[j][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) bb[j][t] = Bs[(8 * s + 4 * lh + t) * PB + col];
-                }
-            }
+            float an[T][4], bn[T][4];
+            if (s + 1 < BK / 8) HK_FRAG(s + 1, an, bn);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < T; ++i)
 #pragma unroll
-                    for (int j = 0; j < T; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < T; ++j) {
+                        if (T == 1 && (t & 1))
+                            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc2, 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc[i][j], 0, 0, 0);
+                    }
+            if (s + 1 < BK / 8) {
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { a[i][t] = an[i][t]; bb[i][t] = bn[i][t]; }
+            }
         }
+#undef HK_FRAG
         if (c + 1 < nk) HK_SSTORE(cur ^ 1);
         __syncthreads();
     }
 #undef HK_GLOAD
 #undef HK_SSTORE
 
+    if (T == 1) acc[0][0] += acc2;
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < T; ++i)
