@@ -21,6 +21,7 @@
 //   64-wide tiles); each of the 4 waves owns 16 rows x 208 columns (13 accumulators).
 //   The next K-block's operands are prefetched into registers during the MFMA loop;
 //   68 KB of LDS per workgroup -> 2 workgroups per CU overlap each other's phases.
+#include <cstdlib>
 #include "hk_common.h"
 
 namespace hk {
@@ -378,6 +379,174 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     }
 }
 
+// ----------------------------------------------------------------------------- backward, producer / consumer waves
+// (opt-in experiment, see bwd_launch)  Same math and tiling as bcnn_bwd_panel_kernel, but the phases no longer
+// alternate inside one wave.  A 512-thread
+// workgroup (one per CU, 152 KB LDS) has 4 CONSUMER waves that only run the 16x16x4 MFMA stream and 4 PRODUCER waves
+// (one of each per SIMD) that fetch y / dy / X tiles, transpose dy(K,I) through LDS, build the P tile and stage the X
+// block into the OTHER half of double-buffered sP / sX.  Two LDS-only barriers per K-block keep the two groups in
+// step (the consumers' MFMA phase is split in two halves around the producers' internal transpose barrier), so the
+// matrix pipe never waits for a load, a division or an LDS write.  A workgroup owns two row blocks {w, w + nb/2}
+// (when that still fills the chip) so the pipeline is primed once per 2*nb K-blocks.
+template <int HW, int NT>
+__device__ __forceinline__ void bwd_mfma_half(const float* sPb, const float* sXb, f32x4 (&acc)[NT], int cw, int l15,
+                                              int lq, int s0) {
+    constexpr int PP = 68;
+    const float* ap = sPb + (cw * 16 + l15) * PP + 4 * lq;
+#pragma unroll
+    for (int s = s0; s < s0 + 2; ++s) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * s);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float* bp = sXb + (16 * s + 4 * lq + t) * HW + l15;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bp[16 * n], acc[n], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void lds_barrier() {   // s_barrier that does not drain vmcnt (prefetches stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int HW, int MODE>
+__global__ __launch_bounds__(512) void bcnn_bwd_pc_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ dy,
+                                                          const float* __restrict__ inv_norm, float* __restrict__ dx,
+                                                          float* __restrict__ tpart, int C, int nb, int B, int two_rows,
+                                                          BwdExtra ex) {
+    constexpr int NT = (HW + 15) / 16;
+    constexpr int XN4 = 64 * HW / 4;
+    constexpr int NSX = (XN4 + 255) / 256;
+    constexpr int PP = 68, TP = 65;
+    constexpr int XS = 64 * HW + 16;
+    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * PP + 2 * XS + 64 * TP + 16];
+    float* sP = lds;                       // [2][64*PP]
+    float* sX = lds + 2 * 64 * PP;         // [2][XS]
+    float* sT = sX + 2 * XS;               // [64*TP]
+    float* sRed = sT + 64 * TP;            // [4]
+
+    int b, w;
+    const int per = two_rows ? nb / 2 : nb;
+    if (!xcd_map(blockIdx.x, B, per, b, w)) return;
+    const int rb0 = w, rb1 = two_rows ? w + nb / 2 : -1;
+    const int T = (two_rows ? 2 : 1) * nb;
+
+    const int tid = threadIdx.x;
+    const bool consumer = tid < 256;                       // wave-uniform
+    const int lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int cw = (tid >> 6) & 3;                         // wave index inside its group
+    const int pt = tid - 256;                              // producer thread id
+    const long long cc = (long long)b * C * C;
+    const float* xb = x + (long long)b * C * HW;
+    float coef = 1.0f / (float)HW;
+    if (MODE == 0) {
+        const float in = inv_norm[b];
+        coef = in * in / (2.0f * (float)HW);
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ry[4], rd[4], rt[4], rx[NSX];
+    float tacc = 0.f;
+    int flush_rb = -1;                                     // row block whose t-partials wait in sRed
+
+    if (!consumer) bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, rb0, 0, pt, ex, b);
+
+    for (int it = 0; it <= T; ++it) {
+        const int kb = it % nb;
+        const int I = (it < nb) ? rb0 : rb1;
+        const int pkb = (it - 1) % nb;                     // block the consumers work on (it >= 1)
+        const int pI = (it - 1 < nb) ? rb0 : rb1;
+        const float* cP = sP + ((it - 1) & 1) * 64 * PP;
+        const float* cX = sX + ((it - 1) & 1) * XS;
+        // ------------------------------------------------------------------ phase A
+        if (consumer) {
+            if (it >= 1) bwd_mfma_half<HW, NT>(cP, cX, acc, cw, l15, lq, 0);
+        } else {
+            if (flush_rb >= 0 && pt == 0 && MODE == 0) {
+                tpart[(long long)b * nb + flush_rb] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+            }
+            flush_rb = -1;
+            if (it < T && MODE != 2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {              // dy(K,I) transposed: T[i][k] = dy[k][i]
+                    const int f = pt + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
+                    sT[(c4 + 0) * TP + r] = rt[u][0];
+                    sT[(c4 + 1) * TP + r] = rt[u][1];
+                    sT[(c4 + 2) * TP + r] = rt[u][2];
+                    sT[(c4 + 3) * TP + r] = rt[u][3];
+                }
+            }
+        }
+        lds_barrier();
+        // ------------------------------------------------------------------ phase B
+        if (consumer) {
+            if (it >= 1) {
+                bwd_mfma_half<HW, NT>(cP, cX, acc, cw, l15, lq, 2);
+                if (pkb == nb - 1) {                       // row block finished: store 16 rows x HW, reset
+                    float* dxb = dx + (long long)b * C * HW + (long long)(pI * 64 + cw * 16 + lq * 4) * HW;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int col = 16 * n + l15;
+                        if (col < HW) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dxb[(long long)r * HW + col] = acc[n][r];
+                        }
+                        acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+        } else if (it < T) {
+            float* pP = sP + (it & 1) * 64 * PP;
+            float* pX = sX + (it & 1) * XS;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = pt + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
+                const float* tp = sT + r * TP + c4;
+                f32x4 p;
+                if (MODE == 0) {
+                    p[0] = (rd[u][0] + tp[0]) * (__builtin_amdgcn_rcpf(ry[u][0]) * coef);
+                    p[1] = (rd[u][1] + tp[1]) * (__builtin_amdgcn_rcpf(ry[u][1]) * coef);
+                    p[2] = (rd[u][2] + tp[2]) * (__builtin_amdgcn_rcpf(ry[u][2]) * coef);
+                    p[3] = (rd[u][3] + tp[3]) * (__builtin_amdgcn_rcpf(ry[u][3]) * coef);
+                    tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
+                } else if (MODE == 1) {
+                    p[0] = (rd[u][0] + tp[0]) * coef;
+                    p[1] = (rd[u][1] + tp[1]) * coef;
+                    p[2] = (rd[u][2] + tp[2]) * coef;
+                    p[3] = (rd[u][3] + tp[3]) * coef;
+                } else {
+                    p = rd[u];
+                }
+                *reinterpret_cast<f32x4*>(&pP[r * PP + c4]) = p;
+            }
+#pragma unroll
+            for (int u = 0; u < NSX; ++u) {
+                const int f = pt + 256 * u;
+                if (f < XN4) reinterpret_cast<f32x4*>(pX)[f] = rx[u];
+            }
+            if (MODE == 0 && kb == nb - 1) {               // row block complete: publish this wave's t partial
+                const float ws = wave_sum(tacc);
+                if (lane == 0) sRed[cw] = ws;
+                tacc = 0.f;
+                flush_rb = I;
+            }
+            if (it + 1 < T) {
+                const int nI = (it + 1 < nb) ? rb0 : rb1;
+                bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, nI, (it + 1) % nb, pt, ex, b);
+            }
+        }
+        lds_barrier();
+    }
+    if (!consumer && flush_rb >= 0 && pt == 0 && MODE == 0)
+        tpart[(long long)b * nb + flush_rb] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+}
+
 // ----------------------------------------------------------------------------- dispatch
 template <int HW, int MODE, bool CENTER>
 static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, const float* mu, float alpha,
@@ -395,6 +564,19 @@ template <int HW, int MODE>
 static int bwd_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
                       int B, int C, const BwdExtra& ex, hipStream_t st) {
     const int nb = C / 64;
+    // HK_BWD_PC=1 opts into the producer/consumer variant.  Measured at B=64, C=512, HW=196: 94 us vs 85 us for the
+    // single-role kernel below - the backward is not purely MFMA-bound (235 MB of HBM traffic against 6656 MFMA
+    // cycles per K-block: the phases need ~4.5 TB/s to keep up) and one 512-thread workgroup per CU has less
+    // memory-level parallelism than two independent 256-thread workgroups.  Kept for shapes with smaller C.
+    const char* e = getenv("HK_BWD_PC");
+    if (e && e[0] == '1') {
+        const int two_rows = (nb % 2 == 0 && (long long)B * nb / 2 >= 256) ? 1 : 0;
+        const int per = two_rows ? nb / 2 : nb;
+        hipLaunchKernelGGL((bcnn_bwd_pc_kernel<HW, MODE>), dim3(xcd_grid(B, per)), dim3(512), 0, st, x, y, dy, inv_norm,
+                           dx, tpart, C, nb, B, two_rows, ex);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     hipLaunchKernelGGL((bcnn_bwd_panel_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
                        tpart, C, nb, B, ex);
     HK_LAUNCH_CHECK();
