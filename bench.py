@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--channels-last', type=int, default=0)
     ap.add_argument('--miopen-find', type=int, default=0)
     ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--backend', default=None, help='process-group backend override (debug: gloo lets N ranks share one GPU)')
+    ap.add_argument('--share-gpu', action='store_true', help='debug: every rank uses cuda:0')
     return ap.parse_args()
 
 
@@ -182,7 +184,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     from hawkeye_amd import ddp
-    rank, world, local = ddp.init_from_env('nccl' if world > 1 else None)
+    if a.share_gpu:
+        os.environ['LOCAL_RANK'] = '0'
+    rank, world, local = ddp.init_from_env((a.backend or 'nccl') if world > 1 else None)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
@@ -240,8 +244,8 @@ def main():
 
     if rank == 0:
         res = {
-            'metric': f'images/sec (train fwd+bwd) {a.model} VGG-16 448^2 bs64' if a.model in ('BCNN', 'CBCNN')
-                      else f'images/sec (train fwd+bwd) {a.model}',
+            'metric': f'images/sec (train fwd+bwd) {a.model} VGG-16 {a.image}^2 bs{a.batch}' if a.model in ('BCNN', 'CBCNN')
+                      else f'images/sec (train fwd+bwd) {a.model} {a.image}^2 bs{a.batch}',
             'value': round(a.batch * world * a.steps / dt, 2), 'unit': 'images/sec',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
