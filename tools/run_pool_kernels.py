@@ -26,3 +26,11 @@ for _ in range(reps):
     lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream())
 torch.cuda.synchronize()
 print('ok')
+
+if len(sys.argv) > 2 and sys.argv[2] == 'ns':          # also the Newton-Schulz chain (generic bgemm_kernel, 256^3 x 64)
+    import hawkeye_amd.functional as F
+    cov = F.covpool(torch.relu(torch.randn(64, 256, 14, 14, device=dev)))
+    for _ in range(2):
+        F.sqrtm(cov, 5)
+    torch.cuda.synchronize()
+    print('ns ok')
