@@ -379,67 +379,38 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     }
 }
 
-// ----------------------------------------------------------------------------- backward, producer / consumer waves
-// (opt-in experiment, see bwd_launch)  Same math and tiling as bcnn_bwd_panel_kernel, but the phases no longer
-// alternate inside one wave.  A 512-thread
-// workgroup (one per CU, 152 KB LDS) has 4 CONSUMER waves that only run the 16x16x4 MFMA stream and 4 PRODUCER waves
-// (one of each per SIMD) that fetch y / dy / X tiles, transpose dy(K,I) through LDS, build the P tile and stage the X
-// block into the OTHER half of double-buffered sP / sX.  Two LDS-only barriers per K-block keep the two groups in
-// step (the consumers' MFMA phase is split in two halves around the producers' internal transpose barrier), so the
-// matrix pipe never waits for a load, a division or an LDS write.  A workgroup owns two row blocks {w, w + nb/2}
-// (when that still fills the chip) so the pipeline is primed once per 2*nb K-blocks.
-template <int HW, int NT>
-__device__ __forceinline__ void bwd_mfma_half(const float* sPb, const float* sXb, f32x4 (&acc)[NT], int cw, int l15,
-                                              int lq, int s0) {
-    constexpr int PP = 68;
-    const float* ap = sPb + (cw * 16 + l15) * PP + 4 * lq;
-#pragma unroll
-    for (int s = s0; s < s0 + 2; ++s) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * s);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float* bp = sXb + (16 * s + 4 * lq + t) * HW + l15;
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bp[16 * n], acc[n], 0, 0, 0);
-        }
-    }
-}
-
-__device__ __forceinline__ void lds_barrier() {   // s_barrier that does not drain vmcnt (prefetches stay in flight)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
+// ----------------------------------------------------------------------------- backward v3: no transposition, 3 WGs / CU
+// dX[I] = sum_K P(I,K) X(K),  P[i][k] = (dy[i][k] + dy[k][i]) * w[i][k]   (w = coef / y for BCNN, 1/M for COV).
+// Instead of building P in LDS (transposing dy(K,I) through a scratch: 4 barriers per K-block, 11 % bank conflicts),
+// the RAW tiles go to LDS exactly as they sit in HBM - y(I,K), dy(I,K) row-major [i][k] and dy(K,I) row-major
+// [k][i] - and the MFMA A-fragment is assembled per lane when it is read: the 16x16x4 A layout wants
+// A[i = lane & 15][k = lane >> 4], which is one ds_read_b128 along k from the [i][k] tiles and four conflict-free
+// ds_read_b32 (lanes along i) from the [k][i] tile; 4 v_rcp + 8 VALU per 52 MFMAs.  y is bitwise symmetric (the forward
+// writes mirrored tiles from one accumulator), so y[k][i] is never loaded.  K-blocks of 32 rows: 51 KB of LDS and
+// ~130 VGPRs per workgroup -> THREE workgroups per CU, two barriers per K-block.
 template <int HW, int MODE>
-__global__ __launch_bounds__(512) void bcnn_bwd_pc_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                          const float* __restrict__ dy,
-                                                          const float* __restrict__ inv_norm, float* __restrict__ dx,
-                                                          float* __restrict__ tpart, int C, int nb, int B, int two_rows,
-                                                          BwdExtra ex) {
+__global__ __launch_bounds__(256, 3) void bcnn_bwd_v3_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy,
+                                                             const float* __restrict__ inv_norm,
+                                                             float* __restrict__ dx, float* __restrict__ tpart, int C,
+                                                             int nb, int B, BwdExtra ex) {
+    constexpr int KB = 32;                       // K rows per block
     constexpr int NT = (HW + 15) / 16;
-    constexpr int XN4 = 64 * HW / 4;
+    constexpr int XN4 = KB * HW / 4;             // float4 of an X block
     constexpr int NSX = (XN4 + 255) / 256;
-    constexpr int PP = 68, TP = 65;
-    constexpr int XS = 64 * HW + 16;
-    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * PP + 2 * XS + 64 * TP + 16];
-    float* sP = lds;                       // [2][64*PP]
-    float* sX = lds + 2 * 64 * PP;         // [2][XS]
-    float* sT = sX + 2 * XS;               // [64*TP]
-    float* sRed = sT + 64 * TP;            // [4]
+    constexpr int PD = KB + 4;                   // pitch of the [i][k] tiles (36: 9 x 16 B, odd -> b128 conflict-free)
+    constexpr int PT = 64 + 4;                   // pitch of the [k][i] tile
+    constexpr int XS = KB * HW + 16;
+    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * PD + KB * PT + XS];
+    float* sY = lds;                             // y(I,K)   [64][PD]   (BCNN only)
+    float* sD = lds + 64 * PD;                   // dy(I,K)  [64][PD]   (COV: g(I,K); CBP: gathered dG + dG^T)
+    float* sDt = sD + 64 * PD;                   // dy(K,I)  [KB][PT]
+    float* sX = sDt + KB * PT;                   // X(K)     [KB][HW]
 
-    int b, w;
-    const int per = two_rows ? nb / 2 : nb;
-    if (!xcd_map(blockIdx.x, B, per, b, w)) return;
-    const int rb0 = w, rb1 = two_rows ? w + nb / 2 : -1;
-    const int T = (two_rows ? 2 : 1) * nb;
-
-    const int tid = threadIdx.x;
-    const bool consumer = tid < 256;                       // wave-uniform
-    const int lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
-    const int cw = (tid >> 6) & 3;                         // wave index inside its group
-    const int pt = tid - 256;                              // producer thread id
+    int b, I;
+    if (!xcd_map(blockIdx.x, B, nb, b, I)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
     const long long cc = (long long)b * C * C;
     const float* xb = x + (long long)b * C * HW;
     float coef = 1.0f / (float)HW;
@@ -447,104 +418,115 @@ __global__ __launch_bounds__(512) void bcnn_bwd_pc_kernel(const float* __restric
         const float in = inv_norm[b];
         coef = in * in / (2.0f * (float)HW);
     }
+    const int nkb = C / KB;
 
     f32x4 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ry[4], rd[4], rt[4], rx[NSX];
     float tacc = 0.f;
-    int flush_rb = -1;                                     // row block whose t-partials wait in sRed
 
-    if (!consumer) bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, rb0, 0, pt, ex, b);
-
-    for (int it = 0; it <= T; ++it) {
-        const int kb = it % nb;
-        const int I = (it < nb) ? rb0 : rb1;
-        const int pkb = (it - 1) % nb;                     // block the consumers work on (it >= 1)
-        const int pI = (it - 1 < nb) ? rb0 : rb1;
-        const float* cP = sP + ((it - 1) & 1) * 64 * PP;
-        const float* cX = sX + ((it - 1) & 1) * XS;
-        // ------------------------------------------------------------------ phase A
-        if (consumer) {
-            if (it >= 1) bwd_mfma_half<HW, NT>(cP, cX, acc, cw, l15, lq, 0);
-        } else {
-            if (flush_rb >= 0 && pt == 0 && MODE == 0) {
-                tpart[(long long)b * nb + flush_rb] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
-            }
-            flush_rb = -1;
-            if (it < T && MODE != 2) {
+    // staging registers: 2 float4 of each 64x32 / 32x64 tile, NSX float4 of the X block
+    f32x4 ry[2], rd[2], rt[2], rx[NSX];
+    auto load = [&](int kb) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {              // dy(K,I) transposed: T[i][k] = dy[k][i]
-                    const int f = pt + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
-                    sT[(c4 + 0) * TP + r] = rt[u][0];
-                    sT[(c4 + 1) * TP + r] = rt[u][1];
-                    sT[(c4 + 2) * TP + r] = rt[u][2];
-                    sT[(c4 + 3) * TP + r] = rt[u][3];
+        for (int u = 0; u < 2; ++u) {
+            const int f = tid + 256 * u;
+            const int r = f >> 3, c4 = (f & 7) * 4;                 // [i][k] tiles: 64 rows x 8 float4
+            const long long o1 = cc + (long long)(I * 64 + r) * C + kb * KB + c4;
+            if (MODE == 0) ry[u] = *reinterpret_cast<const f32x4*>(y + o1);
+            if (MODE != 2) {
+                rd[u] = *reinterpret_cast<const f32x4*>(dy + o1);
+                const int rk = f >> 4, ci = (f & 15) * 4;           // [k][i] tile: 32 rows x 16 float4
+                rt[u] = *reinterpret_cast<const f32x4*>(dy + cc + (long long)(kb * KB + rk) * C + I * 64 + ci);
+            } else {
+                const int i = I * 64 + r;
+                const int h1i = ex.h1[i], h2i = ex.h2[i];
+                const float s1i = ex.s1[i], s2i = ex.s2[i];
+                const float* d = ex.dc + (long long)b * ex.D;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int k = kb * KB + c4 + t;
+                    int ba = h1i + ex.h2[k]; if (ba >= ex.D) ba -= ex.D;
+                    int bb = ex.h1[k] + h2i; if (bb >= ex.D) bb -= ex.D;
+                    rd[u][t] = s1i * ex.s2[k] * d[ba] + ex.s1[k] * s2i * d[bb];
                 }
             }
         }
-        lds_barrier();
-        // ------------------------------------------------------------------ phase B
-        if (consumer) {
-            if (it >= 1) {
-                bwd_mfma_half<HW, NT>(cP, cX, acc, cw, l15, lq, 2);
-                if (pkb == nb - 1) {                       // row block finished: store 16 rows x HW, reset
-                    float* dxb = dx + (long long)b * C * HW + (long long)(pI * 64 + cw * 16 + lq * 4) * HW;
+        const f32x4* xs = reinterpret_cast<const f32x4*>(xb + (long long)kb * KB * HW);
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const int col = 16 * n + l15;
-                        if (col < HW) {
+        for (int u = 0; u < NSX; ++u) {
+            const int f = tid + 256 * u, fc = f < XN4 ? f : XN4 - 1;
+            rx[u] = xs[fc];
+            if (MODE == 1) rx[u] -= ex.mu[(long long)b * C + kb * KB + (4 * fc) / HW];
+        }
+    };
+
+    load(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();                                   // previous MFMA phase finished with the LDS tiles
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) dxb[(long long)r * HW + col] = acc[n][r];
-                        }
-                        acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-                }
+        for (int u = 0; u < 2; ++u) {
+            const int f = tid + 256 * u;
+            const int r = f >> 3, c4 = (f & 7) * 4;
+            if (MODE == 0) {
+                *reinterpret_cast<f32x4*>(&sY[r * PD + c4]) = ry[u];
+                tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
             }
-        } else if (it < T) {
-            float* pP = sP + (it & 1) * 64 * PP;
-            float* pX = sX + (it & 1) * XS;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = pt + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
-                const float* tp = sT + r * TP + c4;
-                f32x4 p;
-                if (MODE == 0) {
-                    p[0] = (rd[u][0] + tp[0]) * (__builtin_amdgcn_rcpf(ry[u][0]) * coef);
-                    p[1] = (rd[u][1] + tp[1]) * (__builtin_amdgcn_rcpf(ry[u][1]) * coef);
-                    p[2] = (rd[u][2] + tp[2]) * (__builtin_amdgcn_rcpf(ry[u][2]) * coef);
-                    p[3] = (rd[u][3] + tp[3]) * (__builtin_amdgcn_rcpf(ry[u][3]) * coef);
-                    tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
-                } else if (MODE == 1) {
-                    p[0] = (rd[u][0] + tp[0]) * coef;
-                    p[1] = (rd[u][1] + tp[1]) * coef;
-                    p[2] = (rd[u][2] + tp[2]) * coef;
-                    p[3] = (rd[u][3] + tp[3]) * coef;
-                } else {
-                    p = rd[u];
-                }
-                *reinterpret_cast<f32x4*>(&pP[r * PP + c4]) = p;
-            }
-#pragma unroll
-            for (int u = 0; u < NSX; ++u) {
-                const int f = pt + 256 * u;
-                if (f < XN4) reinterpret_cast<f32x4*>(pX)[f] = rx[u];
-            }
-            if (MODE == 0 && kb == nb - 1) {               // row block complete: publish this wave's t partial
-                const float ws = wave_sum(tacc);
-                if (lane == 0) sRed[cw] = ws;
-                tacc = 0.f;
-                flush_rb = I;
-            }
-            if (it + 1 < T) {
-                const int nI = (it + 1 < nb) ? rb0 : rb1;
-                bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, nI, (it + 1) % nb, pt, ex, b);
+            *reinterpret_cast<f32x4*>(&sD[r * PD + c4]) = rd[u];
+            if (MODE != 2) {
+                const int rk = f >> 4, ci = (f & 15) * 4;
+                *reinterpret_cast<f32x4*>(&sDt[rk * PT + ci]) = rt[u];
             }
         }
-        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < NSX; ++u) {
+            const int f = tid + 256 * u;
+            if (f < XN4) reinterpret_cast<f32x4*>(sX)[f] = rx[u];
+        }
+        __syncthreads();
+        load(kb + 1 < nkb ? kb + 1 : kb);                  // in flight during the MFMA phase (last: harmless re-read)
+
+        const int arow = (wave * 16 + l15) * PD + 4 * lq;
+#pragma unroll
+        for (int s = 0; s < KB / 16; ++s) {
+            f32x4 av = *reinterpret_cast<const f32x4*>(&sD[arow + 16 * s]);
+            if (MODE != 2) {
+                f32x4 tv;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) tv[t] = sDt[(16 * s + 4 * lq + t) * PT + wave * 16 + l15];
+                av += tv;
+            }
+            if (MODE == 0) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(&sY[arow + 16 * s]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) av[t] *= __builtin_amdgcn_rcpf(yv[t]) * coef;
+            } else if (MODE == 1) {
+                av *= coef;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float* bp = sX + (16 * s + 4 * lq + t) * HW + l15;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bp[16 * n], acc[n], 0, 0, 0);
+            }
+        }
     }
-    if (!consumer && flush_rb >= 0 && pt == 0 && MODE == 0)
-        tpart[(long long)b * nb + flush_rb] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+
+    float* dxb = dx + (long long)b * C * HW + (long long)(I * 64 + wave * 16 + lq * 4) * HW;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = 16 * n + l15;
+        if (col < HW) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dxb[(long long)r * HW + col] = acc[n][r];
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        const float tsum = block_sum<4>(tacc, lds);
+        if (tid == 0) tpart[(long long)b * nb + I] = tsum;
+    }
 }
 
 // ----------------------------------------------------------------------------- dispatch
@@ -564,16 +546,15 @@ template <int HW, int MODE>
 static int bwd_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
                       int B, int C, const BwdExtra& ex, hipStream_t st) {
     const int nb = C / 64;
-    // HK_BWD_PC=1 opts into the producer/consumer variant.  Measured at B=64, C=512, HW=196: 94 us vs 85 us for the
-    // single-role kernel below - the backward is not purely MFMA-bound (235 MB of HBM traffic against 6656 MFMA
-    // cycles per K-block: the phases need ~4.5 TB/s to keep up) and one 512-thread workgroup per CU has less
-    // memory-level parallelism than two independent 256-thread workgroups.  Kept for shapes with smaller C.
-    const char* e = getenv("HK_BWD_PC");
-    if (e && e[0] == '1') {
-        const int two_rows = (nb % 2 == 0 && (long long)B * nb / 2 >= 256) ? 1 : 0;
-        const int per = two_rows ? nb / 2 : nb;
-        hipLaunchKernelGGL((bcnn_bwd_pc_kernel<HW, MODE>), dim3(xcd_grid(B, per)), dim3(512), 0, st, x, y, dy, inv_norm,
-                           dx, tpart, C, nb, B, two_rows, ex);
+    // Three structures were measured at B=64, C=512, HW=196 (all bit-compatible):
+    //   bcnn_bwd_panel_kernel (below, default)   64-row K-blocks, P built in LDS, 2 WGs/CU          85-88 us
+    //   bcnn_bwd_v3_kernel    (HK_BWD_V=3)       32-row K-blocks, raw tiles, no transposition, 3/CU  92 us
+    //   producer/consumer 512-thread variant     (removed)                94 us
+    // All sit at ~65 % matrix-pipe occupancy at the ~1.9 GHz DVFS clock; the backward moves 235 MB per launch.
+    const char* v = getenv("HK_BWD_V");
+    if (v && v[0] == '3') {
+        hipLaunchKernelGGL((bcnn_bwd_v3_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
+                           tpart, C, nb, B, ex);
         HK_LAUNCH_CHECK();
         return HK_OK;
     }

@@ -26,7 +26,9 @@ def use_in_tree_cache(base=None):
     base = base or os.environ.get('HAWKEYE_MIOPEN_DIR')
     try:
         if base is None:
-            base = os.path.join(tempfile.gettempdir(), f'hawkeye_miopen_{os.getuid()}')
+            # one scratch copy per rank: MIOpen's sqlite cache is not meant to be shared by concurrently starting processes
+            base = os.path.join(tempfile.gettempdir(),
+                                f"hawkeye_miopen_{os.getuid()}_r{os.environ.get('LOCAL_RANK', '0')}")
             for sub in ('cache', 'db'):
                 dst, src = os.path.join(base, sub), os.path.join(SEED, sub)
                 os.makedirs(dst, exist_ok=True)
