@@ -118,10 +118,10 @@ struct EpAffine {
 // Newton-Schulz shape (256^3 x 64 samples): T=2 gives 256 workgroups = 1 per CU with nothing to overlap its
 // load/barrier phases and is 1.3x SLOWER than T=1 (1024 workgroups, 4 per CU), so T=1 is the default;
 // allow_big=1 opts in (useful only when tiles >> CUs).
-template <int T, bool A_KC, bool B_KC, class AL, class BL, class EP>
+template <int T, int BKT, bool A_KC, bool B_KC, class AL, class BL, class EP>
 __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb,
                                                      int tilesM, int tilesN) {
-    constexpr int BM = 64 * T, BN = 64 * T, BK = 32;
+    constexpr int BM = 64 * T, BN = 64 * T, BK = BKT;
     constexpr int PA = A_KC ? BK + 4 : BM + 4;
     constexpr int PB = B_KC ? BK + 4 : BN + 4;
     constexpr int SA = (A_KC ? BM : BK) * PA;
@@ -269,14 +269,22 @@ template <bool A_KC, bool B_KC, class AL, class BL, class EP>
 static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb,
                                hipStream_t st, int allow_big = 0) {
     if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
-    if (allow_big && M >= 128 && N >= 128) {
+    if (allow_big == 1 && M >= 128 && N >= 128) {
         const int tm = (M + 127) / 128, tn = (N + 127) / 128;
-        hipLaunchKernelGGL((bgemm_kernel<2, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al,
-                           bl, ep, M, N, K, nb, tm, tn);
+        hipLaunchKernelGGL((bgemm_kernel<2, 32, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st,
+                           al, bl, ep, M, N, K, nb, tm, tn);
+    } else if (allow_big == 2 && K >= 128) {   // 64-deep K chunks: half the barriers, 70 KB LDS (2 WGs/CU)
+        const int tm = (M + 63) / 64, tn = (N + 63) / 64;
+        hipLaunchKernelGGL((bgemm_kernel<1, 64, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st,
+                           al, bl, ep, M, N, K, nb, tm, tn);
+    } else if (allow_big == 3) {               // 16-deep K chunks: 19 KB LDS -> up to 8 WGs/CU
+        const int tm = (M + 63) / 64, tn = (N + 63) / 64;
+        hipLaunchKernelGGL((bgemm_kernel<1, 16, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st,
+                           al, bl, ep, M, N, K, nb, tm, tn);
     } else {
         const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-        hipLaunchKernelGGL((bgemm_kernel<1, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al,
-                           bl, ep, M, N, K, nb, tm, tn);
+        hipLaunchKernelGGL((bgemm_kernel<1, 32, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st,
+                           al, bl, ep, M, N, K, nb, tm, tn);
     }
     HK_LAUNCH_CHECK();
     return HK_OK;

@@ -150,7 +150,8 @@ static inline int mm(const float* A, long long sa, const float* Bm, long long sb
     const LdPlain la = make_plain(A, sa, d, d, d);
     const LdPlain lb = make_plain(Bm, sb, d, d, d);
     const EpAffine ep = make_affine(C, sc, d, alpha, bscale, beta, diag);
-    return bgemm_launch<true, false>(la, lb, ep, d, d, d, nb, st);
+    static const int variant = [] { const char* e = getenv("HK_NS_GEMM"); return e ? atoi(e) : 0; }();   // A/B: 0 = 64x64x32, 1 = 128x128x32, 2 = 64x64x64
+    return bgemm_launch<true, false>(la, lb, ep, d, d, d, nb, st, variant);
 }
 
 static inline dim3 ew_grid(long long n, int B) {
