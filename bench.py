@@ -48,7 +48,9 @@ def parse():
     ap.add_argument('--model', default='BCNN', choices=['BCNN', 'CBCNN', 'MPN', 'APCNN'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernels', action='store_true')
-    ap.add_argument('--channels-last', type=int, default=0)
+    ap.add_argument('--channels-last', type=int, default=1,
+                    help='NHWC tensors through the backbone: MIOpen picks NHWC igemm kernels either way; this removes its '
+                         'NCHW<->NHWC batched_transpose passes (5.7%% of the step): measured 298.8 vs 273.2 img/s')
     ap.add_argument('--miopen-find', type=int, default=0)
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--backend', default=None, help='process-group backend override (debug: gloo lets N ranks share one GPU)')

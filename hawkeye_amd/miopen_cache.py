@@ -2,7 +2,7 @@
 (torch/share/miopen/db has gfx942/gfx90a only), so every new convolution shape is
 JIT-compiled on first use: measured on a fresh MI355X box, the first BCNN step at
 batch 64 / 448x448 costs 20 s (forward) + 253 s (backward) before a single image is
-trained; with the kernels cached the same step starts in ~2 s.  MIOpen keeps what it
+trained (419 s with channels_last tensors); with the find results cached the same step starts in ~2 s.  MIOpen keeps what it
 compiled in $MIOPEN_CUSTOM_CACHE_DIR (kernel binaries, *.ukdb) and
 $MIOPEN_USER_DB_PATH (find db).  hawkeye_amd/miopen_db/ holds a ~200 KB cache
 populated by `tools/warm_miopen.sh` on a GPU box for the shapes bench.py / smoke()
@@ -41,6 +41,12 @@ def use_in_tree_cache(base=None):
             os.makedirs(os.path.join(base, 'db'), exist_ok=True)
     except OSError:
         return None
+    # MIOpen's first-use "find" times every applicable solver, including the naive reference convolutions
+    # (measured in the find db: 0.3-1.8 s PER RUN at the bench shapes vs 4-20 ms for the real solvers) - that, not
+    # compilation, is what makes a cold start take minutes.  They are never selected; keep them out of the search.
+    for k in ('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', 'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD',
+              'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'):
+        os.environ.setdefault(k, '0')
     os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(base, 'cache'))
     os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(base, 'db'))
     return base
