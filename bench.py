@@ -104,11 +104,13 @@ def kernel_rooflines(B, C, HW, dev):
     inv = torch.empty(B, device=dev)
     cs = torch.empty(B, HW, device=dev)
     tp = torch.empty(B, (C + 63) // 64, device=dev)
-    lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, stream())
+    nwsc = lib.hk_bcnn_pool_ws_bytes(B, C, HW)
+    wsc = torch.empty(nwsc, dtype=torch.uint8, device=dev)
+    lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream())
     lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream())
     flops = 2.0 * B * C * C * HW
     stages = [
-        ('bcnn_colsum_norm_kernel', lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, stream()),
+        ('bcnn_colsum_partial+finalize', lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream()),
          0.0, 4.0 * B * C * HW),
         ('bcnn_gram_panel_kernel<196>', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
          flops, 4.0 * B * C * HW + 4.0 * B * C * C),

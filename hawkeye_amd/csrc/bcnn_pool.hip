@@ -67,6 +67,49 @@ __global__ __launch_bounds__(1024) void bcnn_colsum_norm_kernel(const float* __r
     }
 }
 
+// Two-stage variant with 8x more parallelism (the single kernel above runs on only B workgroups = a quarter of the
+// chip at B = 64): stage 1 sums 64-channel groups (grid B x C/64, coalesced row reads, thread per column), stage 2
+// adds the group partials in a fixed order and produces inv_norm.  Same summation tree for every launch: deterministic.
+__global__ __launch_bounds__(256) void bcnn_colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                                  int C, int HW, int G) {
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int c0 = g * 64, c1 = (c0 + 64 < C) ? c0 + 64 : C;
+    const float* xb = x + ((long long)b * C + c0) * HW;
+    float* pp = part + ((long long)b * G + g) * HW;
+    for (int hw = threadIdx.x; hw < HW; hw += 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int c = 0;
+        const int n = c1 - c0;
+        for (; c + 4 <= n; c += 4) {
+            s0 += xb[(long long)(c + 0) * HW + hw];
+            s1 += xb[(long long)(c + 1) * HW + hw];
+            s2 += xb[(long long)(c + 2) * HW + hw];
+            s3 += xb[(long long)(c + 3) * HW + hw];
+        }
+        for (; c < n; ++c) s0 += xb[(long long)c * HW + hw];
+        pp[hw] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+__global__ __launch_bounds__(256) void bcnn_norm_finalize_kernel(const float* __restrict__ part, float* __restrict__ colsum,
+                                                                 float* __restrict__ inv_norm, int C, int HW, int G) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* pp = part + (long long)b * G * HW;
+    float ssq = 0.f;
+    for (int hw = threadIdx.x; hw < HW; hw += 256) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += pp[(long long)g * HW + hw];
+        colsum[(long long)b * HW + hw] = s;
+        ssq += s * s;
+    }
+    const float tot = block_sum<4>(ssq, red);
+    if (threadIdx.x == 0) {
+        const float n2 = tot / (float)HW + (float)C * (float)C * 1e-5f;
+        inv_norm[b] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    }
+}
+
 // Gram epilogue: y = sqrt(acc / M + 1e-5) * inv_norm[b]
 struct EpBcnn {
     float* y;
@@ -154,14 +197,23 @@ __global__ __launch_bounds__(256) void bcnn_rank1_fix_kernel(float* __restrict__
 using namespace hk;
 
 extern "C" size_t hk_bcnn_pool_ws_bytes(int B, int C, int HW) {
-    (void)HW;
     const size_t tiles = (size_t)((C + 63) / 64);
-    return (size_t)B * tiles * sizeof(float) + 256;
+    // backward: t partials [B][tiles]; forward: column-sum group partials [B][tiles][HW]
+    return (size_t)B * tiles * (size_t)(HW > 1 ? HW : 1) * sizeof(float) + 256;
 }
 
-extern "C" int hk_bcnn_colsum_norm(const float* x, float* colsum, float* inv_norm, int B, int C, int HW,
-                                  hk_stream_t stream) {
+extern "C" int hk_bcnn_colsum_norm(const float* x, float* colsum, float* inv_norm, int B, int C, int HW, void* ws,
+                                  size_t ws_bytes, hk_stream_t stream) {
     if (!x || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    const int G = (C + 63) / 64;
+    if (ws && ws_bytes >= (size_t)B * G * HW * sizeof(float) && G > 1) {      // two-stage, B*G workgroups
+        hipLaunchKernelGGL(bcnn_colsum_partial_kernel, dim3(G, B), dim3(256), 0, (hipStream_t)stream, x, (float*)ws, C, HW, G);
+        HK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bcnn_norm_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, colsum,
+                           inv_norm, C, HW, G);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     const int ncol = HW < 1024 ? HW : 1024;
     const int groups = 1024 / ncol;
     const size_t sm = ((size_t)groups * HW + 16) * sizeof(float);
@@ -186,9 +238,8 @@ extern "C" int hk_bcnn_gram_norm(const float* x, const float* inv_norm, float* y
 
 extern "C" int hk_bcnn_pool_fwd(const float* x, float* y, float* inv_norm, float* colsum, int B, int C, int HW,
                                 void* ws, size_t ws_bytes, hk_stream_t stream) {
-    (void)ws; (void)ws_bytes;
     if (!x || !y || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
-    int rc = hk_bcnn_colsum_norm(x, colsum, inv_norm, B, C, HW, stream);
+    int rc = hk_bcnn_colsum_norm(x, colsum, inv_norm, B, C, HW, ws, ws_bytes, stream);
     if (rc != HK_OK) return rc;
     return hk_bcnn_gram_norm(x, inv_norm, y, B, C, HW, stream);
 }

@@ -36,7 +36,9 @@ class _BilinearPool(torch.autograd.Function):
         y = torch.empty(b, c * c, dtype=torch.float32, device=x.device)
         inv_norm = torch.empty(b, dtype=torch.float32, device=x.device)
         colsum = torch.empty(b, hw, dtype=torch.float32, device=x.device)
-        check(lib.hk_bcnn_pool_fwd(ptr(x), ptr(y), ptr(inv_norm), ptr(colsum), b, c, hw, None, 0, stream()),
+        nws = lib.hk_bcnn_pool_ws_bytes(b, c, hw)
+        ws = _ws(nws, x.device)
+        check(lib.hk_bcnn_pool_fwd(ptr(x), ptr(y), ptr(inv_norm), ptr(colsum), b, c, hw, ptr(ws), nws, stream()),
               'hk_bcnn_pool_fwd')
         ctx.save_for_backward(x, y, inv_norm, colsum)
         return y

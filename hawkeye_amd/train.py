@@ -185,9 +185,14 @@ class Trainer:
         return torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, config.T_max, config.eta_min)
 
     def to_device(self, m, parallel=False):
+        """`experiment.channels_last: True` keeps images / conv weights in NHWC (MIOpen's fp32 kernels on gfx950 are
+        NHWC implicit-GEMMs: this removes its layout transposes, +10 % on the BCNN step - DESIGN.md section 5)."""
+        cl = 'channels_last' in self.config.experiment and self.config.experiment.channels_last
         if isinstance(m, torch.Tensor):
-            return m.to(self.device, non_blocking=True)
-        return m.to(self.device)
+            m = m.to(self.device, non_blocking=True)
+            return m.contiguous(memory_format=torch.channels_last) if (cl and m.dim() == 4) else m
+        m = m.to(self.device)
+        return m.to(memory_format=torch.channels_last) if cl else m
 
     def get_model_module(self, model=None):
         return self.model if model is None else model       # never wrapped: attribute access stays direct

@@ -62,7 +62,9 @@ int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy, const floa
 /* The two stages of each direction, individually callable (hk_bcnn_pool_fwd = colsum_norm + gram_norm,
  * hk_bcnn_pool_bwd = bwd_gemm + bwd_rank1); bench.py times them separately.
  *   tpart [B, ceil(C/64)] partial sums of <y,dy> written by bwd_gemm, consumed by bwd_rank1 */
-int hk_bcnn_colsum_norm(const float* x, float* colsum, float* inv_norm, int B, int C, int HW, hk_stream_t stream);
+/* ws (optional, hk_bcnn_pool_ws_bytes): enables the two-stage column sum (B*C/64 workgroups instead of B) */
+int hk_bcnn_colsum_norm(const float* x, float* colsum, float* inv_norm, int B, int C, int HW, void* ws,
+                        size_t ws_bytes, hk_stream_t stream);
 int hk_bcnn_gram_norm(const float* x, const float* inv_norm, float* y, int B, int C, int HW, hk_stream_t stream);
 int hk_bcnn_bwd_gemm(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx,
                      float* tpart, int B, int C, int HW, hk_stream_t stream);

@@ -53,8 +53,9 @@ B = 64
 C, HW = 512, 196
 x = torch.relu(R(B, C, HW)); y = E(B, C * C); dy = R(B, C * C); dx = E(B, C, HW)
 inv = E(B); cs = E(B, HW); tp = E(B, C // 64)
+nwsc = lib.hk_bcnn_pool_ws_bytes(B, C, HW); wsc = E(nwsc, dtype=torch.uint8)
 fl = 2.0 * B * C * C * HW
-report('bcnn colsum_norm', lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, stream()), 0, 4.0 * B * C * HW)
+report('bcnn colsum_norm', lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream()), 0, 4.0 * B * C * HW)
 report('bcnn gram_norm', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()), fl, 4.0 * B * (C * HW + C * C))
 report('bcnn bwd_gemm', lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream()), fl, 8.0 * B * (C * C + C * HW))
 report('bcnn bwd_rank1', lambda: lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream()), 0, 8.0 * B * C * HW)

@@ -19,8 +19,10 @@ dx = torch.empty_like(x)
 inv = torch.empty(B, device=dev)
 cs = torch.empty(B, HW, device=dev)
 tp = torch.empty(B, C // 64, device=dev)
+nwsc = lib.hk_bcnn_pool_ws_bytes(B, C, HW)
+wsc = torch.empty(nwsc, dtype=torch.uint8, device=dev)
 for _ in range(reps):
-    lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, stream())
+    lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream())
     lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream())
     lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream())
     lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream())
