@@ -12,29 +12,45 @@ from ..registry import MODEL
 from ..utils import initialize_weights
 
 
+FEATURE_CHANNELS = 512          # VGG-16 conv5_3 width: the bilinear descriptor has 512 x 512 entries
+
+
 class BilinearPooling(nn.Module):
-    """[B,C,H,W] -> [B,C*C]: sqrt(X X^T / HW + 1e-5) then l2-normalise (BCNN.py:13-27)."""
+    """Parameter-free second-order pooling: [B,C,H,W] -> [B,C*C].
+
+    y = normalize( sqrt( X X^T / HW + 1e-5 ) ) per image (X = the map flattened to C x HW).  One column-sum launch
+    + one Gram launch whose epilogue writes the final y; backward = one GEMM-shaped launch + one rank-1 fix-up
+    (hawkeye_amd/csrc/bcnn_fast.hip, bcnn_pool.hip)."""
 
     def forward(self, x):
         return HF.bilinear_pool(x)
 
 
+def _frozen(module):
+    for weight in module.parameters():
+        weight.requires_grad = False
+    return module
+
+
 @MODEL.register
 class BCNN(nn.Module):
+    """VGG-16 conv trunk -> BilinearPooling -> Linear.  Stage 1 trains the classifier on a frozen trunk (the trunk's
+    output is detached so no backward kernel is launched for it), stage 2 (default when `config.stage` is absent)
+    fine-tunes everything."""
+
     def __init__(self, config):
         super().__init__()
-        self.stage = config.stage if 'stage' in config else 2     # BCNN.py:36
-        # all 31 layers of VGG-16 `features`, last MaxPool included (BCNN.py:38-39)
-        self.backbone = nn.Sequential(*list(vgg16(pretrained=True).features.children()))
+        self.stage = config.stage if 'stage' in config else 2
+        trunk = vgg16(pretrained=True).features            # the whole `features` stack, final MaxPool included:
+        self.backbone = nn.Sequential(*trunk.children())    # 448x448 input -> [B,512,14,14]
         self.bilinear_pooling = BilinearPooling()
-        self.classifier = nn.Linear(512 ** 2, config.num_classes)
+        self.classifier = nn.Linear(FEATURE_CHANNELS * FEATURE_CHANNELS, config.num_classes)
         self.classifier.apply(initialize_weights)
         if self.stage == 1:
-            for p in self.backbone.parameters():
-                p.requires_grad = False
+            _frozen(self.backbone)
 
     def forward(self, x):
-        x = self.backbone(x)
+        feats = self.backbone(x)
         if self.stage == 1:
-            x = x.detach()
-        return self.classifier(self.bilinear_pooling(x))
+            feats = feats.detach()
+        return self.classifier(self.bilinear_pooling(feats))

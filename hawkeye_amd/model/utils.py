@@ -1,24 +1,41 @@
-"""Weight init / lenient checkpoint loading with the reference's behaviour
-(model/utils.py:5-28): they decide the random-init statistics of synthetic runs."""
+"""Initialisers and lenient checkpoint loading.
+
+The initial statistics matter for synthetic-data runs and for the seeded whole-model parity tests, so they follow
+the reference (model/utils.py:5-28): convolutions Kaiming-normal on fan-out for ReLU with zero bias, BatchNorm2d to
+(1, 0), Linear layers Kaiming-normal (default fan-in) with zero bias.  `load_state_dict` is the reference's
+"take what matches by name and shape" loader used for ImageNet checkpoints.
+"""
 import torch.nn as nn
+from torch.nn import init
+
+
+def _zero_bias(layer):
+    if getattr(layer, 'bias', None) is not None:
+        init.zeros_(layer.bias)
 
 
 def initialize_weights(m):
+    """`module.apply(initialize_weights)`-style visitor."""
     if isinstance(m, nn.Conv2d):
-        nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-        if m.bias is not None:
-            nn.init.constant_(m.bias, 0)
-    elif isinstance(m, nn.BatchNorm2d):
-        nn.init.constant_(m.weight, 1)
-        nn.init.constant_(m.bias, 0)
-    elif isinstance(m, nn.Linear):
-        nn.init.kaiming_normal_(m.weight.data)
-        if m.bias is not None:
-            nn.init.constant_(m.bias.data, val=0)
+        init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        _zero_bias(m)
+        return
+    if isinstance(m, nn.BatchNorm2d):
+        init.ones_(m.weight)
+        init.zeros_(m.bias)
+        return
+    if isinstance(m, nn.Linear):
+        init.kaiming_normal_(m.weight.data)
+        _zero_bias(m)
 
 
 def load_state_dict(model, state_dict):
-    """Copy only the entries whose name and shape match (model/utils.py:24-28)."""
-    own = model.state_dict()
-    own.update({k: v for k, v in state_dict.items() if k in own and v.shape == own[k].shape})
-    model.load_state_dict(own)
+    """Copy the entries of `state_dict` whose key exists in `model` with the same shape; keep the rest as initialised."""
+    target = model.state_dict()
+    usable = {}
+    for key, value in state_dict.items():
+        if key in target and tuple(value.shape) == tuple(target[key].shape):
+            usable[key] = value
+    target.update(usable)
+    model.load_state_dict(target)
+    return sorted(usable)
