@@ -37,8 +37,13 @@ struct CbpPlan {  // device-side view of the plan blob
     const float* s2;
     const int* off;      // [D+1]
     const unsigned* ent; // [C*C]  bit31 = negative sign, low bits = i*C + j
-    const unsigned* ell; // [E][D] transposed (ELL) copy of the bins: entry e of bin k at ell[e*D + k], 0xffffffff = none
-    int E;               // max entries per bin
+    // inverse of h2 over its NON-EMPTY bins (row-sketch kernel): slot t holds bin nzb[t] and the channels
+    // nzj[nzo[t] .. nzo[t+1]) hashed there (bit31 = negative s2)
+    const int* nzb;      // [C]
+    const int* nzo;      // [C+1]
+    const unsigned* nzj; // [C]
+    int nzn;             // number of non-empty h2 bins (<= C)
+    int emax;            // largest number of channels sharing one h2 bin
 };
 
 __host__ __device__ inline size_t cbp_align(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -52,16 +57,19 @@ static inline CbpPlan cbp_view(const void* plan, int C, int D) {
     v.s2 = (const float*)p;          p += cbp_align((size_t)C * 4);
     v.off = (const int*)p;           p += cbp_align((size_t)(D + 1) * 4);
     v.ent = (const unsigned*)p;      p += cbp_align((size_t)C * C * 4);
-    v.ell = (const unsigned*)p;
-    v.E = ((const int*)plan)[2];
+    v.nzb = (const int*)p;           p += cbp_align((size_t)C * 4);
+    v.nzo = (const int*)p;           p += cbp_align((size_t)(C + 1) * 4);
+    v.nzj = (const unsigned*)p;
+    v.nzn = ((const int*)plan)[2];
+    v.emax = ((const int*)plan)[3];
     return v;
 }
 
 // c_raw[b,k] = sum over the bin's (i,j) list of +-G[b,i,j]; one wave per bin, lanes stride over its ~44 entries,
 // butterfly reduction (fixed order).  The gathers touch one 64-B sector per 4-B entry, so this stage is bound by
-// L2 sector traffic (~130 us at B=64); a lane-per-bin walk of the transposed (ELL) table - cbp_bin_ell_kernel below,
-// coalesced entry reads, 8 gathers in flight per lane - was measured SLOWER (190 us): same sector traffic, fewer
-// waves.  The real fix (round 2) is to bin inside the Gram epilogue from LDS so G never leaves the chip.
+// L2 sector traffic (~130 us at B=64); a lane-per-bin walk of a transposed (ELL) table - coalesced entry reads,
+// 8 gathers in flight per lane - was measured SLOWER (190 us): same sector traffic, fewer waves.  Kept as the
+// fallback for C > 512 / D > 8192; the default is cbp_rowsketch_kernel below.
 __global__ __launch_bounds__(256) void cbp_bin_kernel(const float* __restrict__ G, const int* __restrict__ off,
                                                       const unsigned* __restrict__ ent, float* __restrict__ c_raw,
                                                       int CC, int D) {
@@ -81,40 +89,183 @@ __global__ __launch_bounds__(256) void cbp_bin_kernel(const float* __restrict__ 
     if (lane == 0) c_raw[(long long)b * D + k] = s;
 }
 
-__global__ __launch_bounds__(256) void cbp_bin_ell_kernel(const float* __restrict__ G, const unsigned* __restrict__ ell,
-                                                          int E, float* __restrict__ c_raw, int CC, int D) {
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= D) return;
-    const float* g = G + (long long)b * CC;
-    float s = 0.f;
-    int e = 0;
-    for (; e + 8 <= E; e += 8) {
-        unsigned u[8];
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) u[q] = ell[(long long)(e + q) * D + k];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (u[q] != 0xffffffffu) ? g[u[q] & 0x7fffffffu] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += (u[q] >> 31) ? -v[q] : v[q];      // padding: u>>31 = 1, v = 0 -> -0 adds nothing
+// Row-sketch binning (default for C <= 512, D <= 8192).  For one row i of G, its contribution to the output is a
+// circular shift of the count sketch of that row:  c[k] += s1_i * r_i[(k - h1_i) mod D],  r_i[m] = sum_{j: h2_j = m} s2_j G_ij.
+// A workgroup owns 64 rows of one sample's G: r_i (D floats, <= 512 non-zeros) lives in LDS, each thread owns the
+// non-empty h2 bins t, t+256 (their G entries are fetched one row ahead, so the gathers overlap the accumulate
+// phase) and D/256 output bins in registers.  Reads of G are confined to one 2 KB row at a time (vs one 64-B sector
+// per 4-B entry anywhere in a 1 MB matrix for the CSR gather above), every bin is summed in a fixed order, and the
+// 64-row partials are added in a fixed order by cbp_partsum_kernel: deterministic, no atomics.
+
+constexpr int CBP_EMAX = 4;      // channels per non-empty h2 bin held in registers (plan build checks the hashes)
+constexpr int CBP_RB = 4;        // rows of G staged per LDS block
+
+// Measured history of this kernel (C=512, D=6000, per launch, independent of B up to 2 workgroups / CU):
+//   v1 entries gathered from global memory one row ahead                       ~190 us (a memory latency per row)
+//   v2 G streamed through LDS in row blocks, coalesced 16-B loads              112 us (rocprofv3): the per-bin `if`s
+//      made every LDS read its own basic block, so ~32 LDS latencies per row were exposed
+//   v3 (this) branch-free: padded entries carry sign 0, invalid bins write to a dump slot, and the sketch is kept
+//      REPLICATED (r[i + D] = r[i]) so the circular shift by h1[i] is a plain base + 256 q with immediate offsets
+template <int NBT, int NQ8>
+__global__ __launch_bounds__(256) void cbp_rowsketch_kernel(const float* __restrict__ G, CbpPlan pl,
+                                                            float* __restrict__ part, int C, int D, int nchunk) {
+    constexpr int NQ = 8 * NQ8;                        // output bins per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int RS = D + 256 * NQ;                       // replicated sketch length; r[RS] is the dump slot
+    float* r = smem;
+    const int poff = ((RS + 1 + 3) / 4) * 4;
+    int* sh1 = reinterpret_cast<int*>(smem + poff);    // [64]  h1 of the chunk's rows
+    float* ss1 = smem + poff + 64;                     // [64]  s1 of the chunk's rows
+    float* gb = smem + poff + 128;                     // [2][CBP_RB * C] staged rows of G
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int i0 = ch * 64, i1 = (i0 + 64 < C) ? i0 + 64 : C;
+    const int nrows = i1 - i0, nblk = (nrows + CBP_RB - 1) / CBP_RB;
+    const int blk4 = CBP_RB * C / 4;                   // float4 per full block (<= 512 for C <= 512)
+    const float* gbase = G + ((long long)b * C + i0) * C;
+
+    for (int k = tid; k <= RS; k += 256) r[k] = 0.f;
+    if (tid < 64 && tid < nrows) {
+        sh1[tid] = pl.h1[i0 + tid];
+        ss1[tid] = pl.s1[i0 + tid];
     }
-    for (; e < E; ++e) {
-        const unsigned u = ell[(long long)e * D + k];
-        if (u != 0xffffffffu) {
-            const float v = g[u & 0x7fffffffu];
-            s += (u >> 31) ? -v : v;
+    int jx[NBT][CBP_EMAX], w[NBT][3];
+    float sg[NBT][CBP_EMAX];
+#pragma unroll
+    for (int u = 0; u < NBT; ++u) {
+        const int t = tid + 256 * u;
+        const bool ok = t < pl.nzn;
+        const int mb = ok ? pl.nzb[t] : -1;
+#pragma unroll
+        for (int cpy = 0; cpy < 3; ++cpy) {            // D >= RS / 3 (dispatch): at most 3 replicas of a bin
+            const int idx = mb + cpy * D;
+            w[u][cpy] = (mb >= 0 && idx < RS) ? idx : RS;
+        }
+        const int lo = ok ? pl.nzo[t] : 0, hi = ok ? pl.nzo[t + 1] : 0;
+#pragma unroll
+        for (int e = 0; e < CBP_EMAX; ++e) {
+            const bool valid = lo + e < hi;
+            const unsigned v = valid ? pl.nzj[lo + e] : 0u;
+            jx[u][e] = (int)(v & 0x7fffffffu);
+            sg[u][e] = valid ? ((v >> 31) ? -1.f : 1.f) : 0.f;
         }
     }
+    float c[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) c[q] = 0.f;
+
+    f32x4 st[2];                                       // this thread's share of one staged block
+#define HK_BLK_LOAD(blk_)                                                                            \
+    do {                                                                                             \
+        const int left_ = nrows - (blk_) * CBP_RB;                                                   \
+        const int lim4_ = ((left_ < CBP_RB ? left_ : CBP_RB) * C) / 4;                               \
+        const f32x4* src_ = reinterpret_cast<const f32x4*>(gbase + (long long)(blk_) * CBP_RB * C);  \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
+            const int f_ = tid + 256 * u;                                                            \
+            st[u] = src_[f_ < lim4_ ? f_ : 0];                                                       \
+        }                                                                                            \
+    } while (0)
+#define HK_BLK_STORE(buf_)                                                                           \
+    do {                                                                                             \
+        f32x4* dst_ = reinterpret_cast<f32x4*>(gb + (buf_) * CBP_RB * C);                            \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
+            const int f_ = tid + 256 * u;                                                            \
+            if (f_ < blk4) dst_[f_] = st[u];                                                         \
+        }                                                                                            \
+    } while (0)
+#define HK_LDS_BARRIER()                                                                             \
+    do {                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+        __builtin_amdgcn_s_barrier();                                                                \
+        asm volatile("" ::: "memory");                                                               \
+    } while (0)
+
+    HK_BLK_LOAD(0);
+    HK_BLK_STORE(0);
+    __syncthreads();
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1;
+        if (blk + 1 < nblk) HK_BLK_LOAD(blk + 1);            // in flight while this block is consumed
+        const float* gcur = gb + cur * CBP_RB * C;
+        const int left = nrows - blk * CBP_RB;
+        const int rmax = left < CBP_RB ? left : CBP_RB;
+        for (int rr = 0; rr < rmax; ++rr) {
+            const float* grow = gcur + rr * C;
+            float x[NBT][CBP_EMAX];
+#pragma unroll
+            for (int u = 0; u < NBT; ++u)
+#pragma unroll
+                for (int e = 0; e < CBP_EMAX; ++e) x[u][e] = grow[jx[u][e]];
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) {
+                float sacc = 0.f;                            // signed sum in channel order (padding adds 0 * x)
+#pragma unroll
+                for (int e = 0; e < CBP_EMAX; ++e) sacc += sg[u][e] * x[u][e];
+                r[w[u][0]] = sacc;                           // non-empty bins are overwritten every row, empty stay 0
+                r[w[u][1]] = sacc;
+                r[w[u][2]] = sacc;
+            }
+            HK_LDS_BARRIER();
+            const int li = blk * CBP_RB + rr;
+            const float s1i = ss1[li];
+            int base = tid - sh1[li];
+            if (base < 0) base += D;
+            const float* rb = r + base;                      // c[k] += s1 r[(k - h1) mod D], k = tid + 256 q
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) c[q] += s1i * rb[256 * q];
+            HK_LDS_BARRIER();
+        }
+        if (blk + 1 < nblk) {
+            HK_BLK_STORE(cur ^ 1);
+            HK_LDS_BARRIER();
+        }
+    }
+#undef HK_BLK_LOAD
+#undef HK_BLK_STORE
+#undef HK_LDS_BARRIER
+    float* pp = part + ((long long)b * nchunk + ch) * D;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int k = tid + 256 * q;
+        if (k < D) pp[k] = c[q];
+    }
+}
+
+template <int NBT, int NQ8>
+static int rowsketch_launch(const float* G, const CbpPlan& pl, float* part, int B, int C, int D, int nchunk,
+                            hipStream_t st) {
+    const int RS = D + 256 * 8 * NQ8;
+    const size_t lds = ((size_t)((RS + 1 + 3) / 4) * 4 + 128 + 2 * CBP_RB * (size_t)C) * sizeof(float);
+    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cbp_rowsketch_kernel<NBT, NQ8>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((cbp_rowsketch_kernel<NBT, NQ8>), dim3(nchunk, B), dim3(256), lds, st, G, pl, part, C, D, nchunk);
+    return HK_OK;
+}
+
+// c_raw[b][k] = sum over the 64-row chunks of part[b][chunk][k], in chunk order (one thread per bin: coalesced, and
+// B*D/256 workgroups - summing inside the one-workgroup-per-sample norm kernel serialised 192 loads per thread).
+__global__ __launch_bounds__(256) void cbp_partsum_kernel(const float* __restrict__ part, float* __restrict__ c_raw,
+                                                         int D, int nchunk) {
+    const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (k >= D) return;
+    const float* pp = part + (long long)b * nchunk * D + k;
+    float s = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < nchunk; ++q) s += pp[(long long)q * D];
     c_raw[(long long)b * D + k] = s;
 }
 
 // u = sign(c) sqrt(|c| + 1e-10) ; y = u / max(|u|_2, 1e-12)      (CBCNN.py:132-133)
-__global__ __launch_bounds__(256) void cbp_norm_kernel(const float* __restrict__ c_raw, float* __restrict__ y,
+// part != nullptr: c_raw[b,k] = sum of the nchunk row-chunk partials (fixed order) is formed here first
+__global__ __launch_bounds__(256) void cbp_norm_kernel(float* __restrict__ c_raw, float* __restrict__ y,
                                                        float* __restrict__ inv_norm, int D) {
     __shared__ float red[4];
     const int b = blockIdx.x;
-    const float* c = c_raw + (long long)b * D;
+    float* c = c_raw + (long long)b * D;
     float ss = 0.f;   // u^2 = |c| + 1e-10 where c != 0; sign(0) = 0 makes u = 0 exactly there
     for (int k = threadIdx.x; k < D; k += 256) ss += (c[k] != 0.f) ? fabsf(c[k]) + 1e-10f : 0.f;
     ss = block_sum<4>(ss, red);
@@ -180,19 +331,9 @@ struct LdCbpDG {
 
 using namespace hk;
 
-// upper bound of the ELL depth used for sizing: the true maximum bin population is only known after hashing, so the
-// blob reserves HK_CBP_MAX_E rows (bins hold C*C/D entries on average; 4x that plus slack is never reached by the
-// reference's hashes: C=512, D=6000 -> mean 43.7, max 71)
-static inline int cbp_max_e(int C, int D) {
-    const long long mean = ((long long)C * C + D - 1) / D;
-    long long e = 4 * mean + 32;
-    if (e > (long long)C * C) e = (long long)C * C;
-    return (int)e;
-}
-
 extern "C" size_t hk_cbp_plan_bytes(int C, int D) {
     return 16 + 4 * cbp_align((size_t)C * 4) + cbp_align((size_t)(D + 1) * 4) + cbp_align((size_t)C * C * 4) +
-           cbp_align((size_t)cbp_max_e(C, D) * D * 4);
+           cbp_align((size_t)C * 4) + cbp_align((size_t)(C + 1) * 4) + cbp_align((size_t)C * 4);
 }
 
 extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32_t* h2, const float* s2, int C, int D,
@@ -222,15 +363,26 @@ extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32
             const unsigned neg = (s1[i] * s2[j] < 0.f) ? 0x80000000u : 0u;
             ent[cur[k]++] = neg | (unsigned)(i * C + j);
         }
-    // transposed (ELL) copy for the lane-per-bin reduction kernel
-    int E = 0;
-    for (int k = 0; k < D; ++k) E = cnt[k] > E ? cnt[k] : E;
-    if (E > cbp_max_e(C, D)) return HK_ERR_UNSUPPORTED;      // pathological hashes (all channels in a few bins)
-    ((int*)blob.data())[2] = E;
-    unsigned* ell = (unsigned*)((char*)ent + cbp_align((size_t)C * C * 4));
-    for (long long q = 0; q < (long long)E * D; ++q) ell[q] = 0xffffffffu;
-    for (int k = 0; k < D; ++k)
-        for (int q = 0; q < cnt[k]; ++q) ell[(long long)q * D + k] = ent[off[k] + q];
+    // inverse of h2 over its non-empty bins (row-sketch kernel), channels ascending inside a bin
+    {
+        int* nzb = (int*)((char*)ent + cbp_align((size_t)C * C * 4));
+        int* nzo = (int*)((char*)nzb + cbp_align((size_t)C * 4));
+        unsigned* nzj = (unsigned*)((char*)nzo + cbp_align((size_t)(C + 1) * 4));
+        std::vector<std::vector<int>> inv(D);
+        for (int j = 0; j < C; ++j) inv[h2[j]].push_back(j);
+        int t = 0, e = 0;
+        nzo[0] = 0;
+        for (int mbin = 0; mbin < D; ++mbin) {
+            if (inv[mbin].empty()) continue;
+            nzb[t] = mbin;
+            for (int j : inv[mbin]) nzj[e++] = (unsigned)j | (s2[j] < 0.f ? 0x80000000u : 0u);
+            nzo[++t] = e;
+        }
+        ((int*)blob.data())[2] = t;
+        int emax = 0;
+        for (int mbin = 0; mbin < D; ++mbin) emax = (int)inv[mbin].size() > emax ? (int)inv[mbin].size() : emax;
+        ((int*)blob.data())[3] = emax;
+    }
     hipError_t e = hipMemcpyAsync(plan, blob.data(), blob.size(), hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize((hipStream_t)stream);   // one-time setup: the host blob dies at return
@@ -239,7 +391,7 @@ extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32
 
 extern "C" size_t hk_cbp_ws_bytes(int B, int C, int HW, int D) {
     (void)HW;
-    const size_t g = (size_t)B * C * C * sizeof(float);
+    const size_t g = (size_t)B * C * C * sizeof(float) + (size_t)B * ((C + 63) / 64) * D * sizeof(float);  // G + row-chunk partials
     const size_t dc = (size_t)B * D * sizeof(float);
     return (g > dc ? g : dc) + 256;
 }
@@ -256,15 +408,37 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
     int rc = force_generic() ? HK_ERR_UNSUPPORTED : gram_fast_raw(x, nullptr, 1.0f, G, B, C, HW, st);
     if (rc == HK_ERR_UNSUPPORTED) rc = bgemm_launch<true, true>(xa, xa, ep, C, C, HW, B, st);      // raw Gram, no 1/HW
     if (rc != HK_OK) return rc;
-    const char* use_ell = getenv("HK_CBP_ELL");      // A/B switch for the measured-slower lane-per-bin variant
-    if (use_ell && use_ell[0] == '1')
-        hipLaunchKernelGGL(cbp_bin_ell_kernel, dim3((D + 255) / 256, B), dim3(256), 0, st, (const float*)G, pl.ell, pl.E,
-                           c_raw, C * C, D);
-    else
+    const int nchunk = (C + 63) / 64;
+    float* part = G + (long long)B * C * C;
+    // Binning stage, measured at C=512, D=6000 (whole hk_cbp_fwd, HIP events): row-sketch 107.0 us @B=64 / 87.9 @B=16,
+    // CSR gather 175.9 us @B=64 / 81.2 @B=16.  The row-sketch kernel is latency-bound per workgroup (~49 us for its 64
+    // rows whatever B is), the CSR gather is throughput-bound, so the row-sketch is used once B * C/64 workgroups fill the
+    // 256 CUs.  HK_CBP_CSR=1 / HK_CBP_CSR=0 force one or the other (A/B switch).
+    const char* csr = getenv("HK_CBP_CSR");
+    const int nq8 = ((D + 255) / 256 + 7) / 8;               // 8-bin groups per thread
+    const bool rowsketch = C <= 512 && C % 4 == 0 && nq8 <= 4 && D >= 1024 * nq8 && pl.emax <= CBP_EMAX &&
+                           (csr ? csr[0] == '0' : B * nchunk >= 256);
+    if (rowsketch) {
+        int rc2 = HK_ERR_UNSUPPORTED;
+        const bool one = C <= 256;
+        switch (nq8) {
+            case 1: rc2 = one ? rowsketch_launch<1, 1>(G, pl, part, B, C, D, nchunk, st) : rowsketch_launch<2, 1>(G, pl, part, B, C, D, nchunk, st); break;
+            case 2: rc2 = one ? rowsketch_launch<1, 2>(G, pl, part, B, C, D, nchunk, st) : rowsketch_launch<2, 2>(G, pl, part, B, C, D, nchunk, st); break;
+            case 3: rc2 = one ? rowsketch_launch<1, 3>(G, pl, part, B, C, D, nchunk, st) : rowsketch_launch<2, 3>(G, pl, part, B, C, D, nchunk, st); break;
+            case 4: rc2 = one ? rowsketch_launch<1, 4>(G, pl, part, B, C, D, nchunk, st) : rowsketch_launch<2, 4>(G, pl, part, B, C, D, nchunk, st); break;
+        }
+        if (rc2 != HK_OK) return rc2;
+    } else {
         hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 3) / 4, B), dim3(256), 0, st, (const float*)G, pl.off, pl.ent, c_raw,
                            C * C, D);
+    }
     HK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(cbp_norm_kernel, dim3(B), dim3(256), 0, st, (const float*)c_raw, y, inv_norm, D);
+    if (rowsketch) {
+        hipLaunchKernelGGL(cbp_partsum_kernel, dim3((D + 255) / 256, B), dim3(256), 0, st, (const float*)part, c_raw, D,
+                           nchunk);
+        HK_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(cbp_norm_kernel, dim3(B), dim3(256), 0, st, c_raw, y, inv_norm, D);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

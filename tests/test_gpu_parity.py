@@ -290,8 +290,37 @@ def test_cbp_dense_small_and_512(F):
         if 'dx' in g.files:
             assert rel(xg.grad, g['dx']) < 1e-4
         else:
-            np.testing.assert_allclose(sub(xg.grad.cpu()).numpy(), g['dx_sub'], rtol=1e-3, atol=1e-7)
+            np.testing.assert_allclose(sub(xg.grad.cpu()).numpy(), g['dx_sub'], rtol=1e-3, atol=2e-6)
         assert yg.argmax(dim=1).cpu().tolist() == y.argmax(dim=1).tolist()
+
+
+@pytest.mark.parametrize('csr', ['0', '1'])
+def test_cbp_512_both_binning_kernels(F, csr, monkeypatch):
+    """hk_cbp_fwd picks the binning kernel by batch size (row-sketch once B*C/64 >= 256 workgroups, CSR gather below);
+    HK_CBP_CSR forces one: both must reproduce the reference at the yaml shape."""
+    monkeypatch.setenv('HK_CBP_CSR', csr)
+    g = load('cbp_512')
+    xn, wn = rs_relu_randn(1234, (2, 512, 14, 14)).astype(np.float32), rs_randn(1236, (2, 6000))
+    x, y, xg, yg = _cbp_case(F, xn, wn, 6000)
+    assert rel(yg, g['y']) < 1e-5 and rel(yg, y) < 1e-5
+    assert rel(xg.grad, x.grad) < 1e-4
+    assert yg.argmax(dim=1).cpu().tolist() == y.argmax(dim=1).tolist()
+
+
+@pytest.mark.parametrize('c,d,b', [(128, 1024, 3), (256, 2048, 2), (512, 4096, 2), (512, 8192, 2), (512, 6000, 40)])
+def test_cbp_rowsketch_equals_csr(F, c, d, b, monkeypatch):
+    """Every template instance of the row-sketch kernel (1/2 bins per thread x 8..32 outputs per thread) against the
+    CSR gather; b=40 is above the automatic switch-over, so the default path is covered too."""
+    x = torch.relu(torch.randn(b, c, 7, 7, generator=torch.Generator().manual_seed(c + d))).to(DEV)
+    plan = _plan(F, c, d)
+    monkeypatch.setenv('HK_CBP_CSR', '1')
+    y_csr = F.compact_bilinear_pool(x, plan)
+    monkeypatch.setenv('HK_CBP_CSR', '0')
+    y_row = F.compact_bilinear_pool(x, plan)
+    monkeypatch.delenv('HK_CBP_CSR')
+    y_def = F.compact_bilinear_pool(x, plan)
+    assert rel(y_row, y_csr) < 2e-6 and rel(y_def, y_csr) < 2e-6
+    assert torch.equal(y_def, y_row if b * (c // 64) >= 256 else y_csr)
 
 
 def test_cbp_zero_bins(F):
