@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void att_pool_bwd_kernel(const float* __restri
                                                            const float* __restrict__ dgap,
                                                            const float* __restrict__ dsgap, float* __restrict__ df,
                                                            float* __restrict__ da_s, int C, int HW) {
-    extern __shared__ float sm[];  // dgap[C], dsgap[C] of this image
+    HK_DYN_LDS(sm);  // dgap[C], dsgap[C] of this image
     const int b = blockIdx.y;
     float* sg = sm;
     float* ss = sm + C;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void att_roi_select_kernel(const float* __rest
                                                              int* __restrict__ count, int h, int w, int stride,
                                                              float anchor, int img_h, int img_w, int r0, int r1, int c0,
                                                              int c1, float thr, int topk) {
-    extern __shared__ float sm[];  // score[h*w] ; alive flags packed as floats (>0 alive)
+    HK_DYN_LDS(sm);  // score[h*w] ; alive flags packed as floats (>0 alive)
     __shared__ float red[4];
     __shared__ Cand wbest[4];
     __shared__ Cand winner;

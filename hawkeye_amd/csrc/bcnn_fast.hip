@@ -198,9 +198,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
             ep.offdiag = (I != J);
             has_prev = true;
             // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for every epilogue store of this tile
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            HK_LDS_BARRIER();
             if (next_blk >= 0) {
                 if (newrow) { a_idx = n_idx; b_idx = n_idx; }
                 else b_idx = n_idx;

@@ -35,7 +35,7 @@ static inline bool force_generic() {   // HK_BCNN_GENERIC=1: A/B switch used by 
 __global__ __launch_bounds__(1024) void bcnn_colsum_norm_kernel(const float* __restrict__ x,
                                                                 float* __restrict__ colsum,
                                                                 float* __restrict__ inv_norm, int C, int HW) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [groups][HW] + 16
+    HK_DYN_LDS16(sm);  // [groups][HW] + 16
     const int b = blockIdx.x;
     const float* xb = x + (long long)b * C * HW;
     const int tid = threadIdx.x;

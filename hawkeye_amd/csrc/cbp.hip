@@ -110,7 +110,7 @@ template <int NBT, int NQ8>
 __global__ __launch_bounds__(256) void cbp_rowsketch_kernel(const float* __restrict__ G, CbpPlan pl,
                                                             float* __restrict__ part, int C, int D, int nchunk) {
     constexpr int NQ = 8 * NQ8;                        // output bins per thread
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    HK_DYN_LDS16(smem);
     const int RS = D + 256 * NQ;                       // replicated sketch length; r[RS] is the dump slot
     float* r = smem;
     const int poff = ((RS + 1 + 3) / 4) * 4;
@@ -172,12 +172,6 @@ __global__ __launch_bounds__(256) void cbp_rowsketch_kernel(const float* __restr
             if (f_ < blk4) dst_[f_] = st[u];                                                         \
         }                                                                                            \
     } while (0)
-#define HK_LDS_BARRIER()                                                                             \
-    do {                                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
-        __builtin_amdgcn_s_barrier();                                                                \
-        asm volatile("" ::: "memory");                                                               \
-    } while (0)
 
     HK_BLK_LOAD(0);
     HK_BLK_STORE(0);
@@ -221,7 +215,6 @@ __global__ __launch_bounds__(256) void cbp_rowsketch_kernel(const float* __restr
     }
 #undef HK_BLK_LOAD
 #undef HK_BLK_STORE
-#undef HK_LDS_BARRIER
     float* pp = part + ((long long)b * nchunk + ch) * D;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {

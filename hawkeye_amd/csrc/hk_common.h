@@ -12,6 +12,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HK_ERR_WORKSPACE (-2)
 #define HK_ERR_UNSUPPORTED (-3)
 
+// The two spellings below have no meaning off the GPU; the CPU emulation used by the test tier (tests/emu) supplies
+// its own before this header is read.
+#ifndef HK_DYN_LDS     // dynamic LDS of the launch as `float name[]` (HK_DYN_LDS16: declared 16-byte aligned)
+#define HK_DYN_LDS(name) extern __shared__ float name[]
+#define HK_DYN_LDS16(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#endif
+#ifndef HK_LDS_BARRIER  // workgroup barrier that waits for LDS traffic only (global loads stay in flight across it)
+#define HK_LDS_BARRIER()                                   \
+    do {                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                      \
+        asm volatile("" ::: "memory");                     \
+    } while (0)
+#endif
+
 #define HK_LAUNCH_CHECK()                                 \
     do {                                                  \
         hipError_t e__ = hipGetLastError();               \

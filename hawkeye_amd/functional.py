@@ -19,6 +19,11 @@ def _f32c(t):
     return t.contiguous()
 
 
+def _on(device):
+    """Make `device` the current HIP device for a host-side ABI call (memcpy + stream of that device)."""
+    return torch.cuda.device(device)
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -195,7 +200,7 @@ class CbpPlan:
         s1 = np.ascontiguousarray(s1, dtype=np.float32)
         s2 = np.ascontiguousarray(s2, dtype=np.float32)
         self.blob = torch.empty(lib.hk_cbp_plan_bytes(self.C, self.D), dtype=torch.uint8, device=device)
-        with torch.cuda.device(device):
+        with _on(device):
             check(lib.hk_cbp_plan_build(h1.ctypes.data, s1.ctypes.data, h2.ctypes.data, s2.ctypes.data,
                                         self.C, self.D, ptr(self.blob), stream()), 'hk_cbp_plan_build')
 

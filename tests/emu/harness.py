@@ -1,0 +1,47 @@
+"""Route hawkeye_amd.functional through the CPU-emulated build of the kernel sources - for tests only.
+
+`emulated()` is a context manager that (1) builds/loads tests/emu/_build/libhawkeye_emu.so, (2) swaps it in for the
+gfx950 library inside hawkeye_amd._lib and (3) lets CPU tensors through the pointer/stream helpers of
+hawkeye_amd.functional.  Outside the context the product behaviour (HIP tensors only, no CPU fallback) is untouched.
+"""
+import contextlib
+import ctypes
+
+import torch
+
+from hawkeye_amd import _lib
+import hawkeye_amd.functional as F
+
+from . import build_emu
+
+_emu = None
+
+
+def load_emu():
+    global _emu
+    if _emu is None:
+        lib = ctypes.CDLL(build_emu.build())
+        for name, (res, args) in _lib.SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _emu = lib
+    return _emu
+
+
+def _cpu_ptr(t):
+    if t is None:
+        return None
+    assert not t.is_cuda and t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())
+
+
+@contextlib.contextmanager
+def emulated():
+    lib = load_emu()
+    saved = (_lib._lib, F.ptr, F.stream, F._on)
+    _lib._lib, F.ptr, F.stream, F._on = lib, _cpu_ptr, (lambda: None), (lambda device: contextlib.nullcontext())
+    try:
+        yield F
+    finally:
+        _lib._lib, F.ptr, F.stream, F._on = saved

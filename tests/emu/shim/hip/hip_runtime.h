@@ -1,0 +1,305 @@
+// CPU emulation of the slice of the HIP device model that hawkeye_amd/csrc uses.
+//
+// TEST INFRASTRUCTURE ONLY.  tests/emu/build_emu.py compiles the *unchanged* kernel sources (hawkeye_amd/csrc/*.hip)
+// for x86 against this header into tests/emu/_build/libhawkeye_emu.so, so that the CPU test tier can run the real
+// kernel code (index arithmetic, LDS staging, barriers, MFMA operand layouts, reduction orders) against the oracle
+// without a GPU.  Nothing under hawkeye_amd/ loads it: the product library is libhawkeye_hip.so (gfx950) and the
+// product path raises without a GPU.  It says nothing about speed.
+//
+// Model: one workgroup at a time; its work-items are ucontext fibers run round-robin on one OS thread, switching
+// only at __syncthreads()/s_barrier and at wave-wide collectives (__shfl_xor, MFMA), which is where real wave64
+// hardware synchronises too.  A barrier that not every live work-item reaches aborts with a message instead of
+// hanging.  Dynamic and static LDS are plain host memory (dynamic LDS is poisoned with NaNs at every block start).
+//
+// MFMA operand/result layouts (CDNA3/4 ISA guide, "Matrix Arithmetic Instructions"):
+//   v_mfma_f32_32x32x2_f32 : lane l supplies A[i=l%32][k=l/32], B[k=l/32][j=l%32];
+//                            result reg v (0..15) of lane l is C[i = 8*(v/4) + 4*(l/32) + v%4][j = l%32]
+//   v_mfma_f32_16x16x4_f32 : lane l supplies A[i=l%16][k=l/16], B[k=l/16][j=l%16];
+//                            result reg v (0..3) of lane l is C[i = 4*(l/16) + v][j = l%16]
+// The GPU-validated kernels of round 1 are the emulator's own test: they only reproduce the oracle if these hold.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(8) float2 {
+    float x, y;
+};
+struct alignas(16) float4 {
+    float x, y, z, w;
+};
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline int min(int a, int b) { return a < b ? a : b; }       // HIP's device-side integer overloads
+inline int max(int a, int b) { return a > b ? a : b; }
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+struct hipemu_stream_tag;
+typedef hipemu_stream_tag* hipStream_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+    memset(d, v, n);
+    return hipSuccess;
+}
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+namespace hipemu {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+enum { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+constexpr size_t STACK_BYTES = 512 * 1024;
+
+struct Wave {
+    int alive = 0, arrived = 0;
+    unsigned gen = 0;
+    uint64_t slot[2][64][2];   // exchange slots of the two most recent collectives
+};
+struct Fiber {
+    ucontext_t ctx;
+    int state = READY;
+    unsigned wait_gen = 0;
+    dim3 tid;
+    int lin = 0, wave = 0, lane = 0;
+    unsigned parity = 0;
+    char* stack = nullptr;
+};
+struct Block {
+    dim3 grid, block, bid;
+    int alive = 0, arrived = 0;
+    unsigned gen = 0;
+    std::vector<Wave> waves;
+    char* dyn_lds = nullptr;
+};
+
+inline Block* B = nullptr;
+inline Fiber* cur = nullptr;
+inline ucontext_t sched;
+inline const std::function<void()>* body = nullptr;
+inline std::vector<Fiber> pool;
+
+inline void release_block() {
+    B->arrived = 0;
+    B->gen++;
+}
+inline void release_wave(Wave& w) {
+    w.arrived = 0;
+    w.gen++;
+}
+inline void block_barrier() {
+    const unsigned g = B->gen;
+    if (++B->arrived == B->alive) {
+        release_block();
+        return;
+    }
+    cur->state = WAIT_BLOCK;
+    cur->wait_gen = g;
+    swapcontext(&cur->ctx, &sched);
+}
+inline void wave_barrier() {
+    Wave& w = B->waves[cur->wave];
+    const unsigned g = w.gen;
+    if (++w.arrived == w.alive) {
+        release_wave(w);
+        return;
+    }
+    cur->state = WAIT_WAVE;
+    cur->wait_gen = g;
+    swapcontext(&cur->ctx, &sched);
+}
+inline void trampoline() {
+    (*body)();
+    Fiber* f = cur;
+    f->state = DONE;
+    Wave& w = B->waves[f->wave];
+    if (--B->alive > 0 && B->arrived == B->alive) release_block();     // exited work-items do not take part in barriers
+    if (--w.alive > 0 && w.arrived == w.alive) release_wave(w);
+    swapcontext(&f->ctx, &sched);
+}
+
+inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, dim3 bid, size_t lds_bytes) {
+    const int n = (int)(block.x * block.y * block.z);
+    Block blk;
+    blk.grid = grid;
+    blk.block = block;
+    blk.bid = bid;
+    blk.alive = n;
+    blk.waves.resize((n + 63) / 64);
+    std::vector<uint32_t> lds((lds_bytes + 3) / 4 + 4, 0x7fc00000u);   // NaN poison
+    blk.dyn_lds = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(lds.data()) + 15) & ~uintptr_t(15));
+    if ((int)pool.size() < n) pool.resize(n);
+    B = &blk;
+    body = &fn;
+    for (int t = 0; t < n; ++t) {
+        Fiber& f = pool[t];
+        if (!f.stack) f.stack = static_cast<char*>(malloc(STACK_BYTES));
+        f.state = READY;
+        f.parity = 0;
+        f.lin = t;
+        f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+        f.wave = t / 64;
+        f.lane = t % 64;
+        blk.waves[f.wave].alive++;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STACK_BYTES;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, trampoline, 0);
+    }
+    int remaining = n;
+    while (remaining) {
+        bool progressed = false;
+        for (int t = 0; t < n; ++t) {
+            Fiber& f = pool[t];
+            if (f.state == DONE) continue;
+            if (f.state == WAIT_BLOCK && blk.gen == f.wait_gen) continue;
+            if (f.state == WAIT_WAVE && blk.waves[f.wave].gen == f.wait_gen) continue;
+            f.state = READY;
+            cur = &f;
+            swapcontext(&sched, &f.ctx);
+            progressed = true;
+            if (f.state == DONE) --remaining;
+        }
+        if (!progressed) {
+            fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): a barrier or wave collective was not reached by every "
+                            "live work-item\n", bid.x, bid.y, bid.z);
+            abort();
+        }
+    }
+    B = nullptr;
+    cur = nullptr;
+}
+
+inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& fn) {
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) run_block(fn, grid, block, dim3(x, y, z), lds_bytes);
+}
+
+// value of `v` held by lane `src(lane)` of the calling wave (own value if that lane does not exist)
+template <class T, class SrcFn>
+inline T wave_exchange(T v, SrcFn src) {
+    static_assert(sizeof(T) <= 8, "wave_exchange: 4- or 8-byte types");
+    Wave& w = B->waves[cur->wave];
+    const unsigned p = cur->parity;
+    cur->parity ^= 1u;
+    uint64_t raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    w.slot[p][cur->lane][0] = raw;
+    wave_barrier();
+    const int s = src(cur->lane);
+    const int width = (int)(B->block.x * B->block.y * B->block.z) - cur->wave * 64;
+    T out = v;
+    if (s >= 0 && s < 64 && s < width) memcpy(&out, &w.slot[p][s][0], sizeof(T));
+    return out;
+}
+
+inline v16f mfma_f32_32x32x2(float a, float b, v16f c, int, int, int) {
+    Wave& w = B->waves[cur->wave];
+    const unsigned p = cur->parity;
+    cur->parity ^= 1u;
+    const int l = cur->lane;
+    float ab[2] = {a, b};
+    memcpy(&w.slot[p][l][0], ab, 8);
+    wave_barrier();
+    const int j = l % 32, hb = l / 32;
+    for (int v = 0; v < 16; ++v) {
+        const int i = 8 * (v / 4) + 4 * hb + v % 4;
+        float acc = c[v];
+        for (int k = 0; k < 2; ++k) {
+            float ai[2], bj[2];
+            memcpy(ai, &w.slot[p][32 * k + i][0], 8);
+            memcpy(bj, &w.slot[p][32 * k + j][0], 8);
+            acc = fmaf(ai[0], bj[1], acc);
+        }
+        c[v] = acc;
+    }
+    return c;
+}
+
+inline v4f mfma_f32_16x16x4(float a, float b, v4f c, int, int, int) {
+    Wave& w = B->waves[cur->wave];
+    const unsigned p = cur->parity;
+    cur->parity ^= 1u;
+    const int l = cur->lane;
+    float ab[2] = {a, b};
+    memcpy(&w.slot[p][l][0], ab, 8);
+    wave_barrier();
+    const int j = l % 16, hb = l / 16;
+    for (int v = 0; v < 4; ++v) {
+        const int i = 4 * hb + v;
+        float acc = c[v];
+        for (int k = 0; k < 4; ++k) {
+            float ai[2], bj[2];
+            memcpy(ai, &w.slot[p][16 * k + i][0], 8);
+            memcpy(bj, &w.slot[p][16 * k + j][0], 8);
+            acc = fmaf(ai[0], bj[1], acc);
+        }
+        c[v] = acc;
+    }
+    return c;
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur->tid)
+#define blockIdx (hipemu::B->bid)
+#define blockDim (hipemu::B->block)
+#define gridDim (hipemu::B->grid)
+
+#define __syncthreads() hipemu::block_barrier()
+#define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_sqrtf(x) sqrtf(x)
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_f32_32x32x2
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_f32_16x16x4
+
+template <class T>
+inline T __shfl_xor(T v, int mask, int = 64) {
+    return hipemu::wave_exchange(v, [mask](int lane) { return lane ^ mask; });
+}
+template <class T>
+inline T __shfl_down(T v, unsigned delta, int = 64) {
+    return hipemu::wave_exchange(v, [delta](int lane) { return lane + (int)delta; });
+}
+template <class T>
+inline T __shfl(T v, int srclane, int = 64) {
+    return hipemu::wave_exchange(v, [srclane](int) { return srclane; });
+}
+
+// hk_common.h routes its two non-portable spellings through these (it defines them for gfx950 when they are unset)
+#define HK_DYN_LDS(name) float* name = reinterpret_cast<float*>(hipemu::B->dyn_lds)
+#define HK_DYN_LDS16(name) HK_DYN_LDS(name)
+#define HK_LDS_BARRIER() hipemu::block_barrier()
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                                         \
+    do {                                                                                                  \
+        (void)(stream);                                                                                   \
+        hipemu::launch(dim3(grid), dim3(block), (size_t)(lds), [=]() { kernel(__VA_ARGS__); });           \
+    } while (0)

@@ -1,0 +1,45 @@
+"""CPU tier: the parity cases of tests/test_gpu_parity.py run against the kernel SOURCES compiled for x86 on the HIP
+emulation of tests/emu (fibers for work-items, emulated wave collectives and MFMA).  Same inputs, same oracle, same
+tolerances as on the GPU - so indexing, LDS staging, barrier placement, reduction orders and the host-side dispatch of
+every entry point are checked here, without a GPU.  It does not replace the `-m gpu` tier (which runs the gfx950
+binary) and nothing in the product imports it.
+"""
+import importlib.util
+import os
+
+import pytest
+
+from emu.harness import emulated
+
+_src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'test_gpu_parity.py')
+_spec = importlib.util.spec_from_file_location('_gpu_parity_cases_on_emu', _src)
+_cases = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_cases)
+_cases.DEV = 'cpu'
+
+# cases that are only meaningful on the device (timing / determinism of the real scheduler) or too slow emulated
+_SKIP = {'test_bcnn_full_size_properties', 'test_bcnn_full_size_backward_vs_generic'}   # B=64 full-size: minutes when emulated
+
+for _name, _obj in list(vars(_cases).items()):
+    if _name.startswith('test_') and callable(_obj) and _name not in _SKIP:
+        globals()[_name] = _obj
+
+
+# parameter sets that take 25 s .. 2 min each when emulated: run them with HK_EMU_FULL=1
+_HEAVY = {'test_cbp_rowsketch_equals_csr[512-6000-40]', 'test_cov_and_cbp_panel_kernels_vs_generic[70-256-8]',
+          'test_mpn_256_vs_golden', 'test_bcnn_panel_kernels_vs_oracle_and_generic[90-192-8]'}
+
+
+@pytest.fixture(autouse=True)
+def _skip_heavy(request):
+    if request.node.name in _HEAVY and os.environ.get('HK_EMU_FULL') != '1':
+        pytest.skip('slow under emulation (HK_EMU_FULL=1 runs it)')
+
+
+@pytest.fixture(scope='module')
+def F():
+    from emu import build_emu
+    if build_emu._compiler() is None:
+        pytest.skip('no clang++ to build the emulated kernels (they use ext_vector_type)')
+    with emulated() as f:
+        yield f

@@ -258,7 +258,8 @@ def test_triuvec_roundtrip(F):
 
 # ------------------------------------------------------------------ CBP
 def _plan(F, c, d):
-    return F.CbpPlan(*F.sketch_hashes(c, c, d), d, torch.device('cuda', torch.cuda.current_device()))
+    dev = torch.device('cuda', torch.cuda.current_device()) if DEV == 'cuda' else torch.device(DEV)
+    return F.CbpPlan(*F.sketch_hashes(c, c, d), d, dev)
 
 
 def test_cbp_hashes_match_golden(F):
@@ -277,16 +278,26 @@ def _cbp_case(F, xn, wn, d):
     return x, y, xg, yg
 
 
+def _cbp_grad_f64(xn, wn, d):
+    """The same function in fp64 (Gram identity): the yardstick for the gradient.  At C=512, D=6000 the reference's own
+    fp32 FFT gradient is 8.5e-5 away from it (dc = du / 2 sqrt|c| amplifies round-off in small bins), so a 1e-4 bound
+    against the fp32 reference alone would be a coin toss; the bound that means something is the one against fp64."""
+    x = t(xn).double().requires_grad_(True)
+    (O.compact_bilinear_pool_gram(x, d) * t(wn).double()).sum().backward()
+    return x.grad
+
+
 def test_cbp_dense_small_and_512(F):
     """Inputs with no exactly-zero bin: forward AND backward against the reference's FFT route."""
     cases = (('cbp_small_dense', np.abs(rs_randn(23, (2, 16, 3, 5))) + 0.1, rs_randn(24, (2, 64)), 64),
              ('cbp_512', rs_relu_randn(1234, (2, 512, 14, 14)), rs_randn(1236, (2, 6000)), 6000))
     for tag, xn, wn, d in cases:
         g = load(tag)
-        x, y, xg, yg = _cbp_case(F, xn.astype(np.float32), wn, d)
+        xn = xn.astype(np.float32)
+        x, y, xg, yg = _cbp_case(F, xn, wn, d)
         assert rel(yg, g['y']) < 1e-5 and rel(yg, y) < 1e-5
         np.testing.assert_allclose(yg.detach().norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
-        assert rel(xg.grad, x.grad) < 1e-4
+        assert rel(xg.grad, _cbp_grad_f64(xn, wn, d)) < 1e-4 and rel(xg.grad, x.grad) < 2.5e-4
         if 'dx' in g.files:
             assert rel(xg.grad, g['dx']) < 1e-4
         else:
@@ -303,7 +314,7 @@ def test_cbp_512_both_binning_kernels(F, csr, monkeypatch):
     xn, wn = rs_relu_randn(1234, (2, 512, 14, 14)).astype(np.float32), rs_randn(1236, (2, 6000))
     x, y, xg, yg = _cbp_case(F, xn, wn, 6000)
     assert rel(yg, g['y']) < 1e-5 and rel(yg, y) < 1e-5
-    assert rel(xg.grad, x.grad) < 1e-4
+    assert rel(xg.grad, _cbp_grad_f64(xn, wn, 6000)) < 1e-4 and rel(xg.grad, x.grad) < 2.5e-4
     assert yg.argmax(dim=1).cpu().tolist() == y.argmax(dim=1).tolist()
 
 
