@@ -172,11 +172,31 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, trampoline, 0);
     }
+    // Order in which runnable work-items are resumed.  Results must not depend on it: a kernel that gives different
+    // answers under HK_EMU_ORDER=rev / rand:<seed> is missing a barrier (the emulator only switches work-items at
+    // barriers and wave collectives, so a race is invisible in any single fixed order).
+    std::vector<int> order(n);
+    for (int t = 0; t < n; ++t) order[t] = t;
+    if (const char* o = getenv("HK_EMU_ORDER")) {
+        if (!strncmp(o, "rev", 3)) {
+            for (int t = 0; t < n; ++t) order[t] = n - 1 - t;
+        } else if (!strncmp(o, "rand", 4)) {
+            uint64_t st = 0x9e3779b97f4a7c15ull ^ (o[4] == ':' ? strtoull(o + 5, nullptr, 10) : 0) ^
+                          (uint64_t(bid.x) * 1315423911u + bid.y * 2654435761u + bid.z);
+            for (int t = n - 1; t > 0; --t) {
+                st = st * 6364136223846793005ull + 1442695040888963407ull;
+                const int j = (int)((st >> 33) % (uint64_t)(t + 1));
+                const int tmp = order[t];
+                order[t] = order[j];
+                order[j] = tmp;
+            }
+        }
+    }
     int remaining = n;
     while (remaining) {
         bool progressed = false;
-        for (int t = 0; t < n; ++t) {
-            Fiber& f = pool[t];
+        for (int q = 0; q < n; ++q) {
+            Fiber& f = pool[order[q]];
             if (f.state == DONE) continue;
             if (f.state == WAIT_BLOCK && blk.gen == f.wait_gen) continue;
             if (f.state == WAIT_WAVE && blk.waves[f.wave].gen == f.wait_gen) continue;

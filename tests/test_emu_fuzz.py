@@ -1,0 +1,208 @@
+"""CPU tier: seeded shape fuzzing of every op through the emulated kernels (tests/emu) against the oracle - ragged
+channel counts, 1-pixel maps, prime sketch sizes, tied NMS scores, random ROI sets - and an order-independence check
+(the emulator resumes work-items in reversed / shuffled order: a kernel whose result changes is missing a barrier)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hawkeye_oracle as O
+from emu.harness import emulated
+import test_gpu_parity as P
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope='module')
+def F():
+    from emu import build_emu
+    if build_emu._compiler() is None:
+        pytest.skip('no clang++ to build the emulated kernels')
+    with emulated() as f:
+        yield f
+
+
+def test_fuzz_bgemm(F):
+    rng = np.random.default_rng(0)
+    for _ in range(16):
+        nb, m, n, k = (int(v) for v in rng.integers(1, 150, 4))
+        nb = nb % 10 + 1
+        ta, tb = bool(rng.integers(2)), bool(rng.integers(2))
+        a = torch.randn((nb, k, m) if ta else (nb, m, k))
+        b = torch.randn((nb, n, k) if tb else (nb, k, n))
+        c0 = torch.randn(nb, m, n)
+        al, be, dg = (float(v) for v in rng.normal(size=3))
+        ref = al * torch.bmm(a.transpose(1, 2).double() if ta else a.double(),
+                             b.transpose(1, 2).double() if tb else b.double()) + be * c0.double() + dg * torch.eye(m, n).double()
+        assert rel(F.bgemm(a, b, ta, tb, alpha=al, beta=be, diag=dg, out=c0.clone()), ref) < 3e-6, (nb, m, n, k, ta, tb)
+
+
+def test_fuzz_bcnn_pool(F):
+    rng = np.random.default_rng(1)
+    for _ in range(12):
+        b, h, w = int(rng.integers(1, 10)), int(rng.integers(1, 15)), int(rng.integers(1, 15))
+        c = int(rng.choice([2, 3, 17, 32, 63, 64, 65, 96, 128, 130]))
+        x = torch.relu(torch.randn(b, c, h, w)).requires_grad_(True)
+        wt = torch.randn(b, c * c)
+        y = O.bilinear_pool(x)
+        (y * wt).sum().backward()
+        xe = x.detach().clone().requires_grad_(True)
+        ye = F.bilinear_pool(xe)
+        (ye * wt).sum().backward()
+        assert rel(ye, y) < 1e-6 and rel(xe.grad, x.grad) < 2e-5, (b, c, h, w)
+
+
+def test_fuzz_mpn_chain(F):
+    rng = np.random.default_rng(2)
+    for _ in range(8):
+        b, h, w, itn = int(rng.integers(1, 10)), int(rng.integers(2, 9)), int(rng.integers(2, 9)), int(rng.integers(1, 7))
+        d = int(rng.choice([2, 5, 16, 31, 33, 64, 70]))
+        x = torch.relu(torch.randn(b, d, h, w)) + 0.01 * torch.randn(b, d, h, w)
+        xo = x.clone().requires_grad_(True)
+        yo = O.triuvec(O.sqrtm(O.covpool(xo), itn))
+        wt = torch.randn_like(yo)
+        (yo * wt).sum().backward()
+        xe = x.clone().requires_grad_(True)
+        ye = F.triuvec(F.sqrtm(F.covpool(xe), itn))
+        (ye * wt).sum().backward()
+        assert rel(ye, yo) < 1e-5 and rel(xe.grad, xo.grad) < 1e-4, (b, d, h, w, itn)
+
+
+def test_fuzz_cbp_small(F):
+    rng = np.random.default_rng(3)
+    for _ in range(8):
+        b, h, w = int(rng.integers(1, 5)), int(rng.integers(1, 8)), int(rng.integers(1, 8))
+        c, d = int(rng.choice([3, 8, 17, 32, 64, 96])), int(rng.choice([7, 16, 50, 128, 333]))
+        x = torch.rand(b, c, h, w) + 0.1
+        x64 = x.double().requires_grad_(True)
+        y64 = O.compact_bilinear_pool_gram(x64, d)
+        wt = torch.randn(b, d)
+        (y64 * wt.double()).sum().backward()
+        plan = F.CbpPlan(*F.sketch_hashes(c, c, d), d, torch.device('cpu'))
+        xe = x.clone().requires_grad_(True)
+        ye = F.compact_bilinear_pool(xe, plan)
+        (ye * wt).sum().backward()
+        assert rel(ye, y64) < 1e-5 and rel(xe.grad, x64.grad) < 2e-4, (b, c, d, h, w)
+
+
+def test_fuzz_att_pool_and_osme(F):
+    rng = np.random.default_rng(4)
+    for _ in range(8):
+        b, c, h, w = int(rng.integers(1, 6)), int(rng.integers(1, 70)), int(rng.integers(1, 30)), int(rng.integers(1, 30))
+        f = torch.randn(b, c, h, w, requires_grad=True)
+        a = torch.rand(b, 1, h, w, requires_grad=True)
+        w1, w2 = torch.randn(b, c), torch.randn(b, c)
+        ((f.mean(dim=(2, 3)) * w1).sum() + ((a * f).mean(dim=(2, 3)) * w2).sum()).backward()
+        fe, ae = f.detach().clone().requires_grad_(True), a.detach().clone().requires_grad_(True)
+        gap, sgap = F.att_pool(fe, ae)
+        ((gap * w1).sum() + (sgap * w2).sum()).backward()
+        assert max(rel(gap, f.mean(dim=(2, 3))), rel(sgap, (a * f).mean(dim=(2, 3))), rel(fe.grad, f.grad),
+                   rel(ae.grad, a.grad)) < 2e-5, (b, c, h, w)
+    for _ in range(6):
+        n, c, h, w, p = (int(v) for v in (rng.integers(1, 6), rng.integers(1, 80), rng.integers(1, 9), rng.integers(1, 9),
+                                           rng.integers(1, 4)))
+        x = torch.randn(n, c, h, w, requires_grad=True)
+        m = torch.rand(p, n, c, requires_grad=True)
+        z, s = x.mean(dim=(2, 3)), m[:, :, :, None, None] * x.unsqueeze(0)
+        w1, w2 = torch.randn_like(z), torch.randn_like(s)
+        ((z * w1).sum() + (s * w2).sum()).backward()
+        xe, me = x.detach().clone().requires_grad_(True), m.detach().clone().requires_grad_(True)
+        ze, se = F.osme_gap(xe), F.osme_scale(xe, me).reshape(s.shape)
+        ((ze * w1).sum() + (se * w2).sum()).backward()
+        assert max(rel(ze, z), rel(se, s), rel(xe.grad, x.grad), rel(me.grad, m.grad)) < 1e-5, (n, c, h, w, p)
+
+
+def test_fuzz_att_roi_select_bit_exact(F):
+    rng = np.random.default_rng(5)
+    for it in range(20):
+        b, hw, s = int(rng.integers(1, 5)), int(rng.choice([7, 14, 20, 28, 56])), int(rng.choice([8, 16, 32]))
+        a, k = float(rng.choice([32, 64, 128, 256])), int(rng.integers(1, 7))
+        ncls, thr = int(rng.choice([200, 8142])), float(rng.choice([0.05, 0.3, 0.6]))
+        m = torch.sigmoid(2 * torch.randn(b, 1, hw, hw))
+        if it % 4 == 0:
+            m = (m * 4).round() / 4                      # many exactly tied scores
+        rois, cnt = F.att_roi_select(m, s, a, hw * s, hw * s, ncls, thr, k)
+        got, ref = P._compact(rois, cnt), O.att_roi(m, s, a, hw * s, hw * s, ncls, thr, k)
+        assert got.shape == ref.shape and torch.equal(got, ref), (b, hw, s, a, k, ncls, thr)
+
+
+def test_fuzz_roi_crop(F):
+    rng = np.random.default_rng(6)
+    for _ in range(6):
+        b, c, train = int(rng.integers(1, 4)), int(rng.integers(1, 6)), bool(rng.integers(2))
+        rois = []
+        for k in (5, 3, 1):
+            rows = []
+            for i in range(b):
+                for _j in range(int(rng.integers(1, k + 1))):
+                    x1, y1 = rng.uniform(0, 380, 2)
+                    ww, hh = rng.uniform(16, 448 - max(x1, y1), 2)
+                    rows.append([i, x1, y1, min(x1 + ww, 448), min(y1 + hh, 448), rng.uniform()])
+            rois.append(torch.tensor(rows, dtype=torch.float32))
+        drops = []
+        for i in range(b):
+            u = rng.uniform()
+            if train and u < 0.3:
+                drops.append((3, int(rng.integers(0, int((rois[0][:, 0] == i).sum())))))
+            elif train and u < 0.6:
+                drops.append((4, int(rng.integers(0, int((rois[1][:, 0] == i).sum())))))
+            else:
+                drops.append(None)
+        x = torch.randn(b, c, 56, 56, requires_grad=True)
+        wt = torch.randn(b, c, 56, 56)
+        y = O.roi_crop_feat(x, rois, 8, training=train, drops=drops)
+        (y * wt).sum().backward()
+        box, drop, allr = torch.zeros(b, 4), torch.tensor([[0., 0., -1., -1.]] * b), torch.cat(rois, 0)
+        for i in range(b):
+            r = allr[allr[:, 0] == i] / 8
+            box[i] = torch.cat([r[:, 1:3].min(0)[0], r[:, 3:5].max(0)[0]])
+            if train and drops[i] is not None:
+                src = rois[0] if drops[i][0] == 3 else rois[1]
+                drop[i] = (src[src[:, 0] == i] / 8)[drops[i][1], 1:5]
+        xe = x.detach().clone().requires_grad_(True)
+        ye = F.roi_crop_resize(xe, box, drop, train)
+        (ye * wt).sum().backward()
+        assert rel(ye, y) < 1e-6 and rel(xe.grad, x.grad) < 1e-6, (b, c, train)
+
+
+@pytest.mark.parametrize('order', ['rev', 'rand:11'])
+def test_results_do_not_depend_on_work_item_order(F, order, monkeypatch):
+    """LDS-staged kernels (Gram / backward panels, CBP row-sketch + CSR, covariance, NS chain, attention pooling,
+    NMS) re-run with the work-items of every workgroup resumed in another order: bit-identical results."""
+    def run():
+        torch.manual_seed(5)
+        out = []
+        x = torch.relu(torch.randn(2, 128, 14, 14)).requires_grad_(True)
+        y = F.bilinear_pool(x)
+        (y * torch.randn_like(y)).sum().backward()
+        out += [y.detach(), x.grad]
+        xc = torch.relu(torch.randn(2, 128, 7, 7)).requires_grad_(True)
+        plan = F.CbpPlan(*F.sketch_hashes(128, 128, 1024), 1024, torch.device('cpu'))
+        for csr in ('0', '1'):
+            monkeypatch.setenv('HK_CBP_CSR', csr)
+            yc = F.compact_bilinear_pool(xc, plan)
+            (yc * torch.randn_like(yc)).sum().backward()
+            out += [yc.detach(), xc.grad.clone()]
+        monkeypatch.delenv('HK_CBP_CSR')
+        xm = torch.relu(torch.randn(2, 64, 7, 7)).requires_grad_(True)
+        ym = F.triuvec(F.sqrtm(F.covpool(xm), 5))
+        (ym * torch.randn_like(ym)).sum().backward()
+        out += [ym.detach(), xm.grad]
+        f, a = torch.randn(2, 32, 28, 28, requires_grad=True), torch.rand(2, 1, 28, 28, requires_grad=True)
+        gap, sgap = F.att_pool(f, a)
+        (gap.sum() + (sgap * torch.randn_like(sgap)).sum()).backward()
+        out += [gap.detach(), sgap.detach(), f.grad, a.grad]
+        rois, cnt = F.att_roi_select(torch.sigmoid(torch.randn(2, 1, 28, 28)), 16, 128., 448, 448, 200, 0.05, 3)
+        out += [rois, cnt.float()]
+        return out
+
+    monkeypatch.delenv('HK_EMU_ORDER', raising=False)
+    base = run()
+    monkeypatch.setenv('HK_EMU_ORDER', order)
+    other = run()
+    for i, (p, q) in enumerate(zip(base, other)):
+        assert torch.equal(p, q), i
