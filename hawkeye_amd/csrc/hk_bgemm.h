@@ -118,7 +118,12 @@ struct EpAffine {
 // Newton-Schulz shape (256^3 x 64 samples): T=2 gives 256 workgroups = 1 per CU with nothing to overlap its
 // load/barrier phases and is 1.3x SLOWER than T=1 (1024 workgroups, 4 per CU), so T=1 is the default;
 // allow_big=1 opts in (useful only when tiles >> CUs).
-template <int T, int BKT, bool A_KC, bool B_KC, class AL, class BL, class EP>
+//
+// SYM = true (square problems whose RESULT is symmetric, e.g. products of commuting symmetric matrices in the
+// Newton-Schulz chain): only the tilesM (tilesM + 1) / 2 tiles on or above the diagonal are computed and every
+// off-diagonal tile is also stored mirrored - 10 instead of 16 tiles at d = 256.  The epilogue's beta * C term then
+// reads C[j][i], so C must be symmetric as well.
+template <int T, int BKT, bool A_KC, bool B_KC, class AL, class BL, class EP, bool SYM = false>
 __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb,
                                                      int tilesM, int tilesN) {
     constexpr int BM = 64 * T, BN = 64 * T, BK = BKT;
@@ -133,8 +138,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
     __shared__ __attribute__((aligned(16))) float lds[2 * (SA + SB)];
 
     int b, tile;
-    if (!xcd_map(blockIdx.x, nb, tilesM * tilesN, b, tile)) return;
-    const int tm = tile / tilesN, tn = tile % tilesN;
+    if (!xcd_map(blockIdx.x, nb, SYM ? tilesM * (tilesM + 1) / 2 : tilesM * tilesN, b, tile)) return;
+    int tm = tile / tilesN, tn = tile % tilesN;
+    if (SYM) {                                    // row-major enumeration of the upper triangle
+        tm = 0;
+        int rem = tile;
+        while (rem >= tilesM - tm) { rem -= tilesM - tm; ++tm; }
+        tn = tm + rem;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -259,7 +270,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ii = m0 + (wm * T + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (ii < M && jj < N) ep(b, ii, jj, acc[i][j][r]);
+                if (ii < M && jj < N) {
+                    ep(b, ii, jj, acc[i][j][r]);
+                    if (SYM && tm != tn) ep(b, jj, ii, acc[i][j][r]);
+                }
             }
         }
     al.finish(b, tm, tn, tilesM, lds);
@@ -286,6 +300,17 @@ static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, 
         hipLaunchKernelGGL((bgemm_kernel<1, 32, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st,
                            al, bl, ep, M, N, K, nb, tm, tn);
     }
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+// symmetric-result variant (M == N, 64x64x32 tiles): see SYM above
+template <bool A_KC, bool B_KC, class AL, class BL, class EP>
+static inline int bgemm_launch_sym(const AL& al, const BL& bl, const EP& ep, int M, int K, int nb, hipStream_t st) {
+    if (M <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
+    const int tm = (M + 63) / 64;
+    hipLaunchKernelGGL((bgemm_kernel<1, 32, A_KC, B_KC, AL, BL, EP, true>), dim3(xcd_grid(nb, tm * (tm + 1) / 2)),
+                       dim3(256), 0, st, al, bl, ep, M, M, K, nb, tm, tm);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

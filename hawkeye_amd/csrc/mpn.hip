@@ -144,14 +144,47 @@ __global__ __launch_bounds__(256) void triu_bwd_kernel(const float* __restrict__
     for (int c = threadIdx.x; c < d; c += 256) xp[c] = (c >= r) ? yp[c] : 0.f;
 }
 
+// HK_NS_SYM=1 (opt-in until measured on the GPU): every product of the forward chain and the Y Z products of the
+// backward are products of commuting symmetric matrices (polynomials in A), so their results are symmetric: only
+// the 10 of 16 tiles on or above the diagonal are computed and mirrored (hk_bgemm.h, SYM), and Z Y is not computed
+// at all (it is the transpose of Y Z).  12 -> 7.5 and 38 -> 32.5 GEMM-equivalents at iterN = 5.  Requires a
+// symmetric input (a covariance); CPU experiment (fp32 torch, d = 256): 7e-7 from the reference's full products,
+// the same distance the reference itself is from fp64.
+static inline bool ns_sym() {
+    const char* e = getenv("HK_NS_SYM");
+    return e && e[0] == '1';
+}
+
 // C = alpha * s_b * A B + beta C + diag I for d x d row-major batches with explicit batch strides
 static inline int mm(const float* A, long long sa, const float* Bm, long long sb, float* C, long long sc, int d, int nb,
-                     float alpha, const float* bscale, float beta, float diag, hipStream_t st) {
+                     float alpha, const float* bscale, float beta, float diag, hipStream_t st, bool sym_result = false) {
     const LdPlain la = make_plain(A, sa, d, d, d);
     const LdPlain lb = make_plain(Bm, sb, d, d, d);
     const EpAffine ep = make_affine(C, sc, d, alpha, bscale, beta, diag);
+    if (sym_result && ns_sym()) return bgemm_launch_sym<true, false>(la, lb, ep, d, d, nb, st);
     static const int variant = [] { const char* e = getenv("HK_NS_GEMM"); return e ? atoi(e) : 0; }();   // A/B: 0 = 64x64x32, 1 = 128x128x32, 2 = 64x64x64
     return bgemm_launch<true, false>(la, lb, ep, d, d, d, nb, st, variant);
+}
+
+// two results from one symmetric product P = A B:  C1 = 3 I - P  and  C2 = P   (backward: "YZ" and "ZY" = P^T = P)
+struct EpDualNs {
+    float *c1, *c2;
+    long long bs;
+    int ld;
+    __device__ __forceinline__ void operator()(int b, int i, int j, float v) const {
+        const long long o = (long long)b * bs + (long long)i * ld + j;
+        c1[o] = (i == j ? 3.0f : 0.0f) - v;
+        c2[o] = v;
+    }
+};
+
+static inline int mm_yz_pair(const float* Y, const float* Z, long long sbs, float* W1, float* W2, long long n, int d,
+                             int nb, hipStream_t st) {
+    const LdPlain la = make_plain(Y, sbs, d, d, d);
+    const LdPlain lb = make_plain(Z, sbs, d, d, d);
+    EpDualNs ep;
+    ep.c1 = W1; ep.c2 = W2; ep.bs = n; ep.ld = d;
+    return bgemm_launch_sym<true, false>(la, lb, ep, d, d, nb, st);
 }
 
 static inline dim3 ew_grid(long long n, int B) {
@@ -231,22 +264,22 @@ extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float*
     if (iter_n < 2) {
         hipLaunchKernelGGL(ns_scale_kernel, ew_grid(n, B), dim3(256), 0, st, a, (const float*)norm_a, A, T, n, d);
         HK_LAUNCH_CHECK();
-        return mm(A, n, T, n, out, n, d, B, 1.0f, sq, 0.f, 0.f, st);               // :151,:161
+        return mm(A, n, T, n, out, n, d, B, 1.0f, sq, 0.f, 0.f, st, true);         // :151,:161
     }
     hipLaunchKernelGGL(ns_scale_kernel, ew_grid(n, B), dim3(256), 0, st, a, (const float*)norm_a, A, zsave, sbs, d);
     HK_LAUNCH_CHECK();
-    HK_TRY(mm(A, n, zsave, sbs, ysave, sbs, d, B, 1.f, nullptr, 0.f, 0.f, st));     // Y0 = A ZY   :154
+    HK_TRY(mm(A, n, zsave, sbs, ysave, sbs, d, B, 1.f, nullptr, 0.f, 0.f, st, true));   // Y0 = A ZY   :154
     for (int i = 1; i < iter_n - 1; ++i) {                                           // :156-159
         const float* Yp = ysave + (long long)(i - 1) * n;
         const float* Zp = zsave + (long long)(i - 1) * n;
-        HK_TRY(mm(Zp, sbs, Yp, sbs, T, n, d, B, -0.5f, nullptr, 0.f, 1.5f, st));    // ZY = .5(3I - Z Y)
-        HK_TRY(mm(Yp, sbs, T, n, ysave + (long long)i * n, sbs, d, B, 1.f, nullptr, 0.f, 0.f, st));
-        HK_TRY(mm(T, n, Zp, sbs, zsave + (long long)i * n, sbs, d, B, 1.f, nullptr, 0.f, 0.f, st));
+        HK_TRY(mm(Zp, sbs, Yp, sbs, T, n, d, B, -0.5f, nullptr, 0.f, 1.5f, st, true));    // ZY = .5(3I - Z Y)
+        HK_TRY(mm(Yp, sbs, T, n, ysave + (long long)i * n, sbs, d, B, 1.f, nullptr, 0.f, 0.f, st, true));
+        HK_TRY(mm(T, n, Zp, sbs, zsave + (long long)i * n, sbs, d, B, 1.f, nullptr, 0.f, 0.f, st, true));
     }
     const float* Yl = ysave + (long long)(iter_n - 2) * n;
     const float* Zl = zsave + (long long)(iter_n - 2) * n;
-    HK_TRY(mm(Zl, sbs, Yl, sbs, T, n, d, B, -1.f, nullptr, 0.f, 3.f, st));          // 3I - Z Y      :160
-    return mm(Yl, sbs, T, n, out, n, d, B, 0.5f, sq, 0.f, 0.f, st);                 // .5 Y (.) sqrt(normA)  :160-161
+    HK_TRY(mm(Zl, sbs, Yl, sbs, T, n, d, B, -1.f, nullptr, 0.f, 3.f, st, true));    // 3I - Z Y      :160
+    return mm(Yl, sbs, T, n, out, n, d, B, 0.5f, sq, 0.f, 0.f, st, true);           // .5 Y (.) sqrt(normA)  :160-161
 }
 
 extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* norm_a, const float* ysave,
@@ -282,9 +315,13 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
         const float* Yl = ysave + (long long)(iter_n - 2) * n;
         const float* Zl = zsave + (long long)(iter_n - 2) * n;
         // dldY = .5 (dpc (3I - Yl Zl) - Zl Yl dpc)                                         :180-181
-        HK_TRY(mm(Yl, sbs, Zl, sbs, W1, n, d, B, -1.f, nullptr, 0.f, 3.f, st));
+        if (ns_sym()) {
+            HK_TRY(mm_yz_pair(Yl, Zl, sbs, W1, W2, n, d, B, st));                            // W1 = 3I - Yl Zl, W2 = Zl Yl
+        } else {
+            HK_TRY(mm(Yl, sbs, Zl, sbs, W1, n, d, B, -1.f, nullptr, 0.f, 3.f, st));
+            HK_TRY(mm(Zl, sbs, Yl, sbs, W2, n, d, B, 1.f, nullptr, 0.f, 0.f, st));
+        }
         HK_TRY(mm(g, n, W1, n, dY, n, d, B, 0.5f, sq, 0.f, 0.f, st));
-        HK_TRY(mm(Zl, sbs, Yl, sbs, W2, n, d, B, 1.f, nullptr, 0.f, 0.f, st));
         HK_TRY(mm(W2, n, g, n, dY, n, d, B, -0.5f, sq, 1.f, 0.f, st));
         // dldZ = -.5 Yl dpc Yl                                                             :182
         HK_TRY(mm(Yl, sbs, g, n, W3, n, d, B, 1.f, nullptr, 0.f, 0.f, st));
@@ -292,8 +329,12 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
         for (int i = iter_n - 3; i >= 0; --i) {                                             // :183-193
             const float* Yi = ysave + (long long)i * n;
             const float* Zi = zsave + (long long)i * n;
-            HK_TRY(mm(Yi, sbs, Zi, sbs, W1, n, d, B, -1.f, nullptr, 0.f, 3.f, st));        // YZ = 3I - Y Z
-            HK_TRY(mm(Zi, sbs, Yi, sbs, W2, n, d, B, 1.f, nullptr, 0.f, 0.f, st));         // ZY = Z Y
+            if (ns_sym()) {
+                HK_TRY(mm_yz_pair(Yi, Zi, sbs, W1, W2, n, d, B, st));                      // both from one product
+            } else {
+                HK_TRY(mm(Yi, sbs, Zi, sbs, W1, n, d, B, -1.f, nullptr, 0.f, 3.f, st));    // YZ = 3I - Y Z
+                HK_TRY(mm(Zi, sbs, Yi, sbs, W2, n, d, B, 1.f, nullptr, 0.f, 0.f, st));     // ZY = Z Y
+            }
             HK_TRY(mm(dY, n, W1, n, dYn, n, d, B, 0.5f, nullptr, 0.f, 0.f, st));           // .5 dldY YZ
             HK_TRY(mm(Zi, sbs, dZ, n, W3, n, d, B, 1.f, nullptr, 0.f, 0.f, st));           // Z dldZ
             HK_TRY(mm(W3, n, Zi, sbs, dYn, n, d, B, -0.5f, nullptr, 1.f, 0.f, st));        //  - .5 (Z dldZ) Z

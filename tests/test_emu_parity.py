@@ -11,18 +11,22 @@ import pytest
 
 from emu.harness import emulated
 
-_src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'test_gpu_parity.py')
-_spec = importlib.util.spec_from_file_location('_gpu_parity_cases_on_emu', _src)
-_cases = importlib.util.module_from_spec(_spec)
-_spec.loader.exec_module(_cases)
-_cases.DEV = 'cpu'
+_here = os.path.dirname(os.path.abspath(__file__))
+_modules = []
+for _file in ('test_gpu_parity.py', 'test_gpu_zz_candidates.py'):
+    _spec = importlib.util.spec_from_file_location('_emu_cases_' + _file[:-3], os.path.join(_here, _file))
+    _mod = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(_mod)
+    _mod.DEV = 'cpu'
+    _modules.append(_mod)
 
 # cases that are only meaningful on the device (timing / determinism of the real scheduler) or too slow emulated
 _SKIP = {'test_bcnn_full_size_properties', 'test_bcnn_full_size_backward_vs_generic'}   # B=64 full-size: minutes when emulated
 
-for _name, _obj in list(vars(_cases).items()):
-    if _name.startswith('test_') and callable(_obj) and _name not in _SKIP:
-        globals()[_name] = _obj
+for _mod in _modules:
+    for _name, _obj in list(vars(_mod).items()):
+        if _name.startswith('test_') and callable(_obj) and _name not in _SKIP:
+            globals()[_name] = _obj
 
 
 # parameter sets that take 25 s .. 2 min each when emulated: run them with HK_EMU_FULL=1
