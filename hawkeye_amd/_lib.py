@@ -50,6 +50,9 @@ SIGNATURES = {
     'hk_osme_gap': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
     'hk_osme_scale_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'hk_osme_scale_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'hk_linear_ws_bytes': (c_sz, [c_i, c_i, c_i]),
+    'hk_linear_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_linear_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     'hk_bgemm_f32': (c_i, [c_f, c_i, c_ll, c_i, c_f, c_i, c_ll, c_i, c_f, c_i, c_ll, c_i, c_i, c_i, c_i,
                            c_fl, c_fl, c_fl, c_f]),
 }

@@ -416,6 +416,48 @@ def osme_scale(x, m):
 
 
 # --------------------------------------------------------------------- generic
+# --------------------------------------------------------------------- classifier
+class _Linear(torch.autograd.Function):
+    """replaces nn.Linear on the pooled vector (model/methods/BCNN.py:42,54 and the other heads' classifiers)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias):
+        lib = _lib.load()
+        y, weight = _f32c(y), _f32c(weight)
+        b, j = y.shape
+        k = weight.shape[0]
+        if weight.shape[1] != j:
+            raise _lib.HawkeyeHipError(f'linear: weight {tuple(weight.shape)} does not match input {tuple(y.shape)}')
+        bias_c = _f32c(bias) if bias is not None else None
+        out = torch.empty(b, k, dtype=torch.float32, device=y.device)
+        nws = lib.hk_linear_ws_bytes(b, j, k)
+        ws = _ws(nws, y.device)
+        check(lib.hk_linear_fwd(ptr(y), ptr(weight), ptr(bias_c), ptr(out), b, j, k, ptr(ws), nws, stream()),
+              'hk_linear_fwd')
+        ctx.save_for_backward(y, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        y, weight = ctx.saved_tensors
+        g = _f32c(g)
+        b, j = y.shape
+        k = weight.shape[0]
+        dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        db = torch.empty(k, dtype=torch.float32, device=y.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        check(lib.hk_linear_bwd(ptr(y), ptr(weight), ptr(g), ptr(dy), ptr(dw), ptr(db), b, j, k, stream()),
+              'hk_linear_bwd')
+        return dy, dw, db
+
+
+def linear(y, weight, bias=None):
+    """y [B,J] @ weight[K,J]^T + bias[K] -> [B,K] on the split-K f32-MFMA path."""
+    return _Linear.apply(y, weight, bias)
+
+
 def bgemm(a, b, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, diag=0.0, out=None):
     """Batched fp32 MFMA GEMM (test / composition helper).  a [B,M,K] (or [B,K,M]), b [B,K,N] (or [B,N,K])."""
     lib = _lib.load()

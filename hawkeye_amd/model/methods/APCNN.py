@@ -229,7 +229,9 @@ class ResNet(nn.Module):
                                                self.num_classes, iou_thred, topk))
 
     def _drop_uniforms(self, n, device):
-        u = torch.tensor([[random.random(), random.random()] for _ in range(n)], dtype=torch.float32).pin_memory()
+        u = torch.tensor([[random.random(), random.random()] for _ in range(n)], dtype=torch.float32)
+        if torch.device(device).type == 'cuda':
+            u = u.pin_memory()                       # async H2D: no host sync on the step
         return u.to(device, non_blocking=True)
 
     def _boxes_exact_stream(self, tables, scale):

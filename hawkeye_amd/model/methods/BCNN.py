@@ -9,7 +9,7 @@ import torch.nn as nn
 from ... import functional as HF
 from ..backbone import vgg16
 from ..registry import MODEL
-from ..utils import initialize_weights
+from ..utils import initialize_weights, wide_linear
 
 
 FEATURE_CHANNELS = 512          # VGG-16 conv5_3 width: the bilinear descriptor has 512 x 512 entries
@@ -53,4 +53,4 @@ class BCNN(nn.Module):
         feats = self.backbone(x)
         if self.stage == 1:
             feats = feats.detach()
-        return self.classifier(self.bilinear_pooling(feats))
+        return wide_linear(self.classifier, self.bilinear_pooling(feats))

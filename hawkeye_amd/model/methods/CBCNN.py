@@ -10,7 +10,7 @@ import torch.nn as nn
 from ... import functional as HF
 from ..backbone import vgg16
 from ..registry import MODEL
-from ..utils import initialize_weights
+from ..utils import initialize_weights, wide_linear
 
 
 class CompactBilinearPooling(nn.Module):
@@ -61,4 +61,4 @@ class CBCNN(nn.Module):
         x = self.backbone(x)
         if self.config.stage == 1:
             x = x.detach()
-        return self.classifier(self.bilinear_pooling(x))
+        return wide_linear(self.classifier, self.bilinear_pooling(x))

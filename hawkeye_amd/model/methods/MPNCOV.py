@@ -6,6 +6,7 @@ import torch.nn as nn
 from ... import functional as HF
 from ..backbone import resnet50
 from ..registry import MODEL
+from ..utils import wide_linear
 
 
 class MPNCOV(nn.Module):
@@ -48,4 +49,4 @@ class MPN(nn.Module):
 
     def forward(self, x):
         x = self.pool(self.backbone(x))
-        return self.classifier(x.view(x.size(0), -1))
+        return wide_linear(self.classifier, x.view(x.size(0), -1))

@@ -16,6 +16,7 @@ import torch.nn as nn
 from ... import functional as HF
 from ..backbone import resnet101
 from ..registry import MODEL
+from ..utils import wide_linear
 
 REDUCTION = 16          # squeeze ratio of the excitation MLP (reference: reduce_ratio = 16)
 PART_DIM = 1024         # width of each part descriptor
@@ -61,7 +62,7 @@ class OSME(nn.Module):
         squeezed = HF.osme_gap(x)                                          # [N,C], one pass over x
         gates = torch.stack([b.gate(squeezed) for b in self.blocks])       # [P,N,C]
         scaled = HF.osme_scale(x, gates)                                   # [P,N,C,H,W], one pass over x
-        parts = [head(scaled[p].reshape(batch, -1)) for p, head in enumerate(self.fcs)]
+        parts = [wide_linear(head, scaled[p].reshape(batch, -1)) for p, head in enumerate(self.fcs)]
         return sum(parts), torch.stack(parts, dim=1)                       # [N,1024], [N,P,1024]
 
 

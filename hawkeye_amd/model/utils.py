@@ -5,6 +5,8 @@ the reference (model/utils.py:5-28): convolutions Kaiming-normal on fan-out for 
 (1, 0), Linear layers Kaiming-normal (default fan-in) with zero bias.  `load_state_dict` is the reference's
 "take what matches by name and shape" loader used for ImageNet checkpoints.
 """
+import os
+
 import torch.nn as nn
 from torch.nn import init
 
@@ -39,3 +41,16 @@ def load_state_dict(model, state_dict):
     target.update(usable)
     model.load_state_dict(target)
     return sorted(usable)
+
+
+def wide_linear(layer, x):
+    """`layer(x)` for the classifier / part FCs that sit directly on a pooled vector (tens of thousands of features,
+    a few hundred outputs).  HAWKEYE_HIP_LINEAR=1 routes it through the split-K f32-MFMA kernels
+    (hk_linear_fwd/bwd); the `nn.Linear` stays the parameter holder, so `state_dict` keys, initialisers
+    and optimiser groups are untouched.  Off by default until it has a measured number on the GPU (rocBLAS picks a
+    16x64 macro-tile for the BCNN shape: 400 us for a 45 us HBM-bound product, profiles/r1d_bench_bcnn_kernel_stats.csv).
+    """
+    if os.environ.get('HAWKEYE_HIP_LINEAR') == '1':
+        from .. import functional as F        # hawkeye_amd.functional
+        return F.linear(x, layer.weight, layer.bias)
+    return layer(x)

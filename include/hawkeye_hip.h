@@ -194,6 +194,20 @@ int hk_osme_scale_fwd(const float* x, const float* m, float* s, int P, int N, in
 int hk_osme_scale_bwd(const float* x, const float* m, const float* ds, const float* dz, float* dx, float* dm,
                       int P, int N, int C, int HW, hk_stream_t stream);
 
+/* ------------------------------------------------------- classifier (8f-1) ----
+ * out = y W^T + bias for the wide pooled vector and its backward: split-K f32-MFMA
+ * GEMM with a deterministic slab reduction (forward), plain tiles (backward).
+ * replaces nn.Linear at model/methods/BCNN.py:42,54 ; CBCNN.py:31 ; MPNCOV.py:31 ;
+ * OSME.py:33-34,42 (same operand layouts: W is [K][J] as in nn.Linear.weight).
+ *   y [B,J] ; w [K,J] ; bias [K] or NULL ; out [B,K] ; ws: hk_linear_ws_bytes(B,J,K)
+ *   g [B,K] = dL/dout ; dy [B,J], dw [K,J], db [K]: each may be NULL (skipped)
+ */
+size_t hk_linear_ws_bytes(int B, int J, int K);
+int hk_linear_fwd(const float* y, const float* w, const float* bias, float* out, int B, int J, int K, void* ws,
+                  size_t ws_bytes, hk_stream_t stream);
+int hk_linear_bwd(const float* y, const float* w, const float* g, float* dy, float* dw, float* db, int B, int J, int K,
+                  hk_stream_t stream);
+
 /* ------------------------------------------------------- generic primitive ----
  * Batched fp32 GEMM on the f32 MFMA path (exact fp32 fma chain):
  *   C[b] = alpha * op(A[b]) op(B[b]) + beta * C[b] + diag * I

@@ -51,3 +51,67 @@ def test_ns_symmetric_tile_mode(F, b, d, itn, monkeypatch):
             assert rel(s, s.transpose(1, 2)) < 1e-6            # off-diagonal tiles mirrored, diagonal tiles computed
         res.append((yg.detach(), xg.grad))
     assert rel(res[1][0], res[0][0]) < 5e-6 and rel(res[1][1], res[0][1]) < 5e-5
+
+
+@pytest.mark.parametrize('b,j,k,bias', [(3, 1000, 7, True), (64, 4096, 200, True), (5, 333, 130, False), (10, 6272, 96, True),
+                                        (1, 40, 1, True)])
+def test_linear_split_k(F, b, j, k, bias, monkeypatch):
+    """hk_linear_fwd/bwd (classifier on the pooled vector) vs torch's Linear in fp64; slab counts forced
+    through HK_LINEAR_SLABS cover one slab, ragged last slabs and the automatic choice."""
+    gen = torch.Generator().manual_seed(b * 1000 + j)
+    y = torch.randn(b, j, generator=gen)
+    w = torch.randn(k, j, generator=gen) / j ** 0.5
+    bv = torch.randn(k, generator=gen) if bias else None
+    g = torch.randn(b, k, generator=gen)
+    y64, w64 = y.double().requires_grad_(True), w.double().requires_grad_(True)
+    b64 = bv.double().requires_grad_(True) if bias else None
+    o64 = torch.nn.functional.linear(y64, w64, b64)
+    (o64 * g.double()).sum().backward()
+    for slabs in (None, '1', '3', '7'):
+        if slabs is None:
+            monkeypatch.delenv('HK_LINEAR_SLABS', raising=False)
+        else:
+            monkeypatch.setenv('HK_LINEAR_SLABS', slabs)
+        yg, wg = y.clone().to(DEV).requires_grad_(True), w.clone().to(DEV).requires_grad_(True)
+        bg = bv.clone().to(DEV).requires_grad_(True) if bias else None
+        og = F.linear(yg, wg, bg)
+        (og * g.to(DEV)).sum().backward()
+        assert rel(og, o64) < 2e-6, slabs
+        assert rel(yg.grad, y64.grad) < 2e-6 and rel(wg.grad, w64.grad) < 2e-6
+        if bias:
+            assert rel(bg.grad, b64.grad) < 2e-6
+
+
+_MODEL_CFG = {
+    'BCNN': dict(stage=2, num_classes=200),
+    'CBCNN': dict(stage=2, num_classes=200, input_channel=512, output_channel=6000),
+    'MPN': dict(iter_num=5, is_sqrt=True, is_vec=True, input_dim=2048, dimension_reduction=256, num_classes=200),
+}
+
+
+@pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN'])
+def test_models_with_hip_classifier(F, name, monkeypatch):
+    """HAWKEYE_HIP_LINEAR=1: the classifier on the pooled vector runs on hk_linear_* - logits still match the REFERENCE
+    model's (tests/golden/model_logits.npz) and a train step gives the same classifier gradient as torch's Linear."""
+    import os
+
+    import hawkeye_amd.model  # noqa: F401
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.registry import MODEL
+    from inputs import rs_randn, seeded_init
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'model_logits.npz'))
+    m = MODEL.get(name)(CfgNode(dict(name=name, **_MODEL_CFG[name])))
+    seeded_init(m, 900)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(np.ascontiguousarray(rs_randn(901, (2, 3, 64, 64)))).to(DEV)
+    grads = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('HAWKEYE_HIP_LINEAR', flag)
+        m.zero_grad()
+        y = m(x)
+        assert rel(y, g[name]) < 1e-4 and y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
+        torch.nn.functional.cross_entropy(y, torch.tensor([3, 77], device=y.device)).backward()
+        grads.append((m.classifier.weight.grad.clone(), m.classifier.bias.grad.clone(),
+                      next(m.backbone.parameters()).grad.clone()))
+    for p, q in zip(grads[0], grads[1]):
+        assert rel(q, p) < 1e-5
