@@ -26,6 +26,16 @@ class SyntheticDataset(Dataset):
         return {'img': torch.randn(3, self.size, self.size, generator=g),
                 'label': int(torch.randint(0, self.k, (1,), generator=g))}
 
+    @property
+    def labels(self):
+        # same draw order as __getitem__ (image first, then label) so that both agree
+        out = []
+        for i in range(self.n):
+            g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+            torch.randn(3, self.size, self.size, generator=g)
+            out.append(int(torch.randint(0, self.k, (1,), generator=g)))
+        return out
+
 
 def _to_tensor(img):
     a = np.asarray(img.convert('RGB'), dtype=np.uint8)
@@ -81,8 +91,48 @@ class FGDataset(Dataset):
     def __len__(self):
         return len(self.items)
 
+    @property
+    def labels(self):
+        return [lab for lab, _ in self.items]
+
     def __getitem__(self, i):
         from PIL import Image
         lab, rel = self.items[i]
         img = Image.open(os.path.join(self.root, rel))
         return {'img': self.transform(img) if self.transform else _to_tensor(img), 'label': lab}
+
+
+class BalancedBatchSampler(torch.utils.data.Sampler):
+    """Batches of `n_classes` distinct classes x `n_samples` images each - what the MAMC n-pairs loss needs to have
+    same-class pairs in every batch (reference dataset/sampler.py:5-38, used by Examples/OSMENet.py:20-23).
+    Own organisation: one shuffled queue per class that is refilled when it runs short; `seed`/`rank` make the
+    stream reproducible and different on every data-parallel rank."""
+
+    def __init__(self, labels, n_classes, n_samples, seed=0, rank=0):
+        self.by_class = {}
+        for idx, lab in enumerate(labels):
+            self.by_class.setdefault(int(lab), []).append(idx)
+        self.classes = sorted(c for c, v in self.by_class.items() if len(v) >= n_samples)
+        if len(self.classes) < n_classes:
+            raise ValueError(f'need {n_classes} classes with >= {n_samples} images, found {len(self.classes)}')
+        self.n_classes, self.n_samples, self.total = int(n_classes), int(n_samples), len(labels)
+        self.rng = np.random.RandomState(seed * 9973 + rank)
+        self.queues = {c: [] for c in self.classes}
+
+    def __len__(self):
+        return self.total // (self.n_classes * self.n_samples)
+
+    def _take(self, c):
+        q = self.queues[c]
+        if len(q) < self.n_samples:
+            q[:] = [int(i) for i in self.rng.permutation(self.by_class[c])]
+        out = q[:self.n_samples]
+        del q[:self.n_samples]
+        return out
+
+    def __iter__(self):
+        for _ in range(len(self)):
+            batch = []
+            for c in self.rng.choice(self.classes, self.n_classes, replace=False):
+                batch.extend(self._take(int(c)))
+            yield batch

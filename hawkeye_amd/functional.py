@@ -416,6 +416,39 @@ def osme_scale(x, m):
 
 
 # --------------------------------------------------------------------- generic
+# --------------------------------------------------------------------- MAMC n-pairs loss
+class _NPairsLoss(torch.autograd.Function):
+    """replaces NPairsLoss.forward, model/loss/MAMC_loss.py:34-90.  The kernel returns the loss and its gradient
+    with respect to the parts in one pass; backward only scales it."""
+
+    @staticmethod
+    def forward(ctx, parts, targets):
+        lib = _lib.load()
+        parts = _f32c(parts)
+        b, p, d = parts.shape
+        labels = targets.to(device=parts.device, dtype=torch.int32).contiguous()
+        if labels.shape != (b,):
+            raise _lib.HawkeyeHipError(f'npairs_loss: {b} samples but targets of shape {tuple(targets.shape)}')
+        loss = torch.empty(1, dtype=torch.float32, device=parts.device)
+        dx = torch.empty_like(parts)
+        nws = lib.hk_npairs_ws_bytes(b * p, d)
+        ws = _ws(nws, parts.device)
+        check(lib.hk_npairs_loss(ptr(parts), ptr(labels), ptr(loss), ptr(dx), b, p, d, ptr(ws), nws, stream()),
+              'hk_npairs_loss')
+        ctx.save_for_backward(dx)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None
+
+
+def npairs_loss(parts, targets):
+    """parts [B,P,D] (OSMENet's second output), targets [B] -> scalar n-pairs loss (MAMC eq. 11)."""
+    return _NPairsLoss.apply(parts, targets)
+
+
 # --------------------------------------------------------------------- classifier
 class _Linear(torch.autograd.Function):
     """replaces nn.Linear on the pooled vector (model/methods/BCNN.py:42,54 and the other heads' classifiers)."""

@@ -74,14 +74,7 @@ class Trainer:
         self.tb_writer = ScalarWriter(self.log_root) if self.is_main else None
         self.logger.info(f'Train Config:\n{cfg}')
 
-        # device: `experiment.cuda` non-empty list -> this process's GPU (LOCAL_RANK), [] / None -> refuse:
-        # the HIP heads have no CPU path (the CPU reference lives in oracle/ as test infrastructure).
-        want_gpu = isinstance(cfg.experiment.cuda, list) and len(cfg.experiment.cuda) > 0
-        if want_gpu and torch.cuda.is_available():
-            self.device = torch.device('cuda', self.local_rank)
-            torch.cuda.set_device(self.device)
-        else:
-            raise RuntimeError('hawkeye_amd trains on MI355X only: set experiment.cuda: [0] and run on a GPU host')
+        self.device = self.select_device(cfg)
         self.logger.info(f'rank {self.rank}/{self.world} on {self.device}')
 
         if 'seed' in cfg.experiment and cfg.experiment.seed is not None:
@@ -112,6 +105,16 @@ class Trainer:
         self.logger.info('Training Preparation Done!')
 
     # ------------------------------------------------------------------ plumbing
+    def select_device(self, cfg):
+        """`experiment.cuda` non-empty list -> this process's GPU (LOCAL_RANK); [] / None or no GPU -> refuse: the HIP
+        heads have no CPU path (the CPU reference lives in oracle/ as test infrastructure)."""
+        want_gpu = isinstance(cfg.experiment.cuda, list) and len(cfg.experiment.cuda) > 0
+        if not (want_gpu and torch.cuda.is_available()):
+            raise RuntimeError('hawkeye_amd trains on MI355X only: set experiment.cuda: [0] and run on a GPU host')
+        device = torch.device('cuda', self.local_rank)
+        torch.cuda.set_device(device)
+        return device
+
     def get_logger(self):
         logger = logging.getLogger()
         logger.handlers = []

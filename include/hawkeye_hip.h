@@ -208,6 +208,16 @@ int hk_linear_fwd(const float* y, const float* w, const float* bias, float* out,
 int hk_linear_bwd(const float* y, const float* w, const float* g, float* dy, float* dw, float* db, int B, int J, int K,
                   hk_stream_t stream);
 
+/* ------------------------------------------------------ MAMC n-pairs loss (8f-4) ----
+ * loss = NPairsLoss(parts, targets) and dx = d loss / d parts in one call.
+ * replaces model/loss/MAMC_loss.py:34-90 (python loop over the b*p anchors).
+ *   x [b*p, D] part features (row i = sample i / p, attention i % p) ; labels int32 [b]
+ *   loss [1] ; dx [b*p, D] ; ws: hk_npairs_ws_bytes(b*p, D)
+ */
+size_t hk_npairs_ws_bytes(int n, int D);
+int hk_npairs_loss(const float* x, const int32_t* labels, float* loss, float* dx, int b, int p, int D, void* ws,
+                   size_t ws_bytes, hk_stream_t stream);
+
 /* ------------------------------------------------------- generic primitive ----
  * Batched fp32 GEMM on the f32 MFMA path (exact fp32 fma chain):
  *   C[b] = alpha * op(A[b]) op(B[b]) + beta * C[b] + diag * I

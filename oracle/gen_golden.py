@@ -205,6 +205,37 @@ def gen_osme():
          f=f, parts=parts, dx=x.grad)
 
 
+# ---------------------------------------------------------------- MAMC loss
+MAMC_CASES = {          # name: (batch, parts, dim, labels)
+    'balanced': (10, 2, 1024, [3, 3, 7, 7, 1, 1, 9, 9, 4, 4]),        # configs/OSMENet.yaml: 5 classes x 2 samples
+    'mixed': (6, 3, 16, [2, 5, 2, 2, 0, 5]),
+    'all_distinct': (4, 1, 8, [0, 1, 2, 3]),                          # no same-class pairs: two of the three terms empty
+    'one_class': (3, 2, 8, [6, 6, 6]),                                # no negatives of another class
+}
+
+
+def gen_mamc():
+    from yacs.config import CfgNode as CN
+    from model.loss.MAMC_loss import MAMCLoss, NPairsLoss
+    out = {}
+    for i, (name, (b, p, d, labels)) in enumerate(MAMC_CASES.items()):
+        x = t(rs_randn(300 + i, (b, p, d))).requires_grad_(True)
+        y = torch.tensor(labels)
+        loss = NPairsLoss()(x, y)
+        loss.backward()
+        out[name + '_loss'] = loss.detach()
+        out[name + '_dx'] = x.grad.clone()
+    b, p, d, labels = MAMC_CASES['balanced']
+    x = t(rs_randn(300, (b, p, d))).requires_grad_(True)
+    pred = t(rs_randn(310, (b, 200))).requires_grad_(True)
+    total = MAMCLoss(CN(dict(lambda_a=0.5, use_mamc=True)))((pred, x), torch.tensor(labels))
+    total.backward()
+    out['mamc_total'] = total.detach()
+    out['mamc_dpred'] = pred.grad.clone()
+    out['mamc_dx'] = x.grad.clone()
+    save('mamc_loss', **out)
+
+
 # ---------------------------------------------------------------- key contracts
 def gen_keys():
     from yacs.config import CfgNode as CN
@@ -270,6 +301,11 @@ def gen_models(models):
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:                       # regenerate selected fixtures only, e.g. `gen_golden.py mamc`
+        for which in sys.argv[1:]:
+            globals()['gen_' + which]()
+        sys.exit(0)
+    gen_mamc()
     gen_bcnn()
     gen_cbp()
     gen_mpn()

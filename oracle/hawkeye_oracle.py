@@ -385,6 +385,45 @@ def osme_forward(x, gates, fcs):
 
 
 # ----------------------------------------------------------------------------
+# MAMC n-pairs loss  (model/loss/MAMC_loss.py:24-90) - SURVEY 8f-4
+# ----------------------------------------------------------------------------
+def npairs_masks(targets, p):
+    """The four pair sets of MAMC_loss.py:47-55 for the n = b*p anchors (row i = sample i // p, attention i % p):
+    same-attention-same-class (contains the anchor itself), sa-different-class, da-same-class, da-dc."""
+    cls = torch.repeat_interleave(targets, p)                                # :43
+    att = torch.arange(p).repeat(targets.shape[0])                           # :44
+    sc = cls[:, None] == cls[None, :]                                        # :49
+    sa = att[:, None] == att[None, :]                                        # :50
+    return sc & sa, (~sc) & sa, sc & (~sa), (~sc) & (~sa)                    # :52-55
+
+
+def npairs_loss(inputs, targets):
+    """NPairsLoss.forward (MAMC_loss.py:34-90) without the python loop over anchors:
+        L = 1/n sum_i [ sum_{j in SASC_i} log(1 + sum_{k in SADC_i u DASC_i u DADC_i} e^{s_ik - s_ij})
+                      + sum_{j in SADC_i} log(1 + sum_{k in DADC_i} e^{s_ik - s_ij})
+                      + sum_{j in DASC_i} log(1 + sum_{k in DADC_i} e^{s_ik - s_ij}) ],   s = x_hat x_hat^T.
+    Empty positive or negative sets contribute 0 exactly as the reference's empty `repeat`/`sum` do (:64-88)."""
+    b, p, _ = inputs.shape
+    n = b * p
+    x = F.normalize(inputs.contiguous().view(n, -1), p=2, dim=1)             # :40-42
+    s = x @ x.t()                                                            # :45
+    sasc, sadc, dasc, dadc = npairs_masks(targets, p)
+    diff = s[:, None, :] - s[:, :, None]                                     # [i, j, k] = s_ik - s_ij   (:68,:78,:88)
+
+    def term(pos, neg):
+        e = torch.exp(diff) * neg[:, None, :].to(s.dtype)
+        return (torch.log(1 + e.sum(dim=2)) * pos.to(s.dtype)).sum()
+
+    return (term(sasc, sadc | dasc | dadc) + term(sadc, dadc) + term(dasc, dadc)) / n   # :90
+
+
+def mamc_loss(pred, parts, targets, lambda_a=0.5, use_mamc=True):
+    """MAMCLoss.forward, MAMC_loss.py:14-21: CE(label_smoothing=0.1) + lambda_a * n-pairs."""
+    ce = F.cross_entropy(pred, targets, label_smoothing=0.1)
+    return ce + lambda_a * npairs_loss(parts, targets) if use_mamc else ce
+
+
+# ----------------------------------------------------------------------------
 # Whole-model restatements used by bench.py's cpu_baseline leg and smoke()
 # ----------------------------------------------------------------------------
 _VGG16 = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']

@@ -45,3 +45,12 @@ def seeded_init(module, seed):
             else:
                 a = 0.1 * a
             v.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)))
+
+
+# MAMC n-pairs loss cases (oracle/gen_golden.py:gen_mamc): name -> (batch, parts, dim, labels); inputs rs_randn(300 + i)
+MAMC_CASES = {
+    'balanced': (10, 2, 1024, [3, 3, 7, 7, 1, 1, 9, 9, 4, 4]),
+    'mixed': (6, 3, 16, [2, 5, 2, 2, 0, 5]),
+    'all_distinct': (4, 1, 8, [0, 1, 2, 3]),
+    'one_class': (3, 2, 8, [6, 6, 6]),
+}

@@ -115,3 +115,49 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
                       next(m.backbone.parameters()).grad.clone()))
     for p, q in zip(grads[0], grads[1]):
         assert rel(q, p) < 1e-5
+
+
+def test_mamc_npairs_loss_vs_reference_goldens(F):
+    """hk_npairs_loss vs the REFERENCE's NPairsLoss / MAMCLoss (tests/golden/mamc_loss.npz) and the
+    oracle, including empty positive / negative sets."""
+    import os
+
+    from inputs import MAMC_CASES, rs_randn
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.loss import MAMCLoss
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mamc_loss.npz'))
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    for i, (name, (b, p, d, labels)) in enumerate(MAMC_CASES.items()):
+        x = tt(rs_randn(300 + i, (b, p, d))).to(DEV).requires_grad_(True)
+        loss = F.npairs_loss(x, torch.tensor(labels).to(DEV))
+        (3.0 * loss).backward()
+        xo = tt(rs_randn(300 + i, (b, p, d))).requires_grad_(True)
+        lo = O.npairs_loss(xo, torch.tensor(labels))
+        lo.backward()
+        assert abs(float(loss) - float(g[name + '_loss'])) <= 2e-6 * max(1.0, abs(float(g[name + '_loss']))), name
+        assert abs(float(loss) - float(lo)) <= 2e-6 * max(1.0, abs(float(lo)))
+        if float(np.abs(g[name + '_dx']).max()) > 0:
+            assert rel(x.grad / 3.0, g[name + '_dx']) < 2e-5 and rel(x.grad / 3.0, xo.grad) < 2e-5, name
+        else:
+            assert float(x.grad.abs().max()) < 1e-7
+    b, p, d, labels = MAMC_CASES['balanced']
+    x = tt(rs_randn(300, (b, p, d))).to(DEV).requires_grad_(True)
+    pred = tt(rs_randn(310, (b, 200))).to(DEV).requires_grad_(True)
+    total = MAMCLoss(CfgNode(dict(lambda_a=0.5, use_mamc=True)))((pred, x), torch.tensor(labels).to(DEV))
+    total.backward()
+    assert abs(float(total) - float(g['mamc_total'])) <= 2e-6 * abs(float(g['mamc_total']))
+    assert rel(pred.grad, g['mamc_dpred']) < 1e-5 and rel(x.grad, g['mamc_dx']) < 2e-5
+
+
+def test_mamc_npairs_loss_larger_batch(F):
+    """n = 96 anchors (32 samples x 3 attentions, 7 classes): more than one 64-row tile in both GEMMs."""
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 3, 200, generator=gen)
+    y = torch.randint(0, 7, (32,), generator=gen)
+    xo = x.clone().requires_grad_(True)
+    lo = O.npairs_loss(xo, y)
+    lo.backward()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    lg = F.npairs_loss(xg, y.to(DEV))
+    lg.backward()
+    assert abs(float(lg) - float(lo)) <= 5e-6 * abs(float(lo)) and rel(xg.grad, xo.grad) < 2e-5

@@ -197,3 +197,24 @@ def test_osme():
     close(f, g['f'], rtol=1e-5, atol=1e-6)
     close(parts, g['parts'], rtol=1e-5, atol=1e-6)
     close(x.grad, g['dx'], rtol=1e-4, atol=1e-6)
+
+
+def test_mamc_npairs_loss():
+    """oracle npairs_loss / mamc_loss (vectorised) vs the reference's per-anchor python loop (MAMC_loss.py:57-90),
+    including the cases where positive or negative sets are empty."""
+    from inputs import MAMC_CASES
+    g = load('mamc_loss')
+    for i, (name, (b, p, d, labels)) in enumerate(MAMC_CASES.items()):
+        x = t(rs_randn(300 + i, (b, p, d))).requires_grad_(True)
+        loss = O.npairs_loss(x, torch.tensor(labels))
+        loss.backward()
+        close(loss, g[name + '_loss'], rtol=2e-6, atol=1e-7)
+        close(x.grad, g[name + '_dx'], rtol=1e-4, atol=2e-7)
+    b, p, d, labels = MAMC_CASES['balanced']
+    x = t(rs_randn(300, (b, p, d))).requires_grad_(True)
+    pred = t(rs_randn(310, (b, 200))).requires_grad_(True)
+    total = O.mamc_loss(pred, x, torch.tensor(labels), 0.5, True)
+    total.backward()
+    close(total, g['mamc_total'], rtol=2e-6, atol=1e-7)
+    close(pred.grad, g['mamc_dpred'], rtol=1e-5, atol=1e-8)
+    close(x.grad, g['mamc_dx'], rtol=1e-4, atol=2e-7)
