@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--model', default='BCNN', choices=['BCNN', 'CBCNN', 'MPN', 'APCNN'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernels', action='store_true')
+    ap.add_argument('--no-candidates', action='store_true',
+                    help='skip the subprocess that times the opt-in variants (tools/candidates.py)')
     ap.add_argument('--channels-last', type=int, default=1,
                     help='NHWC tensors through the backbone: MIOpen picks NHWC igemm kernels either way; this removes its '
                          'NCHW<->NHWC batched_transpose passes (5.7%% of the step): measured 298.8 vs 273.2 img/s')
@@ -183,6 +185,30 @@ def cpu_baseline(image, classes):
                       f'torch CPU fp32, {threads} threads of {os.cpu_count()} host cores'}
 
 
+def candidates(timeout_s=240):
+    """Timings of the opt-in variants / SURVEY-8f rows next to the paths they would replace (tools/candidates.py), in a
+    subprocess AFTER the headline measurement: whatever happens in there (error, timeout) only shows up inside this
+    field.  They are not part of `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'candidates.py'), '--step']
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    except Exception as e:  # noqa: BLE001
+        return {'error': repr(e)[:300]}
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        p.kill()                                          # do not wait for it: the headline must still be printed
+        return {'error': f'timeout after {timeout_s}s'}
+    lines = [ln for ln in out.splitlines() if ln.startswith('[')]
+    if p.returncode != 0 or not lines:
+        return {'error': f'rc={p.returncode}', 'stderr_tail': err[-400:]}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {'error': repr(e)[:300]}
+
+
 def main():
     a = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -274,6 +300,9 @@ def main():
             res['kernels'] = ks
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.image, a.classes)
+        if world == 1 and not a.no_candidates and a.model == 'BCNN':
+            torch.cuda.empty_cache()
+            res['candidates'] = candidates()
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -1,0 +1,190 @@
+"""HIP-event timings of the opt-in variants and SURVEY-8f rows that were written after round 1's GPU budget was spent,
+each next to the path it would replace.  bench.py runs this in a subprocess (after the headline measurement, with a
+timeout; its failure cannot touch the headline) and attaches the rows as `candidates`, so the driver's round-end
+bench run doubles as their first measurement.
+    python tools/candidates.py [--step]        # prints one JSON list
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as TF
+
+from hawkeye_amd.miopen_cache import use_in_tree_cache
+
+use_in_tree_cache()
+import hawkeye_amd.functional as F
+from hawkeye_amd import _lib
+from hawkeye_amd._lib import ptr, stream
+
+lib = _lib.load()
+dev = torch.device('cuda:0')
+rows = []
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        rc = fn()
+        if isinstance(rc, int) and rc != 0:
+            raise RuntimeError(f'C ABI call returned {rc}')
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def row(op, variant, us, flops=0.0, bytes_=0.0, note=''):
+    rows.append({'op': op, 'variant': variant, 'us': round(us, 1), 'tflops': round(flops / us / 1e6, 1),
+                 'gbs': round(bytes_ / us / 1e3), 'note': note})
+
+
+def guarded(fn):
+    try:
+        fn()
+    except Exception as e:  # noqa: BLE001
+        rows.append({'op': fn.__name__, 'error': repr(e)[:300]})
+
+
+def linear():
+    for tag, (B, J, K) in {'bcnn 262144->200': (64, 262144, 200), 'mpn 32896->200': (64, 32896, 200),
+                            'osme 100352->1024 N=10': (10, 100352, 1024)}.items():
+        y = torch.randn(B, J, device=dev)
+        w = torch.randn(K, J, device=dev) * 0.01
+        b = torch.zeros(K, device=dev)
+        g = torch.randn(B, K, device=dev)
+        out = torch.empty(B, K, device=dev)
+        dy, dw, db = torch.empty_like(y), torch.empty_like(w), torch.empty_like(b)
+        nws = lib.hk_linear_ws_bytes(B, J, K)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        fl = 2.0 * B * J * K
+        row(f'linear fwd {tag}', 'hk_linear_fwd (split-K MFMA)',
+            timeit(lambda: lib.hk_linear_fwd(ptr(y), ptr(w), ptr(b), ptr(out), B, J, K, ptr(ws), nws, stream())), fl,
+            4.0 * (B * J + K * J))
+        row(f'linear fwd {tag}', 'torch F.linear (rocBLAS/hipBLASLt)', timeit(lambda: TF.linear(y, w, b)), fl,
+            4.0 * (B * J + K * J))
+        row(f'linear bwd {tag}', 'hk_linear_bwd (dy + dW + db)',
+            timeit(lambda: lib.hk_linear_bwd(ptr(y), ptr(w), ptr(g), ptr(dy), ptr(dw), ptr(db), B, J, K, stream())), 2 * fl,
+            4.0 * (2 * B * J + 2 * K * J))
+        row(f'linear bwd {tag}', 'torch (g @ w, g.t() @ y, g.sum(0))', timeit(lambda: (g @ w, g.t() @ y, g.sum(0))), 2 * fl,
+            4.0 * (2 * B * J + 2 * K * J))
+        err = float((out - TF.linear(y, w, b)).norm() / TF.linear(y, w, b).norm())
+        rows[-4]['rel_err_vs_torch'] = err
+
+
+def ns_sym():
+    B, d = 64, 256
+    x = torch.relu(torch.randn(B, d, 196, device=dev))
+    cov, mu = torch.empty(B, d, d, device=dev), torch.empty(B, d, device=dev)
+    lib.hk_cov_pool_fwd(ptr(x), ptr(cov), ptr(mu), B, d, 196, stream())
+    out, na = torch.empty(B, d, d, device=dev), torch.empty(B, device=dev)
+    ys, zs = torch.empty(B, 4, d, d, device=dev), torch.empty(B, 4, d, d, device=dev)
+    g, da = torch.randn(B, d, d, device=dev).triu(), torch.empty(B, d, d, device=dev)
+    nwf, nwb = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 0), lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 1)
+    wf, wb = torch.empty(nwf, dtype=torch.uint8, device=dev), torch.empty(nwb, dtype=torch.uint8, device=dev)
+    ref = None
+    for flag in ('0', '1'):
+        os.environ['HK_NS_SYM'] = flag
+        f = timeit(lambda: lib.hk_ns_sqrtm_fwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), B, d, 5, ptr(wf), nwf, stream()))
+        b = timeit(lambda: lib.hk_ns_sqrtm_bwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), ptr(g), ptr(da), B, d, 5,
+                                               ptr(wb), nwb, stream()))
+        row('ns_sqrtm fwd B=64 d=256 it=5', f'HK_NS_SYM={flag}', f, 12 * 2.0 * B * d ** 3)
+        row('ns_sqrtm bwd B=64 d=256 it=5', f'HK_NS_SYM={flag}', b, 38 * 2.0 * B * d ** 3)
+        if ref is None:
+            ref = (out.clone(), da.clone())
+        else:
+            rows[-2]['rel_vs_full'] = float((out - ref[0]).norm() / ref[0].norm())
+            rows[-1]['rel_vs_full'] = float((da - ref[1]).norm() / ref[1].norm())
+    os.environ['HK_NS_SYM'] = '0'
+
+
+def npairs():
+    for b, p, D in ((10, 2, 1024), (32, 2, 1024)):
+        x = torch.randn(b, p, D, device=dev)
+        t = torch.arange(b, device=dev) // 2
+        labels = t.to(torch.int32)
+        loss, dx = torch.empty(1, device=dev), torch.empty_like(x)
+        nws = lib.hk_npairs_ws_bytes(b * p, D)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        row(f'npairs loss+grad b={b} p={p} D={D}', 'hk_npairs_loss (5 launches)',
+            timeit(lambda: lib.hk_npairs_loss(ptr(x), ptr(labels), ptr(loss), ptr(dx), b, p, D, ptr(ws), nws, stream())))
+
+        def torch_vectorised():
+            xr = x.clone().requires_grad_(True)
+            n = b * p
+            xn = TF.normalize(xr.view(n, -1))
+            s = xn @ xn.t()
+            cls, att = torch.repeat_interleave(t, p), torch.arange(p, device=dev).repeat(b)
+            sc, sa = cls[:, None] == cls[None, :], att[:, None] == att[None, :]
+            diff = s[:, None, :] - s[:, :, None]
+
+            def term(pos, neg):
+                return (torch.log(1 + (torch.exp(diff) * neg[:, None, :]).sum(2)) * pos).sum()
+            l = (term(sc & sa, ~(sc & sa)) + term(~sc & sa, ~sc & ~sa) + term(sc & ~sa, ~sc & ~sa)) / n
+            l.backward()
+            return l
+        row(f'npairs loss+grad b={b} p={p} D={D}', 'torch vectorised fwd+bwd (not the reference python loop)',
+            timeit(torch_vectorised, iters=10))
+        rows[-2]['loss'] = float(loss)
+        rows[-1]['loss'] = float(torch_vectorised())
+
+
+def cbp():
+    C, HW, D, B = 512, 196, 6000, 64
+    plan = F.CbpPlan(*F.sketch_hashes(C, C, D), D, dev)
+    x = torch.relu(torch.randn(B, C, HW, device=dev))
+    y, craw, inv = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev), torch.empty(B, device=dev)
+    nws = lib.hk_cbp_ws_bytes(B, C, HW, D)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    for flag in ('0', '1'):
+        os.environ['HK_CBP_CSR'] = flag
+        row('cbp fwd B=64', 'row-sketch binning' if flag == '0' else 'CSR gather binning',
+            timeit(lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws,
+                                          stream())), 2.0 * B * C * C * HW)
+    del os.environ['HK_CBP_CSR']
+
+
+def bcnn_step_with_hip_linear():
+    import hawkeye_amd.model  # noqa: F401
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.registry import MODEL
+    torch.manual_seed(0)
+    m = MODEL.get('BCNN')(CfgNode(dict(name='BCNN', stage=2, num_classes=200))).to(dev).to(memory_format=torch.channels_last)
+    m.train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.005, momentum=0.9, weight_decay=1e-5)
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+    x = torch.randn(64, 3, 448, 448, device=dev).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, 200, (64,), device=dev)
+
+    def step():
+        loss = crit(m(x), y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    for flag in ('0', '1'):
+        os.environ['HAWKEYE_HIP_LINEAR'] = flag
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 8 * 1e3
+        rows.append({'op': 'BCNN bs64 448^2 train step', 'variant': f'HAWKEYE_HIP_LINEAR={flag}', 'ms_per_step': round(ms, 2),
+                     'images_per_sec': round(64 / ms * 1e3, 1)})
+    os.environ['HAWKEYE_HIP_LINEAR'] = '0'
+
+
+if __name__ == '__main__':
+    for f in (linear, ns_sym, npairs, cbp):
+        guarded(f)
+    if '--step' in sys.argv:
+        guarded(bcnn_step_with_hip_linear)
+    print(json.dumps(rows), flush=True)
