@@ -1,6 +1,6 @@
 // Classifier GEMMs adjacent to the pooling heads: out = y W^T + bias for a very wide feature vector
 // (BCNN: J = 512^2 = 262144 -> 200 classes; MPN: 32896 -> 200; OSME: 100352 -> 1024) and its backward.
-// replaces nn.Linear at model/methods/BCNN.py:42,54, CBCNN.py:31, MPNCOV.py:31, OSME.py:33-34,42.
+// replaces nn.Linear at model/methods/BCNN.py:42,54, CBCNN.py:26,34, MPNCOV.py:31, OSME.py:34,43.
 //
 // All three products are HBM-bound at these shapes (BCNN, B = 64: W 209.7 MB + y 67.1 MB against 6.7 GFLOP), so the
 // design goal is to stream W and y exactly once with enough workgroups in flight:

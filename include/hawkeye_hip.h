@@ -197,8 +197,8 @@ int hk_osme_scale_bwd(const float* x, const float* m, const float* ds, const flo
 /* ------------------------------------------------------- classifier (8f-1) ----
  * out = y W^T + bias for the wide pooled vector and its backward: split-K f32-MFMA
  * GEMM with a deterministic slab reduction (forward), plain tiles (backward).
- * replaces nn.Linear at model/methods/BCNN.py:42,54 ; CBCNN.py:31 ; MPNCOV.py:31 ;
- * OSME.py:33-34,42 (same operand layouts: W is [K][J] as in nn.Linear.weight).
+ * replaces nn.Linear at model/methods/BCNN.py:42,54 ; CBCNN.py:26,34 ; MPNCOV.py:31 ;
+ * OSME.py:34,43 (same operand layouts: W is [K][J] as in nn.Linear.weight).
  *   y [B,J] ; w [K,J] ; bias [K] or NULL ; out [B,K] ; ws: hk_linear_ws_bytes(B,J,K)
  *   g [B,K] = dL/dout ; dy [B,J], dw [K,J], db [K]: each may be NULL (skipped)
  */
