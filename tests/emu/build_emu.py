@@ -30,7 +30,7 @@ def build(verbose=False):
         raise RuntimeError('no clang++ found: the kernels use ext_vector_type')
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
-    deps = srcs + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, 'shim', 'hip', '*.h')) + \
+    deps = srcs + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, 'shim', 'hip', '*.h')) + glob.glob(os.path.join(HERE, 'shim', '*.S')) + \
         glob.glob(os.path.join(ROOT, 'include', '*.h'))
     if os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps):
         return LIB
@@ -47,7 +47,9 @@ def build(verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, srcs))
-    subprocess.run([cxx, '-shared', '-Wl,-Bsymbolic', '-o', LIB] + objs, check=True)   # never bind to the gfx950 library's symbols
+    sw = os.path.join(OUT, 'hipemu_switch.o')
+    subprocess.run([cxx, '-c', os.path.join(HERE, 'shim', 'hipemu_switch.S'), '-o', sw], check=True)
+    subprocess.run([cxx, '-shared', '-Wl,-Bsymbolic', '-o', LIB] + objs + [sw], check=True)   # never bind to the gfx950 library's symbols
     return LIB
 
 

@@ -6,7 +6,7 @@
 // without a GPU.  Nothing under hawkeye_amd/ loads it: the product library is libhawkeye_hip.so (gfx950) and the
 // product path raises without a GPU.  It says nothing about speed.
 //
-// Model: one workgroup at a time; its work-items are ucontext fibers run round-robin on one OS thread, switching
+// Model: one workgroup at a time; its work-items are fibers (own stacks, hipemu_switch.S) run round-robin on one OS thread, switching
 // only at __syncthreads()/s_barrier and at wave-wide collectives (__shfl_xor, MFMA), which is where real wave64
 // hardware synchronises too.  A barrier that not every live work-item reaches aborts with a message instead of
 // hanging.  Dynamic and static LDS are plain host memory (dynamic LDS is poisoned with NaNs at every block start).
@@ -18,8 +18,6 @@
 //                            result reg v (0..3) of lane l is C[i = 4*(l/16) + v][j = l%16]
 // The GPU-validated kernels of round 1 are the emulator's own test: they only reproduce the oracle if these hold.
 #pragma once
-#include <ucontext.h>
-
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -68,6 +66,8 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 #define __launch_bounds__(...)
 #define __shared__ static
 
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);   // tests/emu/shim/hipemu_switch.S
+
 namespace hipemu {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -82,7 +82,7 @@ struct Wave {
     uint64_t slot[2][64][2];   // exchange slots of the two most recent collectives
 };
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;          // saved stack pointer while switched out
     int state = READY;
     unsigned wait_gen = 0;
     dim3 tid;
@@ -100,7 +100,7 @@ struct Block {
 
 inline Block* B = nullptr;
 inline Fiber* cur = nullptr;
-inline ucontext_t sched;
+inline void* sched_sp = nullptr;
 inline const std::function<void()>* body = nullptr;
 inline std::vector<Fiber> pool;
 
@@ -120,7 +120,7 @@ inline void block_barrier() {
     }
     cur->state = WAIT_BLOCK;
     cur->wait_gen = g;
-    swapcontext(&cur->ctx, &sched);
+    hipemu_switch(&cur->sp, sched_sp);
 }
 inline void wave_barrier() {
     Wave& w = B->waves[cur->wave];
@@ -131,7 +131,7 @@ inline void wave_barrier() {
     }
     cur->state = WAIT_WAVE;
     cur->wait_gen = g;
-    swapcontext(&cur->ctx, &sched);
+    hipemu_switch(&cur->sp, sched_sp);
 }
 inline void trampoline() {
     (*body)();
@@ -140,7 +140,8 @@ inline void trampoline() {
     Wave& w = B->waves[f->wave];
     if (--B->alive > 0 && B->arrived == B->alive) release_block();     // exited work-items do not take part in barriers
     if (--w.alive > 0 && w.arrived == w.alive) release_wave(w);
-    swapcontext(&f->ctx, &sched);
+    hipemu_switch(&f->sp, sched_sp);
+    abort();                                   // a finished fiber is never resumed
 }
 
 inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, dim3 bid, size_t lds_bytes) {
@@ -166,11 +167,13 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
         f.wave = t / 64;
         f.lane = t % 64;
         blk.waves[f.wave].alive++;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = STACK_BYTES;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, trampoline, 0);
+        // initial frame: six callee-saved registers, then the address hipemu_switch "returns" to; the slot above it
+        // stands for trampoline's own return address, so that rsp = 16 n + 8 at its entry as the ABI requires
+        void** top = reinterpret_cast<void**>((reinterpret_cast<uintptr_t>(f.stack) + STACK_BYTES) & ~uintptr_t(15));
+        *--top = nullptr;
+        *--top = reinterpret_cast<void*>(&trampoline);
+        for (int r = 0; r < 6; ++r) *--top = nullptr;
+        f.sp = top;
     }
     // Order in which runnable work-items are resumed.  Results must not depend on it: a kernel that gives different
     // answers under HK_EMU_ORDER=rev / rand:<seed> is missing a barrier (the emulator only switches work-items at
@@ -202,7 +205,7 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
             if (f.state == WAIT_WAVE && blk.waves[f.wave].gen == f.wait_gen) continue;
             f.state = READY;
             cur = &f;
-            swapcontext(&sched, &f.ctx);
+            hipemu_switch(&sched_sp, f.sp);
             progressed = true;
             if (f.state == DONE) --remaining;
         }

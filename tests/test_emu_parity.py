@@ -29,10 +29,9 @@ for _mod in _modules:
             globals()[_name] = _obj
 
 
-# parameter sets that take 25 s .. 2 min each when emulated: run them with HK_EMU_FULL=1
-_HEAVY = {'test_cbp_rowsketch_equals_csr[512-6000-40]', 'test_cov_and_cbp_panel_kernels_vs_generic[70-256-8]',
-          'test_mpn_256_vs_golden', 'test_bcnn_panel_kernels_vs_oracle_and_generic[90-192-8]',
-          'test_models_with_hip_classifier[BCNN]', 'test_models_with_hip_classifier[MPN]'}
+# parameter sets that take 20 s .. 80 s each when emulated: run them with HK_EMU_FULL=1
+_HEAVY = {'test_cbp_rowsketch_equals_csr[512-6000-40]', 'test_models_with_hip_classifier[BCNN]',
+          'test_models_with_hip_classifier[MPN]'}
 
 
 @pytest.fixture(autouse=True)
