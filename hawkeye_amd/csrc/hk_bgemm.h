@@ -279,6 +279,130 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
     al.finish(b, tm, tn, tilesM, lds);
 }
 
+// ---------------------------------------------------------------- 128x128 tile, 8 waves
+// Why: on the Newton-Schulz shape (256^3 x 64 samples) the 64x64 kernel above reads 128 KB of operands per 2.1 MFLOP
+// tile = 16 FLOP/B, i.e. ~10 TB/s of L2->LDS traffic at the fp32 MFMA peak - it is L2-bandwidth/latency bound (45 % of
+// wave time parked at the chunk barrier, profiles/r1c_sq_wait_counters.csv).  The first 128x128 attempt (T = 2 above:
+// 4 waves x 64x64) halves that traffic but leaves one 4-wave workgroup per CU with a one-chunk prefetch, and was
+// 1.3x slower.  This variant keeps the 32 FLOP/B of the big tile and fixes the latency side: 8 waves per workgroup
+// (wave = 32 rows x 64 columns: two independent accumulators, so consecutive MFMAs never depend on each other),
+// and a TWO-chunk prefetch through two register sets - the loads for chunk c+2 are issued before chunk c is computed
+// and are stored to LDS a whole chunk later.  256 tiles at B = 64: exactly one workgroup per CU.
+// Same k-permutation and summation order as bgemm_kernel.  Opt-in (HK_NS_GEMM=4) until it has a measured number.
+template <bool A_KC, bool B_KC, class AL, class BL, class EP>
+__global__ __launch_bounds__(512) void bgemm128_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb, int tilesM,
+                                                       int tilesN) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int PA = A_KC ? BK + 4 : BM + 4;
+    constexpr int PB = B_KC ? BK + 4 : BN + 4;
+    constexpr int SA = (A_KC ? BM : BK) * PA;
+    constexpr int SB = (B_KC ? BN : BK) * PB;
+    constexpr int NL = BM * BK / 4 / 512;       // float4 per thread per operand chunk (2)
+    constexpr int A4 = A_KC ? BK / 4 : BM / 4;
+    constexpr int B4 = B_KC ? BK / 4 : BN / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (SA + SB)];
+
+    int b, tile;
+    if (!xcd_map(blockIdx.x, nb, tilesM * tilesN, b, tile)) return;
+    const int tm = tile / tilesN, tn = tile % tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;    // 4 x 2 waves: rows wm*32.., columns wn*64..
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    al.begin(b, tm, tn);
+    bl.begin(b, tm, tn);
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    float4 ra0[NL], rb0[NL], ra1[NL], rb1[NL];  // two register sets: chunks in flight
+
+#define HK_GLOAD2(RA, RB, k0)                                                                          \
+    do {                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                               \
+            const int f_ = tid + 512 * u, ar_ = f_ / A4, ac_ = f_ % A4, br_ = f_ / B4, bc_ = f_ % B4;  \
+            RA[u] = A_KC ? al.ld4(b, m0 + ar_, (k0) + 4 * ac_) : al.ld4(b, (k0) + ar_, m0 + 4 * ac_);  \
+            RB[u] = B_KC ? bl.ld4(b, n0 + br_, (k0) + 4 * bc_) : bl.ld4(b, (k0) + br_, n0 + 4 * bc_);  \
+        }                                                                                              \
+    } while (0)
+#define HK_SSTORE2(RA, RB, buf)                                                                        \
+    do {                                                                                               \
+        float* As_ = lds + (buf) * (SA + SB);                                                          \
+        float* Bs_ = As_ + SA;                                                                         \
+        _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                               \
+            const int f_ = tid + 512 * u, ar_ = f_ / A4, ac_ = f_ % A4, br_ = f_ / B4, bc_ = f_ % B4;  \
+            *reinterpret_cast<float4*>(&As_[ar_ * PA + 4 * ac_]) = RA[u];                              \
+            *reinterpret_cast<float4*>(&Bs_[br_ * PB + 4 * bc_]) = RB[u];                              \
+        }                                                                                              \
+    } while (0)
+#define HK_COMPUTE2(buf)                                                                               \
+    do {                                                                                               \
+        const float* As = lds + (buf) * (SA + SB);                                                     \
+        const float* Bs = As + SA;                                                                     \
+        const int row_ = wm * 32 + l31, c0_ = wn * 64 + l31, c1_ = c0_ + 32;                           \
+        _Pragma("unroll") for (int s = 0; s < BK / 8; ++s) {                                           \
+            float a_[4], p_[4], q_[4];                                                                 \
+            if (A_KC) {                                                                                \
+                const float4 v_ = *reinterpret_cast<const float4*>(&As[row_ * PA + 8 * s + 4 * lh]);   \
+                a_[0] = v_.x; a_[1] = v_.y; a_[2] = v_.z; a_[3] = v_.w;                                \
+            } else {                                                                                   \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) a_[t] = As[(8 * s + 4 * lh + t) * PA + row_]; \
+            }                                                                                          \
+            if (B_KC) {                                                                                \
+                const float4 v_ = *reinterpret_cast<const float4*>(&Bs[c0_ * PB + 8 * s + 4 * lh]);    \
+                const float4 w_ = *reinterpret_cast<const float4*>(&Bs[c1_ * PB + 8 * s + 4 * lh]);    \
+                p_[0] = v_.x; p_[1] = v_.y; p_[2] = v_.z; p_[3] = v_.w;                                \
+                q_[0] = w_.x; q_[1] = w_.y; q_[2] = w_.z; q_[3] = w_.w;                                \
+            } else {                                                                                   \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                        \
+                    p_[t] = Bs[(8 * s + 4 * lh + t) * PB + c0_];                                       \
+                    q_[t] = Bs[(8 * s + 4 * lh + t) * PB + c1_];                                       \
+                }                                                                                      \
+            }                                                                                          \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                            \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], p_[t], acc0, 0, 0, 0);              \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], q_[t], acc1, 0, 0, 0);              \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+
+    const int nk = (K + BK - 1) / BK;
+    HK_GLOAD2(ra0, rb0, 0);
+    HK_SSTORE2(ra0, rb0, 0);
+    if (nk > 1) HK_GLOAD2(ra1, rb1, BK);
+    __syncthreads();
+    // iteration c computes chunk c from stage c & 1; register set (c + 1) & 1 holds chunk c + 1, set c & 1 is free
+    for (int c = 0; c < nk; c += 2) {
+        if (c + 2 < nk) HK_GLOAD2(ra0, rb0, (c + 2) * BK);
+        HK_COMPUTE2(0);
+        if (c + 1 < nk) HK_SSTORE2(ra1, rb1, 1);
+        __syncthreads();
+        if (c + 1 < nk) {
+            if (c + 3 < nk) HK_GLOAD2(ra1, rb1, (c + 3) * BK);
+            HK_COMPUTE2(1);
+            if (c + 2 < nk) HK_SSTORE2(ra0, rb0, 0);
+            __syncthreads();
+        }
+    }
+#undef HK_GLOAD2
+#undef HK_SSTORE2
+#undef HK_COMPUTE2
+
+    const int ib = m0 + wm * 32 + 4 * lh;
+    const int j0 = n0 + wn * 64 + l31, j1 = j0 + 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ii = ib + (r & 3) + 8 * (r >> 2);
+        if (ii < M) {
+            if (j0 < N) ep(b, ii, j0, acc0[r]);
+            if (j1 < N) ep(b, ii, j1, acc1[r]);
+        }
+    }
+    al.finish(b, tm, tn, tilesM, lds);
+}
+
 template <bool A_KC, bool B_KC, class AL, class BL, class EP>
 static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb,
                                hipStream_t st, int allow_big = 0) {
@@ -300,6 +424,17 @@ static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, 
         hipLaunchKernelGGL((bgemm_kernel<1, 32, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st,
                            al, bl, ep, M, N, K, nb, tm, tn);
     }
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+// 128x128 / 8-wave variant (bgemm128_kernel); only instantiated where it is asked for
+template <bool A_KC, bool B_KC, class AL, class BL, class EP>
+static inline int bgemm128_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
+    const int tm = (M + 127) / 128, tn = (N + 127) / 128;
+    hipLaunchKernelGGL((bgemm128_kernel<A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(512), 0, st, al, bl,
+                       ep, M, N, K, nb, tm, tn);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

@@ -161,3 +161,23 @@ def test_mamc_npairs_loss_larger_batch(F):
     lg = F.npairs_loss(xg, y.to(DEV))
     lg.backward()
     assert abs(float(lg) - float(lo)) <= 5e-6 * abs(float(lo)) and rel(xg.grad, xo.grad) < 2e-5
+
+
+@pytest.mark.parametrize('b,d,itn', [(2, 128, 5), (3, 200, 3), (9, 256, 2)])
+def test_ns_128_tile_gemm_variant(F, b, d, itn, monkeypatch):
+    """HK_NS_GEMM=4: the Newton-Schulz products on bgemm128_kernel (128x128 tile, 8 waves, two-chunk prefetch through
+    two register sets).  Same k order as the 64x64 kernel, so results agree to rounding of the tile boundaries only."""
+    x = torch.relu(torch.randn(b, d, 5, 6, generator=torch.Generator().manual_seed(d + 1))) + 0.01
+    xo = x.clone().requires_grad_(True)
+    yo = O.sqrtm(O.covpool(xo), itn)
+    wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(2))
+    (yo * wt).sum().backward()
+    res = []
+    for flag in ('0', '4'):
+        monkeypatch.setenv('HK_NS_GEMM', flag)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        yg = F.sqrtm(F.covpool(xg), itn)
+        (yg * wt.to(DEV)).sum().backward()
+        assert rel(yg, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
+        res.append((yg.detach(), xg.grad))
+    assert rel(res[1][0], res[0][0]) < 2e-6 and rel(res[1][1], res[0][1]) < 2e-5

@@ -89,19 +89,20 @@ def ns_sym():
     nwf, nwb = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 0), lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 1)
     wf, wb = torch.empty(nwf, dtype=torch.uint8, device=dev), torch.empty(nwb, dtype=torch.uint8, device=dev)
     ref = None
-    for flag in ('0', '1'):
-        os.environ['HK_NS_SYM'] = flag
+    for sym, gemm in (('0', '0'), ('1', '0'), ('0', '4'), ('1', '4')):
+        os.environ['HK_NS_SYM'], os.environ['HK_NS_GEMM'] = sym, gemm
         f = timeit(lambda: lib.hk_ns_sqrtm_fwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), B, d, 5, ptr(wf), nwf, stream()))
         b = timeit(lambda: lib.hk_ns_sqrtm_bwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), ptr(g), ptr(da), B, d, 5,
                                                ptr(wb), nwb, stream()))
-        row('ns_sqrtm fwd B=64 d=256 it=5', f'HK_NS_SYM={flag}', f, 12 * 2.0 * B * d ** 3)
-        row('ns_sqrtm bwd B=64 d=256 it=5', f'HK_NS_SYM={flag}', b, 38 * 2.0 * B * d ** 3)
+        tag = f'HK_NS_SYM={sym} HK_NS_GEMM={gemm}' + (' (round-1 default)' if (sym, gemm) == ('0', '0') else '')
+        row('ns_sqrtm fwd B=64 d=256 it=5', tag, f, 12 * 2.0 * B * d ** 3)
+        row('ns_sqrtm bwd B=64 d=256 it=5', tag, b, 38 * 2.0 * B * d ** 3)
         if ref is None:
             ref = (out.clone(), da.clone())
         else:
-            rows[-2]['rel_vs_full'] = float((out - ref[0]).norm() / ref[0].norm())
-            rows[-1]['rel_vs_full'] = float((da - ref[1]).norm() / ref[1].norm())
-    os.environ['HK_NS_SYM'] = '0'
+            rows[-2]['rel_vs_default'] = float((out - ref[0]).norm() / ref[0].norm())
+            rows[-1]['rel_vs_default'] = float((da - ref[1]).norm() / ref[1].norm())
+    os.environ['HK_NS_SYM'], os.environ['HK_NS_GEMM'] = '0', '0'
 
 
 def npairs():
