@@ -416,6 +416,75 @@ def osme_scale(x, m):
 
 
 # --------------------------------------------------------------------- generic
+# --------------------------------------------------------------------- CIN channel interaction
+class _CinSci(torch.autograd.Function):
+    """W = softmax_rows(-X X^T / HW), Y = W X.  replaces model/methods/CIN.py:31-34.  W is an output too: the
+    contrastive branch (cin_cci) consumes it and sends a gradient back into it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x)
+        b, c, hw = x.shape
+        w = torch.empty(b, c, c, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        check(lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), b, c, hw, stream()), 'hk_cin_sci_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.set_materialize_grads(False)
+        return y, w
+
+    @staticmethod
+    def backward(ctx, dy, dw):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        b, c, hw = x.shape
+        dy = _f32c(dy) if dy is not None else torch.zeros_like(x)
+        dwbuf = _f32c(dw).clone() if dw is not None else torch.empty_like(w)     # overwritten by the kernel chain
+        dx = torch.empty_like(x)
+        check(lib.hk_cin_sci_bwd(ptr(x), ptr(w), ptr(dy), ptr(dwbuf), int(dw is not None), ptr(dx), b, c, hw, stream()),
+              'hk_cin_sci_bwd')
+        return dx
+
+
+class _CinCci(torch.autograd.Function):
+    """Yc[b] = |W[b] - w_b W[(b + B/2) % B]| X[b].  replaces model/methods/CIN.py:51-54."""
+
+    @staticmethod
+    def forward(ctx, w, x, wt):
+        lib = _lib.load()
+        w, x, wt = _f32c(w), _f32c(x), _f32c(wt)
+        b, c, hw = x.shape
+        if b % 2 or wt.shape != (b,):
+            raise _lib.HawkeyeHipError(f'cin_cci: batch {b} must be even and weights [B], got {tuple(wt.shape)}')
+        y = torch.empty_like(x)
+        check(lib.hk_cin_cci_fwd(ptr(x), ptr(w), ptr(wt), ptr(y), b, c, hw, stream()), 'hk_cin_cci_fwd')
+        ctx.save_for_backward(w, x, wt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        w, x, wt = ctx.saved_tensors
+        b, c, hw = x.shape
+        dy = _f32c(dy)
+        dx, dw, dwt = torch.empty_like(x), torch.empty_like(w), torch.empty_like(wt)
+        nws = lib.hk_cin_cci_ws_bytes(b, c)
+        ws = _ws(nws, x.device)
+        check(lib.hk_cin_cci_bwd(ptr(x), ptr(w), ptr(wt), ptr(dy), ptr(dx), ptr(dw), ptr(dwt), b, c, hw, ptr(ws), nws,
+                                 stream()), 'hk_cin_cci_bwd')
+        return dw, dx, dwt
+
+
+def cin_sci(x):
+    """x [B,C,HW] -> (Y [B,C,HW], W_SCI [B,C,C])."""
+    return _CinSci.apply(x)
+
+
+def cin_cci(w_sci, x, weight):
+    """W_SCI [B,C,C], x [B,C,HW], weight [B] (eta for the first half of the batch, gamma for the second) -> Y_CCI."""
+    return _CinCci.apply(w_sci, x, weight)
+
+
 # --------------------------------------------------------------------- MAMC n-pairs loss
 class _NPairsLoss(torch.autograd.Function):
     """replaces NPairsLoss.forward, model/loss/MAMC_loss.py:34-90.  The kernel returns the loss and its gradient

@@ -94,6 +94,10 @@ class Trainer:
         self.scheduler = self.get_scheduler(cfg.train.scheduler)
         # gradient synchronisation (after the optimiser so that requires_grad flags are final)
         self.reducer = ddp.GradientAllReducer(self.model) if self.world > 1 else None
+        # a criterion that owns parameters (CINLoss.h) is data-parallel state too
+        crit_trainable = isinstance(self.criterion, torch.nn.Module) and \
+            any(p.requires_grad for p in self.criterion.parameters())
+        self.criterion_reducer = ddp.GradientAllReducer(self.criterion) if (self.world > 1 and crit_trainable) else None
 
         if self.resume:
             self.logger.info(f'Resuming from `{self.resume}`')
@@ -204,6 +208,8 @@ class Trainer:
     def zero_grad(self):
         if self.reducer is not None:
             self.reducer.zero_grad()
+            if self.criterion_reducer is not None:
+                self.criterion_reducer.zero_grad()
         else:
             self.optimizer.zero_grad()
 
@@ -213,6 +219,8 @@ class Trainer:
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
+            if self.criterion_reducer is not None:
+                self.criterion_reducer.finish()
         self.optimizer.step()
 
     # ------------------------------------------------------------------ loops

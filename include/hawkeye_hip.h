@@ -218,6 +218,22 @@ size_t hk_npairs_ws_bytes(int n, int D);
 int hk_npairs_loss(const float* x, const int32_t* labels, float* loss, float* dx, int b, int p, int D, void* ws,
                    size_t ws_bytes, hk_stream_t stream);
 
+/* ------------------------------------------------ CIN channel interaction (8f-2) ----
+ * SCI: W = softmax_rows(-X X^T / HW), Y = W X ; CCI: Yc[b] = |W[b] - w_b W[(b + B/2) % B]| X[b].
+ * replaces the bmm / softmax / abs / bmm parts of ChannelInteractionModule.forward,
+ * model/methods/CIN.py:24-60 (conv 3x3, residual and the 1-output fc stay on PyTorch).
+ *   x, y, dy, dx [B,C,HW] ; w, dw [B,C,C] ; wt, dwt [B] ; B even for the CCI pair.
+ *   hk_cin_sci_bwd: dwbuf [B,C,C] scratch; holds the gradient reaching W from the CCI
+ *   branch on entry when has_extra != 0 (it is overwritten).
+ */
+int hk_cin_sci_fwd(const float* x, float* w, float* y, int B, int C, int HW, hk_stream_t stream);
+int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, float* dwbuf, int has_extra, float* dx, int B, int C,
+                   int HW, hk_stream_t stream);
+int hk_cin_cci_fwd(const float* x, const float* w, const float* wt, float* y, int B, int C, int HW, hk_stream_t stream);
+size_t hk_cin_cci_ws_bytes(int B, int C);
+int hk_cin_cci_bwd(const float* x, const float* w, const float* wt, const float* dy, float* dx, float* dw, float* dwt,
+                   int B, int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream);
+
 /* ------------------------------------------------------- generic primitive ----
  * Batched fp32 GEMM on the f32 MFMA path (exact fp32 fma chain):
  *   C[b] = alpha * op(A[b]) op(B[b]) + beta * C[b] + diag * I

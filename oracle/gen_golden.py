@@ -236,6 +236,80 @@ def gen_mamc():
     save('mamc_loss', **out)
 
 
+# ---------------------------------------------------------------- CIN channel interaction
+def gen_cin():
+    from yacs.config import CfgNode as CN
+    M_CIN = sys.modules['model.methods.CIN']
+    from model.loss.CIN_loss import CINLoss
+    torch.manual_seed(7)
+    cim = M_CIN.ChannelInteractionModule(in_channel=24, spatial_size=(3, 4))
+    with torch.no_grad():
+        for i, p_ in enumerate(cim.parameters()):
+            p_.copy_(t(rs_randn(400 + i, tuple(p_.shape))) * (0.05 if p_.dim() > 1 else 0.01))
+    sd = {k: v.clone() for k, v in cim.state_dict().items()}
+    out = {'w_' + k.replace('.', '__'): v for k, v in sd.items()}
+    cim.train()
+    x = t(rs_relu_randn(410, (4, 24, 3, 4))).requires_grad_(True)
+    z, zc = cim(x)
+    ((z * t(rs_randn(411, tuple(z.shape)))).sum() + (zc * t(rs_randn(412, tuple(zc.shape)))).sum()).backward()
+    out.update(z=z, z_cci=zc, dx=x.grad.clone(),
+               **{'g_' + k.replace('.', '__'): v.grad.clone() for k, v in cim.named_parameters()})
+    cim.eval()
+    out['z_eval'] = cim(t(rs_relu_randn(410, (4, 24, 3, 4))))
+    # the criterion (its own Linear h)
+    crit = CINLoss(CN(dict(alpha=2.0, beta=0.5, channel=24, feature_size=12, r_channel=8)))
+    with torch.no_grad():
+        crit.h.weight.copy_(t(rs_randn(420, tuple(crit.h.weight.shape))) * 0.1)
+        crit.h.bias.copy_(t(rs_randn(421, tuple(crit.h.bias.shape))) * 0.1)
+    logits = t(rs_randn(422, (4, 5))).requires_grad_(True)
+    zc2 = t(rs_randn(423, (4, 24, 12))).requires_grad_(True)
+    for name, labels in (('pairs', [1, 3, 1, 1]), ('nopairs', [1, 3, 0, 2])):
+        logits.grad = zc2.grad = None
+        loss = crit((logits, zc2), torch.tensor(labels))
+        loss.backward()
+        out[f'loss_{name}'] = loss.detach()
+        out[f'loss_{name}_dlogits'] = logits.grad.clone()
+        out[f'loss_{name}_dz'] = zc2.grad.clone()
+    out['h_w'], out['h_b'] = crit.h.weight.detach().clone(), crit.h.bias.detach().clone()
+    save('cin_small', **out)
+
+
+def gen_cin_model():
+    """Whole reference CIN (ResNet-50 + channel interaction + classifier) at 224x224: eval logits, train-mode outputs
+    (batch statistics, contrastive branch) and the criterion value; plus its state_dict keys."""
+    from yacs.config import CfgNode as CN
+    from inputs import seeded_init
+    from model.loss.CIN_loss import CINLoss
+    M_CIN = sys.modules['model.methods.CIN']
+    real_r50 = M_CIN.resnet50
+    M_CIN.resnet50 = lambda pretrained=True: real_r50(pretrained=False)
+    m = MODEL.get('CIN')(CN(dict(num_classes=200)))
+    keys_path = os.path.join(OUT, 'state_dict_keys.json')
+    keys = json.load(open(keys_path))
+    keys['CIN'] = {
+        'state_dict': [[k, list(v.shape)] for k, v in m.state_dict().items()],
+        'children': [n for n, _ in m.named_children()],
+        'n_params': sum(p.numel() for p in m.parameters()),
+    }
+    json.dump(keys, open(keys_path, 'w'))
+    seeded_init(m, 930)
+    x = t(rs_randn(931, (4, 3, 224, 224)))
+    m.eval()
+    with torch.no_grad():
+        logits_eval = m(x)
+    m.train()
+    with torch.no_grad():
+        logits_train, z_cci = m(x)
+    torch.manual_seed(3)
+    crit = CINLoss(CN(dict(alpha=2.0, beta=0.5, channel=2048, feature_size=49, r_channel=16)))
+    with torch.no_grad():
+        crit.h.weight.copy_(t(rs_randn(932, tuple(crit.h.weight.shape))) * 1e-3)
+        crit.h.bias.zero_()
+        loss = crit((logits_train, z_cci), torch.tensor([5, 9, 5, 9]))
+    save('model_cin', logits_eval=logits_eval, logits_train=logits_train, z_cci_sub=sub(z_cci, 97), z_cci_sum=z_cci.double().sum(),
+         loss=loss)
+
+
 # ---------------------------------------------------------------- key contracts
 def gen_keys():
     from yacs.config import CfgNode as CN

@@ -385,6 +385,52 @@ def osme_forward(x, gates, fcs):
 
 
 # ----------------------------------------------------------------------------
+# CIN channel interaction  (model/methods/CIN.py:24-60, model/loss/CIN_loss.py:27-50) - SURVEY 8f-2
+# ----------------------------------------------------------------------------
+def channel_interaction(x, conv_w, conv_b, fc_w, fc_b, training):
+    """ChannelInteractionModule.forward, CIN.py:24-60.  x [B,C,W,H]; conv 3x3 C->C; fc: 2*C*WH -> 1.
+    eval: Z [B,C,WH]; train: (Z, Z_CCI) with the two batch halves as contrast partners."""
+    b, c, w, h = x.shape
+    assert b % 2 == 0, 'batch size should not be odd!'                       # :27
+    xm = x.view(b, c, w * h)                                                 # :28
+    gram = torch.bmm(xm, xm.transpose(1, 2)) / (w * h)                       # :31
+    w_sci = F.softmax(-gram, dim=2)                                          # :32
+    y = torch.bmm(w_sci, xm)                                                 # :34
+    y = F.conv2d(y.view(b, c, w, h), conv_w, conv_b, 1, 1).view(b, c, w * h) # :36-37
+    z = y + xm                                                               # :38
+    if not training:
+        return z                                                             # :40-41
+    yf = y.reshape(b, -1)                                                    # :44
+    half = b // 2
+    y_a = torch.cat((yf[:half], yf[half:]), dim=1)                           # :45
+    y_b = torch.cat((yf[half:], yf[:half]), dim=1)                           # :46
+    weight = torch.cat((F.linear(y_a, fc_w, fc_b), F.linear(y_b, fc_w, fc_b)), dim=0)   # :47-50
+    w_ba = torch.cat((w_sci[half:], w_sci[:half]), dim=0)                    # :51
+    w_cci = torch.abs(w_sci - weight.view(-1, 1, 1) * w_ba)                  # :52
+    y_cci = torch.bmm(w_cci, xm)                                             # :54
+    y_cci = F.conv2d(y_cci.view(b, c, w, h), conv_w, conv_b, 1, 1).view(b, c, w * h)    # :56-57
+    return z, y_cci + xm                                                     # :58-60
+
+
+def cin_loss(output, target, h_w, h_b, alpha=2.0, beta=0.5):
+    """CINLoss.__call__, CIN_loss.py:27-50, restated literally - including that `pair_label` compares the first half
+    of the labels with the single label target[B//2] (:40) and that `loss_cont_2` is overwritten by
+    `loss_cont_1 ** 2` (:44), so the margin term never contributes."""
+    if not isinstance(output, tuple):
+        return F.cross_entropy(output, target, label_smoothing=0.1)          # :28-29
+    z, z_cci = output
+    b = z_cci.shape[0]
+    loss_ce = F.cross_entropy(z, target, label_smoothing=0.1)                # :35
+    z_ab = F.linear(z_cci.reshape(b, -1), h_w, h_b)                          # :38-39
+    half = b // 2
+    pair = target[:half] == target[half]                                     # :40
+    d_pos = F.pairwise_distance(z_ab[:half][pair], z_ab[half:][pair], p=2)
+    loss_cont_1 = torch.sum(d_pos ** 2)                                      # :41
+    loss_cont_2 = loss_cont_1 ** 2                                           # :42-44 (the margin term is discarded)
+    return loss_ce + alpha * (loss_cont_1 + loss_cont_2)                     # :45-48
+
+
+# ----------------------------------------------------------------------------
 # MAMC n-pairs loss  (model/loss/MAMC_loss.py:24-90) - SURVEY 8f-4
 # ----------------------------------------------------------------------------
 def npairs_masks(targets, p):

@@ -39,7 +39,7 @@ def _emulated_heads():
         yield
 
 
-@pytest.mark.parametrize('which', ['BCNN', 'OSMENet'])
+@pytest.mark.parametrize('which', ['BCNN', 'OSMENet', 'CIN'])
 def test_trainers_end_to_end_on_emulated_heads(which, tmp_path, monkeypatch):
     """Trainer flow from a yaml (build -> train -> validate -> checkpoint) with the device hook pointed at the CPU:
     BCNN (cross entropy) and OSMENet (class-balanced batches + MAMC criterion on hk_npairs_loss)."""
@@ -47,19 +47,25 @@ def test_trainers_end_to_end_on_emulated_heads(which, tmp_path, monkeypatch):
 
     from hawkeye_amd.config import CfgNode
     from hawkeye_amd.train import Trainer
-    if which == 'OSMENet' and os.environ.get('HK_EMU_FULL') != '1':
-        pytest.skip('ResNet-101 at 224x224 on the CPU: HK_EMU_FULL=1 runs it')
+    if which != 'BCNN' and os.environ.get('HK_EMU_FULL') != '1':
+        pytest.skip('ResNet at 224x224 on the CPU: HK_EMU_FULL=1 runs it')
     monkeypatch.setattr(Trainer, 'select_device', lambda self, cfg: torch.device('cpu'))
     root = os.path.dirname(_here)
     if which == 'BCNN':
         from hawkeye_amd.examples.BCNN import BCNNTrainer as T
         cfg = CfgNode.load_cfg(open(os.path.join(root, 'configs', 'BCNN_S2_synthetic.yaml')))
         cfg.dataset.samples, cfg.dataset.batch_size, cfg.dataset.transformer.image_size = 8, 4, 64
-    else:
+    elif which == 'OSMENet':
         from hawkeye_amd.examples.OSMENet import OSMENetTrainer as T
         cfg = CfgNode.load_cfg(open(os.path.join(root, 'configs', 'OSMENet_synthetic.yaml')))
         cfg.dataset.samples, cfg.dataset.batch_size = 12, 4
         cfg.dataset.n_classes, cfg.dataset.n_samples, cfg.model.num_classes = 2, 2, 3
+    else:
+        from hawkeye_amd.examples.CIN import CINTrainer as T
+        cfg = CfgNode.load_cfg(open(os.path.join(root, 'configs', 'CIN_synthetic.yaml')))
+        cfg.dataset.samples, cfg.dataset.batch_size = 12, 4
+        cfg.dataset.n_classes, cfg.dataset.n_samples, cfg.model.num_classes = 2, 2, 3
+        cfg.train.criterion.r_channel = 8
     cfg.experiment.log_dir = str(tmp_path)
     cfg.dataset.num_workers = 0
     cfg.train.save_frequence = 1

@@ -181,3 +181,110 @@ def test_ns_128_tile_gemm_variant(F, b, d, itn, monkeypatch):
         assert rel(yg, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
         res.append((yg.detach(), xg.grad))
     assert rel(res[1][0], res[0][0]) < 2e-6 and rel(res[1][1], res[0][1]) < 2e-5
+
+
+@pytest.mark.parametrize('b,c,hw', [(4, 24, 12), (2, 70, 5), (6, 130, 49)])
+def test_cin_channel_interaction_ops(F, b, c, hw):
+    """hk_cin_sci_* / hk_cin_cci_*  vs torch autograd of the reference's formulas (CIN.py:31-34, 51-54) in
+    fp64: forward values, and the gradients through both branches including the one that reaches W_SCI from the
+    contrastive branch and the per-sample weights."""
+    gen = torch.Generator().manual_seed(b * 100 + c)
+    x = torch.relu(torch.randn(b, c, hw, generator=gen))
+    wt = torch.randn(b, generator=gen) * 0.7
+    g1, g2 = torch.randn(b, c, hw, generator=gen), torch.randn(b, c, hw, generator=gen)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    w_ref = torch.softmax(-torch.bmm(xr, xr.transpose(1, 2)) / hw, dim=2)
+    y_ref = torch.bmm(w_ref, xr)
+    w_ba = torch.cat((w_ref[b // 2:], w_ref[:b // 2]), 0)
+    yc_ref = torch.bmm(torch.abs(w_ref - wr.view(-1, 1, 1) * w_ba), xr)
+    ((y_ref * g1.double()).sum() + (yc_ref * g2.double()).sum()).backward()
+    xg, wg = x.clone().to(DEV).requires_grad_(True), wt.clone().to(DEV).requires_grad_(True)
+    y, w = F.cin_sci(xg)
+    yc = F.cin_cci(w, xg, wg)
+    ((y * g1.to(DEV)).sum() + (yc * g2.to(DEV)).sum()).backward()
+    assert rel(w, w_ref) < 2e-6 and rel(y, y_ref) < 2e-6 and rel(yc, yc_ref) < 5e-6
+    assert rel(xg.grad, xr.grad) < 2e-5 and rel(wg.grad, wr.grad) < 2e-5
+    # SCI alone (eval path / W unused): gradient without the extra term
+    x2 = x.clone().to(DEV).requires_grad_(True)
+    (F.cin_sci(x2)[0] * g1.to(DEV)).sum().backward()
+    x3 = x.double().requires_grad_(True)
+    (torch.bmm(torch.softmax(-torch.bmm(x3, x3.transpose(1, 2)) / hw, dim=2), x3) * g1.double()).sum().backward()
+    assert rel(x2.grad, x3.grad) < 2e-5
+
+
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
+
+
+def test_cin_module_matches_reference(F):
+    """hawkeye_amd's ChannelInteractionModule (HIP interaction, torch conv / fc) vs the REFERENCE module's outputs
+    and gradients (tests/golden/cin_small.npz: train mode with the contrastive branch, and eval mode)."""
+    from hawkeye_amd.model.methods.CIN import ChannelInteractionModule
+    from inputs import rs_randn, rs_relu_randn
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = _golden('cin_small')
+    m = ChannelInteractionModule(in_channel=24, spatial_size=(3, 4))
+    m.load_state_dict({k[2:].replace('__', '.'): tt(g[k]) for k in g.files if k.startswith('w_')})
+    m = m.to(DEV).train()
+    x = tt(rs_relu_randn(410, (4, 24, 3, 4))).to(DEV).requires_grad_(True)
+    z, zc = m(x)
+    ((z * tt(rs_randn(411, tuple(z.shape))).to(DEV)).sum() + (zc * tt(rs_randn(412, tuple(zc.shape))).to(DEV)).sum()).backward()
+    assert rel(z, g['z']) < 1e-5 and rel(zc, g['z_cci']) < 1e-5
+    assert rel(x.grad, g['dx']) < 1e-4
+    for k, p_ in m.named_parameters():
+        assert rel(p_.grad, g['g_' + k.replace('.', '__')]) < 1e-4, k
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(x.detach()), g['z_eval']) < 1e-5
+
+
+def test_cin_loss_matches_reference():
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.loss import CINLoss
+    from inputs import rs_randn
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = _golden('cin_small')
+    crit = CINLoss(CfgNode(dict(alpha=2.0, beta=0.5, channel=24, feature_size=12, r_channel=8)))
+    crit.h.load_state_dict({'weight': tt(g['h_w']), 'bias': tt(g['h_b'])})
+    crit = crit.to(DEV)
+    for name, labels in (('pairs', [1, 3, 1, 1]), ('nopairs', [1, 3, 0, 2])):
+        logits = tt(rs_randn(422, (4, 5))).to(DEV).requires_grad_(True)
+        zc = tt(rs_randn(423, (4, 24, 12))).to(DEV).requires_grad_(True)
+        loss = crit((logits, zc), torch.tensor(labels).to(DEV))
+        loss.backward()
+        assert abs(float(loss) - float(g[f'loss_{name}'])) < 1e-5 * max(1.0, abs(float(g[f'loss_{name}'])))
+        assert rel(logits.grad, g[f'loss_{name}_dlogits']) < 1e-5
+        if float(np.abs(g[f'loss_{name}_dz']).max()) > 0:
+            assert rel(zc.grad, g[f'loss_{name}_dz']) < 1e-4
+    assert abs(float(crit(tt(rs_randn(422, (4, 5))).to(DEV), torch.tensor([1, 3, 1, 1]).to(DEV)))) > 0   # eval: plain CE
+
+
+def test_cin_model_matches_reference(F):
+    """The registered CIN plugin end to end at 224x224 vs the reference model (tests/golden/model_cin.npz): eval logits,
+    train-mode logits and Z_CCI, criterion value."""
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.loss import CINLoss
+    from hawkeye_amd.model.registry import MODEL
+    import hawkeye_amd.model  # noqa: F401
+    from inputs import rs_randn, seeded_init, sub
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = _golden('model_cin')
+    m = MODEL.get('CIN')(CfgNode(dict(name='CIN', num_classes=200)))
+    seeded_init(m, 930)
+    m = m.to(DEV)
+    x = tt(rs_randn(931, (4, 3, 224, 224))).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        le = m(x)
+    assert rel(le, g['logits_eval']) < 1e-4 and le.argmax(1).cpu().tolist() == g['logits_eval'].argmax(1).tolist()
+    m.train()
+    with torch.no_grad():
+        lt, zc = m(x)
+    assert rel(lt, g['logits_train']) < 2e-4 and rel(sub(zc.cpu(), 97), g['z_cci_sub']) < 2e-4
+    crit = CINLoss(CfgNode(dict(alpha=2.0, beta=0.5, channel=2048, feature_size=49, r_channel=16)))
+    with torch.no_grad():
+        crit.h.weight.copy_(tt(rs_randn(932, tuple(crit.h.weight.shape))) * 1e-3)
+        crit.h.bias.zero_()
+        loss = crit.to(DEV)((lt, zc), torch.tensor([5, 9, 5, 9]).to(DEV))
+    assert abs(float(loss) - float(g['loss'])) < 5e-4 * abs(float(g['loss']))

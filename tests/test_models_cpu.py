@@ -23,6 +23,7 @@ CONFIGS = {
     'APCNN': dict(name='APCNN', num_classes=200),
     'APCNN_8142': dict(name='APCNN', num_classes=8142),
     'OSMENet': dict(name='OSMENet', num_attention=2, num_classes=200),
+    'CIN': dict(name='CIN', num_classes=200),
 }
 
 
@@ -36,7 +37,7 @@ def test_registry_semantics():
     assert r.get('foo') is foo and r['foo']() == 1
     with pytest.raises(AssertionError):
         r.register(foo)                      # uniqueness (utils/repository.py:11)
-    assert sorted(MODEL) == ['APCNN', 'BCNN', 'CBCNN', 'MPN', 'OSMENet']
+    assert sorted(MODEL) == ['APCNN', 'BCNN', 'CBCNN', 'CIN', 'MPN', 'OSMENet']
     ref = Repository()
     ref.register(foo)
     ref['BCNN'] = object()

@@ -218,3 +218,27 @@ def test_mamc_npairs_loss():
     close(total, g['mamc_total'], rtol=2e-6, atol=1e-7)
     close(pred.grad, g['mamc_dpred'], rtol=1e-5, atol=1e-8)
     close(x.grad, g['mamc_dx'], rtol=1e-4, atol=2e-7)
+
+
+def test_cin_channel_interaction_and_loss():
+    """oracle channel_interaction / cin_loss vs the reference's ChannelInteractionModule (train + eval) and CINLoss."""
+    g = load('cin_small')
+    w = {k[2:].replace('__', '.'): t(g[k]).requires_grad_(True) for k in g.files if k.startswith('w_')}
+    x = t(rs_relu_randn(410, (4, 24, 3, 4))).requires_grad_(True)
+    z, zc = O.channel_interaction(x, w['conv.weight'], w['conv.bias'], w['fc.weight'], w['fc.bias'], True)
+    ((z * t(rs_randn(411, tuple(z.shape)))).sum() + (zc * t(rs_randn(412, tuple(zc.shape)))).sum()).backward()
+    close(z, g['z'], rtol=1e-5, atol=1e-6)
+    close(zc, g['z_cci'], rtol=1e-5, atol=1e-6)
+    close(x.grad, g['dx'], rtol=1e-4, atol=1e-6)
+    for k, v in w.items():
+        close(v.grad, g['g_' + k.replace('.', '__')], rtol=1e-4, atol=1e-6)
+    ze = O.channel_interaction(x.detach(), w['conv.weight'], w['conv.bias'], w['fc.weight'], w['fc.bias'], False)
+    close(ze, g['z_eval'], rtol=1e-5, atol=1e-6)
+    for name, labels in (('pairs', [1, 3, 1, 1]), ('nopairs', [1, 3, 0, 2])):
+        logits = t(rs_randn(422, (4, 5))).requires_grad_(True)
+        zc2 = t(rs_randn(423, (4, 24, 12))).requires_grad_(True)
+        loss = O.cin_loss((logits, zc2), torch.tensor(labels), t(g['h_w']), t(g['h_b']), 2.0, 0.5)
+        loss.backward()
+        close(loss, g[f'loss_{name}'], rtol=1e-5, atol=1e-6)
+        close(logits.grad, g[f'loss_{name}_dlogits'], rtol=1e-5, atol=1e-7)
+        close(zc2.grad if zc2.grad is not None else torch.zeros_like(zc2), g[f'loss_{name}_dz'], rtol=1e-4, atol=1e-6)
