@@ -151,6 +151,35 @@ def cbp():
     del os.environ['HK_CBP_CSR']
 
 
+def cin():
+    B, C, HW = 20, 2048, 49                                   # configs/CIN.yaml: 4 classes x 5 samples, ResNet-50 7x7 map
+    x = torch.relu(torch.randn(B, C, HW, device=dev))
+    wt = torch.randn(B, device=dev)
+    w, y, yc = torch.empty(B, C, C, device=dev), torch.empty_like(x), torch.empty_like(x)
+    dy, dx, dx2 = torch.randn_like(x), torch.empty_like(x), torch.empty_like(x)
+    dw, dwbuf, dwt = torch.empty_like(w), torch.empty_like(w), torch.empty(B, device=dev)
+    nws = lib.hk_cin_cci_ws_bytes(B, C)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    fl = 2.0 * B * C * C * HW
+    row('cin sci fwd B=20 C=2048 HW=49', 'hk_cin_sci_fwd (gemm + softmax + gemm)',
+        timeit(lambda: lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), B, C, HW, stream())), 2 * fl, 4.0 * B * (2 * C * C))
+
+    def torch_sci():
+        ws_ = torch.softmax(-torch.bmm(x, x.transpose(1, 2)) / HW, dim=2)
+        return torch.bmm(ws_, x)
+    row('cin sci fwd B=20 C=2048 HW=49', 'torch bmm + softmax + bmm (reference)', timeit(torch_sci), 2 * fl,
+        4.0 * B * (4 * C * C))
+    rows[-2]['rel_err_vs_torch'] = float((y - torch_sci()).norm() / torch_sci().norm())
+    row('cin cci fwd', 'hk_cin_cci_fwd (|W - w W\'| in the operand loader)',
+        timeit(lambda: lib.hk_cin_cci_fwd(ptr(x), ptr(w), ptr(wt), ptr(yc), B, C, HW, stream())), fl)
+    row('cin cci bwd', 'hk_cin_cci_bwd',
+        timeit(lambda: lib.hk_cin_cci_bwd(ptr(x), ptr(w), ptr(wt), ptr(dy), ptr(dx2), ptr(dw), ptr(dwt), B, C, HW, ptr(ws),
+                                          nws, stream())), 2 * fl)
+    row('cin sci bwd', 'hk_cin_sci_bwd (with the CCI gradient into W)',
+        timeit(lambda: (dwbuf.copy_(dw), lib.hk_cin_sci_bwd(ptr(x), ptr(w), ptr(dy), ptr(dwbuf), 1, ptr(dx), B, C, HW,
+                                                             stream()))[1]), 3 * fl)
+
+
 def bcnn_step_with_hip_linear():
     import hawkeye_amd.model  # noqa: F401
     from hawkeye_amd.config import CfgNode
@@ -184,7 +213,7 @@ def bcnn_step_with_hip_linear():
 
 
 if __name__ == '__main__':
-    for f in (linear, ns_sym, npairs, cbp):
+    for f in (linear, ns_sym, npairs, cbp, cin):
         guarded(f)
     if '--step' in sys.argv:
         guarded(bcnn_step_with_hip_linear)
