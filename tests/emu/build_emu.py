@@ -13,8 +13,18 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'hawkeye_amd', 'csrc')
-OUT = os.path.join(HERE, '_build')
+# HK_EMU_ASAN=1: AddressSanitizer build (out-of-bounds accesses of inputs / outputs / workspaces / LDS abort with a
+# report).  Python must then be started with LD_PRELOAD=asan_runtime() and ASAN_OPTIONS=detect_leaks=0 - see
+# tests/emu/README.md.
+ASAN = os.environ.get('HK_EMU_ASAN') == '1'
+OUT = os.path.join(HERE, '_build_asan' if ASAN else '_build')
 LIB = os.path.join(OUT, 'libhawkeye_emu.so')
+
+
+def asan_runtime():
+    import glob as _g
+    hits = _g.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')
+    return hits[0] if hits else None
 
 
 def _compiler():
@@ -34,7 +44,8 @@ def build(verbose=False):
         glob.glob(os.path.join(ROOT, 'include', '*.h'))
     if os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps):
         return LIB
-    flags = ['-x', 'c++', '-std=c++17', '-O1', '-fPIC', '-ffp-contract=off', '-Wno-unknown-attributes', '-Wno-unused-value',
+    san = ['-fsanitize=address', '-shared-libasan', '-fno-omit-frame-pointer', '-g'] if ASAN else []
+    flags = san + ['-x', 'c++', '-std=c++17', '-O1', '-fPIC', '-ffp-contract=off', '-Wno-unknown-attributes', '-Wno-unused-value',
              '-Wno-pass-failed', '-Wno-unknown-pragmas', '-Wno-psabi',
              '-I' + os.path.join(HERE, 'shim'), '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
     def compile_one(s):
@@ -49,7 +60,8 @@ def build(verbose=False):
         objs = list(ex.map(compile_one, srcs))
     sw = os.path.join(OUT, 'hipemu_switch.o')
     subprocess.run([cxx, '-c', os.path.join(HERE, 'shim', 'hipemu_switch.S'), '-o', sw], check=True)
-    subprocess.run([cxx, '-shared', '-Wl,-Bsymbolic', '-o', LIB] + objs + [sw], check=True)   # never bind to the gfx950 library's symbols
+    subprocess.run([cxx, '-shared', '-Wl,-Bsymbolic'] + (['-fsanitize=address', '-shared-libasan'] if ASAN else []) +
+                   ['-o', LIB] + objs + [sw], check=True)   # never bind to the gfx950 library's symbols
     return LIB
 
 

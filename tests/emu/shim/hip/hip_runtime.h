@@ -67,6 +67,13 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 #define __shared__ static
 
 extern "C" void hipemu_switch(void** save_sp, void* load_sp);   // tests/emu/shim/hipemu_switch.S
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+extern "C" void __asan_poison_memory_region(void const volatile* addr, size_t size);
+#endif
+#endif
 
 namespace hipemu {
 
@@ -152,8 +159,15 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
     blk.bid = bid;
     blk.alive = n;
     blk.waves.resize((n + 63) / 64);
-    std::vector<uint32_t> lds((lds_bytes + 3) / 4 + 4, 0x7fc00000u);   // NaN poison
+    std::vector<uint32_t> lds((lds_bytes + 3) / 4 + 16, 0x7fc00000u);   // NaN poison
     blk.dyn_lds = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(lds.data()) + 15) & ~uintptr_t(15));
+#ifdef HIPEMU_ASAN
+    {   // everything of the buffer past the requested size is a red zone
+        char* end = blk.dyn_lds + ((lds_bytes + 7) & ~size_t(7));
+        char* cap = reinterpret_cast<char*>(lds.data() + lds.size());
+        if (cap > end) __asan_poison_memory_region(end, (size_t)(cap - end));
+    }
+#endif
     if ((int)pool.size() < n) pool.resize(n);
     B = &blk;
     body = &fn;
@@ -167,6 +181,9 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
         f.wave = t / 64;
         f.lane = t % 64;
         blk.waves[f.wave].alive++;
+#ifdef HIPEMU_ASAN
+        __asan_unpoison_memory_region(f.stack, STACK_BYTES);        // stale redzones of the fiber that ran here before
+#endif
         // initial frame: six callee-saved registers, then the address hipemu_switch "returns" to; the slot above it
         // stands for trampoline's own return address, so that rsp = 16 n + 8 at its entry as the ABI requires
         void** top = reinterpret_cast<void**>((reinterpret_cast<uintptr_t>(f.stack) + STACK_BYTES) & ~uintptr_t(15));
@@ -215,6 +232,9 @@ inline void run_block(const std::function<void()>& fn, dim3 grid, dim3 block, di
             abort();
         }
     }
+#ifdef HIPEMU_ASAN
+    __asan_unpoison_memory_region(lds.data(), lds.size() * sizeof(uint32_t));
+#endif
     B = nullptr;
     cur = nullptr;
 }
