@@ -10,27 +10,30 @@ import torch.nn as nn
 from ..utils import initialize_weights
 
 
+# option -> default (reference CIN_loss.py:10-19): weight of the contrastive term, its margin, shape of Z_CCI, width of h
+_OPTIONS = {'alpha': 2.0, 'beta': 0.5, 'channel': 2048, 'feature_size': 7 * 7, 'r_channel': 512}
+
+
 class CINLoss(nn.Module):
     def __init__(self, config):
         super().__init__()
-        self.alpha = config.alpha if 'alpha' in config else 2.0
-        self.beta = config.beta if 'beta' in config else 0.5
-        self.channel = config.channel if 'channel' in config else 2048
-        self.feature_size = config.feature_size if 'feature_size' in config else 7 * 7
-        self.r_channel = config.r_channel if 'r_channel' in config else 512
+        for option, default in _OPTIONS.items():
+            setattr(self, option, config[option] if option in config else default)
         self.pdist = nn.PairwiseDistance(p=2)
         self.ce_loss = nn.CrossEntropyLoss(label_smoothing=0.1)
         self.h = nn.Linear(self.channel * self.feature_size, self.r_channel)
         self.apply(initialize_weights)
 
+    def contrastive(self, z_cci, target):
+        """Squared distances between the embeddings of the pairs (i, i + B/2) that the mask selects, plus its square."""
+        half = z_cci.size(0) // 2
+        embed = self.h(z_cci.flatten(1))
+        same = target[:half] == target[half]
+        positive = self.pdist(embed[:half][same], embed[half:][same]).pow(2).sum()
+        return positive + positive ** 2
+
     def forward(self, output, target):
         if not isinstance(output, tuple):
             return self.ce_loss(output, target)
         logits, z_cci = output
-        batch = z_cci.size(0)
-        half = batch // 2
-        embed = self.h(z_cci.reshape(batch, -1))
-        same = target[:half] == target[half]
-        positive = torch.sum(self.pdist(embed[:half][same], embed[half:][same]) ** 2)
-        contrastive = positive + positive ** 2
-        return self.ce_loss(logits, target) + self.alpha * contrastive
+        return self.ce_loss(logits, target) + self.alpha * self.contrastive(z_cci, target)
