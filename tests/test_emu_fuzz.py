@@ -169,6 +169,73 @@ def test_fuzz_roi_crop(F):
         assert rel(ye, y) < 1e-6 and rel(xe.grad, x.grad) < 1e-6, (b, c, train)
 
 
+def test_fuzz_linear_split_k(F, monkeypatch):
+    rng = np.random.default_rng(7)
+    for _ in range(10):
+        b, j, k = int(rng.integers(1, 70)), int(rng.integers(1, 3000)), int(rng.integers(1, 140))
+        monkeypatch.setenv('HK_LINEAR_SLABS', str(int(rng.integers(1, 12))))
+        y, w, bias, g = torch.randn(b, j), torch.randn(k, j) / j ** 0.5, torch.randn(k), torch.randn(b, k)
+        y64, w64, b64 = (v.double().requires_grad_(True) for v in (y, w, bias))
+        (torch.nn.functional.linear(y64, w64, b64) * g.double()).sum().backward()
+        yg, wg, bg = (v.clone().requires_grad_(True) for v in (y, w, bias))
+        og = F.linear(yg, wg, bg)
+        (og * g).sum().backward()
+        assert max(rel(og, torch.nn.functional.linear(y64, w64, b64)), rel(yg.grad, y64.grad), rel(wg.grad, w64.grad),
+                   rel(bg.grad, b64.grad)) < 3e-6, (b, j, k)
+
+
+def test_fuzz_npairs_loss(F):
+    rng = np.random.default_rng(8)
+    for _ in range(12):
+        b, p, d, ncls = int(rng.integers(1, 20)), int(rng.integers(1, 5)), int(rng.integers(1, 300)), int(rng.integers(1, 6))
+        x = torch.randn(b, p, d) * float(rng.uniform(0.1, 3))
+        t = torch.from_numpy(rng.integers(0, ncls, b))
+        xo = x.clone().requires_grad_(True)
+        lo = O.npairs_loss(xo, t)
+        lo.backward()
+        xe = x.clone().requires_grad_(True)
+        le = F.npairs_loss(xe, t)
+        le.backward()
+        assert abs(float(le.detach()) - float(lo.detach())) <= 5e-6 * max(1.0, abs(float(lo.detach()))), (b, p, d, ncls)
+        assert rel(xe.grad, xo.grad) < 5e-5 or float(xo.grad.abs().max()) < 1e-7, (b, p, d, ncls)
+
+
+def test_fuzz_cin_interaction(F):
+    rng = np.random.default_rng(9)
+    for _ in range(6):
+        b, c, hw = 2 * int(rng.integers(1, 4)), int(rng.integers(1, 150)), int(rng.integers(1, 60))
+        x, wt = torch.relu(torch.randn(b, c, hw)), torch.randn(b)
+        g1, g2 = torch.randn(b, c, hw), torch.randn(b, c, hw)
+        xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+        w_ref = torch.softmax(-torch.bmm(xr, xr.transpose(1, 2)) / hw, dim=2)
+        y_ref = torch.bmm(w_ref, xr)
+        yc_ref = torch.bmm(torch.abs(w_ref - wr.view(-1, 1, 1) * torch.cat((w_ref[b // 2:], w_ref[:b // 2]), 0)), xr)
+        ((y_ref * g1.double()).sum() + (yc_ref * g2.double()).sum()).backward()
+        xg, wg = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        y, w = F.cin_sci(xg)
+        yc = F.cin_cci(w, xg, wg)
+        ((y * g1).sum() + (yc * g2).sum()).backward()
+        assert max(rel(y, y_ref), rel(yc, yc_ref), rel(xg.grad, xr.grad), rel(wg.grad, wr.grad)) < 5e-5, (b, c, hw)
+
+
+def test_fuzz_ns_variants(F, monkeypatch):
+    rng = np.random.default_rng(10)
+    for _ in range(3):
+        b, d, itn = int(rng.integers(1, 4)), int(rng.choice([5, 40, 100, 129, 150])), int(rng.integers(1, 5))
+        x = torch.relu(torch.randn(b, d, 4, 5)) + 0.02
+        xo = x.clone().requires_grad_(True)
+        yo = O.sqrtm(O.covpool(xo), itn)
+        wt = torch.randn_like(yo)
+        (yo * wt).sum().backward()
+        for sym, gemm in (('1', '0'), ('0', '4'), ('1', '4')):
+            monkeypatch.setenv('HK_NS_SYM', sym)
+            monkeypatch.setenv('HK_NS_GEMM', gemm)
+            xe = x.clone().requires_grad_(True)
+            ye = F.sqrtm(F.covpool(xe), itn)
+            (ye * wt).sum().backward()
+            assert rel(ye, yo) < 1e-5 and rel(xe.grad, xo.grad) < 1e-4, (b, d, itn, sym, gemm)
+
+
 @pytest.mark.parametrize('order', ['rev', 'rand:11'])
 def test_results_do_not_depend_on_work_item_order(F, order, monkeypatch):
     """LDS-staged kernels (Gram / backward panels, CBP row-sketch + CSR, covariance, NS chain, attention pooling,
