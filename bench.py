@@ -45,7 +45,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (metric: 64)')
     ap.add_argument('--image', type=int, default=448)
     ap.add_argument('--classes', type=int, default=200)
-    ap.add_argument('--model', default='BCNN', choices=['BCNN', 'CBCNN', 'MPN', 'APCNN'])
+    ap.add_argument('--model', default='BCNN', choices=['BCNN', 'CBCNN', 'MPN', 'APCNN', 'OSMENet', 'CIN'],
+                    help='BCNN is the metric; the others are side measurements (OSMENet / CIN: --image 224, their own criteria)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernels', action='store_true')
     ap.add_argument('--no-candidates', action='store_true',
@@ -70,6 +71,8 @@ def build_model(name, classes):
         'MPN': dict(name='MPN', iter_num=5, is_sqrt=True, is_vec=True, input_dim=2048, dimension_reduction=256,
                     num_classes=classes),
         'APCNN': dict(name='APCNN', num_classes=classes),
+        'OSMENet': dict(name='OSMENet', num_attention=2, num_classes=classes),
+        'CIN': dict(name='CIN', num_classes=classes),
     }
     cfg = CfgNode(cfgs[name])
     cfg.freeze()
@@ -227,8 +230,16 @@ def main():
     if a.channels_last:
         model = model.to(memory_format=torch.channels_last)
     model.train()
-    opt = torch.optim.SGD(model.parameters(), lr=0.005, momentum=0.9, weight_decay=1e-5)   # configs/BCNN_S2
     crit = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+    params = list(model.parameters())
+    if a.model in ('OSMENet', 'CIN'):                      # criteria of their own; 7x7 feature maps: 224x224 images
+        assert a.image == 224, f'{a.model} heads are built for 7x7 maps: run with --image 224'
+        from hawkeye_amd.config import CfgNode
+        from hawkeye_amd.model.loss import CINLoss, MAMCLoss
+        crit = (MAMCLoss(CfgNode(dict(lambda_a=0.5, use_mamc=True))) if a.model == 'OSMENet'
+                else CINLoss(CfgNode(dict(alpha=2.0, beta=0.5))).to(dev))
+        params += list(crit.parameters())
+    opt = torch.optim.SGD(params, lr=0.005, momentum=0.9, weight_decay=1e-5)   # configs/BCNN_S2
     reducer = ddp.GradientAllReducer(model) if world > 1 else None
 
     g = torch.Generator(device=dev).manual_seed(rank)
@@ -236,10 +247,12 @@ def main():
     if a.channels_last:
         images = images.contiguous(memory_format=torch.channels_last)
     labels = torch.randint(0, a.classes, (a.batch,), device=dev, generator=g)
+    if a.model in ('OSMENet', 'CIN'):                      # class-balanced batches (pairs of samples per class)
+        labels = (torch.arange(a.batch, device=dev) // 2) % a.classes
 
     def step():
         out = model(images, labels) if a.model == 'APCNN' else model(images)
-        loss = sum(crit(o, labels) for o in out[1]) if a.model == 'APCNN' else crit(out, labels)
+        loss = sum(crit(o, labels) for o in out[1]) if a.model == 'APCNN' else crit(out, labels)   # tuples: MAMC / CIN
         if reducer is not None:
             reducer.zero_grad()
         else:
