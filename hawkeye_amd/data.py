@@ -1,17 +1,13 @@
 """Datasets for the trainer: an on-the-fly synthetic dataset (what the metric is
-quoted on: N(0,1) 448x448 images, uniform labels - SURVEY.md section 8d) and a
-minimal image-folder dataset with the reference's `label relpath` meta format
-(dataset/dataset.py:22-64) using PIL + torch ops only (torchvision is absent).
-The reference's augmentation stack (TrivialAugmentWide, RandomErasing, mixup) is
-out of scope for the hot path."""
+quoted on: N(0,1) 448x448 images, uniform labels - SURVEY.md section 8d), an
+image-folder dataset with the reference's `label relpath` meta format
+(dataset/dataset.py:22-64) and the class-balanced batch sampler.  The image
+presets live in hawkeye_amd/transforms.py."""
 import os
 
 import numpy as np
 import torch
 from torch.utils.data import Dataset
-
-MEAN = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
-STD = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
 
 
 class SyntheticDataset(Dataset):
@@ -37,45 +33,6 @@ class SyntheticDataset(Dataset):
         return out
 
 
-def _to_tensor(img):
-    a = np.asarray(img.convert('RGB'), dtype=np.uint8)
-    return torch.from_numpy(a).permute(2, 0, 1).float().div_(255.0)
-
-
-class TrainTransform:
-    """random-resized-crop (scale 0.35-1) + horizontal flip + normalise"""
-
-    def __init__(self, crop_size):
-        self.crop = crop_size
-
-    def __call__(self, img):
-        w, h = img.size
-        area = w * h * float(np.random.uniform(0.35, 1.0))
-        ratio = float(np.exp(np.random.uniform(np.log(3 / 4), np.log(4 / 3))))
-        cw, ch = min(w, int(round((area * ratio) ** 0.5))), min(h, int(round((area / ratio) ** 0.5)))
-        x0, y0 = np.random.randint(0, w - cw + 1), np.random.randint(0, h - ch + 1)
-        img = img.crop((x0, y0, x0 + cw, y0 + ch)).resize((self.crop, self.crop), resample=2)
-        t = _to_tensor(img)
-        if np.random.rand() < 0.5:
-            t = t.flip(2)
-        return (t - MEAN) / STD
-
-
-class EvalTransform:
-    """resize shorter side + centre crop + normalise"""
-
-    def __init__(self, crop_size, resize_size):
-        self.crop, self.resize = crop_size, resize_size
-
-    def __call__(self, img):
-        w, h = img.size
-        s = self.resize / min(w, h)
-        img = img.resize((max(self.crop, int(round(w * s))), max(self.crop, int(round(h * s)))), resample=2)
-        w, h = img.size
-        x0, y0 = (w - self.crop) // 2, (h - self.crop) // 2
-        return (_to_tensor(img.crop((x0, y0, x0 + self.crop, y0 + self.crop))) - MEAN) / STD
-
-
 class FGDataset(Dataset):
     """meta file lines: `<label> <relative/path.jpg>` (metadata/cub/train.txt:1)."""
 
@@ -99,7 +56,10 @@ class FGDataset(Dataset):
         from PIL import Image
         lab, rel = self.items[i]
         img = Image.open(os.path.join(self.root, rel))
-        return {'img': self.transform(img) if self.transform else _to_tensor(img), 'label': lab}
+        if self.transform is not None:
+            return {'img': self.transform(img), 'label': lab}
+        from .transforms import to_float_tensor
+        return {'img': to_float_tensor(img), 'label': lab}
 
 
 class BalancedBatchSampler(torch.utils.data.Sampler):

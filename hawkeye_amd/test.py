@@ -28,8 +28,8 @@ class Tester:
         self.average_meters = {'acc': AverageMeter()}
 
     def get_transformer(self, config):
-        from . import data
-        return data.EvalTransform(config['image_size'], config['resize_size'])
+        from . import transforms
+        return transforms.ClassificationPresetEval(crop_size=config['image_size'], resize_size=config['resize_size'])
 
     def get_collate_fn(self):
         return None

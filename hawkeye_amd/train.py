@@ -152,10 +152,13 @@ class Trainer:
         return model
 
     def get_transformers(self, config):
-        from . import data
-        return {'train': data.TrainTransform(config['image_size']),
-                'val': data.EvalTransform(config['image_size'], config['resize_size'] if 'resize_size' in config
-                                          else int(config['image_size'] * 8 / 7))}
+        """The reference's presets (train.py:171-183): RandomResizedCrop + flip + TrivialAugmentWide + RandomErasing(0.1)
+        for training, Resize + CenterCrop for validation - hawkeye_amd/transforms.py (no torchvision in the image)."""
+        from . import transforms
+        resize = config['resize_size'] if 'resize_size' in config else int(config['image_size'] * 8 / 7)
+        return {'train': transforms.ClassificationPresetTrain(crop_size=config['image_size'], auto_augment_policy='ta_wide',
+                                                              random_erase_prob=0.1),
+                'val': transforms.ClassificationPresetEval(crop_size=config['image_size'], resize_size=resize)}
 
     def get_collate_fn(self):
         return {'train': None, 'val': None}
