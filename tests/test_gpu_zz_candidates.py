@@ -113,8 +113,9 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
         torch.nn.functional.cross_entropy(y, torch.tensor([3, 77], device=y.device)).backward()
         grads.append((m.classifier.weight.grad.clone(), m.classifier.bias.grad.clone(),
                       next(m.backbone.parameters()).grad.clone()))
-    for p, q in zip(grads[0], grads[1]):
-        assert rel(q, p) < 1e-5
+    # the trunk gradient goes through MIOpen's weight-gradient kernels (split-K with atomics: not bitwise repeatable)
+    for (p, q), tol in zip(zip(grads[0], grads[1]), (1e-5, 1e-5, 1e-4)):
+        assert rel(q, p) < tol
 
 
 def test_mamc_npairs_loss_vs_reference_goldens(F):
