@@ -60,6 +60,7 @@ SIGNATURES = {
     'hk_cin_cci_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     'hk_cin_cci_ws_bytes': (c_sz, [c_i, c_i]),
     'hk_cin_cci_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_image_finalize': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'hk_bgemm_f32': (c_i, [c_f, c_i, c_ll, c_i, c_f, c_i, c_ll, c_i, c_f, c_i, c_ll, c_i, c_i, c_i, c_i,
                            c_fl, c_fl, c_fl, c_f]),
 }

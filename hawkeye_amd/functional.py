@@ -560,6 +560,29 @@ def linear(y, weight, bias=None):
     return _Linear.apply(y, weight, bias)
 
 
+# --------------------------------------------------------------------- input finalisation
+def image_finalize(u8, erase=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), channels_last=False):
+    """uint8 [B,H,W,3] on the device (+ int32 erase boxes [B,4] = top, left, h, w) -> normalised fp32 [B,3,H,W]
+    (channels_last storage if asked).  No gradient: it is the end of the data pipeline."""
+    import ctypes
+    lib = _lib.load()
+    if u8.dtype != torch.uint8 or u8.dim() != 4 or u8.shape[3] != 3:
+        raise _lib.HawkeyeHipError(f'image_finalize wants uint8 [B,H,W,3], got {u8.dtype} {tuple(u8.shape)}')
+    u8 = u8.contiguous()
+    b, h, w, _ = u8.shape
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    out = torch.empty(b, 3, h, w, dtype=torch.float32, device=u8.device).contiguous(memory_format=fmt)
+    if erase is not None:
+        erase = erase.to(device=u8.device, dtype=torch.int32).contiguous()
+        if erase.shape != (b, 4):
+            raise _lib.HawkeyeHipError(f'image_finalize: erase boxes must be [B,4], got {tuple(erase.shape)}')
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(lib.hk_image_finalize(ptr(u8), ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), ptr(erase),
+                                ptr(out.permute(0, 2, 3, 1) if channels_last else out), b, h, w, int(channels_last),
+                                stream()), 'hk_image_finalize')
+    return out
+
+
 def bgemm(a, b, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, diag=0.0, out=None):
     """Batched fp32 MFMA GEMM (test / composition helper).  a [B,M,K] (or [B,K,M]), b [B,K,N] (or [B,N,K])."""
     lib = _lib.load()

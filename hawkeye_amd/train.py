@@ -156,9 +156,12 @@ class Trainer:
         for training, Resize + CenterCrop for validation - hawkeye_amd/transforms.py (no torchvision in the image)."""
         from . import transforms
         resize = config['resize_size'] if 'resize_size' in config else int(config['image_size'] * 8 / 7)
+        # `device_finalize: True`: workers ship uint8 crops; float conversion + normalise + erase run on the GPU
+        dev = bool(config['device_finalize']) if 'device_finalize' in config else False
         return {'train': transforms.ClassificationPresetTrain(crop_size=config['image_size'], auto_augment_policy='ta_wide',
-                                                              random_erase_prob=0.1),
-                'val': transforms.ClassificationPresetEval(crop_size=config['image_size'], resize_size=resize)}
+                                                              random_erase_prob=0.1, device_finalize=dev),
+                'val': transforms.ClassificationPresetEval(crop_size=config['image_size'], resize_size=resize,
+                                                           device_finalize=dev)}
 
     def get_collate_fn(self):
         return {'train': None, 'val': None}
@@ -198,6 +201,10 @@ class Trainer:
         """`experiment.channels_last: True` keeps images / conv weights in NHWC (MIOpen's fp32 kernels on gfx950 are
         NHWC implicit-GEMMs: this removes its layout transposes, +10 % on the BCNN step - DESIGN.md section 5)."""
         cl = 'channels_last' in self.config.experiment and self.config.experiment.channels_last
+        if isinstance(m, dict) and 'u8' in m:              # uint8 crops from the workers (transformer.device_finalize)
+            from . import functional as HF
+            return HF.image_finalize(m['u8'].to(self.device, non_blocking=True), m['erase'].to(self.device, non_blocking=True),
+                                     channels_last=bool(cl))
         if isinstance(m, torch.Tensor):
             m = m.to(self.device, non_blocking=True)
             return m.contiguous(memory_format=torch.channels_last) if (cl and m.dim() == 4) else m

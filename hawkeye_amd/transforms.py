@@ -166,11 +166,15 @@ class ClassificationPresetTrain:
     """dataset/transforms.py:14-50 as instantiated by train.py:173-177."""
 
     def __init__(self, crop_size, mean=IMAGENET_MEAN, std=IMAGENET_STD, hflip_prob=0.5, auto_augment_policy='ta_wide',
-                 random_erase_prob=0.1):
+                 random_erase_prob=0.1, device_finalize=False):
+        """device_finalize: stop after the PIL stages and return {'u8': uint8 [H,W,3], 'erase': int32 [4]}; the float
+        conversion, normalisation and erasing then run on the GPU (hawkeye_amd.functional.image_finalize) - same
+        numbers, a quarter of the host->device bytes."""
         if auto_augment_policy not in (None, 'ta_wide'):
             raise ValueError('only the policy the reference trainers use (ta_wide) is provided')
         self.size, self.mean, self.std = int(crop_size), mean, std
         self.hflip_prob, self.policy, self.erase_prob = hflip_prob, auto_augment_policy, random_erase_prob
+        self.device_finalize = device_finalize
 
     def __call__(self, img):
         img = img.convert('RGB')
@@ -180,20 +184,25 @@ class ClassificationPresetTrain:
             img = img.transpose(Image.FLIP_LEFT_RIGHT)
         if self.policy == 'ta_wide':
             img = trivial_augment_wide(img)
-        t = normalize(to_float_tensor(img), self.mean, self.std)
+        box = None
         if self.erase_prob > 0 and random.random() < self.erase_prob:
-            box = random_erasing_box(t.shape[1], t.shape[2])
-            if box is not None:
-                top, left, h, w = box
-                t[:, top:top + h, left:left + w] = 0.0
+            box = random_erasing_box(self.size, self.size)
+        if self.device_finalize:
+            return {'u8': torch.from_numpy(np.array(img, dtype=np.uint8)),
+                    'erase': torch.tensor(box if box is not None else (0, 0, 0, 0), dtype=torch.int32)}
+        t = normalize(to_float_tensor(img), self.mean, self.std)
+        if box is not None:
+            top, left, h, w = box
+            t[:, top:top + h, left:left + w] = 0.0
         return t
 
 
 class ClassificationPresetEval:
     """dataset/transforms.py:53-73: shorter side to `resize_size`, centre crop, normalise."""
 
-    def __init__(self, crop_size, resize_size=256, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    def __init__(self, crop_size, resize_size=256, mean=IMAGENET_MEAN, std=IMAGENET_STD, device_finalize=False):
         self.size, self.resize, self.mean, self.std = int(crop_size), int(resize_size), mean, std
+        self.device_finalize = device_finalize
 
     def __call__(self, img):
         img = img.convert('RGB')
@@ -209,4 +218,7 @@ class ClassificationPresetEval:
             canvas.paste(img, ((canvas.size[0] - nw) // 2, (canvas.size[1] - nh) // 2))
             img, (nw, nh) = canvas, canvas.size
             left, top = int(round((nw - self.size) / 2.0)), int(round((nh - self.size) / 2.0))
-        return normalize(to_float_tensor(img.crop((left, top, left + self.size, top + self.size))), self.mean, self.std)
+        img = img.crop((left, top, left + self.size, top + self.size))
+        if self.device_finalize:
+            return {'u8': torch.from_numpy(np.array(img, dtype=np.uint8)), 'erase': torch.zeros(4, dtype=torch.int32)}
+        return normalize(to_float_tensor(img), self.mean, self.std)

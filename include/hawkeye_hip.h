@@ -234,6 +234,17 @@ size_t hk_cin_cci_ws_bytes(int B, int C);
 int hk_cin_cci_bwd(const float* x, const float* w, const float* wt, const float* dy, float* dx, float* dw, float* dwt,
                    int B, int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream);
 
+/* ------------------------------------------------------ input finalisation (8f-3) ----
+ * uint8 HWC crops -> normalised fp32 images on the device, with the random-erasing
+ * rectangle applied: PILToTensor + ConvertImageDtype + Normalize + RandomErasing(value 0)
+ * of dataset/transforms.py:38-46 in one pass; bit-identical to the CPU order of operations.
+ *   u8 [B,H,W,3] (device) ; mean3 / std3: HOST pointers to three floats ;
+ *   erase int32 [B,4] = top, left, h, w (device; h or w <= 0: nothing erased; NULL: none)
+ *   out fp32 [B,3,H,W], or the channels_last storage of the same tensor ([B,H,W,3]) if channels_last != 0
+ */
+int hk_image_finalize(const uint8_t* u8, const float* mean3, const float* std3, const int32_t* erase, float* out, int B,
+                      int H, int W, int channels_last, hk_stream_t stream);
+
 /* ------------------------------------------------------- generic primitive ----
  * Batched fp32 GEMM on the f32 MFMA path (exact fp32 fma chain):
  *   C[b] = alpha * op(A[b]) op(B[b]) + beta * C[b] + diag * I

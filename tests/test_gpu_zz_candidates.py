@@ -290,3 +290,45 @@ def test_cin_model_matches_reference(F):
         crit.h.bias.zero_()
         loss = crit.to(DEV)((lt, zc), torch.tensor([5, 9, 5, 9]).to(DEV))
     assert abs(float(loss) - float(g['loss'])) < 3e-3 * abs(float(g['loss']))
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_image_finalize_bit_exact(F, channels_last):
+    """hk_image_finalize vs the CPU order of operations (u8 / 255 - mean) / std + erase: bit-identical,
+    in both output layouts, including a box that touches the border and an empty box."""
+    from hawkeye_amd import transforms as T
+    gen = torch.Generator().manual_seed(4)
+    u8 = torch.randint(0, 256, (3, 37, 53, 3), generator=gen, dtype=torch.uint8)
+    erase = torch.tensor([[5, 7, 10, 20], [0, 0, 0, 0], [30, 40, 7, 13]], dtype=torch.int32)
+    ref = torch.stack([T.normalize(u8[i].permute(2, 0, 1).to(torch.float32).div(255)) for i in range(3)])
+    for i, (top, left, h, w) in enumerate(erase.tolist()):
+        if h > 0 and w > 0:
+            ref[i, :, top:top + h, left:left + w] = 0.0
+    out = F.image_finalize(u8.to(DEV), erase.to(DEV), channels_last=channels_last)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last if channels_last
+                                                        else torch.contiguous_format)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(F.image_finalize(u8.to(DEV), None, channels_last=channels_last).cpu()[1], ref[1])
+
+
+def test_presets_device_finalize_equals_cpu_path(F):
+    """The training / evaluation presets with `device_finalize=True` (uint8 out of the workers, the rest on the GPU)
+    give the same tensors as the all-CPU presets for the same random draws."""
+    import random
+
+    from PIL import Image
+
+    from hawkeye_amd import transforms as T
+    img = Image.fromarray((np.random.RandomState(5).rand(180, 240, 3) * 255).astype(np.uint8))
+    for seed in range(6):
+        cpu = T.ClassificationPresetTrain(64, random_erase_prob=0.5)
+        dev = T.ClassificationPresetTrain(64, random_erase_prob=0.5, device_finalize=True)
+        random.seed(seed)
+        a = cpu(img)
+        random.seed(seed)
+        d = dev(img)
+        out = F.image_finalize(d['u8'][None].to(DEV), d['erase'][None].to(DEV))[0]
+        assert torch.equal(out.cpu(), a), seed
+    a = T.ClassificationPresetEval(64, 80)(img)
+    d = T.ClassificationPresetEval(64, 80, device_finalize=True)(img)
+    assert torch.equal(F.image_finalize(d['u8'][None].to(DEV), d['erase'][None].to(DEV))[0].cpu(), a)
