@@ -4,7 +4,6 @@ it stands, including two things that look unintended but define what its checkpo
 mask compares the first half of the labels with the single label `target[B//2]` (:40), and the margin term is
 overwritten by the square of the positive term (:42-44), so `beta` never enters the value.  A handful of tiny
 reductions: plain PyTorch-ROCm ops, no kernel of ours."""
-import torch
 import torch.nn as nn
 
 from ..utils import initialize_weights

@@ -7,7 +7,6 @@ hawkeye_amd.functional.  Outside the context the product behaviour (HIP tensors 
 import contextlib
 import ctypes
 
-import torch
 
 from hawkeye_amd import _lib
 import hawkeye_amd.functional as F
