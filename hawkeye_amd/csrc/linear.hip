@@ -124,9 +124,18 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
     }
     if (dw) {      // dW [K][J] = g^T [K][B] y [B][J] : both operands stored k-major (k = sample)
         const LdPlain la = make_plain(g, 0, K, B, K);
-        const LdPlain lb = make_plain(y, 0, J, B, J);
-        const EpAffine ep = make_affine(dw, 0, J, 1.0f, nullptr, 0.f, 0.f);
-        const int rc = bgemm_launch<false, false>(la, lb, ep, K, J, B, 1, st);
+        int rc;
+        if (J % 64 == 0) {
+            // every block of 64 features is one "batch sample": the XCD-affine block map then runs its class tiles
+            // back to back on ONE XCD, so the 64-feature slice of y is fetched from HBM once and re-read from that L2
+            // (with a flat tile order the class tiles of a slice are 4096 workgroups apart: y would be read K/64 times)
+            LdSlab lb;
+            lb.p = y; lb.ld = J; lb.R = B; lb.J = J; lb.KS = 64; lb.vec = (aligned16(y) && J % 4 == 0) ? 1 : 0;
+            rc = bgemm_launch<false, false>(la, lb, make_affine(dw, 64, J, 1.0f, nullptr, 0.f, 0.f), K, 64, B, J / 64, st);
+        } else {
+            const LdPlain lb = make_plain(y, 0, J, B, J);
+            rc = bgemm_launch<false, false>(la, lb, make_affine(dw, 0, J, 1.0f, nullptr, 0.f, 0.f), K, J, B, 1, st);
+        }
         if (rc != HK_OK) return rc;
     }
     if (db) {
