@@ -42,6 +42,17 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def _is_dense_permutation(t):
+    """True when t's strides are a permutation of the contiguous strides (no gaps, no overlap), e.g. channels_last."""
+    dims = sorted(range(t.dim()), key=lambda d: (t.stride(d), t.shape[d]), reverse=True)
+    expect = 1
+    for d in reversed(dims):
+        if t.shape[d] != 1 and t.stride(d) != expect:
+            return False
+        expect *= t.shape[d]
+    return True
+
+
 class _Bucket:
     __slots__ = ('params', 'flat', 'views', 'pending', 'work', 'nbytes')
 
@@ -51,7 +62,11 @@ class _Bucket:
         self.flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
         self.views, off = [], 0
         for p in params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            seg = self.flat[off:off + p.numel()]
+            # same memory layout as the parameter (conv weights of a channels_last model are NHWC-strided): the
+            # gradient then accumulates and the optimiser steps on matching strides instead of strided fall-backs
+            dense = p.is_contiguous() or not _is_dense_permutation(p)
+            self.views.append(seg.view_as(p) if dense else seg.as_strided(p.shape, p.stride()))
             off += p.numel()
         self.pending = len(params)
         self.work = None

@@ -96,3 +96,32 @@ def test_single_process_reducer_is_identity():
     for p, q in zip(model.parameters(), ref.parameters()):
         torch.testing.assert_close(p.grad, q.grad)
     assert sum(n for n, _ in red.describe()) == 6
+
+
+def test_bucket_views_follow_parameter_memory_format():
+    """channels_last conv weights get channels_last gradient views inside the flat bucket (same bytes, matching strides);
+    a step through them equals plain SGD."""
+    import torch
+    from hawkeye_amd import ddp
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 3, padding=1))
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 3, padding=1))
+    ref.load_state_dict(net.state_dict())
+    net = net.to(memory_format=torch.channels_last)
+    red = ddp.GradientAllReducer(net, broadcast=False)
+    for p in net.parameters():
+        assert p.grad.stride() == p.stride() and p.grad.shape == p.shape
+    flat_ptrs = {b.flat.data_ptr() for b in red.buckets}
+    assert all(any(fp <= p.grad.data_ptr() < fp + b.nbytes for fp, b in zip(flat_ptrs, red.buckets)) for p in net.parameters())
+    x = torch.randn(2, 3, 6, 6)
+    o1, o2 = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9), torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9)
+    for _ in range(2):
+        red.zero_grad()
+        net(x.contiguous(memory_format=torch.channels_last)).square().mean().backward()
+        red.finish()
+        o1.step()
+        o2.zero_grad()
+        ref(x).square().mean().backward()
+        o2.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, atol=1e-6)
