@@ -76,6 +76,15 @@ def linear():
             4.0 * (2 * B * J + 2 * K * J))
         err = float((out - TF.linear(y, w, b)).norm() / TF.linear(y, w, b).norm())
         rows[-4]['rel_err_vs_torch'] = err
+        if tag.startswith('bcnn'):                      # slab-count sweep for the split-K forward (auto = 384 here)
+            for slabs in (64, 128, 256, 768, 1024):
+                os.environ['HK_LINEAR_SLABS'] = str(slabs)
+                n2 = lib.hk_linear_ws_bytes(B, J, K)
+                ws2 = torch.empty(n2, dtype=torch.uint8, device=dev)
+                row(f'linear fwd {tag}', f'hk_linear_fwd HK_LINEAR_SLABS={slabs}',
+                    timeit(lambda: lib.hk_linear_fwd(ptr(y), ptr(w), ptr(b), ptr(out), B, J, K, ptr(ws2), n2, stream())), fl,
+                    4.0 * (B * J + K * J))
+            del os.environ['HK_LINEAR_SLABS']
 
 
 def ns_sym():
