@@ -377,6 +377,124 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     }
 }
 
+// ----------------------------------------------------------------------------- backward v4: two barriers per K-block
+// Same tiling, same LDS budget and bit-identical arithmetic as bcnn_bwd_panel_kernel, but the transposed operand
+// dy(K,I)^T is not staged through an LDS scratch: every thread fetches the four dy[k][i] it needs for its own P
+// elements straight from global memory (16 dword loads per K-block instead of 4 dwordx4 - four times the L1 requests
+// for that one operand, the same HBM/L2 sectors, issued a whole K-block ahead like the other operands).  That removes
+// the scatter (11 % LDS bank conflicts) and two of the four barriers of a K-block:
+//     barrier -> P tile from registers -> sP ; X block -> sX -> barrier -> next loads in flight, MFMA phase.
+// MODE 2 (CBP) has no transposition to begin with and simply loses its redundant barrier.
+// Opt-in (HK_BWD_V=4): written after round 1's GPU budget was spent; validated on the CPU emulation tier only.
+template <int HW, int NSX, int MODE>
+__device__ __forceinline__ void bwd_load_v4(f32x4 (&ry)[4], f32x4 (&rd)[4], f32x4 (&rt)[4], f32x4 (&rx)[NSX],
+                                            const float* __restrict__ y, const float* __restrict__ dy,
+                                            const float* __restrict__ xb, long long cc, int C, int I, int kb, int tid,
+                                            const BwdExtra& ex, int b) {
+    bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, kb, tid, ex, b);    // y, dy(I,K) (or the CBP gather), X
+    if (MODE != 2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
+            const float* col = dy + cc + (long long)(kb * 64 + c4) * C + I * 64 + r;     // dy[k = c4 + t][i = r]
+#pragma unroll
+            for (int t = 0; t < 4; ++t) rt[u][t] = col[(long long)t * C];
+        }
+    }
+}
+
+template <int HW, int MODE>
+__global__ __launch_bounds__(256, 2) void bcnn_bwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy,
+                                                             const float* __restrict__ inv_norm, float* __restrict__ dx,
+                                                             float* __restrict__ tpart, int C, int nb, int B, BwdExtra ex) {
+    constexpr int NT = (HW + 15) / 16;
+    constexpr int XN4 = 64 * HW / 4;
+    constexpr int NSX = (XN4 + 255) / 256;
+    constexpr int PP = 68;
+    __shared__ __attribute__((aligned(16))) float lds[64 * PP + 64 * HW + 16];
+    float* sP = lds;
+    float* sX = lds + 64 * PP;
+
+    int b, I;
+    if (!xcd_map(blockIdx.x, B, nb, b, I)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const long long cc = (long long)b * C * C;
+    const float* xb = x + (long long)b * C * HW;
+    float coef = 1.0f / (float)HW;
+    if (MODE == 0) {
+        const float in = inv_norm[b];
+        coef = in * in / (2.0f * (float)HW);
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float tacc = 0.f;
+
+    f32x4 ry[4], rd[4], rt[4], rx[NSX];
+    bwd_load_v4<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, 0, tid, ex, b);
+    for (int kb = 0; kb < nb; ++kb) {
+        __syncthreads();                                   // previous MFMA phase finished with sP / sX
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                      // P tile, straight from registers
+            const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
+            f32x4 p;
+            if (MODE == 0) {
+                p[0] = (rd[u][0] + rt[u][0]) * (__builtin_amdgcn_rcpf(ry[u][0]) * coef);
+                p[1] = (rd[u][1] + rt[u][1]) * (__builtin_amdgcn_rcpf(ry[u][1]) * coef);
+                p[2] = (rd[u][2] + rt[u][2]) * (__builtin_amdgcn_rcpf(ry[u][2]) * coef);
+                p[3] = (rd[u][3] + rt[u][3]) * (__builtin_amdgcn_rcpf(ry[u][3]) * coef);
+                tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
+            } else if (MODE == 1) {
+                p[0] = (rd[u][0] + rt[u][0]) * coef;
+                p[1] = (rd[u][1] + rt[u][1]) * coef;
+                p[2] = (rd[u][2] + rt[u][2]) * coef;
+                p[3] = (rd[u][3] + rt[u][3]) * coef;
+            } else {
+                p = rd[u];
+            }
+            *reinterpret_cast<f32x4*>(&sP[r * PP + c4]) = p;
+        }
+#pragma unroll
+        for (int u = 0; u < NSX; ++u) {                    // X block next to it (its own region: no barrier in between)
+            const int f = tid + 256 * u;
+            if (f < XN4) reinterpret_cast<f32x4*>(sX)[f] = rx[u];
+        }
+        __syncthreads();
+        bwd_load_v4<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, (kb + 1 < nb ? kb + 1 : kb), tid, ex, b);
+
+        const float* ap = sP + (wave * 16 + l15) * PP + 4 * lq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * s);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float* bp = sX + (16 * s + 4 * lq + t) * HW + l15;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bp[16 * n], acc[n], 0, 0, 0);
+            }
+        }
+    }
+
+    float* dxb = dx + (long long)b * C * HW + (long long)(I * 64 + wave * 16 + lq * 4) * HW;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = 16 * n + l15;
+        if (col < HW) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dxb[(long long)r * HW + col] = acc[n][r];
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        const float tsum = block_sum<4>(tacc, lds);
+        if (tid == 0) tpart[(long long)b * nb + I] = tsum;
+    }
+}
+
 // ----------------------------------------------------------------------------- backward v3: no transposition, 3 WGs / CU
 // dX[I] = sum_K P(I,K) X(K),  P[i][k] = (dy[i][k] + dy[k][i]) * w[i][k]   (w = coef / y for BCNN, 1/M for COV).
 // Instead of building P in LDS (transposing dy(K,I) through a scratch: 4 barriers per K-block, 11 % bank conflicts),
@@ -550,6 +668,12 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
     //   producer/consumer 512-thread variant     (removed)                94 us
     // All sit at ~65 % matrix-pipe occupancy at the ~1.9 GHz DVFS clock; the backward moves 235 MB per launch.
     const char* v = getenv("HK_BWD_V");
+    if (v && v[0] == '4') {   // two-barrier variant (direct transposed loads): not yet timed on the GPU
+        hipLaunchKernelGGL((bcnn_bwd_v4_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
+                           tpart, C, nb, B, ex);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     if (v && v[0] == '3') {
         hipLaunchKernelGGL((bcnn_bwd_v3_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
                            tpart, C, nb, B, ex);

@@ -332,3 +332,36 @@ def test_presets_device_finalize_equals_cpu_path(F):
     a = T.ClassificationPresetEval(64, 80)(img)
     d = T.ClassificationPresetEval(64, 80, device_finalize=True)(img)
     assert torch.equal(F.image_finalize(d['u8'][None].to(DEV), d['erase'][None].to(DEV))[0].cpu(), a)
+
+
+@pytest.mark.parametrize('b,c,hw', [(2, 128, 14), (3, 192, 12), (9, 64, 8), (2, 512, 14)])
+def test_backward_two_barrier_variant_bit_identical(F, b, c, hw, monkeypatch):
+    """HK_BWD_V=4 (transposed operand fetched directly, two barriers per K-block instead of four) performs the same
+    fp32 operations in the same order as the default backward: bit-identical dX for the BCNN, covariance and CBP modes."""
+    gen = torch.Generator().manual_seed(c + hw)
+    x = torch.relu(torch.randn(b, c, hw, hw, generator=gen))
+    plan = F.CbpPlan(*F.sketch_hashes(c, c, 2048), 2048, torch.device(DEV) if DEV != 'cuda'
+                     else torch.device('cuda', torch.cuda.current_device()))
+    res = []
+    for flag in ('0', '4'):
+        monkeypatch.setenv('HK_BWD_V', flag)
+        out = []
+        xg = x.clone().to(DEV).requires_grad_(True)
+        y = F.bilinear_pool(xg)
+        (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(DEV)).sum().backward()
+        out.append(xg.grad.clone())
+        xg = x.clone().to(DEV).requires_grad_(True)
+        cv = F.covpool(xg)
+        (cv * torch.randn(cv.shape, generator=torch.Generator().manual_seed(2)).to(DEV)).sum().backward()
+        out.append(xg.grad.clone())
+        xg = x.clone().to(DEV).requires_grad_(True)
+        yc = F.compact_bilinear_pool(xg, plan)
+        (yc * torch.randn(yc.shape, generator=torch.Generator().manual_seed(3)).to(DEV)).sum().backward()
+        out.append(xg.grad.clone())
+        res.append(out)
+    for p, q in zip(res[0], res[1]):
+        assert torch.equal(p, q)
+    xo = x.clone().requires_grad_(True)                    # and both agree with the oracle
+    yo = O.bilinear_pool(xo)
+    (yo * torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))).sum().backward()
+    assert rel(res[1][0], xo.grad) < 2e-5

@@ -160,6 +160,36 @@ def cbp():
     del os.environ['HK_CBP_CSR']
 
 
+def bwd_variants():
+    B, C, HW = 64, 512, 196
+    x = torch.relu(torch.randn(B, C, HW, device=dev))
+    y, dy, dx = torch.empty(B, C * C, device=dev), torch.randn(B, C * C, device=dev), torch.empty_like(x)
+    inv, cs, tp = torch.empty(B, device=dev), torch.empty(B, HW, device=dev), torch.empty(B, C // 64, device=dev)
+    nws = lib.hk_bcnn_pool_ws_bytes(B, C, HW)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(ws), nws, stream())
+    lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream())
+    xm = torch.relu(torch.randn(B, 256, HW, device=dev))
+    mu, g, dxm = torch.zeros(B, 256, device=dev), torch.randn(B, 256, 256, device=dev), torch.empty_like(xm)
+    ref = None
+    for flag in ('0', '4', '3'):
+        os.environ['HK_BWD_V'] = flag
+        tag = {'0': 'HK_BWD_V=0 four barriers per K-block (round-1 default)', '4': 'HK_BWD_V=4 two barriers, direct transposed loads',
+               '3': 'HK_BWD_V=3 raw tiles, 3 WGs/CU'}[flag]
+        row('bcnn bwd_gemm B=64 C=512', tag,
+            timeit(lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream()), iters=40),
+            2.0 * B * C * C * HW, 8.0 * B * (C * C + C * HW))
+        if ref is None:
+            ref = dx.clone()
+        else:
+            rows[-1]['bit_identical_to_default'] = bool(torch.equal(dx, ref))
+        if flag != '3':
+            row('cov_pool bwd B=64 C=256', tag,
+                timeit(lambda: lib.hk_cov_pool_bwd(ptr(xm), ptr(mu), ptr(g), ptr(dxm), B, 256, HW, stream()), iters=40),
+                2.0 * B * 256 * 256 * HW)
+    os.environ['HK_BWD_V'] = '0'
+
+
 def cin():
     B, C, HW = 20, 2048, 49                                   # configs/CIN.yaml: 4 classes x 5 samples, ResNet-50 7x7 map
     x = torch.relu(torch.randn(B, C, HW, device=dev))
@@ -222,7 +252,7 @@ def bcnn_step_with_hip_linear():
 
 
 if __name__ == '__main__':
-    for f in (linear, ns_sym, npairs, cbp, cin):
+    for f in (bwd_variants, linear, ns_sym, npairs, cbp, cin):
         guarded(f)
     if '--step' in sys.argv:
         guarded(bcnn_step_with_hip_linear)
