@@ -20,16 +20,37 @@ import hawkeye_amd.functional as F
 from hawkeye_amd import _lib
 from hawkeye_amd._lib import ptr, stream
 
-lib = _lib.load()
-dev = torch.device('cuda:0')
+# HK_CAND_TINY=1 without a GPU: dry run of this script on the CPU emulation of the kernels (tests/emu) with shrunken
+# shapes - checks every call's argument marshalling before the script runs unattended on the GPU box.
+TINY = os.environ.get('HK_CAND_TINY') == '1'
+if TINY and not torch.cuda.is_available():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    from emu import harness
+    _ctx = harness.emulated()
+    _ctx.__enter__()                                    # stays active for the life of the process
+    lib, ptr, stream, dev = harness.load_emu(), harness._cpu_ptr, (lambda: None), torch.device('cpu')
+else:
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
 rows = []
 
 
+def sz(full, tiny):
+    return tiny if TINY else full
+
+
 def timeit(fn, iters=20, warm=3):
+    if TINY:
+        iters, warm = 1, 1
     for _ in range(warm):
         rc = fn()
         if isinstance(rc, int) and rc != 0:
             raise RuntimeError(f'C ABI call returned {rc}')
+    if dev.type != 'cuda':
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        return (time.perf_counter() - t0) / iters * 1e6
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -53,8 +74,11 @@ def guarded(fn):
 
 
 def linear():
-    for tag, (B, J, K) in {'bcnn 262144->200': (64, 262144, 200), 'mpn 32896->200': (64, 32896, 200),
-                            'osme 100352->1024 N=10': (10, 100352, 1024)}.items():
+    shapes = {'bcnn 262144->200': (64, 262144, 200), 'mpn 32896->200': (64, 32896, 200),
+              'osme 100352->1024 N=10': (10, 100352, 1024)}
+    if TINY:
+        shapes = {'bcnn 262144->200': (5, 640, 70), 'osme 100352->1024 N=10': (3, 200, 9)}
+    for tag, (B, J, K) in shapes.items():
         y = torch.randn(B, J, device=dev)
         w = torch.randn(K, J, device=dev) * 0.01
         b = torch.zeros(K, device=dev)
@@ -77,7 +101,7 @@ def linear():
         err = float((out - TF.linear(y, w, b)).norm() / TF.linear(y, w, b).norm())
         rows[-4]['rel_err_vs_torch'] = err
         if tag.startswith('bcnn'):                      # slab-count sweep for the split-K forward (auto = 384 here)
-            for slabs in (64, 128, 256, 768, 1024):
+            for slabs in sz((64, 128, 256, 768, 1024), (2, 3)):
                 os.environ['HK_LINEAR_SLABS'] = str(slabs)
                 n2 = lib.hk_linear_ws_bytes(B, J, K)
                 ws2 = torch.empty(n2, dtype=torch.uint8, device=dev)
@@ -88,7 +112,7 @@ def linear():
 
 
 def ns_sym():
-    B, d = 64, 256
+    B, d = sz(64, 2), sz(256, 128)
     x = torch.relu(torch.randn(B, d, 196, device=dev))
     cov, mu = torch.empty(B, d, d, device=dev), torch.empty(B, d, device=dev)
     lib.hk_cov_pool_fwd(ptr(x), ptr(cov), ptr(mu), B, d, 196, stream())
@@ -115,7 +139,7 @@ def ns_sym():
 
 
 def npairs():
-    for b, p, D in ((10, 2, 1024), (32, 2, 1024)):
+    for b, p, D in sz(((10, 2, 1024), (32, 2, 1024)), ((4, 2, 24),)):
         x = torch.randn(b, p, D, device=dev)
         t = torch.arange(b, device=dev) // 2
         labels = t.to(torch.int32)
@@ -146,7 +170,7 @@ def npairs():
 
 
 def cbp():
-    C, HW, D, B = 512, 196, 6000, 64
+    C, HW, D, B = sz(512, 128), 196, sz(6000, 1024), sz(64, 2)
     plan = F.CbpPlan(*F.sketch_hashes(C, C, D), D, dev)
     x = torch.relu(torch.randn(B, C, HW, device=dev))
     y, craw, inv = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev), torch.empty(B, device=dev)
@@ -161,7 +185,7 @@ def cbp():
 
 
 def bwd_variants():
-    B, C, HW = 64, 512, 196
+    B, C, HW = sz(64, 2), sz(512, 128), 196
     x = torch.relu(torch.randn(B, C, HW, device=dev))
     y, dy, dx = torch.empty(B, C * C, device=dev), torch.randn(B, C * C, device=dev), torch.empty_like(x)
     inv, cs, tp = torch.empty(B, device=dev), torch.empty(B, HW, device=dev), torch.empty(B, C // 64, device=dev)
@@ -169,8 +193,9 @@ def bwd_variants():
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
     lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(ws), nws, stream())
     lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream())
-    xm = torch.relu(torch.randn(B, 256, HW, device=dev))
-    mu, g, dxm = torch.zeros(B, 256, device=dev), torch.randn(B, 256, 256, device=dev), torch.empty_like(xm)
+    dc = sz(256, 64)
+    xm = torch.relu(torch.randn(B, dc, HW, device=dev))
+    mu, g, dxm = torch.zeros(B, dc, device=dev), torch.randn(B, dc, dc, device=dev), torch.empty_like(xm)
     ref = None
     for flag in ('0', '4', '3'):
         os.environ['HK_BWD_V'] = flag
@@ -185,13 +210,13 @@ def bwd_variants():
             rows[-1]['bit_identical_to_default'] = bool(torch.equal(dx, ref))
         if flag != '3':
             row('cov_pool bwd B=64 C=256', tag,
-                timeit(lambda: lib.hk_cov_pool_bwd(ptr(xm), ptr(mu), ptr(g), ptr(dxm), B, 256, HW, stream()), iters=40),
-                2.0 * B * 256 * 256 * HW)
+                timeit(lambda: lib.hk_cov_pool_bwd(ptr(xm), ptr(mu), ptr(g), ptr(dxm), B, dc, HW, stream()), iters=40),
+                2.0 * B * dc * dc * HW)
     os.environ['HK_BWD_V'] = '0'
 
 
 def cin():
-    B, C, HW = 20, 2048, 49                                   # configs/CIN.yaml: 4 classes x 5 samples, ResNet-50 7x7 map
+    B, C, HW = sz(20, 2), sz(2048, 96), 49                                   # configs/CIN.yaml: 4 classes x 5 samples, ResNet-50 7x7 map
     x = torch.relu(torch.randn(B, C, HW, device=dev))
     wt = torch.randn(B, device=dev)
     w, y, yc = torch.empty(B, C, C, device=dev), torch.empty_like(x), torch.empty_like(x)
@@ -254,6 +279,8 @@ def bcnn_step_with_hip_linear():
 if __name__ == '__main__':
     for f in (bwd_variants, linear, ns_sym, npairs, cbp, cin):
         guarded(f)
-    if '--step' in sys.argv:
+    if '--step' in sys.argv and not TINY:
         guarded(bcnn_step_with_hip_linear)
     print(json.dumps(rows), flush=True)
+    if TINY and dev.type != 'cuda':
+        _ctx.__exit__(None, None, None)
