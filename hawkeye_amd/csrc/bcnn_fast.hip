@@ -227,7 +227,7 @@ struct BwdExtra {
     int D;
 };
 
-template <int HW, int NSX, int MODE>
+template <int HW, int NSX, int MODE, bool LOAD_T = true>
 __device__ __forceinline__ void bwd_load(f32x4 (&ry)[4], f32x4 (&rd)[4], f32x4 (&rt)[4], f32x4 (&rx)[NSX],
                                          const float* __restrict__ y, const float* __restrict__ dy,
                                          const float* __restrict__ xb, long long cc, int C, int I, int kb, int tid,
@@ -241,7 +241,7 @@ __device__ __forceinline__ void bwd_load(f32x4 (&ry)[4], f32x4 (&rd)[4], f32x4 (
         if (MODE == 0) ry[u] = *reinterpret_cast<const f32x4*>(y + o1);
         if (MODE != 2) {
             rd[u] = *reinterpret_cast<const f32x4*>(dy + o1);
-            rt[u] = *reinterpret_cast<const f32x4*>(dy + o2);
+            if (LOAD_T) rt[u] = *reinterpret_cast<const f32x4*>(dy + o2);
         } else {
             const int i = I * 64 + r;
             const int h1i = ex.h1[i], h2i = ex.h2[i];
@@ -391,7 +391,7 @@ __device__ __forceinline__ void bwd_load_v4(f32x4 (&ry)[4], f32x4 (&rd)[4], f32x
                                             const float* __restrict__ y, const float* __restrict__ dy,
                                             const float* __restrict__ xb, long long cc, int C, int I, int kb, int tid,
                                             const BwdExtra& ex, int b) {
-    bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, kb, tid, ex, b);    // y, dy(I,K) (or the CBP gather), X
+    bwd_load<HW, NSX, MODE, false>(ry, rd, rt, rx, y, dy, xb, cc, C, I, kb, tid, ex, b);    // y, dy(I,K) (or the CBP gather), X
     if (MODE != 2) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
