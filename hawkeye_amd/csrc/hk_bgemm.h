@@ -289,15 +289,21 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
 // and a TWO-chunk prefetch through two register sets - the loads for chunk c+2 are issued before chunk c is computed
 // and are stored to LDS a whole chunk later.  256 tiles at B = 64: exactly one workgroup per CU.
 // Same k-permutation and summation order as bgemm_kernel.  Opt-in (HK_NS_GEMM=4) until it has a measured number.
-template <bool A_KC, bool B_KC, class AL, class BL, class EP>
-__global__ __launch_bounds__(512) void bgemm128_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb, int tilesM,
-                                                       int tilesN) {
-    constexpr int BM = 128, BN = 128, BK = 32;
+// BMN = 128: the kernel described above.  BMN = 64 (HK_NS_GEMM=5): the same two-chunk prefetch on the 64x64 tile of
+// bgemm_kernel (4 waves of 32x32, two k-chains per wave, 4 workgroups per CU) - isolates the effect of the deeper
+// prefetch from the effect of the bigger tile.
+template <int BMN, bool A_KC, bool B_KC, class AL, class BL, class EP>
+__global__ __launch_bounds__(BMN == 128 ? 512 : 256) void bgemm_p2_kernel(AL al, BL bl, EP ep, int M, int N, int K,
+                                                                          int nb, int tilesM, int tilesN) {
+    static_assert(BMN == 128 || BMN == 64, "tile is 128x128 (8 waves) or 64x64 (4 waves)");
+    constexpr int BM = BMN, BN = BMN, BK = 32;
+    constexpr int NTH = BMN == 128 ? 512 : 256;
+    constexpr int WCOLS = BMN == 128 ? 64 : 32;          // columns per wave
     constexpr int PA = A_KC ? BK + 4 : BM + 4;
     constexpr int PB = B_KC ? BK + 4 : BN + 4;
     constexpr int SA = (A_KC ? BM : BK) * PA;
     constexpr int SB = (B_KC ? BN : BK) * PB;
-    constexpr int NL = BM * BK / 4 / 512;       // float4 per thread per operand chunk (2)
+    constexpr int NL = BM * BK / 4 / NTH;       // float4 per thread per operand chunk (2)
     constexpr int A4 = A_KC ? BK / 4 : BM / 4;
     constexpr int B4 = B_KC ? BK / 4 : BN / 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * (SA + SB)];
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(512) void bgemm128_kernel(AL al, BL bl, EP ep, int 
     const int tm = tile / tilesN, tn = tile % tilesN;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;    // 4 x 2 waves: rows wm*32.., columns wn*64..
+    const int wm = wave >> 1, wn = wave & 1;    // (BMN/32) x 2 waves: rows wm*32.., columns wn*WCOLS..
     const int l31 = lane & 31, lh = lane >> 5;
 
     al.begin(b, tm, tn);
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(512) void bgemm128_kernel(AL al, BL bl, EP ep, int 
 #define HK_GLOAD2(RA, RB, k0)                                                                          \
     do {                                                                                               \
         _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                               \
-            const int f_ = tid + 512 * u, ar_ = f_ / A4, ac_ = f_ % A4, br_ = f_ / B4, bc_ = f_ % B4;  \
+            const int f_ = tid + NTH * u, ar_ = f_ / A4, ac_ = f_ % A4, br_ = f_ / B4, bc_ = f_ % B4;  \
             RA[u] = A_KC ? al.ld4(b, m0 + ar_, (k0) + 4 * ac_) : al.ld4(b, (k0) + ar_, m0 + 4 * ac_);  \
             RB[u] = B_KC ? bl.ld4(b, n0 + br_, (k0) + 4 * bc_) : bl.ld4(b, (k0) + br_, n0 + 4 * bc_);  \
         }                                                                                              \
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(512) void bgemm128_kernel(AL al, BL bl, EP ep, int 
         float* As_ = lds + (buf) * (SA + SB);                                                          \
         float* Bs_ = As_ + SA;                                                                         \
         _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                               \
-            const int f_ = tid + 512 * u, ar_ = f_ / A4, ac_ = f_ % A4, br_ = f_ / B4, bc_ = f_ % B4;  \
+            const int f_ = tid + NTH * u, ar_ = f_ / A4, ac_ = f_ % A4, br_ = f_ / B4, bc_ = f_ % B4;  \
             *reinterpret_cast<float4*>(&As_[ar_ * PA + 4 * ac_]) = RA[u];                              \
             *reinterpret_cast<float4*>(&Bs_[br_ * PB + 4 * bc_]) = RB[u];                              \
         }                                                                                              \
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(512) void bgemm128_kernel(AL al, BL bl, EP ep, int 
     do {                                                                                               \
         const float* As = lds + (buf) * (SA + SB);                                                     \
         const float* Bs = As + SA;                                                                     \
-        const int row_ = wm * 32 + l31, c0_ = wn * 64 + l31, c1_ = c0_ + 32;                           \
+        const int row_ = wm * 32 + l31, c0_ = wn * WCOLS + l31, c1_ = WCOLS == 64 ? c0_ + 32 : c0_;          \
         _Pragma("unroll") for (int s = 0; s < BK / 8; ++s) {                                           \
             float a_[4], p_[4], q_[4];                                                                 \
             if (A_KC) {                                                                                \
@@ -362,8 +368,14 @@ __global__ __launch_bounds__(512) void bgemm128_kernel(AL al, BL bl, EP ep, int 
                 }                                                                                      \
             }                                                                                          \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                            \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], p_[t], acc0, 0, 0, 0);              \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], q_[t], acc1, 0, 0, 0);              \
+                if (WCOLS == 64) {      /* two column tiles */                                         \
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], p_[t], acc0, 0, 0, 0);          \
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], q_[t], acc1, 0, 0, 0);          \
+                } else if (t & 1) {     /* one tile, two k-chains (as bgemm_kernel) */                  \
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], p_[t], acc1, 0, 0, 0);          \
+                } else {                                                                               \
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[t], p_[t], acc0, 0, 0, 0);          \
+                }                                                                                      \
             }                                                                                          \
         }                                                                                              \
     } while (0)
@@ -390,14 +402,15 @@ __global__ __launch_bounds__(512) void bgemm128_kernel(AL al, BL bl, EP ep, int 
 #undef HK_SSTORE2
 #undef HK_COMPUTE2
 
+    if (WCOLS == 32) acc0 += acc1;
     const int ib = m0 + wm * 32 + 4 * lh;
-    const int j0 = n0 + wn * 64 + l31, j1 = j0 + 32;
+    const int j0 = n0 + wn * WCOLS + l31, j1 = j0 + 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ii = ib + (r & 3) + 8 * (r >> 2);
         if (ii < M) {
             if (j0 < N) ep(b, ii, j0, acc0[r]);
-            if (j1 < N) ep(b, ii, j1, acc1[r]);
+            if (WCOLS == 64 && j1 < N) ep(b, ii, j1, acc1[r]);
         }
     }
     al.finish(b, tm, tn, tilesM, lds);
@@ -428,12 +441,23 @@ static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, 
     return HK_OK;
 }
 
-// 128x128 / 8-wave variant (bgemm128_kernel); only instantiated where it is asked for
+// 128x128 / 8-wave variant (bgemm_p2_kernel<128>); only instantiated where it is asked for
 template <bool A_KC, bool B_KC, class AL, class BL, class EP>
 static inline int bgemm128_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
     const int tm = (M + 127) / 128, tn = (N + 127) / 128;
-    hipLaunchKernelGGL((bgemm128_kernel<A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(512), 0, st, al, bl,
+    hipLaunchKernelGGL((bgemm_p2_kernel<128, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(512), 0, st, al,
+                       bl, ep, M, N, K, nb, tm, tn);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+// 64x64 tile with the two-chunk prefetch of bgemm_p2_kernel
+template <bool A_KC, bool B_KC, class AL, class BL, class EP>
+static inline int bgemm64p2_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
+    const int tm = (M + 63) / 64, tn = (N + 63) / 64;
+    hipLaunchKernelGGL((bgemm_p2_kernel<64, A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl,
                        ep, M, N, K, nb, tm, tn);
     HK_LAUNCH_CHECK();
     return HK_OK;

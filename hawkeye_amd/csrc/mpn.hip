@@ -162,10 +162,12 @@ static inline int mm(const float* A, long long sa, const float* Bm, long long sb
     const LdPlain lb = make_plain(Bm, sb, d, d, d);
     const EpAffine ep = make_affine(C, sc, d, alpha, bscale, beta, diag);
     if (sym_result && ns_sym()) return bgemm_launch_sym<true, false>(la, lb, ep, d, d, nb, st);
-    // A/B switch: 0 = 64x64x32 (default), 1 = 128x128x32 / 4 waves, 2 = 64x64x64, 3 = 64x64x16, 4 = 128x128x32 / 8 waves
+    // A/B switch: 0 = 64x64x32 (default), 1 = 128x128x32 / 4 waves, 2 = 64x64x64, 3 = 64x64x16,
+    //             4 = 128x128x32 / 8 waves / two-chunk prefetch, 5 = 64x64x32 / two-chunk prefetch
     const char* e = getenv("HK_NS_GEMM");
     const int variant = e ? atoi(e) : 0;
     if (variant == 4 && d >= 128) return bgemm128_launch<true, false>(la, lb, ep, d, d, d, nb, st);
+    if (variant == 5) return bgemm64p2_launch<true, false>(la, lb, ep, d, d, d, nb, st);
     return bgemm_launch<true, false>(la, lb, ep, d, d, d, nb, st, variant);
 }
 

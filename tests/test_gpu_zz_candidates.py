@@ -164,7 +164,7 @@ def test_mamc_npairs_loss_larger_batch(F):
     assert abs(float(lg) - float(lo)) <= 5e-6 * abs(float(lo)) and rel(xg.grad, xo.grad) < 2e-5
 
 
-@pytest.mark.parametrize('b,d,itn', [(2, 128, 5), (3, 200, 3), (9, 256, 2)])
+@pytest.mark.parametrize('b,d,itn', [(2, 128, 5), (3, 200, 3), (9, 256, 2), (3, 70, 4)])
 def test_ns_128_tile_gemm_variant(F, b, d, itn, monkeypatch):
     """HK_NS_GEMM=4: the Newton-Schulz products on bgemm128_kernel (128x128 tile, 8 waves, two-chunk prefetch through
     two register sets).  Same k order as the 64x64 kernel, so results agree to rounding of the tile boundaries only."""
@@ -174,7 +174,7 @@ def test_ns_128_tile_gemm_variant(F, b, d, itn, monkeypatch):
     wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(2))
     (yo * wt).sum().backward()
     res = []
-    for flag in ('0', '4'):
+    for flag in ('0', '4', '5'):                         # 5: the same two-chunk prefetch on the 64x64 tile
         monkeypatch.setenv('HK_NS_GEMM', flag)
         xg = x.clone().to(DEV).requires_grad_(True)
         yg = F.sqrtm(F.covpool(xg), itn)
@@ -182,6 +182,7 @@ def test_ns_128_tile_gemm_variant(F, b, d, itn, monkeypatch):
         assert rel(yg, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
         res.append((yg.detach(), xg.grad))
     assert rel(res[1][0], res[0][0]) < 2e-6 and rel(res[1][1], res[0][1]) < 2e-5
+    assert torch.equal(res[2][0], res[0][0]) and torch.equal(res[2][1], res[0][1])    # same tile, same k order: bit-identical
 
 
 @pytest.mark.parametrize('b,c,hw', [(4, 24, 12), (2, 70, 5), (6, 130, 49)])
