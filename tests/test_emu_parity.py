@@ -32,7 +32,8 @@ for _mod in _modules:
 # parameter sets that take 20 s .. 80 s each when emulated: run them with HK_EMU_FULL=1
 _HEAVY = {'test_cbp_rowsketch_equals_csr[512-6000-40]', 'test_models_with_hip_classifier[BCNN]',
           'test_models_with_hip_classifier[MPN]', 'test_cin_model_matches_reference',
-          'test_ns_128_tile_gemm_variant[9-256-2]'}
+          'test_ns_128_tile_gemm_variant[9-256-2]', 'test_ns_128_tile_gemm_variant[3-200-3]',
+          'test_cov_and_cbp_panel_kernels_vs_generic[70-256-8]', 'test_mpn_256_vs_golden'}
 
 
 @pytest.fixture(autouse=True)
