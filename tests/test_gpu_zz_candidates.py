@@ -366,3 +366,22 @@ def test_backward_two_barrier_variant_bit_identical(F, b, c, hw, monkeypatch):
     yo = O.bilinear_pool(xo)
     (yo * torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))).sum().backward()
     assert rel(res[1][0], xo.grad) < 2e-5
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_roi_crop_backward_lds_variant_bit_identical(F, mode, monkeypatch):
+    """HK_ROI_BWD=2 (tables shared by 4 channel maps, dY map staged in LDS) adds the same taps in the same order as the
+    default table-driven backward: bit-identical dX, for several boxes including a dropped block and a tiny crop."""
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 10, 56, 56, generator=gen)                         # 10 channels: 2 full groups of 4 + a ragged one
+    wt = torch.randn(4, 10, 56, 56, generator=gen)
+    box = torch.tensor([[3.2, 5.9, 40.1, 33.3], [0., 0., 56., 56.], [20.5, 21.5, 24.4, 25.9], [10., 2., 55.9, 17.2]])
+    drop = torch.tensor([[10., 12., 20., 30.], [0., 0., -1., -1.], [0., 0., -1., -1.], [12., 3., 30., 9.]])
+    res = []
+    for flag in ('0', '2'):
+        monkeypatch.setenv('HK_ROI_BWD', flag)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        y = F.roi_crop_resize(xg, box.to(DEV), drop.to(DEV), mode == 'train')
+        (y * wt.to(DEV)).sum().backward()
+        res.append(xg.grad.clone())
+    assert torch.equal(res[0], res[1]) and float(res[0].abs().sum()) > 0

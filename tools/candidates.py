@@ -215,6 +215,24 @@ def bwd_variants():
     os.environ['HK_BWD_V'] = '0'
 
 
+def roi_bwd():
+    B, C = sz(16, 2), sz(512, 8)
+    dy, dx = torch.randn(B, C, 56, 56, device=dev), torch.empty(B, C, 56, 56, device=dev)
+    box = torch.tensor([[3.2, 5.9, 40.1, 33.3]] * B, device=dev)
+    drop = torch.tensor([[10., 12., 20., 30.]] * B, device=dev)
+    ref = None
+    for flag in ('0', '2'):
+        os.environ['HK_ROI_BWD'] = flag
+        row(f'roi_crop_resize bwd B={B} C={C} 56x56', 'default table kernel' if flag == '0' else 'HK_ROI_BWD=2 LDS-staged, 4 maps / WG',
+            timeit(lambda: lib.hk_roi_crop_resize_bwd(ptr(dy), ptr(box), ptr(drop), ptr(dx), B, C, 56, 56, 1, stream())), 0.0,
+            8.0 * B * C * 3136)
+        if ref is None:
+            ref = dx.clone()
+        else:
+            rows[-1]['bit_identical_to_default'] = bool(torch.equal(dx, ref))
+    os.environ['HK_ROI_BWD'] = '0'
+
+
 def cin():
     B, C, HW = sz(20, 2), sz(2048, 96), 49                                   # configs/CIN.yaml: 4 classes x 5 samples, ResNet-50 7x7 map
     x = torch.relu(torch.randn(B, C, HW, device=dev))
@@ -277,7 +295,7 @@ def bcnn_step_with_hip_linear():
 
 
 if __name__ == '__main__':
-    for f in (bwd_variants, linear, ns_sym, npairs, cbp, cin):
+    for f in (bwd_variants, roi_bwd, linear, ns_sym, npairs, cbp, cin):
         guarded(f)
     if '--step' in sys.argv and not TINY:
         guarded(bcnn_step_with_hip_linear)
