@@ -17,9 +17,7 @@ class Tester:
         self.logger = logging.getLogger()
         self.logger.handlers = [TqdmHandler()]
         self.logger.setLevel(logging.INFO)
-        if not (isinstance(cfg.experiment.cuda, list) and cfg.experiment.cuda and torch.cuda.is_available()):
-            raise RuntimeError('hawkeye_amd evaluates on MI355X only: set experiment.cuda: [0] and run on a GPU host')
-        self.device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        self.device = self.select_device(cfg)
         self.transformer = self.get_transformer(cfg.dataset.transformer)
         self.collate_fn = self.get_collate_fn()
         self.dataset = self.get_dataset(cfg.dataset)
@@ -27,9 +25,17 @@ class Tester:
         self.model = self.to_device(self.get_model(cfg.model), parallel=True)
         self.average_meters = {'acc': AverageMeter()}
 
+    def select_device(self, cfg):
+        """This process's GPU; no CPU path (the HIP heads have none - the CPU reference is test infrastructure)."""
+        if not (isinstance(cfg.experiment.cuda, list) and cfg.experiment.cuda and torch.cuda.is_available()):
+            raise RuntimeError('hawkeye_amd evaluates on MI355X only: set experiment.cuda: [0] and run on a GPU host')
+        return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+
     def get_transformer(self, config):
         from . import transforms
-        return transforms.ClassificationPresetEval(crop_size=config['image_size'], resize_size=config['resize_size'])
+        dev = bool(config['device_finalize']) if 'device_finalize' in config else False
+        return transforms.ClassificationPresetEval(crop_size=config['image_size'], resize_size=config['resize_size'],
+                                                   device_finalize=dev)
 
     def get_collate_fn(self):
         return None
@@ -53,6 +59,9 @@ class Tester:
         return model
 
     def to_device(self, m, parallel=False):
+        if isinstance(m, dict) and 'u8' in m:              # uint8 crops from the workers (transformer.device_finalize)
+            from . import functional as HF
+            return HF.image_finalize(m['u8'].to(self.device, non_blocking=True), m['erase'].to(self.device, non_blocking=True))
         return m.to(self.device, non_blocking=True) if isinstance(m, torch.Tensor) else m.to(self.device)
 
     def test(self):

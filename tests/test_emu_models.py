@@ -91,3 +91,52 @@ def test_candidates_tool_dry_run():
     rows = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('[')][-1])
     assert len(rows) > 25 and not [r for r in rows if 'error' in r], [r for r in rows if 'error' in r]
     assert all(r.get('bit_identical_to_default', True) for r in rows)
+
+
+def test_tester_evaluates_a_trainer_checkpoint(tmp_path, monkeypatch):
+    """Trainer -> checkpoint -> Tester (reference test.py flow: strict load of `model.load`, validation pass, top-1)
+    and a real image folder through the presets, with the input finalised on the device (uint8 from the workers)."""
+    import numpy as np
+    import torch
+    from PIL import Image
+
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.examples.BCNN import BCNNTrainer
+    from hawkeye_amd.test import Tester
+    from hawkeye_amd.train import Trainer
+    monkeypatch.setattr(Trainer, 'select_device', lambda self, cfg: torch.device('cpu'))
+    monkeypatch.setattr(Tester, 'select_device', lambda self, cfg: torch.device('cpu'))
+    root = os.path.dirname(_here)
+    # a tiny image folder in the reference's `label relpath` format
+    img_root, meta = tmp_path / 'images', tmp_path / 'meta'
+    (img_root / 'a').mkdir(parents=True)
+    meta.mkdir()
+    rs = np.random.RandomState(0)
+    lines = []
+    for i in range(8):
+        Image.fromarray((rs.rand(90, 120, 3) * 255).astype(np.uint8)).save(img_root / 'a' / f'{i}.jpg')
+        lines.append(f'{i % 3} a/{i}.jpg')
+    for split in ('train', 'val'):
+        (meta / f'{split}.txt').write_text('\n'.join(lines) + '\n')
+    cfg = CfgNode.load_cfg(open(os.path.join(root, 'configs', 'BCNN_S2_synthetic.yaml')))
+    cfg.experiment.log_dir = str(tmp_path / 'logs')
+    cfg.dataset.name, cfg.dataset.root_dir, cfg.dataset.meta_dir = 'folder', str(img_root), str(meta)
+    cfg.dataset.batch_size, cfg.dataset.num_workers = 4, 0
+    cfg.dataset.transformer.image_size, cfg.dataset.transformer.resize_size = 64, 72
+    cfg.dataset.transformer.device_finalize = True
+    cfg.model.num_classes = 3
+    cfg.train.save_frequence = 1
+    cfg.freeze()
+    tr = BCNNTrainer(cfg)
+    tr.train()
+    ckpt = os.path.join(tr.log_root, 'BCNN_epoch_1.pth')
+    assert os.path.isfile(ckpt)
+    tcfg = cfg.clone() if hasattr(cfg, 'clone') else CfgNode(cfg.to_dict())
+    tcfg.defrost() if hasattr(tcfg, 'defrost') else None
+    tcfg.model.load = ckpt
+    te = Tester(tcfg)
+    te.test()
+    assert te.average_meters['acc'].count == 8 and 0.0 <= te.average_meters['acc'].avg <= 100.0
+    # same weights in both
+    for (k1, v1), (k2, v2) in zip(tr.model.state_dict().items(), te.model.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
