@@ -111,5 +111,27 @@ dxo = E(10, 2048, 49); dmo = E(2, 10, 2048)
 report('osme_gap N=10', lambda: lib.hk_osme_gap(ptr(xo), ptr(zo), 10, 2048, 49, stream()), 0, 4.0 * 10 * 2048 * 49)
 report('osme_scale fwd N=10 P=2', lambda: lib.hk_osme_scale_fwd(ptr(xo), ptr(mo), ptr(so), 2, 10, 2048, 49, stream()), 0, 4.0 * 10 * 2048 * 49 * 3)
 report('osme_scale bwd N=10 P=2', lambda: lib.hk_osme_scale_bwd(ptr(xo), ptr(mo), ptr(so), None, ptr(dxo), ptr(dmo), 2, 10, 2048, 49, stream()), 0, 4.0 * 10 * 2048 * 49 * 4)
+# ---------------------------------------------------------------- SURVEY 8f rows (first timed in round 2)
+Bc, J, K = 64, 262144, 200
+yl, wl, bl, gl = R(Bc, J), R(K, J) * 0.01, R(K), R(Bc, K)
+ol, dyl, dwl, dbl = E(Bc, K), E(Bc, J), E(K, J), E(K)
+nwl = lib.hk_linear_ws_bytes(Bc, J, K); wsl = E(nwl, dtype=torch.uint8)
+report('linear fwd 262144->200 B=64', lambda: lib.hk_linear_fwd(ptr(yl), ptr(wl), ptr(bl), ptr(ol), Bc, J, K, ptr(wsl), nwl, stream()),
+       2.0 * Bc * J * K, 4.0 * (Bc * J + K * J))
+report('linear bwd 262144->200 B=64', lambda: lib.hk_linear_bwd(ptr(yl), ptr(wl), ptr(gl), ptr(dyl), ptr(dwl), ptr(dbl), Bc, J, K, stream()),
+       4.0 * Bc * J * K, 4.0 * (2 * Bc * J + 2 * K * J))
+del yl, wl, dyl, dwl
+xp_ = R(10, 2, 1024); lab = (torch.arange(10, device=dev) // 2).to(torch.int32); ls, dxp = E(1), E(10, 2, 1024)
+nwn = lib.hk_npairs_ws_bytes(20, 1024); wsn = E(nwn, dtype=torch.uint8)
+report('npairs loss+grad b=10 p=2', lambda: lib.hk_npairs_loss(ptr(xp_), ptr(lab), ptr(ls), ptr(dxp), 10, 2, 1024, ptr(wsn), nwn, stream()))
+Bi, Ci, HWi = 20, 2048, 49
+xi = torch.relu(R(Bi, Ci, HWi)); wi, yi = E(Bi, Ci, Ci), E(Bi, Ci, HWi)
+report('cin sci fwd B=20 C=2048', lambda: lib.hk_cin_sci_fwd(ptr(xi), ptr(wi), ptr(yi), Bi, Ci, HWi, stream()), 4.0 * Bi * Ci * Ci * HWi,
+       4.0 * Bi * 2 * Ci * Ci)
+u8 = torch.randint(0, 256, (64, 448, 448, 3), dtype=torch.uint8, device=dev); oi = E(64, 3, 448, 448)
+import ctypes
+m3 = (ctypes.c_float * 3)(0.485, 0.456, 0.406); s3 = (ctypes.c_float * 3)(0.229, 0.224, 0.225)
+report('image_finalize B=64 448x448', lambda: lib.hk_image_finalize(ptr(u8), ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p),
+                                                                     None, ptr(oi), 64, 448, 448, 0, stream()), 0, 15.0 * 64 * 448 * 448)
 if '--json' in sys.argv:
     json.dump(rows, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
