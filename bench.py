@@ -188,7 +188,7 @@ def cpu_baseline(image, classes):
                       f'torch CPU fp32, {threads} threads of {os.cpu_count()} host cores'}
 
 
-def candidates(timeout_s=240):
+def candidates(timeout_s=150):
     """Timings of the opt-in variants / SURVEY-8f rows next to the paths they would replace (tools/candidates.py), in a
     subprocess AFTER the headline measurement: whatever happens in there (error, timeout) only shows up inside this
     field.  They are not part of `value`."""
