@@ -223,6 +223,125 @@ __global__ __launch_bounds__(256) void cbp_rowsketch_kernel(const float* __restr
     }
 }
 
+// Row-scatter variant (HK_CBP_CSR=2; written after round 1's GPU budget was spent, emulation-validated, not yet timed).
+// The row-sketch kernel above is bound by LDS bandwidth, not latency: every row it re-reads the whole replicated sketch
+// (24 KB per row and workgroup, 91 % of it zeros - a row has <= C = 512 non-empty bins out of D = 6000), 1.25 GB of
+// LDS traffic per launch at B = 64.  Here the partial result c[D] of the chunk lives in LDS instead and each row ADDS
+// its <= 512 non-zero sketch entries into it at (m + h1_i) mod D: within one row the targets are distinct (distinct m),
+// so plain read-modify-writes are race-free, and one LDS barrier per row orders the rows - the same per-bin summation
+// order (rows ascending) and the same `c += s1 * r` expression as the row-sketch kernel, hence bit-identical partials,
+// with ~8x less LDS traffic, one barrier per row instead of two and 41 KB of LDS (3 workgroups per CU).
+template <int NBT>
+__global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __restrict__ G, CbpPlan pl,
+                                                             float* __restrict__ part, int C, int D, int nchunk) {
+    HK_DYN_LDS16(smem);
+    float* c = smem;                                   // [D] bins of this chunk; c[D] is the dump slot
+    const int poff = ((D + 1 + 3) / 4) * 4;
+    int* sh1 = reinterpret_cast<int*>(smem + poff);    // [64]  h1 of the chunk's rows
+    float* ss1 = smem + poff + 64;                     // [64]  s1 of the chunk's rows
+    float* gb = smem + poff + 128;                     // [2][CBP_RB * C] staged rows of G
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int i0 = ch * 64, i1 = (i0 + 64 < C) ? i0 + 64 : C;
+    const int nrows = i1 - i0, nblk = (nrows + CBP_RB - 1) / CBP_RB;
+    const int blk4 = CBP_RB * C / 4;
+    const float* gbase = G + ((long long)b * C + i0) * C;
+
+    for (int k = tid; k <= D; k += 256) c[k] = 0.f;
+    if (tid < 64 && tid < nrows) {
+        sh1[tid] = pl.h1[i0 + tid];
+        ss1[tid] = pl.s1[i0 + tid];
+    }
+    int jx[NBT][CBP_EMAX], mb[NBT];
+    float sg[NBT][CBP_EMAX];
+#pragma unroll
+    for (int u = 0; u < NBT; ++u) {
+        const int t = tid + 256 * u;
+        const bool ok = t < pl.nzn;
+        mb[u] = ok ? pl.nzb[t] : -1;
+        const int lo = ok ? pl.nzo[t] : 0, hi = ok ? pl.nzo[t + 1] : 0;
+#pragma unroll
+        for (int e = 0; e < CBP_EMAX; ++e) {
+            const bool valid = lo + e < hi;
+            const unsigned v = valid ? pl.nzj[lo + e] : 0u;
+            jx[u][e] = (int)(v & 0x7fffffffu);
+            sg[u][e] = valid ? ((v >> 31) ? -1.f : 1.f) : 0.f;
+        }
+    }
+
+    f32x4 st[2];
+#define HK_BLK_LOAD(blk_)                                                                            \
+    do {                                                                                             \
+        const int left_ = nrows - (blk_) * CBP_RB;                                                   \
+        const int lim4_ = ((left_ < CBP_RB ? left_ : CBP_RB) * C) / 4;                               \
+        const f32x4* src_ = reinterpret_cast<const f32x4*>(gbase + (long long)(blk_) * CBP_RB * C);  \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
+            const int f_ = tid + 256 * u;                                                            \
+            st[u] = src_[f_ < lim4_ ? f_ : 0];                                                       \
+        }                                                                                            \
+    } while (0)
+#define HK_BLK_STORE(buf_)                                                                           \
+    do {                                                                                             \
+        f32x4* dst_ = reinterpret_cast<f32x4*>(gb + (buf_) * CBP_RB * C);                            \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
+            const int f_ = tid + 256 * u;                                                            \
+            if (f_ < blk4) dst_[f_] = st[u];                                                         \
+        }                                                                                            \
+    } while (0)
+
+    HK_BLK_LOAD(0);
+    HK_BLK_STORE(0);
+    __syncthreads();
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1;
+        if (blk + 1 < nblk) HK_BLK_LOAD(blk + 1);
+        const float* gcur = gb + cur * CBP_RB * C;
+        const int left = nrows - blk * CBP_RB;
+        const int rmax = left < CBP_RB ? left : CBP_RB;
+        for (int rr = 0; rr < rmax; ++rr) {
+            const float* grow = gcur + rr * C;
+            const int li = blk * CBP_RB + rr;
+            const int h1i = sh1[li];
+            const float s1i = ss1[li];
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) {
+                float sacc = 0.f;                            // signed sum in channel order (padding adds 0 * x)
+#pragma unroll
+                for (int e = 0; e < CBP_EMAX; ++e) sacc += sg[u][e] * grow[jx[u][e]];
+                int idx = mb[u] + h1i;                       // bin (h1_i + h2_j) mod D of this row's entry
+                if (idx >= D) idx -= D;
+                idx = mb[u] >= 0 ? idx : D;
+                c[idx] += s1i * sacc;
+            }
+            HK_LDS_BARRIER();                                // the next row may hit the same bins from other lanes
+        }
+        if (blk + 1 < nblk) {
+            HK_BLK_STORE(cur ^ 1);
+            HK_LDS_BARRIER();
+        }
+    }
+#undef HK_BLK_LOAD
+#undef HK_BLK_STORE
+    __syncthreads();
+    float* pp = part + ((long long)b * nchunk + ch) * D;
+    for (int k = tid; k < D; k += 256) pp[k] = c[k];
+}
+
+template <int NBT>
+static int rowscatter_launch(const float* G, const CbpPlan& pl, float* part, int B, int C, int D, int nchunk,
+                             hipStream_t st) {
+    const size_t lds = ((size_t)((D + 1 + 3) / 4) * 4 + 128 + 2 * CBP_RB * (size_t)C) * sizeof(float);
+    if (lds > 150 * 1024) return HK_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cbp_rowscatter_kernel<NBT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((cbp_rowscatter_kernel<NBT>), dim3(nchunk, B), dim3(256), lds, st, G, pl, part, C, D, nchunk);
+    return HK_OK;
+}
+
 template <int NBT, int NQ8>
 static int rowsketch_launch(const float* G, const CbpPlan& pl, float* part, int B, int C, int D, int nchunk,
                             hipStream_t st) {
@@ -406,12 +525,18 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
     // Binning stage, measured at C=512, D=6000 (whole hk_cbp_fwd, HIP events): row-sketch 107.0 us @B=64 / 87.9 @B=16,
     // CSR gather 175.9 us @B=64 / 81.2 @B=16.  The row-sketch kernel is latency-bound per workgroup (~49 us for its 64
     // rows whatever B is), the CSR gather is throughput-bound, so the row-sketch is used once B * C/64 workgroups fill the
-    // 256 CUs.  HK_CBP_CSR=1 / HK_CBP_CSR=0 force one or the other (A/B switch).
+    // 256 CUs.  HK_CBP_CSR=1 / HK_CBP_CSR=0 force one or the other (A/B switch); HK_CBP_CSR=2 selects the row-scatter
+    // kernel (bit-identical partials, not yet timed).
     const char* csr = getenv("HK_CBP_CSR");
     const int nq8 = ((D + 255) / 256 + 7) / 8;               // 8-bin groups per thread
     const bool rowsketch = C <= 512 && C % 4 == 0 && nq8 <= 4 && D >= 1024 * nq8 && pl.emax <= CBP_EMAX &&
                            (csr ? csr[0] == '0' : B * nchunk >= 256);
-    if (rowsketch) {
+    const bool scatter = csr && csr[0] == '2' && C <= 512 && C % 4 == 0 && pl.emax <= CBP_EMAX;
+    if (scatter) {
+        const int rc2 = C <= 256 ? rowscatter_launch<1>(G, pl, part, B, C, D, nchunk, st)
+                                 : rowscatter_launch<2>(G, pl, part, B, C, D, nchunk, st);
+        if (rc2 != HK_OK) return rc2;
+    } else if (rowsketch) {
         int rc2 = HK_ERR_UNSUPPORTED;
         const bool one = C <= 256;
         switch (nq8) {
@@ -426,7 +551,7 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
                            C * C, D);
     }
     HK_LAUNCH_CHECK();
-    if (rowsketch) {
+    if (rowsketch || scatter) {
         hipLaunchKernelGGL(cbp_partsum_kernel, dim3((D + 255) / 256, B), dim3(256), 0, st, (const float*)part, c_raw, D,
                            nchunk);
         HK_LAUNCH_CHECK();

@@ -385,3 +385,29 @@ def test_roi_crop_backward_lds_variant_bit_identical(F, mode, monkeypatch):
         (y * wt.to(DEV)).sum().backward()
         res.append(xg.grad.clone())
     assert torch.equal(res[0], res[1]) and float(res[0].abs().sum()) > 0
+
+
+@pytest.mark.parametrize('c,d,b', [(128, 1024, 3), (256, 2048, 2), (512, 6000, 2), (512, 8192, 2), (64, 50, 3), (96, 333, 2)])
+def test_cbp_row_scatter_binning(F, c, d, b, monkeypatch):
+    """HK_CBP_CSR=2: the chunk's bins live in LDS and every row adds its <= C non-zero sketch entries into them (one
+    barrier per row, ~8x less LDS traffic than the row-sketch kernel).  Same summation order and expression as the
+    row-sketch kernel -> bit-identical to it wherever that one applies; equal to the CSR gather up to rounding; works
+    for any D (the row-sketch kernel needs D >= 1024)."""
+    x = torch.relu(torch.randn(b, c, 7, 7, generator=torch.Generator().manual_seed(c + d))).to(DEV)
+    plan = F.CbpPlan(*F.sketch_hashes(c, c, d), d, torch.device(DEV) if DEV != 'cuda'
+                     else torch.device('cuda', torch.cuda.current_device()))
+    out = {}
+    for flag in ('1', '0', '2'):
+        monkeypatch.setenv('HK_CBP_CSR', flag)
+        xg = x.clone().requires_grad_(True)
+        y = F.compact_bilinear_pool(xg, plan)
+        (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(DEV)).sum().backward()
+        out[flag] = (y.detach(), xg.grad)
+    # (the gradient divides by 2 sqrt|c|: last-bit differences of small bins between the two summation orders are
+    #  amplified, so only the forward is compared with the CSR gather; the gradient is compared where it is bit-exact)
+    assert rel(out['2'][0], out['1'][0]) < 2e-6 and rel(out['2'][1], out['1'][1]) < 5e-3
+    if d >= 1024:                                            # row-sketch kernel in use for flag '0'
+        assert torch.equal(out['2'][0], out['0'][0]) and torch.equal(out['2'][1], out['0'][1])
+    x64 = x.cpu().double().requires_grad_(True)
+    y64 = O.compact_bilinear_pool_gram(x64, d)
+    assert rel(out['2'][0], y64) < 1e-5

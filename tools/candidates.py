@@ -176,11 +176,17 @@ def cbp():
     y, craw, inv = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev), torch.empty(B, device=dev)
     nws = lib.hk_cbp_ws_bytes(B, C, HW, D)
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    for flag in ('0', '1'):
+    ref = None
+    for flag, tag in (('0', 'row-sketch binning (round-1 default at B=64)'), ('1', 'CSR gather binning'),
+                      ('2', 'row-scatter binning (bins in LDS, one barrier per row)')):
         os.environ['HK_CBP_CSR'] = flag
-        row('cbp fwd B=64', 'row-sketch binning' if flag == '0' else 'CSR gather binning',
+        row(f'cbp fwd B={B}', tag,
             timeit(lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws,
                                           stream())), 2.0 * B * C * C * HW)
+        if flag == '0':
+            ref = y.clone()
+        elif flag == '2':
+            rows[-1]['bit_identical_to_default'] = bool(torch.equal(y, ref))
     del os.environ['HK_CBP_CSR']
 
 
