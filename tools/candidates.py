@@ -170,23 +170,24 @@ def npairs():
 
 
 def cbp():
-    C, HW, D, B = sz(512, 128), 196, sz(6000, 1024), sz(64, 2)
+    C, HW, D = sz(512, 128), 196, sz(6000, 1024)
     plan = F.CbpPlan(*F.sketch_hashes(C, C, D), D, dev)
-    x = torch.relu(torch.randn(B, C, HW, device=dev))
-    y, craw, inv = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev), torch.empty(B, device=dev)
-    nws = lib.hk_cbp_ws_bytes(B, C, HW, D)
-    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    ref = None
-    for flag, tag in (('0', 'row-sketch binning (round-1 default at B=64)'), ('1', 'CSR gather binning'),
-                      ('2', 'row-scatter binning (bins in LDS, one barrier per row)')):
-        os.environ['HK_CBP_CSR'] = flag
-        row(f'cbp fwd B={B}', tag,
-            timeit(lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws,
-                                          stream())), 2.0 * B * C * C * HW)
-        if flag == '0':
-            ref = y.clone()
-        elif flag == '2':
-            rows[-1]['bit_identical_to_default'] = bool(torch.equal(y, ref))
+    for B in sz((64, 16), (2,)):                        # the metric's batch and the yaml's (configs/CBCNN_S2.yaml:10)
+        x = torch.relu(torch.randn(B, C, HW, device=dev))
+        y, craw, inv = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev), torch.empty(B, device=dev)
+        nws = lib.hk_cbp_ws_bytes(B, C, HW, D)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        ref = None
+        for flag, tag in (('0', 'row-sketch binning (round-1 default at B=64)'), ('1', 'CSR gather binning (round-1 default at B=16)'),
+                          ('2', 'row-scatter binning (bins in LDS, one barrier per row)')):
+            os.environ['HK_CBP_CSR'] = flag
+            row(f'cbp fwd B={B}', tag,
+                timeit(lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws,
+                                              stream())), 2.0 * B * C * C * HW)
+            if flag == '0':
+                ref = y.clone()
+            elif flag == '2':
+                rows[-1]['bit_identical_to_default'] = bool(torch.equal(y, ref))
     del os.environ['HK_CBP_CSR']
 
 
