@@ -29,310 +29,9 @@ def F():
     return F_
 
 
-@pytest.mark.parametrize('b,d,itn', [(3, 70, 5), (2, 128, 5), (9, 64, 3), (2, 33, 2)])
-def test_ns_symmetric_tile_mode(F, b, d, itn, monkeypatch):
-    """HK_NS_SYM=1: upper-triangle tiles only + mirrored stores for the symmetric products of the Newton-Schulz chain,
-    and Z Y taken as the transpose of Y Z in the backward (38 -> 34 launches).  Same tolerances as the full products."""
-    x = torch.relu(torch.randn(b, d, 6, 7, generator=torch.Generator().manual_seed(d))) + 0.01
-    xo = x.clone().requires_grad_(True)
-    yo = O.triuvec(O.sqrtm(O.covpool(xo), itn))
-    wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))
-    (yo * wt).sum().backward()
-    res = []
-    for flag in ('0', '1'):
-        monkeypatch.setenv('HK_NS_SYM', flag)
-        xg = x.clone().to(DEV).requires_grad_(True)
-        cov = F.covpool(xg)
-        s = F.sqrtm(cov, itn)
-        yg = F.triuvec(s)
-        (yg * wt.to(DEV)).sum().backward()
-        assert rel(yg, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
-        if flag == '1':
-            assert rel(s, s.transpose(1, 2)) < 1e-6            # off-diagonal tiles mirrored, diagonal tiles computed
-        res.append((yg.detach(), xg.grad))
-    assert rel(res[1][0], res[0][0]) < 5e-6 and rel(res[1][1], res[0][1]) < 5e-5
-
-
-@pytest.mark.parametrize('b,j,k,bias', [(3, 1000, 7, True), (64, 4096, 200, True), (5, 333, 130, False), (10, 6272, 96, True),
-                                        (1, 40, 1, True)])
-def test_linear_split_k(F, b, j, k, bias, monkeypatch):
-    """hk_linear_fwd/bwd (classifier on the pooled vector, SURVEY 8f-1) vs torch's Linear in fp64; slab counts forced
-    through HK_LINEAR_SLABS cover one slab, ragged last slabs and the automatic choice."""
-    gen = torch.Generator().manual_seed(b * 1000 + j)
-    y = torch.randn(b, j, generator=gen)
-    w = torch.randn(k, j, generator=gen) / j ** 0.5
-    bv = torch.randn(k, generator=gen) if bias else None
-    g = torch.randn(b, k, generator=gen)
-    y64, w64 = y.double().requires_grad_(True), w.double().requires_grad_(True)
-    b64 = bv.double().requires_grad_(True) if bias else None
-    o64 = torch.nn.functional.linear(y64, w64, b64)
-    (o64 * g.double()).sum().backward()
-    for slabs in (None, '1', '3', '7'):
-        if slabs is None:
-            monkeypatch.delenv('HK_LINEAR_SLABS', raising=False)
-        else:
-            monkeypatch.setenv('HK_LINEAR_SLABS', slabs)
-        yg, wg = y.clone().to(DEV).requires_grad_(True), w.clone().to(DEV).requires_grad_(True)
-        bg = bv.clone().to(DEV).requires_grad_(True) if bias else None
-        og = F.linear(yg, wg, bg)
-        (og * g.to(DEV)).sum().backward()
-        assert rel(og, o64) < 2e-6, slabs
-        assert rel(yg.grad, y64.grad) < 2e-6 and rel(wg.grad, w64.grad) < 2e-6
-        if bias:
-            assert rel(bg.grad, b64.grad) < 2e-6
-
-
-_MODEL_CFG = {
-    'BCNN': dict(stage=2, num_classes=200),
-    'CBCNN': dict(stage=2, num_classes=200, input_channel=512, output_channel=6000),
-    'MPN': dict(iter_num=5, is_sqrt=True, is_vec=True, input_dim=2048, dimension_reduction=256, num_classes=200),
-}
-
-
-@pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN'])
-def test_models_with_hip_classifier(F, name, monkeypatch):
-    """HAWKEYE_HIP_LINEAR=1: the classifier on the pooled vector runs on hk_linear_* - logits still match the REFERENCE
-    model's (tests/golden/model_logits.npz) and a train step gives the same classifier gradient as torch's Linear."""
-    import os
-
-    import hawkeye_amd.model  # noqa: F401
-    from hawkeye_amd.config import CfgNode
-    from hawkeye_amd.model.registry import MODEL
-    from inputs import rs_randn, seeded_init
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'model_logits.npz'))
-    m = MODEL.get(name)(CfgNode(dict(name=name, **_MODEL_CFG[name])))
-    seeded_init(m, 900)
-    m = m.to(DEV).eval()
-    x = torch.from_numpy(np.ascontiguousarray(rs_randn(901, (2, 3, 64, 64)))).to(DEV)
-    grads = []
-    for flag in ('0', '1'):
-        monkeypatch.setenv('HAWKEYE_HIP_LINEAR', flag)
-        m.zero_grad()
-        y = m(x)
-        assert rel(y, g[name]) < 1e-4 and y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
-        torch.nn.functional.cross_entropy(y, torch.tensor([3, 77], device=y.device)).backward()
-        grads.append((m.classifier.weight.grad.clone(), m.classifier.bias.grad.clone(),
-                      next(m.backbone.parameters()).grad.clone()))
-    # the trunk gradient goes through MIOpen's weight-gradient kernels (split-K with atomics: not bitwise repeatable)
-    for (p, q), tol in zip(zip(grads[0], grads[1]), (1e-5, 1e-5, 1e-4)):
-        assert rel(q, p) < tol
-
-
-def test_mamc_npairs_loss_vs_reference_goldens(F):
-    """hk_npairs_loss (SURVEY 8f-4) vs the REFERENCE's NPairsLoss / MAMCLoss (tests/golden/mamc_loss.npz) and the
-    oracle, including empty positive / negative sets."""
-    import os
-
-    from inputs import MAMC_CASES, rs_randn
-    from hawkeye_amd.config import CfgNode
-    from hawkeye_amd.model.loss import MAMCLoss
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mamc_loss.npz'))
-    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    for i, (name, (b, p, d, labels)) in enumerate(MAMC_CASES.items()):
-        x = tt(rs_randn(300 + i, (b, p, d))).to(DEV).requires_grad_(True)
-        loss = F.npairs_loss(x, torch.tensor(labels).to(DEV))
-        (3.0 * loss).backward()
-        xo = tt(rs_randn(300 + i, (b, p, d))).requires_grad_(True)
-        lo = O.npairs_loss(xo, torch.tensor(labels))
-        lo.backward()
-        assert abs(float(loss) - float(g[name + '_loss'])) <= 2e-6 * max(1.0, abs(float(g[name + '_loss']))), name
-        assert abs(float(loss) - float(lo)) <= 2e-6 * max(1.0, abs(float(lo)))
-        if float(np.abs(g[name + '_dx']).max()) > 0:
-            assert rel(x.grad / 3.0, g[name + '_dx']) < 2e-5 and rel(x.grad / 3.0, xo.grad) < 2e-5, name
-        else:
-            assert float(x.grad.abs().max()) < 1e-7
-    b, p, d, labels = MAMC_CASES['balanced']
-    x = tt(rs_randn(300, (b, p, d))).to(DEV).requires_grad_(True)
-    pred = tt(rs_randn(310, (b, 200))).to(DEV).requires_grad_(True)
-    total = MAMCLoss(CfgNode(dict(lambda_a=0.5, use_mamc=True)))((pred, x), torch.tensor(labels).to(DEV))
-    total.backward()
-    assert abs(float(total) - float(g['mamc_total'])) <= 2e-6 * abs(float(g['mamc_total']))
-    assert rel(pred.grad, g['mamc_dpred']) < 1e-5 and rel(x.grad, g['mamc_dx']) < 2e-5
-
-
-def test_mamc_npairs_loss_larger_batch(F):
-    """n = 96 anchors (32 samples x 3 attentions, 7 classes): more than one 64-row tile in both GEMMs."""
-    gen = torch.Generator().manual_seed(5)
-    x = torch.randn(32, 3, 200, generator=gen)
-    y = torch.randint(0, 7, (32,), generator=gen)
-    xo = x.clone().requires_grad_(True)
-    lo = O.npairs_loss(xo, y)
-    lo.backward()
-    xg = x.clone().to(DEV).requires_grad_(True)
-    lg = F.npairs_loss(xg, y.to(DEV))
-    lg.backward()
-    assert abs(float(lg) - float(lo)) <= 5e-6 * abs(float(lo)) and rel(xg.grad, xo.grad) < 2e-5
-
-
-@pytest.mark.parametrize('b,d,itn', [(2, 128, 5), (3, 200, 3), (9, 256, 2), (3, 70, 4)])
-def test_ns_128_tile_gemm_variant(F, b, d, itn, monkeypatch):
-    """HK_NS_GEMM=4: the Newton-Schulz products on bgemm128_kernel (128x128 tile, 8 waves, two-chunk prefetch through
-    two register sets).  Same k order as the 64x64 kernel, so results agree to rounding of the tile boundaries only."""
-    x = torch.relu(torch.randn(b, d, 5, 6, generator=torch.Generator().manual_seed(d + 1))) + 0.01
-    xo = x.clone().requires_grad_(True)
-    yo = O.sqrtm(O.covpool(xo), itn)
-    wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(2))
-    (yo * wt).sum().backward()
-    res = []
-    for flag in ('0', '4', '5'):                         # 5: the same two-chunk prefetch on the 64x64 tile
-        monkeypatch.setenv('HK_NS_GEMM', flag)
-        xg = x.clone().to(DEV).requires_grad_(True)
-        yg = F.sqrtm(F.covpool(xg), itn)
-        (yg * wt.to(DEV)).sum().backward()
-        assert rel(yg, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
-        res.append((yg.detach(), xg.grad))
-    assert rel(res[1][0], res[0][0]) < 2e-6 and rel(res[1][1], res[0][1]) < 2e-5
-    assert torch.equal(res[2][0], res[0][0]) and torch.equal(res[2][1], res[0][1])    # same tile, same k order: bit-identical
-
-
-@pytest.mark.parametrize('b,c,hw', [(4, 24, 12), (2, 70, 5), (6, 130, 49)])
-def test_cin_channel_interaction_ops(F, b, c, hw):
-    """hk_cin_sci_* / hk_cin_cci_* (SURVEY 8f-2) vs torch autograd of the reference's formulas (CIN.py:31-34, 51-54) in
-    fp64: forward values, and the gradients through both branches including the one that reaches W_SCI from the
-    contrastive branch and the per-sample weights."""
-    gen = torch.Generator().manual_seed(b * 100 + c)
-    x = torch.relu(torch.randn(b, c, hw, generator=gen))
-    wt = torch.randn(b, generator=gen) * 0.7
-    g1, g2 = torch.randn(b, c, hw, generator=gen), torch.randn(b, c, hw, generator=gen)
-    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
-    w_ref = torch.softmax(-torch.bmm(xr, xr.transpose(1, 2)) / hw, dim=2)
-    y_ref = torch.bmm(w_ref, xr)
-    w_ba = torch.cat((w_ref[b // 2:], w_ref[:b // 2]), 0)
-    yc_ref = torch.bmm(torch.abs(w_ref - wr.view(-1, 1, 1) * w_ba), xr)
-    ((y_ref * g1.double()).sum() + (yc_ref * g2.double()).sum()).backward()
-    xg, wg = x.clone().to(DEV).requires_grad_(True), wt.clone().to(DEV).requires_grad_(True)
-    y, w = F.cin_sci(xg)
-    yc = F.cin_cci(w, xg, wg)
-    ((y * g1.to(DEV)).sum() + (yc * g2.to(DEV)).sum()).backward()
-    assert rel(w, w_ref) < 2e-6 and rel(y, y_ref) < 2e-6 and rel(yc, yc_ref) < 5e-6
-    assert rel(xg.grad, xr.grad) < 2e-5 and rel(wg.grad, wr.grad) < 2e-5
-    # SCI alone (eval path / W unused): gradient without the extra term
-    x2 = x.clone().to(DEV).requires_grad_(True)
-    (F.cin_sci(x2)[0] * g1.to(DEV)).sum().backward()
-    x3 = x.double().requires_grad_(True)
-    (torch.bmm(torch.softmax(-torch.bmm(x3, x3.transpose(1, 2)) / hw, dim=2), x3) * g1.double()).sum().backward()
-    assert rel(x2.grad, x3.grad) < 2e-5
-
-
 def _golden(name):
     import os
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
-
-
-def test_cin_module_matches_reference(F):
-    """hawkeye_amd's ChannelInteractionModule (HIP interaction, torch conv / fc) vs the REFERENCE module's outputs
-    and gradients (tests/golden/cin_small.npz: train mode with the contrastive branch, and eval mode)."""
-    from hawkeye_amd.model.methods.CIN import ChannelInteractionModule
-    from inputs import rs_randn, rs_relu_randn
-    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    g = _golden('cin_small')
-    m = ChannelInteractionModule(in_channel=24, spatial_size=(3, 4))
-    m.load_state_dict({k[2:].replace('__', '.'): tt(g[k]) for k in g.files if k.startswith('w_')})
-    m = m.to(DEV).train()
-    x = tt(rs_relu_randn(410, (4, 24, 3, 4))).to(DEV).requires_grad_(True)
-    z, zc = m(x)
-    ((z * tt(rs_randn(411, tuple(z.shape))).to(DEV)).sum() + (zc * tt(rs_randn(412, tuple(zc.shape))).to(DEV)).sum()).backward()
-    assert rel(z, g['z']) < 1e-5 and rel(zc, g['z_cci']) < 1e-5
-    assert rel(x.grad, g['dx']) < 1e-4
-    for k, p_ in m.named_parameters():
-        assert rel(p_.grad, g['g_' + k.replace('.', '__')]) < 1e-4, k
-    m.eval()
-    with torch.no_grad():
-        assert rel(m(x.detach()), g['z_eval']) < 1e-5
-
-
-def test_cin_loss_matches_reference():
-    from hawkeye_amd.config import CfgNode
-    from hawkeye_amd.model.loss import CINLoss
-    from inputs import rs_randn
-    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    g = _golden('cin_small')
-    crit = CINLoss(CfgNode(dict(alpha=2.0, beta=0.5, channel=24, feature_size=12, r_channel=8)))
-    crit.h.load_state_dict({'weight': tt(g['h_w']), 'bias': tt(g['h_b'])})
-    crit = crit.to(DEV)
-    for name, labels in (('pairs', [1, 3, 1, 1]), ('nopairs', [1, 3, 0, 2])):
-        logits = tt(rs_randn(422, (4, 5))).to(DEV).requires_grad_(True)
-        zc = tt(rs_randn(423, (4, 24, 12))).to(DEV).requires_grad_(True)
-        loss = crit((logits, zc), torch.tensor(labels).to(DEV))
-        loss.backward()
-        assert abs(float(loss) - float(g[f'loss_{name}'])) < 1e-5 * max(1.0, abs(float(g[f'loss_{name}'])))
-        assert rel(logits.grad, g[f'loss_{name}_dlogits']) < 1e-5
-        if float(np.abs(g[f'loss_{name}_dz']).max()) > 0:
-            assert rel(zc.grad, g[f'loss_{name}_dz']) < 1e-4
-    assert abs(float(crit(tt(rs_randn(422, (4, 5))).to(DEV), torch.tensor([1, 3, 1, 1]).to(DEV)))) > 0   # eval: plain CE
-
-
-def test_cin_model_matches_reference(F):
-    """The registered CIN plugin end to end at 224x224 vs the reference model (tests/golden/model_cin.npz): eval logits,
-    train-mode logits and Z_CCI, criterion value."""
-    from hawkeye_amd.config import CfgNode
-    from hawkeye_amd.model.loss import CINLoss
-    from hawkeye_amd.model.registry import MODEL
-    import hawkeye_amd.model  # noqa: F401
-    from inputs import rs_randn, seeded_init, sub
-    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    g = _golden('model_cin')
-    m = MODEL.get('CIN')(CfgNode(dict(name='CIN', num_classes=200)))
-    seeded_init(m, 930)
-    m = m.to(DEV)
-    x = tt(rs_randn(931, (4, 3, 224, 224))).to(DEV)
-    m.eval()
-    with torch.no_grad():
-        le = m(x)
-    assert rel(le, g['logits_eval']) < 1e-4 and le.argmax(1).cpu().tolist() == g['logits_eval'].argmax(1).tolist()
-    m.train()
-    with torch.no_grad():
-        lt, zc = m(x)
-    # train mode: BatchNorm over 4 images divides by batch statistics, which amplifies conv-algorithm differences
-    assert rel(lt, g['logits_train']) < 1e-3 and rel(sub(zc.cpu(), 97), g['z_cci_sub']) < 1e-3
-    crit = CINLoss(CfgNode(dict(alpha=2.0, beta=0.5, channel=2048, feature_size=49, r_channel=16)))
-    with torch.no_grad():
-        crit.h.weight.copy_(tt(rs_randn(932, tuple(crit.h.weight.shape))) * 1e-3)
-        crit.h.bias.zero_()
-        loss = crit.to(DEV)((lt, zc), torch.tensor([5, 9, 5, 9]).to(DEV))
-    assert abs(float(loss) - float(g['loss'])) < 3e-3 * abs(float(g['loss']))
-
-
-@pytest.mark.parametrize('channels_last', [False, True])
-def test_image_finalize_bit_exact(F, channels_last):
-    """hk_image_finalize (SURVEY 8f-3) vs the CPU order of operations (u8 / 255 - mean) / std + erase: bit-identical,
-    in both output layouts, including a box that touches the border and an empty box."""
-    from hawkeye_amd import transforms as T
-    gen = torch.Generator().manual_seed(4)
-    u8 = torch.randint(0, 256, (3, 37, 53, 3), generator=gen, dtype=torch.uint8)
-    erase = torch.tensor([[5, 7, 10, 20], [0, 0, 0, 0], [30, 40, 7, 13]], dtype=torch.int32)
-    ref = torch.stack([T.normalize(u8[i].permute(2, 0, 1).to(torch.float32).div(255)) for i in range(3)])
-    for i, (top, left, h, w) in enumerate(erase.tolist()):
-        if h > 0 and w > 0:
-            ref[i, :, top:top + h, left:left + w] = 0.0
-    out = F.image_finalize(u8.to(DEV), erase.to(DEV), channels_last=channels_last)
-    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last if channels_last
-                                                        else torch.contiguous_format)
-    assert torch.equal(out.cpu(), ref)
-    assert torch.equal(F.image_finalize(u8.to(DEV), None, channels_last=channels_last).cpu()[1], ref[1])
-
-
-def test_presets_device_finalize_equals_cpu_path(F):
-    """The training / evaluation presets with `device_finalize=True` (uint8 out of the workers, the rest on the GPU)
-    give the same tensors as the all-CPU presets for the same random draws."""
-    import random
-
-    from PIL import Image
-
-    from hawkeye_amd import transforms as T
-    img = Image.fromarray((np.random.RandomState(5).rand(180, 240, 3) * 255).astype(np.uint8))
-    for seed in range(6):
-        cpu = T.ClassificationPresetTrain(64, random_erase_prob=0.5)
-        dev = T.ClassificationPresetTrain(64, random_erase_prob=0.5, device_finalize=True)
-        random.seed(seed)
-        a = cpu(img)
-        random.seed(seed)
-        d = dev(img)
-        out = F.image_finalize(d['u8'][None].to(DEV), d['erase'][None].to(DEV))[0]
-        assert torch.equal(out.cpu(), a), seed
-    a = T.ClassificationPresetEval(64, 80)(img)
-    d = T.ClassificationPresetEval(64, 80, device_finalize=True)(img)
-    assert torch.equal(F.image_finalize(d['u8'][None].to(DEV), d['erase'][None].to(DEV))[0].cpu(), a)
 
 
 @pytest.mark.parametrize('b,c,hw', [(2, 128, 14), (3, 192, 12), (9, 64, 8), (2, 512, 14)])
@@ -411,3 +110,304 @@ def test_cbp_row_scatter_binning(F, c, d, b, monkeypatch):
     x64 = x.cpu().double().requires_grad_(True)
     y64 = O.compact_bilinear_pool_gram(x64, d)
     assert rel(out['2'][0], y64) < 1e-5
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_image_finalize_bit_exact(F, channels_last):
+    """hk_image_finalize (SURVEY 8f-3) vs the CPU order of operations (u8 / 255 - mean) / std + erase: bit-identical,
+    in both output layouts, including a box that touches the border and an empty box."""
+    from hawkeye_amd import transforms as T
+    gen = torch.Generator().manual_seed(4)
+    u8 = torch.randint(0, 256, (3, 37, 53, 3), generator=gen, dtype=torch.uint8)
+    erase = torch.tensor([[5, 7, 10, 20], [0, 0, 0, 0], [30, 40, 7, 13]], dtype=torch.int32)
+    ref = torch.stack([T.normalize(u8[i].permute(2, 0, 1).to(torch.float32).div(255)) for i in range(3)])
+    for i, (top, left, h, w) in enumerate(erase.tolist()):
+        if h > 0 and w > 0:
+            ref[i, :, top:top + h, left:left + w] = 0.0
+    out = F.image_finalize(u8.to(DEV), erase.to(DEV), channels_last=channels_last)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last if channels_last
+                                                        else torch.contiguous_format)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(F.image_finalize(u8.to(DEV), None, channels_last=channels_last).cpu()[1], ref[1])
+
+
+def test_presets_device_finalize_equals_cpu_path(F):
+    """The training / evaluation presets with `device_finalize=True` (uint8 out of the workers, the rest on the GPU)
+    give the same tensors as the all-CPU presets for the same random draws."""
+    import random
+
+    from PIL import Image
+
+    from hawkeye_amd import transforms as T
+    img = Image.fromarray((np.random.RandomState(5).rand(180, 240, 3) * 255).astype(np.uint8))
+    for seed in range(6):
+        cpu = T.ClassificationPresetTrain(64, random_erase_prob=0.5)
+        dev = T.ClassificationPresetTrain(64, random_erase_prob=0.5, device_finalize=True)
+        random.seed(seed)
+        a = cpu(img)
+        random.seed(seed)
+        d = dev(img)
+        out = F.image_finalize(d['u8'][None].to(DEV), d['erase'][None].to(DEV))[0]
+        assert torch.equal(out.cpu(), a), seed
+    a = T.ClassificationPresetEval(64, 80)(img)
+    d = T.ClassificationPresetEval(64, 80, device_finalize=True)(img)
+    assert torch.equal(F.image_finalize(d['u8'][None].to(DEV), d['erase'][None].to(DEV))[0].cpu(), a)
+
+
+@pytest.mark.parametrize('b,j,k,bias', [(3, 1000, 7, True), (64, 4096, 200, True), (5, 333, 130, False), (10, 6272, 96, True),
+                                        (1, 40, 1, True)])
+def test_linear_split_k(F, b, j, k, bias, monkeypatch):
+    """hk_linear_fwd/bwd (classifier on the pooled vector, SURVEY 8f-1) vs torch's Linear in fp64; slab counts forced
+    through HK_LINEAR_SLABS cover one slab, ragged last slabs and the automatic choice."""
+    gen = torch.Generator().manual_seed(b * 1000 + j)
+    y = torch.randn(b, j, generator=gen)
+    w = torch.randn(k, j, generator=gen) / j ** 0.5
+    bv = torch.randn(k, generator=gen) if bias else None
+    g = torch.randn(b, k, generator=gen)
+    y64, w64 = y.double().requires_grad_(True), w.double().requires_grad_(True)
+    b64 = bv.double().requires_grad_(True) if bias else None
+    o64 = torch.nn.functional.linear(y64, w64, b64)
+    (o64 * g.double()).sum().backward()
+    for slabs in (None, '1', '3', '7'):
+        if slabs is None:
+            monkeypatch.delenv('HK_LINEAR_SLABS', raising=False)
+        else:
+            monkeypatch.setenv('HK_LINEAR_SLABS', slabs)
+        yg, wg = y.clone().to(DEV).requires_grad_(True), w.clone().to(DEV).requires_grad_(True)
+        bg = bv.clone().to(DEV).requires_grad_(True) if bias else None
+        og = F.linear(yg, wg, bg)
+        (og * g.to(DEV)).sum().backward()
+        assert rel(og, o64) < 2e-6, slabs
+        assert rel(yg.grad, y64.grad) < 2e-6 and rel(wg.grad, w64.grad) < 2e-6
+        if bias:
+            assert rel(bg.grad, b64.grad) < 2e-6
+
+
+def test_mamc_npairs_loss_vs_reference_goldens(F):
+    """hk_npairs_loss (SURVEY 8f-4) vs the REFERENCE's NPairsLoss / MAMCLoss (tests/golden/mamc_loss.npz) and the
+    oracle, including empty positive / negative sets."""
+    import os
+
+    from inputs import MAMC_CASES, rs_randn
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.loss import MAMCLoss
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mamc_loss.npz'))
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    for i, (name, (b, p, d, labels)) in enumerate(MAMC_CASES.items()):
+        x = tt(rs_randn(300 + i, (b, p, d))).to(DEV).requires_grad_(True)
+        loss = F.npairs_loss(x, torch.tensor(labels).to(DEV))
+        (3.0 * loss).backward()
+        xo = tt(rs_randn(300 + i, (b, p, d))).requires_grad_(True)
+        lo = O.npairs_loss(xo, torch.tensor(labels))
+        lo.backward()
+        assert abs(float(loss) - float(g[name + '_loss'])) <= 2e-6 * max(1.0, abs(float(g[name + '_loss']))), name
+        assert abs(float(loss) - float(lo)) <= 2e-6 * max(1.0, abs(float(lo)))
+        if float(np.abs(g[name + '_dx']).max()) > 0:
+            assert rel(x.grad / 3.0, g[name + '_dx']) < 2e-5 and rel(x.grad / 3.0, xo.grad) < 2e-5, name
+        else:
+            assert float(x.grad.abs().max()) < 1e-7
+    b, p, d, labels = MAMC_CASES['balanced']
+    x = tt(rs_randn(300, (b, p, d))).to(DEV).requires_grad_(True)
+    pred = tt(rs_randn(310, (b, 200))).to(DEV).requires_grad_(True)
+    total = MAMCLoss(CfgNode(dict(lambda_a=0.5, use_mamc=True)))((pred, x), torch.tensor(labels).to(DEV))
+    total.backward()
+    assert abs(float(total) - float(g['mamc_total'])) <= 2e-6 * abs(float(g['mamc_total']))
+    assert rel(pred.grad, g['mamc_dpred']) < 1e-5 and rel(x.grad, g['mamc_dx']) < 2e-5
+
+
+def test_mamc_npairs_loss_larger_batch(F):
+    """n = 96 anchors (32 samples x 3 attentions, 7 classes): more than one 64-row tile in both GEMMs."""
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 3, 200, generator=gen)
+    y = torch.randint(0, 7, (32,), generator=gen)
+    xo = x.clone().requires_grad_(True)
+    lo = O.npairs_loss(xo, y)
+    lo.backward()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    lg = F.npairs_loss(xg, y.to(DEV))
+    lg.backward()
+    assert abs(float(lg) - float(lo)) <= 5e-6 * abs(float(lo)) and rel(xg.grad, xo.grad) < 2e-5
+
+
+@pytest.mark.parametrize('b,c,hw', [(4, 24, 12), (2, 70, 5), (6, 130, 49)])
+def test_cin_channel_interaction_ops(F, b, c, hw):
+    """hk_cin_sci_* / hk_cin_cci_* (SURVEY 8f-2) vs torch autograd of the reference's formulas (CIN.py:31-34, 51-54) in
+    fp64: forward values, and the gradients through both branches including the one that reaches W_SCI from the
+    contrastive branch and the per-sample weights."""
+    gen = torch.Generator().manual_seed(b * 100 + c)
+    x = torch.relu(torch.randn(b, c, hw, generator=gen))
+    wt = torch.randn(b, generator=gen) * 0.7
+    g1, g2 = torch.randn(b, c, hw, generator=gen), torch.randn(b, c, hw, generator=gen)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    w_ref = torch.softmax(-torch.bmm(xr, xr.transpose(1, 2)) / hw, dim=2)
+    y_ref = torch.bmm(w_ref, xr)
+    w_ba = torch.cat((w_ref[b // 2:], w_ref[:b // 2]), 0)
+    yc_ref = torch.bmm(torch.abs(w_ref - wr.view(-1, 1, 1) * w_ba), xr)
+    ((y_ref * g1.double()).sum() + (yc_ref * g2.double()).sum()).backward()
+    xg, wg = x.clone().to(DEV).requires_grad_(True), wt.clone().to(DEV).requires_grad_(True)
+    y, w = F.cin_sci(xg)
+    yc = F.cin_cci(w, xg, wg)
+    ((y * g1.to(DEV)).sum() + (yc * g2.to(DEV)).sum()).backward()
+    assert rel(w, w_ref) < 2e-6 and rel(y, y_ref) < 2e-6 and rel(yc, yc_ref) < 5e-6
+    assert rel(xg.grad, xr.grad) < 2e-5 and rel(wg.grad, wr.grad) < 2e-5
+    # SCI alone (eval path / W unused): gradient without the extra term
+    x2 = x.clone().to(DEV).requires_grad_(True)
+    (F.cin_sci(x2)[0] * g1.to(DEV)).sum().backward()
+    x3 = x.double().requires_grad_(True)
+    (torch.bmm(torch.softmax(-torch.bmm(x3, x3.transpose(1, 2)) / hw, dim=2), x3) * g1.double()).sum().backward()
+    assert rel(x2.grad, x3.grad) < 2e-5
+
+
+def test_cin_module_matches_reference(F):
+    """hawkeye_amd's ChannelInteractionModule (HIP interaction, torch conv / fc) vs the REFERENCE module's outputs
+    and gradients (tests/golden/cin_small.npz: train mode with the contrastive branch, and eval mode)."""
+    from hawkeye_amd.model.methods.CIN import ChannelInteractionModule
+    from inputs import rs_randn, rs_relu_randn
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = _golden('cin_small')
+    m = ChannelInteractionModule(in_channel=24, spatial_size=(3, 4))
+    m.load_state_dict({k[2:].replace('__', '.'): tt(g[k]) for k in g.files if k.startswith('w_')})
+    m = m.to(DEV).train()
+    x = tt(rs_relu_randn(410, (4, 24, 3, 4))).to(DEV).requires_grad_(True)
+    z, zc = m(x)
+    ((z * tt(rs_randn(411, tuple(z.shape))).to(DEV)).sum() + (zc * tt(rs_randn(412, tuple(zc.shape))).to(DEV)).sum()).backward()
+    assert rel(z, g['z']) < 1e-5 and rel(zc, g['z_cci']) < 1e-5
+    assert rel(x.grad, g['dx']) < 1e-4
+    for k, p_ in m.named_parameters():
+        assert rel(p_.grad, g['g_' + k.replace('.', '__')]) < 1e-4, k
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(x.detach()), g['z_eval']) < 1e-5
+
+
+def test_cin_loss_matches_reference():
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.loss import CINLoss
+    from inputs import rs_randn
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = _golden('cin_small')
+    crit = CINLoss(CfgNode(dict(alpha=2.0, beta=0.5, channel=24, feature_size=12, r_channel=8)))
+    crit.h.load_state_dict({'weight': tt(g['h_w']), 'bias': tt(g['h_b'])})
+    crit = crit.to(DEV)
+    for name, labels in (('pairs', [1, 3, 1, 1]), ('nopairs', [1, 3, 0, 2])):
+        logits = tt(rs_randn(422, (4, 5))).to(DEV).requires_grad_(True)
+        zc = tt(rs_randn(423, (4, 24, 12))).to(DEV).requires_grad_(True)
+        loss = crit((logits, zc), torch.tensor(labels).to(DEV))
+        loss.backward()
+        assert abs(float(loss) - float(g[f'loss_{name}'])) < 1e-5 * max(1.0, abs(float(g[f'loss_{name}'])))
+        assert rel(logits.grad, g[f'loss_{name}_dlogits']) < 1e-5
+        if float(np.abs(g[f'loss_{name}_dz']).max()) > 0:
+            assert rel(zc.grad, g[f'loss_{name}_dz']) < 1e-4
+    assert abs(float(crit(tt(rs_randn(422, (4, 5))).to(DEV), torch.tensor([1, 3, 1, 1]).to(DEV)))) > 0   # eval: plain CE
+
+
+@pytest.mark.parametrize('b,d,itn', [(3, 70, 5), (2, 128, 5), (9, 64, 3), (2, 33, 2)])
+def test_ns_symmetric_tile_mode(F, b, d, itn, monkeypatch):
+    """HK_NS_SYM=1: upper-triangle tiles only + mirrored stores for the symmetric products of the Newton-Schulz chain,
+    and Z Y taken as the transpose of Y Z in the backward (38 -> 34 launches).  Same tolerances as the full products."""
+    x = torch.relu(torch.randn(b, d, 6, 7, generator=torch.Generator().manual_seed(d))) + 0.01
+    xo = x.clone().requires_grad_(True)
+    yo = O.triuvec(O.sqrtm(O.covpool(xo), itn))
+    wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))
+    (yo * wt).sum().backward()
+    res = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('HK_NS_SYM', flag)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        cov = F.covpool(xg)
+        s = F.sqrtm(cov, itn)
+        yg = F.triuvec(s)
+        (yg * wt.to(DEV)).sum().backward()
+        assert rel(yg, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
+        if flag == '1':
+            assert rel(s, s.transpose(1, 2)) < 1e-6            # off-diagonal tiles mirrored, diagonal tiles computed
+        res.append((yg.detach(), xg.grad))
+    assert rel(res[1][0], res[0][0]) < 5e-6 and rel(res[1][1], res[0][1]) < 5e-5
+
+
+@pytest.mark.parametrize('b,d,itn', [(2, 128, 5), (3, 200, 3), (9, 256, 2), (3, 70, 4)])
+def test_ns_128_tile_gemm_variant(F, b, d, itn, monkeypatch):
+    """HK_NS_GEMM=4: the Newton-Schulz products on bgemm128_kernel (128x128 tile, 8 waves, two-chunk prefetch through
+    two register sets).  Same k order as the 64x64 kernel, so results agree to rounding of the tile boundaries only."""
+    x = torch.relu(torch.randn(b, d, 5, 6, generator=torch.Generator().manual_seed(d + 1))) + 0.01
+    xo = x.clone().requires_grad_(True)
+    yo = O.sqrtm(O.covpool(xo), itn)
+    wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(2))
+    (yo * wt).sum().backward()
+    res = []
+    for flag in ('0', '4', '5'):                         # 5: the same two-chunk prefetch on the 64x64 tile
+        monkeypatch.setenv('HK_NS_GEMM', flag)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        yg = F.sqrtm(F.covpool(xg), itn)
+        (yg * wt.to(DEV)).sum().backward()
+        assert rel(yg, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
+        res.append((yg.detach(), xg.grad))
+    assert rel(res[1][0], res[0][0]) < 2e-6 and rel(res[1][1], res[0][1]) < 2e-5
+    assert torch.equal(res[2][0], res[0][0]) and torch.equal(res[2][1], res[0][1])    # same tile, same k order: bit-identical
+
+
+_MODEL_CFG = {
+    'BCNN': dict(stage=2, num_classes=200),
+    'CBCNN': dict(stage=2, num_classes=200, input_channel=512, output_channel=6000),
+    'MPN': dict(iter_num=5, is_sqrt=True, is_vec=True, input_dim=2048, dimension_reduction=256, num_classes=200),
+}
+
+
+@pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN'])
+def test_models_with_hip_classifier(F, name, monkeypatch):
+    """HAWKEYE_HIP_LINEAR=1: the classifier on the pooled vector runs on hk_linear_* - logits still match the REFERENCE
+    model's (tests/golden/model_logits.npz) and a train step gives the same classifier gradient as torch's Linear."""
+    import os
+
+    import hawkeye_amd.model  # noqa: F401
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.registry import MODEL
+    from inputs import rs_randn, seeded_init
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'model_logits.npz'))
+    m = MODEL.get(name)(CfgNode(dict(name=name, **_MODEL_CFG[name])))
+    seeded_init(m, 900)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(np.ascontiguousarray(rs_randn(901, (2, 3, 64, 64)))).to(DEV)
+    grads = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('HAWKEYE_HIP_LINEAR', flag)
+        m.zero_grad()
+        y = m(x)
+        assert rel(y, g[name]) < 1e-4 and y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
+        torch.nn.functional.cross_entropy(y, torch.tensor([3, 77], device=y.device)).backward()
+        grads.append((m.classifier.weight.grad.clone(), m.classifier.bias.grad.clone(),
+                      next(m.backbone.parameters()).grad.clone()))
+    # the trunk gradient goes through MIOpen's weight-gradient kernels (split-K with atomics: not bitwise repeatable)
+    for (p, q), tol in zip(zip(grads[0], grads[1]), (1e-5, 1e-5, 1e-4)):
+        assert rel(q, p) < tol
+
+
+def test_cin_model_matches_reference(F):
+    """The registered CIN plugin end to end at 224x224 vs the reference model (tests/golden/model_cin.npz): eval logits,
+    train-mode logits and Z_CCI, criterion value."""
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.loss import CINLoss
+    from hawkeye_amd.model.registry import MODEL
+    import hawkeye_amd.model  # noqa: F401
+    from inputs import rs_randn, seeded_init, sub
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = _golden('model_cin')
+    m = MODEL.get('CIN')(CfgNode(dict(name='CIN', num_classes=200)))
+    seeded_init(m, 930)
+    m = m.to(DEV)
+    x = tt(rs_randn(931, (4, 3, 224, 224))).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        le = m(x)
+    assert rel(le, g['logits_eval']) < 1e-4 and le.argmax(1).cpu().tolist() == g['logits_eval'].argmax(1).tolist()
+    m.train()
+    with torch.no_grad():
+        lt, zc = m(x)
+    # train mode: BatchNorm over 4 images divides by batch statistics, which amplifies conv-algorithm differences
+    assert rel(lt, g['logits_train']) < 1e-3 and rel(sub(zc.cpu(), 97), g['z_cci_sub']) < 1e-3
+    crit = CINLoss(CfgNode(dict(alpha=2.0, beta=0.5, channel=2048, feature_size=49, r_channel=16)))
+    with torch.no_grad():
+        crit.h.weight.copy_(tt(rs_randn(932, tuple(crit.h.weight.shape))) * 1e-3)
+        crit.h.bias.zero_()
+        loss = crit.to(DEV)((lt, zc), torch.tensor([5, 9, 5, 9]).to(DEV))
+    assert abs(float(loss) - float(g['loss'])) < 3e-3 * abs(float(g['loss']))
