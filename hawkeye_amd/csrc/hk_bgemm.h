@@ -416,6 +416,145 @@ __global__ __launch_bounds__(BMN == 128 ? 512 : 256) void bgemm_p2_kernel(AL al,
     al.finish(b, tm, tn, tilesM, lds);
 }
 
+// ---------------------------------------------------------------- fp32 product on the bf16 matrix pipe (split operands)
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of the f32-input MFMA.  An fp32 value splits EXACTLY into three
+// bf16 pieces a = a1 + a2 + a3 (8 mantissa bits each: a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2); the
+// subtractions are exact in fp32), every piece product is exact in the fp32 accumulator, and
+//     a b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + O(2^-32 |a b|)
+// so SIX bf16 MFMAs per 16-deep k step reproduce the fp32 product to the accumulator's own rounding (NT = 6: 16/6 =
+// 2.7x the f32-MFMA rate), and THREE keep everything above 2^-16 |a b| (NT = 3: 5.3x, relative error ~1e-5 per product
+// before averaging).  Terms are added smallest first.  The operands are split once, when the tile is staged into
+// LDS (three bf16 planes per operand; B is transposed on the way in so that both fragments are 16-byte reads).
+// Opt-in for the Newton-Schulz products (HK_NS_GEMM=6 / 7): written after round 1's GPU budget was spent; the
+// emulation models the operand layout as "lane l holds A[i = l % 32][k = 8 (l / 32) .. + 7]" (B alike), which still
+// has to be confirmed on the device - a wrong layout fails the parity tests loudly, it cannot pass by accident.
+typedef __bf16 hk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short hk_u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short hk_u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {           // round to nearest even (finite inputs)
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ void bf16_split3(float a, unsigned short& p1, unsigned short& p2, unsigned short& p3) {
+    p1 = bf16_rne(a);
+    const float r1 = a - bf16_f32(p1);
+    p2 = bf16_rne(r1);
+    p3 = bf16_rne(r1 - bf16_f32(p2));
+}
+
+template <int NT, class AL, class BL, class EP>
+__global__ __launch_bounds__(256) void bgemm_bf16split_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb, int tilesM,
+                                                              int tilesN) {
+    static_assert(NT == 3 || NT == 6, "three or six piece products");
+    constexpr int BM = 64, BN = 64, BK = 32, PK = BK + 8;      // 80-byte rows: 16-byte aligned fragments
+    constexpr int PLANE = 64 * PK;                               // one bf16 plane of one operand
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 2 * 3 * PLANE];   // [stage][A|B][piece]
+
+    int b, tile;
+    if (!xcd_map(blockIdx.x, nb, tilesM * tilesN, b, tile)) return;
+    const int tm = tile / tilesN, tn = tile % tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    float4 ra[2], rb[2];                                         // A: [m][k] k-contiguous ; B: [k][n] n-contiguous
+#define HK_GLOADX(k0)                                                                   \
+    do {                                                                                \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                 \
+            const int f_ = tid + 256 * u;                                               \
+            ra[u] = al.ld4(b, m0 + f_ / 8, (k0) + 4 * (f_ % 8));                        \
+            rb[u] = bl.ld4(b, (k0) + f_ / 16, n0 + 4 * (f_ % 16));                      \
+        }                                                                               \
+    } while (0)
+#define HK_SSTOREX(buf)                                                                 \
+    do {                                                                                \
+        unsigned short* As_ = lds + (buf) * 6 * PLANE;                                  \
+        unsigned short* Bs_ = As_ + 3 * PLANE;                                          \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                 \
+            const int f_ = tid + 256 * u;                                               \
+            const float av_[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w};                  \
+            const float bv_[4] = {rb[u].x, rb[u].y, rb[u].z, rb[u].w};                  \
+            hk_u16x4 p1_, p2_, p3_;                                                     \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                             \
+                unsigned short x1_, x2_, x3_;                                           \
+                bf16_split3(av_[t], x1_, x2_, x3_);                                     \
+                p1_[t] = x1_; p2_[t] = x2_; p3_[t] = x3_;                               \
+            }                                                                           \
+            const int ao_ = (f_ / 8) * PK + 4 * (f_ % 8);           /* row m, 4 consecutive k */ \
+            *reinterpret_cast<hk_u16x4*>(&As_[ao_]) = p1_;                              \
+            *reinterpret_cast<hk_u16x4*>(&As_[PLANE + ao_]) = p2_;                      \
+            *reinterpret_cast<hk_u16x4*>(&As_[2 * PLANE + ao_]) = p3_;                  \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {         /* B transposed: [n][k] */ \
+                unsigned short x1_, x2_, x3_;                                           \
+                bf16_split3(bv_[t], x1_, x2_, x3_);                                     \
+                const int bo_ = (4 * (f_ % 16) + t) * PK + f_ / 16;                     \
+                Bs_[bo_] = x1_; Bs_[PLANE + bo_] = x2_; Bs_[2 * PLANE + bo_] = x3_;     \
+            }                                                                           \
+        }                                                                               \
+    } while (0)
+
+    const int nk = (K + BK - 1) / BK;
+    HK_GLOADX(0);
+    HK_SSTOREX(0);
+    __syncthreads();
+    for (int c = 0; c < nk; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nk) HK_GLOADX((c + 1) * BK);
+        const unsigned short* As = lds + cur * 6 * PLANE;
+        const unsigned short* Bs = As + 3 * PLANE;
+        const int arow = (wm * 32 + l31) * PK, bcol = (wn * 32 + l31) * PK;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int ko = 16 * s + 8 * lh;
+            hk_bf16x8 a[3], q[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = __builtin_bit_cast(hk_bf16x8, *reinterpret_cast<const hk_u16x8*>(&As[p * PLANE + arow + ko]));
+                q[p] = __builtin_bit_cast(hk_bf16x8, *reinterpret_cast<const hk_u16x8*>(&Bs[p * PLANE + bcol + ko]));
+            }
+            if (NT == 6) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], q[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], q[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], q[2], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], q[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], q[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], q[0], acc, 0, 0, 0);
+        }
+        if (c + 1 < nk) HK_SSTOREX(cur ^ 1);
+        __syncthreads();
+    }
+#undef HK_GLOADX
+#undef HK_SSTOREX
+
+    const int jj = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ii = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ii < M && jj < N) ep(b, ii, jj, acc[r]);
+    }
+}
+
+// A row-major [M][K], B row-major [K][N] (the Newton-Schulz `mm` form)
+template <int NT, class AL, class BL, class EP>
+static inline int bgemm_bf16split_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb,
+                                         hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
+    const int tm = (M + 63) / 64, tn = (N + 63) / 64;
+    hipLaunchKernelGGL((bgemm_bf16split_kernel<NT, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl, ep, M,
+                       N, K, nb, tm, tn);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
 template <bool A_KC, bool B_KC, class AL, class BL, class EP>
 static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb,
                                hipStream_t st, int allow_big = 0) {

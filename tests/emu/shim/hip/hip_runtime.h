@@ -86,7 +86,7 @@ constexpr size_t STACK_BYTES = 512 * 1024;
 struct Wave {
     int alive = 0, arrived = 0;
     unsigned gen = 0;
-    uint64_t slot[2][64][2];   // exchange slots of the two most recent collectives
+    uint64_t slot[2][64][4];   // exchange slots (32 bytes per lane) of the two most recent collectives
 };
 struct Fiber {
     void* sp = nullptr;          // saved stack pointer while switched out
@@ -309,6 +309,39 @@ inline v4f mfma_f32_16x16x4(float a, float b, v4f c, int, int, int) {
     return c;
 }
 
+// v_mfma_f32_32x32x16_bf16 (gfx950): lane l supplies eight consecutive k of row / column l % 32, k = 8 (l / 32) + 0..7;
+// C/D as the other 32x32 forms.  (The A/B layout is this model's assumption - see hk_bgemm.h - until confirmed on
+// the device.)  Piece products are exact in fp32; they are accumulated as an fp32 fma chain in k order.
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+inline v16f mfma_f32_32x32x16_bf16(v8bf a, v8bf b, v16f c, int, int, int) {
+    Wave& w = B->waves[cur->wave];
+    const unsigned p = cur->parity;
+    cur->parity ^= 1u;
+    const int l = cur->lane;
+    memcpy(&w.slot[p][l][0], &a, 16);
+    memcpy(&w.slot[p][l][2], &b, 16);
+    wave_barrier();
+    const int j = l % 32, hb = l / 32;
+    for (int v = 0; v < 16; ++v) {
+        const int i = 8 * (v / 4) + 4 * hb + v % 4;
+        float acc = c[v];
+        for (int kb = 0; kb < 2; ++kb) {
+            uint16_t ai[8], bj[8];
+            memcpy(ai, &w.slot[p][32 * kb + i][0], 16);
+            memcpy(bj, &w.slot[p][32 * kb + j][2], 16);
+            for (int t = 0; t < 8; ++t) {
+                uint32_t ua = (uint32_t)ai[t] << 16, ub = (uint32_t)bj[t] << 16;
+                float fa, fb;
+                memcpy(&fa, &ua, 4);
+                memcpy(&fb, &ub, 4);
+                acc = fmaf(fa, fb, acc);
+            }
+        }
+        c[v] = acc;
+    }
+    return c;
+}
+
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur->tid)
@@ -322,6 +355,7 @@ inline v4f mfma_f32_16x16x4(float a, float b, v4f c, int, int, int) {
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_f32_32x32x2
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_f32_16x16x4
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_f32_32x32x16_bf16
 
 template <class T>
 inline T __shfl_xor(T v, int mask, int = 64) {

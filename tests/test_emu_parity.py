@@ -33,7 +33,8 @@ for _mod in _modules:
 _HEAVY = {'test_cbp_rowsketch_equals_csr[512-6000-40]', 'test_models_with_hip_classifier[BCNN]',
           'test_models_with_hip_classifier[MPN]', 'test_cin_model_matches_reference',
           'test_ns_128_tile_gemm_variant[9-256-2]', 'test_ns_128_tile_gemm_variant[3-200-3]',
-          'test_cov_and_cbp_panel_kernels_vs_generic[70-256-8]', 'test_mpn_256_vs_golden'}
+          'test_cov_and_cbp_panel_kernels_vs_generic[70-256-8]', 'test_mpn_256_vs_golden',
+          'test_ns_bf16_split_products[2-200-4]', 'test_ns_bf16_split_products[2-128-5]'}
 
 
 @pytest.fixture(autouse=True)

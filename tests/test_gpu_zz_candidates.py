@@ -346,6 +346,27 @@ def test_ns_128_tile_gemm_variant(F, b, d, itn, monkeypatch):
     assert torch.equal(res[2][0], res[0][0]) and torch.equal(res[2][1], res[0][1])    # same tile, same k order: bit-identical
 
 
+@pytest.mark.parametrize('b,d,itn', [(2, 128, 5), (3, 70, 3), (2, 200, 4)])
+def test_ns_bf16_split_products(F, b, d, itn, monkeypatch):
+    """HK_NS_GEMM=6 / 7: the fp32 products of the Newton-Schulz chain computed on the bf16 matrix pipe from operands
+    split exactly into three bf16 pieces - six piece products reproduce fp32 to its own rounding level (same bounds as
+    the f32-MFMA path), three keep 1e-5 (inside the 1e-4 parity budget).  On the device this also confirms the
+    operand layout assumed for v_mfma_f32_32x32x16_bf16: a wrong one cannot pass."""
+    x = torch.relu(torch.randn(b, d, 6, 7, generator=torch.Generator().manual_seed(d + 3))) + 0.01
+    xo = x.clone().requires_grad_(True)
+    yo = O.sqrtm(O.covpool(xo), itn)
+    wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(4))
+    (yo * wt).sum().backward()
+    for flag, tol_f, tol_b in (('6', 1e-5, 1e-4), ('7', 1e-4, 1e-3)):
+        monkeypatch.setenv('HK_NS_GEMM', flag)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        yg = F.sqrtm(F.covpool(xg), itn)
+        (yg * wt.to(DEV)).sum().backward()
+        assert rel(yg, yo) < tol_f and rel(xg.grad, xo.grad) < tol_b, flag
+        if flag == '6':
+            assert rel(yg, yo) < 4e-6 and rel(xg.grad, xo.grad) < 4e-6       # fp32-equivalent in practice
+
+
 _MODEL_CFG = {
     'BCNN': dict(stage=2, num_classes=200),
     'CBCNN': dict(stage=2, num_classes=200, input_channel=512, output_channel=6000),
