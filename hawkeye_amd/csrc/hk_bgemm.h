@@ -543,6 +543,138 @@ __global__ __launch_bounds__(256) void bgemm_bf16split_kernel(AL al, BL bl, EP e
     }
 }
 
+// The same split products on the 128x128 / 8-wave / two-chunk-prefetch structure of bgemm_p2_kernel<128>: half the
+// split work per multiply-add of the 64x64 tile (the split costs ~10 VALU operations per staged element, more than the
+// six MFMAs of a 64x64x32 chunk take), 32 FLOP/B of L2 traffic, 120 KB of LDS (one 8-wave workgroup per CU).
+template <int NT, class AL, class BL, class EP>
+__global__ __launch_bounds__(512) void bgemm_bf16split128_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb,
+                                                                 int tilesM, int tilesN) {
+    static_assert(NT == 3 || NT == 6, "three or six piece products");
+    constexpr int BM = 128, BN = 128, BK = 32, PK = BK + 8;
+    constexpr int PLANE = 128 * PK;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 2 * 3 * PLANE];   // [stage][A|B][piece] = 120 KB
+
+    int b, tile;
+    if (!xcd_map(blockIdx.x, nb, tilesM * tilesN, b, tile)) return;
+    const int tm = tile / tilesN, tn = tile % tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves: 32 rows x 64 columns each
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    float4 ra0[2], rb0[2], ra1[2], rb1[2];                       // two register sets: chunks in flight
+#define HK_GLOADY(RA, RB, k0)                                                           \
+    do {                                                                                \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                 \
+            const int f_ = tid + 512 * u;                                               \
+            RA[u] = al.ld4(b, m0 + f_ / 8, (k0) + 4 * (f_ % 8));                        \
+            RB[u] = bl.ld4(b, (k0) + f_ / 32, n0 + 4 * (f_ % 32));                      \
+        }                                                                               \
+    } while (0)
+#define HK_SSTOREY(RA, RB, buf)                                                         \
+    do {                                                                                \
+        unsigned short* As_ = lds + (buf) * 6 * PLANE;                                  \
+        unsigned short* Bs_ = As_ + 3 * PLANE;                                          \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                 \
+            const int f_ = tid + 512 * u;                                               \
+            const float av_[4] = {RA[u].x, RA[u].y, RA[u].z, RA[u].w};                  \
+            const float bv_[4] = {RB[u].x, RB[u].y, RB[u].z, RB[u].w};                  \
+            hk_u16x4 p1_, p2_, p3_;                                                     \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                             \
+                unsigned short x1_, x2_, x3_;                                           \
+                bf16_split3(av_[t], x1_, x2_, x3_);                                     \
+                p1_[t] = x1_; p2_[t] = x2_; p3_[t] = x3_;                               \
+            }                                                                           \
+            const int ao_ = (f_ / 8) * PK + 4 * (f_ % 8);                               \
+            *reinterpret_cast<hk_u16x4*>(&As_[ao_]) = p1_;                              \
+            *reinterpret_cast<hk_u16x4*>(&As_[PLANE + ao_]) = p2_;                      \
+            *reinterpret_cast<hk_u16x4*>(&As_[2 * PLANE + ao_]) = p3_;                  \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {         /* B transposed: [n][k] */ \
+                unsigned short x1_, x2_, x3_;                                           \
+                bf16_split3(bv_[t], x1_, x2_, x3_);                                     \
+                const int bo_ = (4 * (f_ % 32) + t) * PK + f_ / 32;                     \
+                Bs_[bo_] = x1_; Bs_[PLANE + bo_] = x2_; Bs_[2 * PLANE + bo_] = x3_;     \
+            }                                                                           \
+        }                                                                               \
+    } while (0)
+#define HK_COMPUTEY(buf)                                                                \
+    do {                                                                                \
+        const unsigned short* As = lds + (buf) * 6 * PLANE;                             \
+        const unsigned short* Bs = As + 3 * PLANE;                                      \
+        const int arow_ = (wm * 32 + l31) * PK, c0_ = (wn * 64 + l31) * PK, c1_ = c0_ + 32 * PK; \
+        _Pragma("unroll") for (int s = 0; s < BK / 16; ++s) {                           \
+            const int ko_ = 16 * s + 8 * lh;                                            \
+            hk_bf16x8 a_[3], p_[3], q_[3];                                              \
+            _Pragma("unroll") for (int e = 0; e < 3; ++e) {                             \
+                a_[e] = __builtin_bit_cast(hk_bf16x8, *reinterpret_cast<const hk_u16x8*>(&As[e * PLANE + arow_ + ko_])); \
+                p_[e] = __builtin_bit_cast(hk_bf16x8, *reinterpret_cast<const hk_u16x8*>(&Bs[e * PLANE + c0_ + ko_]));   \
+                q_[e] = __builtin_bit_cast(hk_bf16x8, *reinterpret_cast<const hk_u16x8*>(&Bs[e * PLANE + c1_ + ko_]));   \
+            }                                                                           \
+            if (NT == 6) {                                                              \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[2], p_[0], acc0, 0, 0, 0); \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[2], q_[0], acc1, 0, 0, 0); \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], p_[1], acc0, 0, 0, 0); \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], q_[1], acc1, 0, 0, 0); \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], p_[2], acc0, 0, 0, 0); \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], q_[2], acc1, 0, 0, 0); \
+            }                                                                           \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], p_[0], acc0, 0, 0, 0);     \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], q_[0], acc1, 0, 0, 0);     \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], p_[1], acc0, 0, 0, 0);     \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], q_[1], acc1, 0, 0, 0);     \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], p_[0], acc0, 0, 0, 0);     \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], q_[0], acc1, 0, 0, 0);     \
+        }                                                                               \
+    } while (0)
+
+    const int nk = (K + BK - 1) / BK;
+    HK_GLOADY(ra0, rb0, 0);
+    HK_SSTOREY(ra0, rb0, 0);
+    if (nk > 1) HK_GLOADY(ra1, rb1, BK);
+    __syncthreads();
+    for (int c = 0; c < nk; c += 2) {                            // same two-register-set schedule as bgemm_p2_kernel
+        if (c + 2 < nk) HK_GLOADY(ra0, rb0, (c + 2) * BK);
+        HK_COMPUTEY(0);
+        if (c + 1 < nk) HK_SSTOREY(ra1, rb1, 1);
+        __syncthreads();
+        if (c + 1 < nk) {
+            if (c + 3 < nk) HK_GLOADY(ra1, rb1, (c + 3) * BK);
+            HK_COMPUTEY(1);
+            if (c + 2 < nk) HK_SSTOREY(ra0, rb0, 0);
+            __syncthreads();
+        }
+    }
+#undef HK_GLOADY
+#undef HK_SSTOREY
+#undef HK_COMPUTEY
+
+    const int ib = m0 + wm * 32 + 4 * lh;
+    const int j0 = n0 + wn * 64 + l31, j1 = j0 + 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ii = ib + (r & 3) + 8 * (r >> 2);
+        if (ii < M) {
+            if (j0 < N) ep(b, ii, j0, acc0[r]);
+            if (j1 < N) ep(b, ii, j1, acc1[r]);
+        }
+    }
+}
+
+template <int NT, class AL, class BL, class EP>
+static inline int bgemm_bf16split128_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb,
+                                            hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
+    const int tm = (M + 127) / 128, tn = (N + 127) / 128;
+    hipLaunchKernelGGL((bgemm_bf16split128_kernel<NT, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(512), 0, st, al, bl, ep,
+                       M, N, K, nb, tm, tn);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
 // A row-major [M][K], B row-major [K][N] (the Newton-Schulz `mm` form)
 template <int NT, class AL, class BL, class EP>
 static inline int bgemm_bf16split_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb,

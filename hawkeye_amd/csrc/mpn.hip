@@ -164,13 +164,16 @@ static inline int mm(const float* A, long long sa, const float* Bm, long long sb
     if (sym_result && ns_sym()) return bgemm_launch_sym<true, false>(la, lb, ep, d, d, nb, st);
     // A/B switch: 0 = 64x64x32 (default), 1 = 128x128x32 / 4 waves, 2 = 64x64x64, 3 = 64x64x16,
     //             4 = 128x128x32 / 8 waves / two-chunk prefetch, 5 = 64x64x32 / two-chunk prefetch,
-    //             6 / 7 = fp32 product from six / three bf16 piece products on the bf16 matrix pipe (hk_bgemm.h)
+    //             6 / 7 = fp32 product from six / three bf16 piece products on the bf16 matrix pipe (hk_bgemm.h),
+    //             8 / 9 = the same on the 128x128 / 8-wave / two-chunk-prefetch tile
     const char* e = getenv("HK_NS_GEMM");
     const int variant = e ? atoi(e) : 0;
     if (variant == 4 && d >= 128) return bgemm128_launch<true, false>(la, lb, ep, d, d, d, nb, st);
     if (variant == 5) return bgemm64p2_launch<true, false>(la, lb, ep, d, d, d, nb, st);
     if (variant == 6) return bgemm_bf16split_launch<6>(la, lb, ep, d, d, d, nb, st);
     if (variant == 7) return bgemm_bf16split_launch<3>(la, lb, ep, d, d, d, nb, st);
+    if (variant == 8 && d >= 128) return bgemm_bf16split128_launch<6>(la, lb, ep, d, d, d, nb, st);
+    if (variant == 9 && d >= 128) return bgemm_bf16split128_launch<3>(la, lb, ep, d, d, d, nb, st);
     return bgemm_launch<true, false>(la, lb, ep, d, d, d, nb, st, variant);
 }
 

@@ -122,7 +122,7 @@ def ns_sym():
     nwf, nwb = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 0), lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 1)
     wf, wb = torch.empty(nwf, dtype=torch.uint8, device=dev), torch.empty(nwb, dtype=torch.uint8, device=dev)
     ref = None
-    for sym, gemm in (('0', '0'), ('1', '0'), ('0', '4'), ('1', '4'), ('0', '5'), ('0', '6'), ('0', '7')):
+    for sym, gemm in (('0', '0'), ('1', '0'), ('0', '4'), ('1', '4'), ('0', '5'), ('0', '6'), ('0', '7'), ('0', '8'), ('0', '9')):
         os.environ['HK_NS_SYM'], os.environ['HK_NS_GEMM'] = sym, gemm
         f = timeit(lambda: lib.hk_ns_sqrtm_fwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), B, d, 5, ptr(wf), nwf, stream()))
         b = timeit(lambda: lib.hk_ns_sqrtm_bwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), ptr(g), ptr(da), B, d, 5,
