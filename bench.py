@@ -5,6 +5,7 @@ BASELINE.json configs[1] (`BCNN_S2.yaml on 1xMI355X`).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+(the first form with N > 1 re-executes itself as the second one: one process per GPU over RCCL)
 
 One step = one minibatch already resident in HBM -> model forward (VGG-16 on
 MIOpen, bilinear pooling on the gfx950 kernels) -> CrossEntropy(label_smoothing
@@ -58,7 +59,35 @@ def parse():
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--backend', default=None, help='process-group backend override (debug: gloo lets N ranks share one GPU)')
     ap.add_argument('--share-gpu', action='store_true', help='debug: every rank uses cuda:0')
+    ap.add_argument('--force-pg', action='store_true',
+                    help='create the process group even for one rank: the bucketed RCCL all-reduce path then executes on a '
+                         'one-GPU box (adds `ddp_timeline` to the JSON line)')
+    ap.add_argument('--ddp-trace', action='store_true', help='N > 1: add `ddp_timeline` (where in the backward each '
+                                                             'gradient bucket\'s all-reduce was issued)')
+    ap.add_argument('--no-other-models', action='store_true',
+                    help='skip the subprocess that times the other BASELINE.json configs (MPN, CBCNN, APCNN-8142)')
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def respawn_one_rank_per_gpu(a):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` (one process per
+    GPU; rank 0 prints the JSON line).  Replaces train.py:220-228's single-process nn.DataParallel."""
+    if not a.share_gpu and torch.cuda.device_count() < a.gpus:
+        sys.exit(f'bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} GPU(s) visible '
+                 f'(--share-gpu --backend gloo runs the ranks on one GPU for a functional check)')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def build_model(name, classes):
@@ -212,14 +241,39 @@ def candidates(timeout_s=150):
         return {'error': repr(e)[:300]}
 
 
+def other_models(timeout_s=240):
+    """The other BASELINE.json configs on this GPU (configs[2..4] at their single-GPU shapes): MPN bs64, CBCNN bs64 /
+    bs16, AP-CNN with the iNat2018 class count (8142) bs16 - ms/step, images/sec and the per-kernel rooflines of their
+    pooling heads (tools/model_rows.py).  Subprocess after the headline, like `candidates`: cannot touch `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'model_rows.py')]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {'error': f'timeout after {timeout_s}s'}
+    except Exception as e:  # noqa: BLE001
+        return {'error': repr(e)[:300]}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('[')]
+    if p.returncode != 0 or not lines:
+        return {'error': f'rc={p.returncode}', 'stderr_tail': p.stderr[-400:]}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {'error': repr(e)[:300]}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        respawn_one_rank_per_gpu(a)                        # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    if world != a.gpus:
+        sys.exit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}')
     from hawkeye_amd import ddp
     if a.share_gpu:
         os.environ['LOCAL_RANK'] = '0'
-    rank, world, local = ddp.init_from_env((a.backend or 'nccl') if world > 1 else None)
+    use_pg = world > 1 or a.force_pg
+    rank, world, local = ddp.init_from_env((a.backend or 'nccl') if use_pg else None, force=a.force_pg)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
@@ -240,7 +294,7 @@ def main():
                 else CINLoss(CfgNode(dict(alpha=2.0, beta=0.5))).to(dev))
         params += list(crit.parameters())
     opt = torch.optim.SGD(params, lr=0.005, momentum=0.9, weight_decay=1e-5)   # configs/BCNN_S2
-    reducer = ddp.GradientAllReducer(model) if world > 1 else None
+    reducer = ddp.GradientAllReducer(model, trace=a.force_pg or a.ddp_trace) if use_pg else None
 
     g = torch.Generator(device=dev).manual_seed(rank)
     images = torch.randn(a.batch, 3, a.image, a.image, device=dev, generator=g)
@@ -313,9 +367,15 @@ def main():
             res['kernels'] = ks
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.image, a.classes)
+        if reducer is not None and reducer.trace:
+            res['ddp_timeline'] = reducer.timeline()
+            res['ddp_buckets_mib'] = [mb for _, mb in reducer.describe()]
         if world == 1 and not a.no_candidates and a.model == 'BCNN':
             torch.cuda.empty_cache()
             res['candidates'] = candidates()
+        if world == 1 and not a.no_other_models and a.model == 'BCNN' and not a.force_pg:
+            torch.cuda.empty_cache()
+            res['other_models'] = other_models()
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -22,6 +22,8 @@ c_fl = ctypes.c_float
 # name -> (restype, argtypes); mirrors include/hawkeye_hip.h one to one
 SIGNATURES = {
     'hk_version': (ctypes.c_char_p, []),
+    'hk_tuning_set': (c_i, [ctypes.c_char_p, c_i]),
+    'hk_tuning_get': (c_i, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     'hk_bcnn_pool_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'hk_bcnn_pool_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
@@ -105,7 +107,37 @@ def ptr(t):
                               'the CPU reference lives in oracle/ and is test infrastructure)')
     if not t.is_contiguous():
         raise HawkeyeHipError('internal error: non-contiguous tensor handed to the C ABI')
+    if t.device.index != torch.cuda.current_device():
+        # the library launches on the CURRENT device's stream (one process per GPU: Trainer / Tester / bench.py call
+        # torch.cuda.set_device once); a tensor of another device would be touched from the wrong stream
+        raise HawkeyeHipError(f'tensor lives on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: '
+                              f'call torch.cuda.set_device({t.device.index}) (one process per GPU) or wrap the call in '
+                              f'`with torch.cuda.device(...)`')
     return ctypes.c_void_p(t.data_ptr())
+
+
+class tuning:
+    """`with tuning(ns_tn=64, bcnn_generic=1): ...` - flips A/B knobs of the library (hk_tuning_set) for tests and
+    benchmarks and restores the previous values on exit.  Not used by the product path."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+        self.saved = {}
+
+    def __enter__(self):
+        lib = load()
+        for name, value in self.knobs.items():
+            old = ctypes.c_int(0)
+            check(lib.hk_tuning_get(name.encode(), ctypes.byref(old)), f'hk_tuning_get({name})')
+            self.saved[name] = old.value
+            check(lib.hk_tuning_set(name.encode(), int(value)), f'hk_tuning_set({name})')
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for name, value in self.saved.items():
+            lib.hk_tuning_set(name.encode(), value)
+        return False
 
 
 def stream():

@@ -1,8 +1,59 @@
 // Library identification + the generic batched f32-MFMA GEMM entry point.
+#include <cstdlib>
+#include <cstring>
+
 #include "hk_bgemm.h"
 #include "../../include/hawkeye_hip.h"
 
+namespace hk {
+
+namespace {
+struct Knob {
+    const char* name;
+    const char* env;
+    int Tuning::*field;
+};
+const Knob kKnobs[] = {
+    {"bcnn_generic", "HK_BCNN_GENERIC", &Tuning::bcnn_generic}, {"cbp_bin", "HK_CBP_BIN", &Tuning::cbp_bin},
+    {"roi_bwd", "HK_ROI_BWD", &Tuning::roi_bwd},                {"linear_slabs", "HK_LINEAR_SLABS", &Tuning::linear_slabs},
+    {"ns_tn", "HK_NS_TN", &Tuning::ns_tn},                      {"bwd_v", "HK_BWD_V", &Tuning::bwd_v},
+};
+Tuning from_env() {
+    Tuning t;
+    for (const Knob& k : kKnobs)
+        if (const char* e = getenv(k.env)) t.*(k.field) = atoi(e);
+    return t;
+}
+}  // namespace
+
+Tuning& tuning() {
+    static Tuning t = from_env();
+    return t;
+}
+
+}  // namespace hk
+
 using namespace hk;
+
+extern "C" int hk_tuning_set(const char* name, int value) {
+    if (!name) return HK_ERR_BAD_ARG;
+    for (const Knob& k : kKnobs)
+        if (!strcmp(name, k.name)) {
+            tuning().*(k.field) = value;
+            return HK_OK;
+        }
+    return HK_ERR_BAD_ARG;
+}
+
+extern "C" int hk_tuning_get(const char* name, int* value) {
+    if (!name || !value) return HK_ERR_BAD_ARG;
+    for (const Knob& k : kKnobs)
+        if (!strcmp(name, k.name)) {
+            *value = tuning().*(k.field);
+            return HK_OK;
+        }
+    return HK_ERR_BAD_ARG;
+}
 
 extern "C" const char* hk_version(void) { return "hawkeye_hip 0.1 gfx950"; }
 

@@ -667,14 +667,14 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
     //   bcnn_bwd_v3_kernel    (HK_BWD_V=3)       32-row K-blocks, raw tiles, no transposition, 3/CU  92 us
     //   producer/consumer 512-thread variant     (removed)                94 us
     // All sit at ~65 % matrix-pipe occupancy at the ~1.9 GHz DVFS clock; the backward moves 235 MB per launch.
-    const char* v = getenv("HK_BWD_V");
-    if (v && v[0] == '4') {   // two-barrier variant (direct transposed loads): not yet timed on the GPU
+    const int v = tuning().bwd_v;
+    if (v == 4) {   // two-barrier variant (direct transposed loads): not yet timed on the GPU
         hipLaunchKernelGGL((bcnn_bwd_v4_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
                            tpart, C, nb, B, ex);
         HK_LAUNCH_CHECK();
         return HK_OK;
     }
-    if (v && v[0] == '3') {
+    if (v == 3) {
         hipLaunchKernelGGL((bcnn_bwd_v3_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
                            tpart, C, nb, B, ex);
         HK_LAUNCH_CHECK();

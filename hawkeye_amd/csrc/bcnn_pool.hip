@@ -24,10 +24,7 @@ namespace hk {
 int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C, int HW, hipStream_t st);
 int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart, int B,
                   int C, int HW, hipStream_t st);
-static inline bool force_generic() {   // HK_BCNN_GENERIC=1: A/B switch used by the tests and bench
-    const char* e = getenv("HK_BCNN_GENERIC");
-    return e && e[0] == '1';
-}
+static inline bool force_generic() { return tuning().bcnn_generic == 1; }   // A/B lever (hk_tuning_set)
 
 // colsum[b,hw] = sum_c x[b,c,hw];  inv_norm[b] = 1 / max(sqrt(sum_hw colsum^2 / M + C*C*1e-5), 1e-12)
 // One workgroup (1024 threads) per sample; threads stride over channel rows with
@@ -259,7 +256,7 @@ extern "C" int hk_bcnn_bwd_gemm(const float* x, const float* y, const float* dy,
     const LdPlain xb = make_plain(x, (long long)C * HW, HW, C, HW);  // K x N, N contiguous
     const EpAffine ep = make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f);
     // 64-row tiles only: tpart is indexed by 64-row block (hk_bcnn_bwd_rank1 sums ceil(C/64) partials)
-    return bgemm_launch<true, false>(pa, xb, ep, C, HW, C, B, (hipStream_t)stream, /*allow_big=*/0);
+    return bgemm_launch<true, false>(pa, xb, ep, C, HW, C, B, (hipStream_t)stream);
 }
 
 extern "C" int hk_bcnn_bwd_rank1(float* dx, const float* tpart, const float* inv_norm, const float* colsum, int B, int C,

@@ -25,10 +25,7 @@ namespace hk {
 int gram_fast_raw(const float* x, const float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
 int cbp_fast_bwd(const float* x, const int* h1, const int* h2, const float* s1, const float* s2, const float* dc, int D,
                  float* dx, int B, int C, int HW, hipStream_t st);
-static inline bool force_generic() {
-    const char* e = getenv("HK_BCNN_GENERIC");
-    return e && e[0] == '1';
-}
+static inline bool force_generic() { return tuning().bcnn_generic == 1; }   // A/B lever (hk_tuning_set)
 
 struct CbpPlan {  // device-side view of the plan blob
     const int* h1;
@@ -326,10 +323,14 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
     for (int k = tid; k < D; k += 256) pp[k] = c[k];
 }
 
+static inline size_t rowscatter_lds(int C, int D) {
+    return ((size_t)((D + 1 + 3) / 4) * 4 + 128 + 2 * CBP_RB * (size_t)C) * sizeof(float);
+}
+
 template <int NBT>
 static int rowscatter_launch(const float* G, const CbpPlan& pl, float* part, int B, int C, int D, int nchunk,
                              hipStream_t st) {
-    const size_t lds = ((size_t)((D + 1 + 3) / 4) * 4 + 128 + 2 * CBP_RB * (size_t)C) * sizeof(float);
+    const size_t lds = rowscatter_lds(C, D);
     if (lds > 150 * 1024) return HK_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
@@ -522,16 +523,16 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
     if (rc != HK_OK) return rc;
     const int nchunk = (C + 63) / 64;
     float* part = G + (long long)B * C * C;
-    // Binning stage, measured at C=512, D=6000 (whole hk_cbp_fwd, HIP events): row-sketch 107.0 us @B=64 / 87.9 @B=16,
-    // CSR gather 175.9 us @B=64 / 81.2 @B=16.  The row-sketch kernel is latency-bound per workgroup (~49 us for its 64
-    // rows whatever B is), the CSR gather is throughput-bound, so the row-sketch is used once B * C/64 workgroups fill the
-    // 256 CUs.  HK_CBP_CSR=1 / HK_CBP_CSR=0 force one or the other (A/B switch); HK_CBP_CSR=2 selects the row-scatter
-    // kernel (bit-identical partials, not yet timed).
-    const char* csr = getenv("HK_CBP_CSR");
+    // Binning stage, measured at C=512, D=6000 (whole hk_cbp_fwd, HIP events, BENCH_r01): row-scatter 89.0 us @B=64 /
+    // 76.4 @B=16, row-sketch 108.3 / 85.7, CSR gather 176.7 / 79.9.  Row-scatter (bins in LDS) is the default wherever
+    // its bins fit the LDS; otherwise the row-sketch kernel once B * C/64 workgroups fill the 256 CUs, else the CSR
+    // gather.  tuning().cbp_bin forces one (0 row-sketch, 1 CSR gather, 2 row-scatter); all produce identical partials.
+    const int bin = tuning().cbp_bin;                        // -1: automatic
     const int nq8 = ((D + 255) / 256 + 7) / 8;               // 8-bin groups per thread
     const bool rowsketch = C <= 512 && C % 4 == 0 && nq8 <= 4 && D >= 1024 * nq8 && pl.emax <= CBP_EMAX &&
-                           (csr ? csr[0] == '0' : B * nchunk >= 256);
-    const bool scatter = csr && csr[0] == '2' && C <= 512 && C % 4 == 0 && pl.emax <= CBP_EMAX;
+                           (bin >= 0 ? bin == 0 : B * nchunk >= 256);
+    const bool scatter = (bin < 0 || bin == 2) && C <= 512 && C % 4 == 0 && pl.emax <= CBP_EMAX &&
+                         rowscatter_lds(C, D) <= 150 * 1024;
     if (scatter) {
         const int rc2 = C <= 256 ? rowscatter_launch<1>(G, pl, part, B, C, D, nchunk, st)
                                  : rowscatter_launch<2>(G, pl, part, B, C, D, nchunk, st);

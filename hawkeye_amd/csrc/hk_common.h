@@ -35,6 +35,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace hk {
 
+// A/B levers for tests, benchmarks and profiling (hk_tuning_set / hk_tuning_get in the C ABI).  The values are seeded
+// from the environment ONCE, when the library is first used; the launch paths read plain ints - no getenv per call.
+// The product never sets them: every default is the measured winner.
+struct Tuning {
+    int bcnn_generic = 0;   // HK_BCNN_GENERIC  1: generic GEMM path instead of the panel-resident Gram / backward kernels
+    int cbp_bin = -1;       // HK_CBP_BIN      -1: by batch size, 0: row-sketch, 1: CSR gather, 2: row-scatter
+    int roi_bwd = 0;        // HK_ROI_BWD       0: default ROI-refinement backward, 1: the other variant
+    int linear_slabs = 0;   // HK_LINEAR_SLABS  0: automatic split-K slab count of hk_linear_fwd
+    int ns_tn = 0;          // HK_NS_TN         0: automatic, 64 / 128: forced tile width of the Newton-Schulz products
+    int bwd_v = 0;          // HK_BWD_V         variant of the Gram backward kernel (bcnn_fast.hip)
+};
+Tuning& tuning();           // api.hip
+
 constexpr int WAVE = 64;
 constexpr int NXCD = 8;
 

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __re
 static inline void slab_plan(int B, int J, int K, int& KS, int& S) {
     const long long tiles = (long long)((B + 63) / 64) * ((K + 63) / 64);
     long long want = (1536 + tiles - 1) / tiles;                 // ~6 workgroups per CU over the 256 CUs
-    if (const char* e = getenv("HK_LINEAR_SLABS")) want = atoll(e);
+    if (tuning().linear_slabs > 0) want = tuning().linear_slabs;
     const long long max_s = (J + 255) / 256;                       // at least 256 features (8 K-chunks) per slab
     if (want > max_s) want = max_s;
     if (want < 1) want = 1;

@@ -1,13 +1,14 @@
 // Fast MPN-COV head (replaces model/methods/MPNCOV.py:105-230):
 //   covariance pooling, Newton-Schulz matrix square root (forward + the
 //   hand-derived backward), upper-triangle vectorisation.
-// All contractions run on the fp32 MFMA path through hk::bgemm_kernel with fused
-// epilogues (alpha * s_b * acc + beta * C + diag * I); the elementwise glue the
-// reference spends ~25 small kernels on per direction is folded into those
-// epilogues or into four small kernels below.  No host loop over the batch
+// All contractions run on the fp32 MFMA path: the covariance on the panel kernels of
+// bcnn_fast.hip (generic fallback hk::bgemm_kernel), the Newton-Schulz chain on the grouped
+// kernel of hk_nsmm.h (9 launches per direction); the elementwise glue the reference spends
+// ~25 small kernels on per direction is folded into GEMM epilogues or the four small kernels below.  No host loop over the batch
 // (reference: MPNCOV.py:198-201), no CPU-side index rebuild (:213-214).
 #include <cstdlib>
 #include "hk_bgemm.h"
+#include "hk_nsmm.h"
 #include "../../include/hawkeye_hip.h"
 
 namespace hk {
@@ -15,10 +16,7 @@ namespace hk {
 // bcnn_fast.hip (panel-resident kernels; HK_ERR_UNSUPPORTED when the shape is not covered)
 int gram_fast_raw(const float* x, const float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
 int cov_fast_bwd(const float* x, const float* mu, const float* g, float* dx, int B, int C, int HW, hipStream_t st);
-static inline bool force_generic() {
-    const char* e = getenv("HK_BCNN_GENERIC");
-    return e && e[0] == '1';
-}
+static inline bool force_generic() { return tuning().bcnn_generic == 1; }   // A/B lever (hk_tuning_set)
 
 // ----------------------------------------------------------------- covariance
 // mu[b,c] = mean_m x[b,c,m] : one wave per row, 4 rows per workgroup
@@ -68,19 +66,6 @@ __global__ __launch_bounds__(256) void ns_scale_kernel(const float* __restrict__
             z[e] = 0.5f * ((i == j ? 3.0f : 0.0f) - v);
         }
     }
-}
-
-// out = ca * x * (sb ? sb[b] : 1) + cb * y      (elementwise, per batch scale)
-__global__ __launch_bounds__(256) void ns_axpby_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                       const float* __restrict__ sb, float ca, float cb,
-                                                       float* __restrict__ out, long long n) {
-    const int b = blockIdx.y;
-    const float s = sb ? ca * sb[b] : ca;
-    const float* xp = x + b * n;
-    const float* yp = y ? y + b * n : nullptr;
-    float* o = out + b * n;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256)
-        o[e] = s * xp[e] + (yp ? cb * yp[e] : 0.f);
 }
 
 // red0[b] = sum(g o out) ; red1[b] = sum(D^T o a)   (MPNCOV.py:175,197) - one workgroup per sample
@@ -144,58 +129,34 @@ __global__ __launch_bounds__(256) void triu_bwd_kernel(const float* __restrict__
     for (int c = threadIdx.x; c < d; c += 256) xp[c] = (c >= r) ? yp[c] : 0.f;
 }
 
-// HK_NS_SYM=1 (opt-in until measured on the GPU): every product of the forward chain and the Y Z products of the
-// backward are products of commuting symmetric matrices (polynomials in A), so their results are symmetric: only
-// the 10 of 16 tiles on or above the diagonal are computed and mirrored (hk_bgemm.h, SYM), and Z Y is not computed
-// at all (it is the transpose of Y Z).  12 -> 7.5 and 38 -> 32.5 GEMM-equivalents at iterN = 5.  Requires a
-// symmetric input (a covariance); CPU experiment (fp32 torch, d = 256): 7e-7 from the reference's full products,
-// the same distance the reference itself is from fp64.
-static inline bool ns_sym() {
-    const char* e = getenv("HK_NS_SYM");
-    return e && e[0] == '1';
+// ----------------------------------------------------------------- Newton-Schulz products (hk_nsmm.h)
+// Every product of the chain is a launch of hk::nsmm_kernel over a GROUP of independent problems.  The iterates
+// Y_i, Z_i are polynomials in the (symmetric) normalised covariance A, so they commute and Z_i Y_i = Y_i Z_i: the
+// backward takes "YZ" and "ZY" (MPNCOV.py:184-185) from ONE product (two results of the same accumulator).  This
+// needs a symmetric input - what Covpool produces and the only thing MPNCOV.forward feeds Sqrtm (MPNCOV.py:52-55);
+// measured distance from the reference's separate products: 7e-7, the distance of the reference itself from fp64.
+static inline NsGroup ns_group(const NsProb& p0) {
+    NsGroup g;
+    g.p[0] = p0; g.p[1] = p0; g.p[2] = p0; g.p[3] = p0;
+    g.np = 1;
+    return g;
 }
-
-// C = alpha * s_b * A B + beta C + diag I for d x d row-major batches with explicit batch strides
-static inline int mm(const float* A, long long sa, const float* Bm, long long sb, float* C, long long sc, int d, int nb,
-                     float alpha, const float* bscale, float beta, float diag, hipStream_t st, bool sym_result = false) {
-    const LdPlain la = make_plain(A, sa, d, d, d);
-    const LdPlain lb = make_plain(Bm, sb, d, d, d);
-    const EpAffine ep = make_affine(C, sc, d, alpha, bscale, beta, diag);
-    if (sym_result && ns_sym()) return bgemm_launch_sym<true, false>(la, lb, ep, d, d, nb, st);
-    // A/B switch: 0 = 64x64x32 (default), 1 = 128x128x32 / 4 waves, 2 = 64x64x64, 3 = 64x64x16,
-    //             4 = 128x128x32 / 8 waves / two-chunk prefetch, 5 = 64x64x32 / two-chunk prefetch,
-    //             6 / 7 = fp32 product from six / three bf16 piece products on the bf16 matrix pipe (hk_bgemm.h),
-    //             8 / 9 = the same on the 128x128 / 8-wave / two-chunk-prefetch tile
-    const char* e = getenv("HK_NS_GEMM");
-    const int variant = e ? atoi(e) : 0;
-    if (variant == 4 && d >= 128) return bgemm128_launch<true, false>(la, lb, ep, d, d, d, nb, st);
-    if (variant == 5) return bgemm64p2_launch<true, false>(la, lb, ep, d, d, d, nb, st);
-    if (variant == 6) return bgemm_bf16split_launch<6>(la, lb, ep, d, d, d, nb, st);
-    if (variant == 7) return bgemm_bf16split_launch<3>(la, lb, ep, d, d, d, nb, st);
-    if (variant == 8 && d >= 128) return bgemm_bf16split128_launch<6>(la, lb, ep, d, d, d, nb, st);
-    if (variant == 9 && d >= 128) return bgemm_bf16split128_launch<3>(la, lb, ep, d, d, d, nb, st);
-    return bgemm_launch<true, false>(la, lb, ep, d, d, d, nb, st, variant);
+static inline NsGroup& operator+=(NsGroup& g, const NsProb& p) {
+    g.p[g.np++] = p;
+    return g;
 }
-
-// two results from one symmetric product P = A B:  C1 = 3 I - P  and  C2 = P   (backward: "YZ" and "ZY" = P^T = P)
-struct EpDualNs {
-    float *c1, *c2;
-    long long bs;
-    int ld;
-    __device__ __forceinline__ void operator()(int b, int i, int j, float v) const {
-        const long long o = (long long)b * bs + (long long)i * ld + j;
-        c1[o] = (i == j ? 3.0f : 0.0f) - v;
-        c2[o] = v;
-    }
-};
-
-static inline int mm_yz_pair(const float* Y, const float* Z, long long sbs, float* W1, float* W2, long long n, int d,
-                             int nb, hipStream_t st) {
-    const LdPlain la = make_plain(Y, sbs, d, d, d);
-    const LdPlain lb = make_plain(Z, sbs, d, d, d);
-    EpDualNs ep;
-    ep.c1 = W1; ep.c2 = W2; ep.bs = n; ep.ld = d;
-    return bgemm_launch_sym<true, false>(la, lb, ep, d, d, nb, st);
+// single product C = alpha * s_b * A B + diag I
+static inline NsProb ns_single(const float* A, long long sa, const float* Bm, long long sb, float* C, long long sc,
+                               float alpha, float diag, const float* bscale = nullptr) {
+    NsProb p = ns_prob(C, sc, alpha, diag, bscale);
+    p += ns_term(A, sa, Bm, sb);
+    return p;
+}
+// P = Y Z  ->  W1 = 3 I - P ,  W2 = P      (MPNCOV.py:180,184-185)
+static inline NsProb ns_yz_pair(const float* Y, const float* Z, long long sbs, float* W1, float* W2, long long n) {
+    NsProb p = ns_single(Y, sbs, Z, sbs, W1, n, -1.f, 3.f);
+    p.C2 = W2; p.sc2 = n; p.alpha2 = 1.f; p.diag2 = 0.f;
+    return p;
 }
 
 static inline dim3 ew_grid(long long n, int B) {
@@ -254,9 +215,11 @@ extern "C" size_t hk_ns_sqrtm_ws_bytes(int B, int d, int iter_n, int backward) {
     (void)iter_n;
     const size_t mat = (size_t)B * d * d * sizeof(float);
     const size_t small = (size_t)4 * B * sizeof(float) + 256;
-    return (backward ? 9 * mat : 2 * mat) + small;
+    return (backward ? 10 * mat : 2 * mat) + small;
 }
 
+// Forward schedule at iterN = 5 (MPNCOV.py:137-164): 12 products in 9 launches -
+//   Y0 = A ZY0 | for i = 1..3: ZY = .5 (3I - Z Y) | {Y' = Y ZY, Z' = ZY Z} in one launch | 3I - Z Y | .5 sqrt(tr) Y (.)
 extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
                                int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream) {
     if (!a || !out || !norm_a || B <= 0 || d <= 0 || iter_n < 1) return HK_ERR_BAD_ARG;
@@ -275,24 +238,27 @@ extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float*
     if (iter_n < 2) {
         hipLaunchKernelGGL(ns_scale_kernel, ew_grid(n, B), dim3(256), 0, st, a, (const float*)norm_a, A, T, n, d);
         HK_LAUNCH_CHECK();
-        return mm(A, n, T, n, out, n, d, B, 1.0f, sq, 0.f, 0.f, st, true);         // :151,:161
+        return nsmm_launch(ns_group(ns_single(A, n, T, n, out, n, 1.0f, 0.f, sq)), d, B, st);   // :151,:161
     }
     hipLaunchKernelGGL(ns_scale_kernel, ew_grid(n, B), dim3(256), 0, st, a, (const float*)norm_a, A, zsave, sbs, d);
     HK_LAUNCH_CHECK();
-    HK_TRY(mm(A, n, zsave, sbs, ysave, sbs, d, B, 1.f, nullptr, 0.f, 0.f, st, true));   // Y0 = A ZY   :154
-    for (int i = 1; i < iter_n - 1; ++i) {                                           // :156-159
+    HK_TRY(nsmm_launch(ns_group(ns_single(A, n, zsave, sbs, ysave, sbs, 1.f, 0.f)), d, B, st));   // Y0 = A ZY   :154
+    for (int i = 1; i < iter_n - 1; ++i) {                                                          // :156-159
         const float* Yp = ysave + (long long)(i - 1) * n;
         const float* Zp = zsave + (long long)(i - 1) * n;
-        HK_TRY(mm(Zp, sbs, Yp, sbs, T, n, d, B, -0.5f, nullptr, 0.f, 1.5f, st, true));    // ZY = .5(3I - Z Y)
-        HK_TRY(mm(Yp, sbs, T, n, ysave + (long long)i * n, sbs, d, B, 1.f, nullptr, 0.f, 0.f, st, true));
-        HK_TRY(mm(T, n, Zp, sbs, zsave + (long long)i * n, sbs, d, B, 1.f, nullptr, 0.f, 0.f, st, true));
+        HK_TRY(nsmm_launch(ns_group(ns_single(Zp, sbs, Yp, sbs, T, n, -0.5f, 1.5f)), d, B, st));   // ZY = .5(3I - Z Y)
+        NsGroup g = ns_group(ns_single(Yp, sbs, T, n, ysave + (long long)i * n, sbs, 1.f, 0.f));   // Y' = Y ZY
+        g += ns_single(T, n, Zp, sbs, zsave + (long long)i * n, sbs, 1.f, 0.f);                    // Z' = ZY Z
+        HK_TRY(nsmm_launch(g, d, B, st));
     }
     const float* Yl = ysave + (long long)(iter_n - 2) * n;
     const float* Zl = zsave + (long long)(iter_n - 2) * n;
-    HK_TRY(mm(Zl, sbs, Yl, sbs, T, n, d, B, -1.f, nullptr, 0.f, 3.f, st, true));    // 3I - Z Y      :160
-    return mm(Yl, sbs, T, n, out, n, d, B, 0.5f, sq, 0.f, 0.f, st, true);           // .5 Y (.) sqrt(normA)  :160-161
+    HK_TRY(nsmm_launch(ns_group(ns_single(Zl, sbs, Yl, sbs, T, n, -1.f, 3.f)), d, B, st));         // 3I - Z Y      :160
+    return nsmm_launch(ns_group(ns_single(Yl, sbs, T, n, out, n, 0.5f, 0.f, sq)), d, B, st);       // .5 Y (.) sqrt(normA)
 }
 
+// Backward schedule at iterN = 5 (MPNCOV.py:166-202): the reference's 38 products as 34 in 9 launches -
+//   {YZ pair, Yl g} | {dldY, dldZ} | 3 x ( {YZ pair, Z dldZ, Y dldY} | {dldY', dldZ'} as two K = 3d sums ) | der
 extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* norm_a, const float* ysave,
                                const float* zsave, const float* dout, float* da, int B, int d, int iter_n, void* ws,
                                size_t ws_bytes, hk_stream_t stream) {
@@ -302,8 +268,8 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)d * d, bn = (long long)B * n;
     float* A = (float*)ws;
-    float *W1 = A + bn, *W2 = W1 + bn, *W3 = W2 + bn;
-    float *dY = W3 + bn, *dZ = dY + bn, *dYn = dZ + bn, *dZn = dYn + bn, *D = dZn + bn;
+    float *W1 = A + bn, *W2 = W1 + bn, *W3 = W2 + bn, *W4 = W3 + bn;
+    float *dY = W4 + bn, *dZ = dY + bn, *dYn = dZ + bn, *dZn = dYn + bn, *D = dZn + bn;
     float* sq = D + bn;
     float *red0 = sq + B, *red1 = red0 + B;
     const int S = iter_n >= 2 ? iter_n - 1 : 1;
@@ -316,53 +282,60 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
     HK_LAUNCH_CHECK();
 
     if (iter_n < 2) {
-        // der = .5 (dpc (3I - A) - A dpc),  dpc = sq g                                   :178
-        hipLaunchKernelGGL(ns_axpby_kernel, ew_grid(n, B), dim3(256), 0, st, g, (const float*)nullptr,
-                           (const float*)sq, 1.5f, 0.f, D, n);
-        HK_LAUNCH_CHECK();
-        HK_TRY(mm(g, n, A, n, D, n, d, B, -0.5f, sq, 1.f, 0.f, st));
-        HK_TRY(mm(A, n, g, n, D, n, d, B, -0.5f, sq, 1.f, 0.f, st));
+        // der = .5 (dpc (3I - A) - A dpc) = sq (1.5 g - .5 (g A + A g)),  dpc = sq g                 :178
+        NsProb p = ns_prob(D, n, -0.5f, 0.f, sq);
+        p += ns_term(g, n, A, n);
+        p += ns_term(A, n, g, n);
+        p.E1 = g; p.se1 = n; p.e1 = 1.5f; p.e1_scaled = 1;
+        HK_TRY(nsmm_launch(ns_group(p), d, B, st));
     } else {
         const float* Yl = ysave + (long long)(iter_n - 2) * n;
         const float* Zl = zsave + (long long)(iter_n - 2) * n;
-        // dldY = .5 (dpc (3I - Yl Zl) - Zl Yl dpc)                                         :180-181
-        if (ns_sym()) {
-            HK_TRY(mm_yz_pair(Yl, Zl, sbs, W1, W2, n, d, B, st));                            // W1 = 3I - Yl Zl, W2 = Zl Yl
-        } else {
-            HK_TRY(mm(Yl, sbs, Zl, sbs, W1, n, d, B, -1.f, nullptr, 0.f, 3.f, st));
-            HK_TRY(mm(Zl, sbs, Yl, sbs, W2, n, d, B, 1.f, nullptr, 0.f, 0.f, st));
+        {   // W1 = 3I - Yl Zl, W2 = Zl Yl (= Yl Zl), W3 = Yl g
+            NsGroup gr = ns_group(ns_yz_pair(Yl, Zl, sbs, W1, W2, n));
+            gr += ns_single(Yl, sbs, g, n, W3, n, 1.f, 0.f);
+            HK_TRY(nsmm_launch(gr, d, B, st));
         }
-        HK_TRY(mm(g, n, W1, n, dY, n, d, B, 0.5f, sq, 0.f, 0.f, st));
-        HK_TRY(mm(W2, n, g, n, dY, n, d, B, -0.5f, sq, 1.f, 0.f, st));
-        // dldZ = -.5 Yl dpc Yl                                                             :182
-        HK_TRY(mm(Yl, sbs, g, n, W3, n, d, B, 1.f, nullptr, 0.f, 0.f, st));
-        HK_TRY(mm(W3, n, Yl, sbs, dZ, n, d, B, -0.5f, sq, 0.f, 0.f, st));
-        for (int i = iter_n - 3; i >= 0; --i) {                                             // :183-193
+        {   // dldY = .5 sq (g (3I - Yl Zl) - Zl Yl g)   :180-181 ;  dldZ = -.5 sq (Yl g) Yl   :182
+            NsProb py = ns_prob(dY, n, 0.5f, 0.f, sq);
+            py += ns_term(g, n, W1, n);
+            py += ns_term(W2, n, g, n, -1.f);
+            NsGroup gr = ns_group(py);
+            gr += ns_single(W3, n, Yl, sbs, dZ, n, -0.5f, 0.f, sq);
+            HK_TRY(nsmm_launch(gr, d, B, st));
+        }
+        for (int i = iter_n - 3; i >= 0; --i) {                                                      // :183-193
             const float* Yi = ysave + (long long)i * n;
             const float* Zi = zsave + (long long)i * n;
-            if (ns_sym()) {
-                HK_TRY(mm_yz_pair(Yi, Zi, sbs, W1, W2, n, d, B, st));                      // both from one product
-            } else {
-                HK_TRY(mm(Yi, sbs, Zi, sbs, W1, n, d, B, -1.f, nullptr, 0.f, 3.f, st));    // YZ = 3I - Y Z
-                HK_TRY(mm(Zi, sbs, Yi, sbs, W2, n, d, B, 1.f, nullptr, 0.f, 0.f, st));     // ZY = Z Y
+            {   // W1 = YZ = 3I - Y Z, W2 = ZY = Z Y, W3 = Z dldZ, W4 = Y dldY
+                NsGroup gr = ns_group(ns_yz_pair(Yi, Zi, sbs, W1, W2, n));
+                gr += ns_single(Zi, sbs, dZ, n, W3, n, 1.f, 0.f);
+                gr += ns_single(Yi, sbs, dY, n, W4, n, 1.f, 0.f);
+                HK_TRY(nsmm_launch(gr, d, B, st));
             }
-            HK_TRY(mm(dY, n, W1, n, dYn, n, d, B, 0.5f, nullptr, 0.f, 0.f, st));           // .5 dldY YZ
-            HK_TRY(mm(Zi, sbs, dZ, n, W3, n, d, B, 1.f, nullptr, 0.f, 0.f, st));           // Z dldZ
-            HK_TRY(mm(W3, n, Zi, sbs, dYn, n, d, B, -0.5f, nullptr, 1.f, 0.f, st));        //  - .5 (Z dldZ) Z
-            HK_TRY(mm(W2, n, dY, n, dYn, n, d, B, -0.5f, nullptr, 1.f, 0.f, st));          //  - .5 ZY dldY
-            HK_TRY(mm(W1, n, dZ, n, dZn, n, d, B, 0.5f, nullptr, 0.f, 0.f, st));           // .5 YZ dldZ
-            HK_TRY(mm(Yi, sbs, dY, n, W3, n, d, B, 1.f, nullptr, 0.f, 0.f, st));           // Y dldY
-            HK_TRY(mm(W3, n, Yi, sbs, dZn, n, d, B, -0.5f, nullptr, 1.f, 0.f, st));        //  - .5 (Y dldY) Y
-            HK_TRY(mm(dZ, n, W2, n, dZn, n, d, B, -0.5f, nullptr, 1.f, 0.f, st));          //  - .5 dldZ ZY
+            {   // dldY' = .5 (dldY YZ - (Z dldZ) Z - ZY dldY) ;  dldZ' = .5 (YZ dldZ - (Y dldY) Y - dldZ ZY)
+                NsProb py = ns_prob(dYn, n, 0.5f, 0.f);
+                py += ns_term(dY, n, W1, n);
+                py += ns_term(W3, n, Zi, sbs, -1.f);
+                py += ns_term(W2, n, dY, n, -1.f);
+                NsProb pz = ns_prob(dZn, n, 0.5f, 0.f);
+                pz += ns_term(W1, n, dZ, n);
+                pz += ns_term(W4, n, Yi, sbs, -1.f);
+                pz += ns_term(dZ, n, W2, n, -1.f);
+                NsGroup gr = ns_group(py);
+                gr += pz;
+                HK_TRY(nsmm_launch(gr, d, B, st));
+            }
             float* t = dY; dY = dYn; dYn = t;
             t = dZ; dZ = dZn; dZn = t;
         }
-        // der = .5 (dldY (3I - A) - dldZ - A dldY) = 1.5 dldY - .5 dldZ - .5 dldY A - .5 A dldY   :194
-        hipLaunchKernelGGL(ns_axpby_kernel, ew_grid(n, B), dim3(256), 0, st, (const float*)dY, (const float*)dZ,
-                           (const float*)nullptr, 1.5f, -0.5f, D, n);
-        HK_LAUNCH_CHECK();
-        HK_TRY(mm(dY, n, A, n, D, n, d, B, -0.5f, nullptr, 1.f, 0.f, st));
-        HK_TRY(mm(A, n, dY, n, D, n, d, B, -0.5f, nullptr, 1.f, 0.f, st));
+        // der = .5 (dldY (3I - A) - dldZ - A dldY) = 1.5 dldY - .5 dldZ - .5 (dldY A + A dldY)   :194
+        NsProb p = ns_prob(D, n, -0.5f, 0.f);
+        p += ns_term(dY, n, A, n);
+        p += ns_term(A, n, dY, n);
+        p.E1 = dY; p.se1 = n; p.e1 = 1.5f;
+        p.E2 = dZ; p.se2 = n; p.e2 = -0.5f;
+        HK_TRY(nsmm_launch(ns_group(p), d, B, st));
     }
     hipLaunchKernelGGL(ns_bwd_reduce_kernel, dim3(B), dim3(1024), 0, st, g, out, (const float*)D, a, red0, red1, d);
     HK_LAUNCH_CHECK();

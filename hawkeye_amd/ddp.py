@@ -26,12 +26,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, force=False):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank).
+    `force=True` creates the group even for a single rank, so that the collective path (RCCL on a GPU box) executes
+    on a one-GPU machine - used by bench.py --force-pg and the GPU tests."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -54,7 +56,7 @@ def _is_dense_permutation(t):
 
 
 class _Bucket:
-    __slots__ = ('params', 'flat', 'views', 'pending', 'work', 'nbytes')
+    __slots__ = ('params', 'flat', 'views', 'pending', 'work', 'nbytes', 'issued')
 
     def __init__(self, params):
         self.params = params
@@ -70,6 +72,7 @@ class _Bucket:
             off += p.numel()
         self.pending = len(params)
         self.work = None
+        self.issued = None                               # trace mode: event recorded where the all-reduce was issued
         self.nbytes = total * self.flat.element_size()
 
 
@@ -78,15 +81,20 @@ class GradientAllReducer:
     `.backbone` / `.classifier` / `.pool`, cf. Examples/CBCNN.py:14,21 and
     Examples/MPN.py:15-17 which break under a DataParallel wrapper)."""
 
-    def __init__(self, module, bucket_mb=64.0, process_group=None, broadcast=True):
+    def __init__(self, module, bucket_mb=64.0, process_group=None, broadcast=True, trace=False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # collectives are issued whenever a process group exists - also a single-rank one (an all-reduce over one
+        # rank is the identity): that is how the RCCL path is exercised on a one-GPU box
+        self.collective = dist.is_initialized()
+        self.trace = bool(trace) and torch.cuda.is_available()
+        self._t_start = self._t_bwd_end = self._t_joined = None
         self.buckets = []
         self._index = {}
         self._handles = []
-        if broadcast and self.world > 1:
+        if broadcast and self.collective:
             self.broadcast_state()
         self._build(bucket_mb)
 
@@ -125,8 +133,12 @@ class GradientAllReducer:
             b.flat.zero_()
             b.pending = len(b.params)
             b.work = None
+            b.issued = None
             for p, v in zip(b.params, b.views):
                 p.grad = v
+        if self.trace:
+            self._t_start = torch.cuda.Event(enable_timing=True)
+            self._t_start.record()
 
     def _hook(self, p):
         b, i = self._index[p]
@@ -134,20 +146,47 @@ class GradientAllReducer:
             b.views[i].copy_(p.grad)
             p.grad = b.views[i]
         b.pending -= 1
-        if b.pending == 0 and self.world > 1:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b.pending == 0 and self.collective:
+            self._issue(b)
+
+    def _issue(self, b):
+        if self.trace:
+            b.issued = torch.cuda.Event(enable_timing=True)
+            b.issued.record()                           # position in the backward stream where the bucket was complete
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Join all in-flight all-reduces and turn sums into means.  Call after backward, before step."""
+        if self.trace:
+            self._t_bwd_end = torch.cuda.Event(enable_timing=True)
+            self._t_bwd_end.record()
         for b in self.buckets:
-            if self.world > 1:
+            if self.collective:
                 if b.pending != 0:                      # a parameter got no gradient this step: reduce what we have
-                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self._issue(b)
                 if b.work is not None:
                     b.work.wait()
-                    b.flat.div_(self.world)
+                    if self.world > 1:
+                        b.flat.div_(self.world)
             b.pending = len(b.params)
             b.work = None
+        if self.trace:
+            self._t_joined = torch.cuda.Event(enable_timing=True)
+            self._t_joined.record()
+
+    def timeline(self):
+        """Trace mode, after a step: where in the backward each bucket's all-reduce was issued.  Milliseconds on the
+        compute stream since zero_grad(): {'backward_end_ms', 'joined_ms', 'buckets': [(params, MiB, issued_ms)]}.
+        A bucket issued long before `backward_end_ms` has that much backward compute to hide behind."""
+        if not self.trace or self._t_start is None or self._t_bwd_end is None:
+            return None
+        torch.cuda.synchronize()
+        t0 = self._t_start
+        return {'backward_end_ms': round(t0.elapsed_time(self._t_bwd_end), 3),
+                'joined_ms': round(t0.elapsed_time(self._t_joined), 3),
+                'buckets': [(len(b.params), round(b.nbytes / 2 ** 20, 1),
+                             round(t0.elapsed_time(b.issued), 3) if b.issued is not None else None)
+                            for b in self.buckets]}
 
     def remove(self):
         for h in self._handles:

@@ -29,7 +29,9 @@ class Tester:
         """This process's GPU; no CPU path (the HIP heads have none - the CPU reference is test infrastructure)."""
         if not (isinstance(cfg.experiment.cuda, list) and cfg.experiment.cuda and torch.cuda.is_available()):
             raise RuntimeError('hawkeye_amd evaluates on MI355X only: set experiment.cuda: [0] and run on a GPU host')
-        return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(device)           # the C ABI launches on the CURRENT device's stream (functional.stream())
+        return device
 
     def get_transformer(self, config):
         from . import transforms

@@ -61,14 +61,19 @@ class Trainer:
         self.log_root = os.path.join(cfg.experiment.log_dir, cfg.experiment.name)
         self.report_one_line = True
 
-        if self.is_main and not self.resume and not self.debug:
-            assert not os.path.exists(self.log_root), 'Experiment log folder already exists!!'
-            os.makedirs(self.log_root)
-            with open(os.path.join(self.log_root, 'train_config.yaml'), 'w') as f:
-                f.write(str(cfg))
-            if os.path.isfile(sys.argv[0]):
-                copyfile(sys.argv[0], os.path.join(self.log_root, 'train.py'))
-        os.makedirs(self.log_root, exist_ok=True)
+        # only rank 0 checks and creates the experiment folder; the others wait for it (a rank that created the folder
+        # first would make rank 0's "already exists" check fail and leave everybody else hanging in the first broadcast)
+        if self.is_main:
+            if not self.resume and not self.debug:
+                assert not os.path.exists(self.log_root), 'Experiment log folder already exists!!'
+                os.makedirs(self.log_root)
+                with open(os.path.join(self.log_root, 'train_config.yaml'), 'w') as f:
+                    f.write(str(cfg))
+                if os.path.isfile(sys.argv[0]):
+                    copyfile(sys.argv[0], os.path.join(self.log_root, 'train.py'))
+            os.makedirs(self.log_root, exist_ok=True)
+        if self.world > 1:
+            torch.distributed.barrier()
 
         self.logger = self.get_logger()
         self.tb_writer = ScalarWriter(self.log_root) if self.is_main else None
@@ -253,9 +258,12 @@ class Trainer:
             if hasattr(loader.sampler, 'set_epoch'):
                 loader.sampler.set_epoch(epoch)
             for data in loader:
+                self._on_start_forward()
                 self.batch_training(data)
+                self._on_end_forward()
             dt = self.timer.tick()
             self.logger.info(f'Training epoch {epoch + 1} took {dt:.1f}s')
+            self.sync_average_meters()
             self.performance_meters['train']['acc'].update(self.average_meters['acc'].avg)
             self.performance_meters['train']['loss'].update(self.average_meters['loss'].avg)
             self.report(epoch=epoch + 1, split='train')
@@ -263,18 +271,35 @@ class Trainer:
             self.reset_average_meters()
             self.validate()
             self.model.train()
-            self.performance_meters['val']['acc'].update(self.average_meters['acc'].avg)
+            val_acc = self.average_meters['acc'].avg             # over the WHOLE validation set (validate() syncs ranks)
+            m = self.performance_meters['val']['acc']
+            is_best = epoch >= 5 and (not m.values or val_acc > m.best_value)     # train.py:284-288
+            m.update(val_acc)
             self.report(epoch=epoch + 1, split='val')
             self.do_scheduler_step()
-            self._on_end_epoch()
 
             if self.is_main:
                 if (epoch + 1) % config.save_frequence == 0:
                     self.save_model()
-                m = self.performance_meters['val']['acc']
-                if epoch >= 4 and m.best_value == m.current_value:          # best only counted from epoch 5 (:285-288)
+                if is_best:
                     self.save_model('best_model.pth')
+            self._on_end_epoch()
         self.logger.info('Training done.')
+
+    def sync_average_meters(self):
+        """Multi-rank: every AverageMeter becomes the average over ALL ranks' samples (sum and count all-reduced), so
+        that the logged metrics, the scheduler (ReduceLROnPlateau steps on val acc) and the best-model choice see what
+        the reference's single-process DataParallel run computes over the full set - identically on every rank."""
+        if self.world <= 1:
+            return
+        names = sorted(self.average_meters)
+        buf = torch.tensor([[self.average_meters[n].sum, self.average_meters[n].count] for n in names],
+                           dtype=torch.float64, device=self.device)
+        torch.distributed.all_reduce(buf)
+        for n, (s_, c_) in zip(names, buf.tolist()):
+            meter = self.average_meters[n]
+            meter.sum, meter.count = s_, c_
+            meter.avg = s_ / c_ if c_ else 0.0
 
     def batch_training(self, data):
         images, labels = self.to_device(data['img']), self.to_device(data['label'])
@@ -289,6 +314,7 @@ class Trainer:
         with torch.no_grad():
             for data in self.dataloaders['val']:
                 self.batch_validate(data)
+        self.sync_average_meters()
         self.model.train(True)
 
     def batch_validate(self, data):
@@ -315,11 +341,11 @@ class Trainer:
             return
         torch.save({'epoch': self.epoch, 'model': self.model.state_dict(), 'optimizer': self.optimizer.state_dict(),
                     'scheduler': self.scheduler.state_dict() if self.scheduler else None},
-                   os.path.join(self.log_root, 'checkpoint.pth'))
+                   os.path.join(self.log_root, f'checkpoint_epoch_{self.epoch}.pth'))        # train.py:379
 
     def load_checkpoint(self, path):
         ck = torch.load(path, map_location='cpu')
-        self.start_epoch = ck['epoch'] + 1
+        self.start_epoch = ck['epoch']          # the interrupted epoch is redone from its start, as in train.py:391
         self.model.load_state_dict(ck['model'])
         self.optimizer.load_state_dict(ck['optimizer'])
         if self.scheduler is not None and ck.get('scheduler') is not None:
@@ -333,6 +359,20 @@ class Trainer:
     def _on_end_epoch(self):
         self.on_end_epoch(self.config.hook.on_end_epoch if 'hook' in self.config and
                           'on_end_epoch' in self.config.hook else None)
+
+    def _on_start_forward(self):
+        self.on_start_forward(self.config.hook.on_start_forward if 'hook' in self.config and
+                              'on_start_forward' in self.config.hook else None)
+
+    def _on_end_forward(self):
+        self.on_end_forward(self.config.hook.on_end_forward if 'hook' in self.config and
+                            'on_end_forward' in self.config.hook else None)
+
+    def on_start_forward(self, config):
+        pass
+
+    def on_end_forward(self, config):
+        pass
 
     def on_start_epoch(self, config):
         pass

@@ -13,7 +13,8 @@
  *    buffers owned by the caller; nothing is allocated or freed by the library;
  *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream);
  *    every call only enqueues kernels on it: no host synchronisation, no
- *    global mutable state, safe to call from one thread per device;
+ *    global mutable state besides the test-only hk_tuning_* knobs, safe to call
+ *    from one thread per device;
  *  - scratch memory is passed in (`ws`, `ws_bytes`); the matching
  *    hk_*_ws_bytes() tells how much is needed; contents need not be preserved
  *    between calls unless stated ("saved for backward" buffers are explicit
@@ -41,6 +42,16 @@ typedef void* hk_stream_t; /* hipStream_t */
 
 /* library / build identification: returns e.g. "hawkeye_hip 0.1 gfx950" */
 const char* hk_version(void);
+
+/* A/B levers for tests, benchmarks and profiling - never needed by a caller of the ops.  Each knob selects between
+ * implementations that produce the same results (bit-identical or to rounding); the defaults are the measured winners.
+ * Names: "bcnn_generic" (1 = generic GEMM path for the Gram / covariance / CBP kernels), "cbp_bin" (-1 = by batch
+ * size, 0 row-sketch, 1 CSR gather, 2 row-scatter), "roi_bwd", "linear_slabs" (0 = automatic), "ns_tn" (0 = automatic,
+ * 64 / 128), "bwd_v".  Values are seeded once from the environment (HK_<NAME>) when the library is first used; the
+ * launch paths never read the environment.  Returns HK_ERR_BAD_ARG for an unknown name.  Process-wide: set them only
+ * while no other thread is launching. */
+int hk_tuning_set(const char* name, int value);
+int hk_tuning_get(const char* name, int* value);
 
 /* ---------------------------------------------------------------- BCNN ----
  * Bilinear pooling: G = X X^T / HW ; z = sqrt(G + 1e-5) ; y = z / max(|z|_2, 1e-12).

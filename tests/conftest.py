@@ -26,3 +26,25 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if 'gpu' in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture
+def tune():
+    """`tune(name, value)` flips an A/B knob of the loaded library (hk_tuning_set: the gfx950 build on the GPU tier, the
+    emulated build inside tests/emu's context) and restores every touched knob when the test ends."""
+    import ctypes
+
+    from hawkeye_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        lib = _lib.load()
+        if name not in saved:
+            old = ctypes.c_int(0)
+            assert lib.hk_tuning_get(name.encode(), ctypes.byref(old)) == 0, name
+            saved[name] = (lib, old.value)
+        assert lib.hk_tuning_set(name.encode(), int(value)) == 0, name
+
+    yield set_
+    for name, (lib, value) in saved.items():
+        lib.hk_tuning_set(name.encode(), value)

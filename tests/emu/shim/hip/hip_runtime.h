@@ -65,6 +65,10 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
+// instruction-scheduling fences: no meaning off the GPU
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
 
 extern "C" void hipemu_switch(void** save_sp, void* load_sp);   // tests/emu/shim/hipemu_switch.S
 #if defined(__has_feature)

@@ -169,11 +169,11 @@ def test_fuzz_roi_crop(F):
         assert rel(ye, y) < 1e-6 and rel(xe.grad, x.grad) < 1e-6, (b, c, train)
 
 
-def test_fuzz_linear_split_k(F, monkeypatch):
+def test_fuzz_linear_split_k(F, tune):
     rng = np.random.default_rng(7)
     for _ in range(10):
         b, j, k = int(rng.integers(1, 70)), int(rng.integers(1, 3000)), int(rng.integers(1, 140))
-        monkeypatch.setenv('HK_LINEAR_SLABS', str(int(rng.integers(1, 12))))
+        tune('linear_slabs', int(rng.integers(1, 12)))
         y, w, bias, g = torch.randn(b, j), torch.randn(k, j) / j ** 0.5, torch.randn(k), torch.randn(b, k)
         y64, w64, b64 = (v.double().requires_grad_(True) for v in (y, w, bias))
         (torch.nn.functional.linear(y64, w64, b64) * g.double()).sum().backward()
@@ -218,7 +218,7 @@ def test_fuzz_cin_interaction(F):
         assert max(rel(y, y_ref), rel(yc, yc_ref), rel(xg.grad, xr.grad), rel(wg.grad, wr.grad)) < 5e-5, (b, c, hw)
 
 
-def test_fuzz_ns_variants(F, monkeypatch):
+def test_fuzz_ns_variants(F, tune):
     rng = np.random.default_rng(10)
     for _ in range(3):
         b, d, itn = int(rng.integers(1, 4)), int(rng.choice([5, 40, 100, 129, 150])), int(rng.integers(1, 5))
@@ -227,17 +227,16 @@ def test_fuzz_ns_variants(F, monkeypatch):
         yo = O.sqrtm(O.covpool(xo), itn)
         wt = torch.randn_like(yo)
         (yo * wt).sum().backward()
-        for sym, gemm in (('1', '0'), ('0', '4'), ('1', '4')):
-            monkeypatch.setenv('HK_NS_SYM', sym)
-            monkeypatch.setenv('HK_NS_GEMM', gemm)
+        for tn in (0, 64, 128):
+            tune('ns_tn', tn)
             xe = x.clone().requires_grad_(True)
             ye = F.sqrtm(F.covpool(xe), itn)
             (ye * wt).sum().backward()
-            assert rel(ye, yo) < 1e-5 and rel(xe.grad, xo.grad) < 1e-4, (b, d, itn, sym, gemm)
+            assert rel(ye, yo) < 1e-5 and rel(xe.grad, xo.grad) < 1e-4, (b, d, itn, tn)
 
 
 @pytest.mark.parametrize('order', ['rev', 'rand:11'])
-def test_results_do_not_depend_on_work_item_order(F, order, monkeypatch):
+def test_results_do_not_depend_on_work_item_order(F, order, monkeypatch, tune):
     """LDS-staged kernels (Gram / backward panels, CBP row-sketch + CSR, covariance, NS chain, attention pooling,
     NMS) re-run with the work-items of every workgroup resumed in another order: bit-identical results."""
     def run():
@@ -249,12 +248,12 @@ def test_results_do_not_depend_on_work_item_order(F, order, monkeypatch):
         out += [y.detach(), x.grad]
         xc = torch.relu(torch.randn(2, 128, 7, 7)).requires_grad_(True)
         plan = F.CbpPlan(*F.sketch_hashes(128, 128, 1024), 1024, torch.device('cpu'))
-        for csr in ('0', '1'):
-            monkeypatch.setenv('HK_CBP_CSR', csr)
+        for csr in (0, 1, 2):
+            tune('cbp_bin', csr)
             yc = F.compact_bilinear_pool(xc, plan)
             (yc * torch.randn_like(yc)).sum().backward()
             out += [yc.detach(), xc.grad.clone()]
-        monkeypatch.delenv('HK_CBP_CSR')
+        tune('cbp_bin', -1)
         xm = torch.relu(torch.randn(2, 64, 7, 7)).requires_grad_(True)
         ym = F.triuvec(F.sqrtm(F.covpool(xm), 5))
         (ym * torch.randn_like(ym)).sum().backward()

@@ -14,7 +14,8 @@ _spec.loader.exec_module(_mod)
 _mod.DEV = 'cpu'
 
 # device-runtime specific (RCCL reducer on a GPU stream, Trainer device placement)
-_SKIP = {'test_reducer_on_gpu_single_rank_matches_plain_sgd', 'test_trainer_runs_one_synthetic_epoch'}
+_SKIP = {'test_reducer_on_gpu_single_rank_matches_plain_sgd', 'test_trainer_runs_one_synthetic_epoch',
+         'test_rccl_path_executes_on_one_gpu', 'test_bench_spawns_its_own_ranks'}
 for _name, _obj in list(vars(_mod).items()):
     if _name.startswith('test_') and callable(_obj) and _name not in _SKIP:
         globals()[_name] = _obj
@@ -140,3 +141,69 @@ def test_tester_evaluates_a_trainer_checkpoint(tmp_path, monkeypatch):
     # same weights in both
     for (k1, v1), (k2, v2) in zip(tr.model.state_dict().items(), te.model.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def _two_rank_trainer_worker(rank, world, port, log_dir, out_dir):
+    import torch
+
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.examples.BCNN import BCNNTrainer
+    from hawkeye_amd.train import Trainer
+    Trainer.select_device = lambda self, cfg: torch.device('cpu')
+    root = os.path.dirname(_here)
+    with emulated():
+        cfg = CfgNode.load_cfg(open(os.path.join(root, 'configs', 'BCNN_S2_synthetic.yaml')))
+        cfg.experiment.log_dir = log_dir
+        cfg.experiment.debug = False                     # the start-up path with the "folder must not exist" check
+        cfg.dataset.samples, cfg.dataset.batch_size, cfg.dataset.num_workers = 12, 3, 0
+        cfg.dataset.transformer.image_size = 32
+        cfg.model.num_classes = 3
+        cfg.train.epoch, cfg.train.save_frequence = 1, 1
+        cfg.freeze()
+        tr = BCNNTrainer(cfg)
+        tr.train()
+        # what this rank alone saw in validation, recomputed without the cross-rank sync
+        local = torch.zeros(2, dtype=torch.float64)
+        tr.model.eval()
+        with torch.no_grad():
+            for data in tr.dataloaders['val']:
+                out = tr.model(data['img'])
+                local += torch.tensor([float((out.argmax(1) == data['label']).sum()), float(len(data['label']))])
+        torch.save({'val_acc': tr.performance_meters['val']['acc'].current_value,
+                    'train_loss': tr.performance_meters['train']['loss'].current_value,
+                    'val_count': tr.average_meters['acc'].count, 'local': local,
+                    'lr': tr.optimizer.param_groups[0]['lr'],
+                    'w': tr.model.classifier.weight.detach().clone()}, os.path.join(out_dir, f'r{rank}.pt'))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_trainer_metrics_are_global(tmp_path):
+    """Two Trainer processes over gloo (heads on the emulated kernels), `debug: False`: rank 0 alone creates the
+    experiment folder (the other rank waits), validation accuracy / train loss are the averages over BOTH shards on
+    every rank (what the reference's single-process DataParallel run reports, and what ReduceLROnPlateau and the
+    best-model rule consume), and the replicas end the epoch with identical weights."""
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+    from emu import build_emu
+    if build_emu._compiler() is None:
+        pytest.skip('no clang++ to build the emulated kernels')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / 'out'
+    out.mkdir()
+    mp.spawn(_two_rank_trainer_worker, args=(2, port, str(tmp_path / 'logs'), str(out)), nprocs=2, join=True)
+    r0, r1 = torch.load(out / 'r0.pt'), torch.load(out / 'r1.pt')
+    assert r0['val_acc'] == r1['val_acc'] and r0['train_loss'] == r1['train_loss'] and r0['lr'] == r1['lr']
+    assert r0['val_count'] == r1['val_count'] == 12                        # the whole validation set, not one shard
+    both = r0['local'] + r1['local']
+    assert both[1] == 12 and abs(r0['val_acc'] - 100.0 * float(both[0] / both[1])) < 1e-9
+    assert torch.equal(r0['w'], r1['w'])
+    assert os.path.isfile(tmp_path / 'logs' / 'bcnn_s2_synthetic' / 'train_config.yaml')

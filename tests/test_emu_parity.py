@@ -32,9 +32,10 @@ for _mod in _modules:
 # parameter sets that take 20 s .. 80 s each when emulated: run them with HK_EMU_FULL=1
 _HEAVY = {'test_cbp_rowsketch_equals_csr[512-6000-40]', 'test_models_with_hip_classifier[BCNN]',
           'test_models_with_hip_classifier[MPN]', 'test_cin_model_matches_reference',
-          'test_ns_128_tile_gemm_variant[9-256-2]', 'test_ns_128_tile_gemm_variant[3-200-3]',
+          'test_ns_grouped_products[2-256-2]', 'test_ns_grouped_products[3-200-3]',
           'test_cov_and_cbp_panel_kernels_vs_generic[70-256-8]', 'test_mpn_256_vs_golden',
-          'test_ns_bf16_split_products[2-200-4]', 'test_ns_bf16_split_products[2-128-5]'}
+          'test_linear_bwd_direct_at_classifier_shapes[3-262144-200]',
+          'test_linear_bwd_direct_at_classifier_shapes[16-6000-8142]'}
 
 
 @pytest.fixture(autouse=True)

@@ -55,6 +55,32 @@ def test_logits_match_reference(name):
     assert y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
 
 
+def test_pyramid_attentions_module_vs_reference_golden():
+    """SURVEY row A7 at MODULE level: the plugin's PyramidAttentions (spatial gate on MIOpen, hk_att_pool, channel gates
+    averaged bottom-up, pooled = sgap + a_c * gap) with the REFERENCE's weights, against what the reference's
+    PyramidAttentions + GAP returned (tests/golden/apcnn_apn.npz): pooled vectors, attention masks, and the gradient
+    w.r.t. all three pyramid levels (APCNN.py:236-268,561-563)."""
+    from hawkeye_amd.model.methods.APCNN import PyramidAttentions
+    g = load('apcnn_apn')
+    apn = PyramidAttentions(channel_size=32)
+    apn.load_state_dict({k[2:].replace('__', '.'): t(g[k]) for k in g.files if k.startswith('w_')}, strict=True)
+    apn = apn.to(DEV)
+    feats = [t(rs_randn(41 + i, (2, 32, s, s))).to(DEV).requires_grad_(True) for i, s in enumerate((28, 14, 7))]
+    pooled, gaps, masks = apn(feats)
+    ws = [t(rs_randn(44 + i, tuple(p.shape))).to(DEV) for i, p in enumerate(pooled)]
+    sum((p * wi).sum() for p, wi in zip(pooled, ws)).backward()
+    for p, k in zip(pooled, ('pooled3', 'pooled4', 'pooled5')):
+        assert rel(p, g[k]) < 1e-5, k
+    for m, k in zip(masks, ('s3', 's4', 's5')):
+        assert rel(m, g[k]) < 1e-5, k
+    for f, gk in zip(gaps, feats):
+        assert rel(f, gk.detach().mean(dim=(2, 3))) < 1e-6
+    assert rel(feats[2].grad, g['df5']) < 1e-4
+    assert rel(sub(feats[0].grad.cpu()), g['df3']) < 1e-4 and rel(sub(feats[1].grad.cpu()), g['df4']) < 1e-4
+    assert abs(float(feats[0].grad.double().abs().sum()) / float(g['df3_abs']) - 1) < 1e-5
+    assert abs(float(feats[1].grad.double().abs().sum()) / float(g['df4_abs']) - 1) < 1e-5
+
+
 def test_apcnn_eval_matches_reference():
     g = load('model_apcnn')
     m = build('APCNN', num_classes=200)
@@ -156,6 +182,75 @@ def test_reducer_on_gpu_single_rank_matches_plain_sgd():
         if use:
             red.finish()
     torch.testing.assert_close(m1.classifier.weight.grad, m2.classifier.weight.grad)
+
+
+_RCCL_ONE_RANK = r"""
+import json, os, sys
+sys.path.insert(0, os.environ['HK_ROOT'])
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ['HK_PORT'])
+import torch
+import torch.distributed as dist
+from hawkeye_amd import ddp
+rank, world, local = ddp.init_from_env('nccl', force=True)
+assert dist.is_initialized() and dist.get_backend() == 'nccl' and world == 1
+torch.manual_seed(0)
+net = lambda: torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 8, 3, padding=1),
+                                  torch.nn.Flatten(), torch.nn.Linear(8 * 16 * 16, 300000 // 2048 * 8)).cuda()
+m1, m2 = net(), net()
+m2.load_state_dict(m1.state_dict())
+red = ddp.GradientAllReducer(m1, bucket_mb=0.25, trace=True)
+x = torch.randn(4, 3, 16, 16, device='cuda')
+red.zero_grad()
+m1(x).square().mean().backward()
+red.finish()
+m2(x).square().mean().backward()
+err = max(float((p.grad - q.grad).abs().max()) for p, q in zip(m1.parameters(), m2.parameters()))
+print(json.dumps({'max_abs_diff': err, 'buckets': red.describe(), 'timeline': red.timeline()}))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_path_executes_on_one_gpu(tmp_path):
+    """The bucketed all-reduce over RCCL (backend "nccl") with a single-rank process group: every bucket really goes
+    through ncclAllReduce on RCCL's stream from the post-accumulate hooks and is joined before the step - the code path
+    of an 8-GPU run, executed on the one GPU this box has.  Own process: the group is process-global state."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HK_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HK_PORT=str(port))
+    p = subprocess.run([sys.executable, '-c', _RCCL_ONE_RANK], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['max_abs_diff'] == 0.0                       # all-reduce over one rank = identity
+    assert len(out['buckets']) >= 2
+    tl = out['timeline']
+    issued = [b[2] for b in tl['buckets']]
+    assert all(v is not None for v in issued) and issued == sorted(issued)       # last layer's bucket first
+    assert issued[0] <= tl['backward_end_ms'] <= tl['joined_ms']
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (the driver's invocation shape, no torchrun around it) re-executes itself with one
+    process per rank; here both ranks share the box's single GPU over gloo.  Rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--share-gpu', '--backend', 'gloo',
+                        '--steps', '2', '--warmup', '1', '--batch', '2', '--image', '64', '--ddp-trace'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['ddp_buckets_mib'][0] > out['ddp_buckets_mib'][-1] or len(out['ddp_buckets_mib']) == 1
 
 
 def test_trainer_runs_one_synthetic_epoch(tmp_path):

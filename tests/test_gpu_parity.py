@@ -122,40 +122,34 @@ def test_bcnn_full_size_properties(F):
 
 
 @pytest.mark.parametrize('b,c,hw', [(1, 64, 14), (9, 128, 14), (3, 192, 12), (2, 64, 10), (5, 128, 8), (90, 192, 8)])
-def test_bcnn_panel_kernels_vs_oracle_and_generic(F, b, c, hw):
+def test_bcnn_panel_kernels_vs_oracle_and_generic(F, b, c, hw, tune):
     """Shapes served by the panel-resident kernels (C % 64 == 0, HW in {196,144,100,64}); (90,192,8) takes the
     balanced row-block-pair schedule with an odd number of row blocks.  Checked against the oracle and against
-    the generic GEMM path (HK_BCNN_GENERIC=1)."""
+    the generic GEMM path (bcnn_generic knob)."""
     xn, wn = rs_relu_randn(91, (b, c, hw, hw)), rs_randn(92, (b, c * c))
     x, y, xg, yg = _bcnn_case(F, xn, wn)
     assert rel(yg, y) < 1e-6 and rel(xg.grad, x.grad) < 2e-5
     ym = yg.detach().view(b, c, c)
     assert torch.equal(ym, ym.transpose(1, 2))
-    os.environ['HK_BCNN_GENERIC'] = '1'
-    try:
-        xg2 = t(xn).to(DEV).requires_grad_(True)
-        yg2 = F.bilinear_pool(xg2)
-        (yg2 * t(wn).to(DEV)).sum().backward()
-    finally:
-        del os.environ['HK_BCNN_GENERIC']
+    tune('bcnn_generic', 1)
+    xg2 = t(xn).to(DEV).requires_grad_(True)
+    yg2 = F.bilinear_pool(xg2)
+    (yg2 * t(wn).to(DEV)).sum().backward()
     assert rel(yg, yg2) < 1e-6 and rel(xg.grad, xg2.grad) < 1e-5
 
 
-def test_bcnn_full_size_backward_vs_generic(F):
+def test_bcnn_full_size_backward_vs_generic(F, tune):
     """B=64, C=512, 14x14: pair-scheduled forward + row-block backward vs the generic path and the oracle (2 samples)."""
     g = torch.Generator().manual_seed(1)
     x = torch.relu(torch.randn(64, 512, 14, 14, generator=g))
     w = torch.randn(64, 512 * 512, generator=g)
     outs = []
     for generic in ('0', '1'):
-        os.environ['HK_BCNN_GENERIC'] = generic
-        try:
-            xg = x.to(DEV).requires_grad_(True)
-            yg = F.bilinear_pool(xg)
-            (yg * w.to(DEV)).sum().backward()
-            outs.append((yg.detach(), xg.grad))
-        finally:
-            del os.environ['HK_BCNN_GENERIC']
+        tune('bcnn_generic', int(generic))
+        xg = x.to(DEV).requires_grad_(True)
+        yg = F.bilinear_pool(xg)
+        (yg * w.to(DEV)).sum().backward()
+        outs.append((yg.detach(), xg.grad))
     assert rel(outs[0][0], outs[1][0]) < 1e-6 and rel(outs[0][1], outs[1][1]) < 1e-5
     xc = x[62:].clone().requires_grad_(True)
     yo = O.bilinear_pool(xc)
@@ -219,7 +213,7 @@ def test_mpn_49_and_properties(F):
 
 
 @pytest.mark.parametrize('b,c,hw', [(2, 64, 14), (9, 128, 10), (70, 256, 8)])
-def test_cov_and_cbp_panel_kernels_vs_generic(F, b, c, hw):
+def test_cov_and_cbp_panel_kernels_vs_generic(F, b, c, hw, tune):
     """Covariance (centred Gram) and CBP (raw Gram + gathered dG) reuse the panel-resident kernels for
     C % 64 == 0, HW in {196,144,100,64}: check them against the generic GEMM path and the oracle."""
     xn = rs_relu_randn(93, (b, c, hw, hw))
@@ -227,17 +221,14 @@ def test_cov_and_cbp_panel_kernels_vs_generic(F, b, c, hw):
     plan = _plan(F, c, d)
     res = []
     for generic in ('0', '1'):
-        os.environ['HK_BCNN_GENERIC'] = generic
-        try:
-            xg = t(xn).to(DEV).requires_grad_(True)
-            cov = F.covpool(xg)
-            cov.backward(t(rs_randn(94, (b, c, c))).to(DEV))
-            xg2 = t(xn).to(DEV).requires_grad_(True)
-            yc = F.compact_bilinear_pool(xg2, plan)
-            yc.backward(t(rs_randn(95, (b, d))).to(DEV))
-            res.append((cov.detach(), xg.grad, yc.detach(), xg2.grad))
-        finally:
-            del os.environ['HK_BCNN_GENERIC']
+        tune('bcnn_generic', int(generic))
+        xg = t(xn).to(DEV).requires_grad_(True)
+        cov = F.covpool(xg)
+        cov.backward(t(rs_randn(94, (b, c, c))).to(DEV))
+        xg2 = t(xn).to(DEV).requires_grad_(True)
+        yc = F.compact_bilinear_pool(xg2, plan)
+        yc.backward(t(rs_randn(95, (b, d))).to(DEV))
+        res.append((cov.detach(), xg.grad, yc.detach(), xg2.grad))
     for a, g, tol in zip(res[0], res[1], (1e-5, 1e-5, 1e-5, 1e-4)):   # CBP gradient: sqrt slope amplifies rounding
         assert rel(a, g) < tol
     xo = t(xn[:2]).requires_grad_(True)
@@ -305,11 +296,11 @@ def test_cbp_dense_small_and_512(F):
         assert yg.argmax(dim=1).cpu().tolist() == y.argmax(dim=1).tolist()
 
 
-@pytest.mark.parametrize('csr', ['0', '1'])
-def test_cbp_512_both_binning_kernels(F, csr, monkeypatch):
-    """hk_cbp_fwd picks the binning kernel by batch size (row-sketch once B*C/64 >= 256 workgroups, CSR gather below);
-    HK_CBP_CSR forces one: both must reproduce the reference at the yaml shape."""
-    monkeypatch.setenv('HK_CBP_CSR', csr)
+@pytest.mark.parametrize('csr', ['0', '1', '2'])
+def test_cbp_512_both_binning_kernels(F, csr, tune):
+    """hk_cbp_fwd has three binning kernels (row-scatter: the default; row-sketch; CSR gather); the cbp_bin knob forces
+    one: each must reproduce the reference at the yaml shape."""
+    tune('cbp_bin', int(csr))
     g = load('cbp_512')
     xn, wn = rs_relu_randn(1234, (2, 512, 14, 14)).astype(np.float32), rs_randn(1236, (2, 6000))
     x, y, xg, yg = _cbp_case(F, xn, wn, 6000)
@@ -319,19 +310,19 @@ def test_cbp_512_both_binning_kernels(F, csr, monkeypatch):
 
 
 @pytest.mark.parametrize('c,d,b', [(128, 1024, 3), (256, 2048, 2), (512, 4096, 2), (512, 8192, 2), (512, 6000, 40)])
-def test_cbp_rowsketch_equals_csr(F, c, d, b, monkeypatch):
+def test_cbp_rowsketch_equals_csr(F, c, d, b, tune):
     """Every template instance of the row-sketch kernel (1/2 bins per thread x 8..32 outputs per thread) against the
     CSR gather; b=40 is above the automatic switch-over, so the default path is covered too."""
     x = torch.relu(torch.randn(b, c, 7, 7, generator=torch.Generator().manual_seed(c + d))).to(DEV)
     plan = _plan(F, c, d)
-    monkeypatch.setenv('HK_CBP_CSR', '1')
+    tune('cbp_bin', 1)
     y_csr = F.compact_bilinear_pool(x, plan)
-    monkeypatch.setenv('HK_CBP_CSR', '0')
+    tune('cbp_bin', 0)
     y_row = F.compact_bilinear_pool(x, plan)
-    monkeypatch.delenv('HK_CBP_CSR')
-    y_def = F.compact_bilinear_pool(x, plan)
+    tune('cbp_bin', -1)
+    y_def = F.compact_bilinear_pool(x, plan)                  # automatic: row-scatter, same partial sums as the row-sketch
     assert rel(y_row, y_csr) < 2e-6 and rel(y_def, y_csr) < 2e-6
-    assert torch.equal(y_def, y_row if b * (c // 64) >= 256 else y_csr)
+    assert torch.equal(y_def, y_row)
 
 
 def test_cbp_zero_bins(F):

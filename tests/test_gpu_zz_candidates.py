@@ -35,8 +35,8 @@ def _golden(name):
 
 
 @pytest.mark.parametrize('b,c,hw', [(2, 128, 14), (3, 192, 12), (9, 64, 8), (2, 512, 14)])
-def test_backward_two_barrier_variant_bit_identical(F, b, c, hw, monkeypatch):
-    """HK_BWD_V=4 (transposed operand fetched directly, two barriers per K-block instead of four) performs the same
+def test_backward_two_barrier_variant_bit_identical(F, b, c, hw, tune):
+    """bwd_v=4 (transposed operand fetched directly, two barriers per K-block instead of four) performs the same
     fp32 operations in the same order as the default backward: bit-identical dX for the BCNN, covariance and CBP modes."""
     gen = torch.Generator().manual_seed(c + hw)
     x = torch.relu(torch.randn(b, c, hw, hw, generator=gen))
@@ -44,7 +44,7 @@ def test_backward_two_barrier_variant_bit_identical(F, b, c, hw, monkeypatch):
                      else torch.device('cuda', torch.cuda.current_device()))
     res = []
     for flag in ('0', '4'):
-        monkeypatch.setenv('HK_BWD_V', flag)
+        tune('bwd_v', int(flag))
         out = []
         xg = x.clone().to(DEV).requires_grad_(True)
         y = F.bilinear_pool(xg)
@@ -68,8 +68,8 @@ def test_backward_two_barrier_variant_bit_identical(F, b, c, hw, monkeypatch):
 
 
 @pytest.mark.parametrize('mode', ['train', 'eval'])
-def test_roi_crop_backward_lds_variant_bit_identical(F, mode, monkeypatch):
-    """HK_ROI_BWD=2 (tables shared by 4 channel maps, dY map staged in LDS) adds the same taps in the same order as the
+def test_roi_crop_backward_lds_variant_bit_identical(F, mode, tune):
+    """roi_bwd=2 (tables shared by 4 channel maps, dY map staged in LDS) adds the same taps in the same order as the
     default table-driven backward: bit-identical dX, for several boxes including a dropped block and a tiny crop."""
     gen = torch.Generator().manual_seed(9)
     x = torch.randn(4, 10, 56, 56, generator=gen)                         # 10 channels: 2 full groups of 4 + a ragged one
@@ -78,7 +78,7 @@ def test_roi_crop_backward_lds_variant_bit_identical(F, mode, monkeypatch):
     drop = torch.tensor([[10., 12., 20., 30.], [0., 0., -1., -1.], [0., 0., -1., -1.], [12., 3., 30., 9.]])
     res = []
     for flag in ('0', '2'):
-        monkeypatch.setenv('HK_ROI_BWD', flag)
+        tune('roi_bwd', int(flag))
         xg = x.clone().to(DEV).requires_grad_(True)
         y = F.roi_crop_resize(xg, box.to(DEV), drop.to(DEV), mode == 'train')
         (y * wt.to(DEV)).sum().backward()
@@ -87,8 +87,8 @@ def test_roi_crop_backward_lds_variant_bit_identical(F, mode, monkeypatch):
 
 
 @pytest.mark.parametrize('c,d,b', [(128, 1024, 3), (256, 2048, 2), (512, 6000, 2), (512, 8192, 2), (64, 50, 3), (96, 333, 2)])
-def test_cbp_row_scatter_binning(F, c, d, b, monkeypatch):
-    """HK_CBP_CSR=2: the chunk's bins live in LDS and every row adds its <= C non-zero sketch entries into them (one
+def test_cbp_row_scatter_binning(F, c, d, b, tune):
+    """cbp_bin=2 (the default wherever its bins fit the LDS): the chunk's bins live in LDS and every row adds its <= C non-zero sketch entries into them (one
     barrier per row, ~8x less LDS traffic than the row-sketch kernel).  Same summation order and expression as the
     row-sketch kernel -> bit-identical to it wherever that one applies; equal to the CSR gather up to rounding; works
     for any D (the row-sketch kernel needs D >= 1024)."""
@@ -97,7 +97,7 @@ def test_cbp_row_scatter_binning(F, c, d, b, monkeypatch):
                      else torch.device('cuda', torch.cuda.current_device()))
     out = {}
     for flag in ('1', '0', '2'):
-        monkeypatch.setenv('HK_CBP_CSR', flag)
+        tune('cbp_bin', int(flag))
         xg = x.clone().requires_grad_(True)
         y = F.compact_bilinear_pool(xg, plan)
         (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(DEV)).sum().backward()
@@ -156,9 +156,9 @@ def test_presets_device_finalize_equals_cpu_path(F):
 
 @pytest.mark.parametrize('b,j,k,bias', [(3, 1000, 7, True), (64, 4096, 200, True), (5, 333, 130, False), (10, 6272, 96, True),
                                         (1, 40, 1, True)])
-def test_linear_split_k(F, b, j, k, bias, monkeypatch):
+def test_linear_split_k(F, b, j, k, bias, tune):
     """hk_linear_fwd/bwd (classifier on the pooled vector) vs torch's Linear in fp64; slab counts forced
-    through HK_LINEAR_SLABS cover one slab, ragged last slabs and the automatic choice."""
+    through the linear_slabs knob cover one slab, ragged last slabs and the automatic choice."""
     gen = torch.Generator().manual_seed(b * 1000 + j)
     y = torch.randn(b, j, generator=gen)
     w = torch.randn(k, j, generator=gen) / j ** 0.5
@@ -169,10 +169,7 @@ def test_linear_split_k(F, b, j, k, bias, monkeypatch):
     o64 = torch.nn.functional.linear(y64, w64, b64)
     (o64 * g.double()).sum().backward()
     for slabs in (None, '1', '3', '7'):
-        if slabs is None:
-            monkeypatch.delenv('HK_LINEAR_SLABS', raising=False)
-        else:
-            monkeypatch.setenv('HK_LINEAR_SLABS', slabs)
+        tune('linear_slabs', 0 if slabs is None else int(slabs))
         yg, wg = y.clone().to(DEV).requires_grad_(True), w.clone().to(DEV).requires_grad_(True)
         bg = bv.clone().to(DEV).requires_grad_(True) if bias else None
         og = F.linear(yg, wg, bg)
@@ -301,73 +298,41 @@ def test_cin_loss_matches_reference():
     assert abs(float(crit(tt(rs_randn(422, (4, 5))).to(DEV), torch.tensor([1, 3, 1, 1]).to(DEV)))) > 0   # eval: plain CE
 
 
-@pytest.mark.parametrize('b,d,itn', [(3, 70, 5), (2, 128, 5), (9, 64, 3), (2, 33, 2)])
-def test_ns_symmetric_tile_mode(F, b, d, itn, monkeypatch):
-    """HK_NS_SYM=1: upper-triangle tiles only + mirrored stores for the symmetric products of the Newton-Schulz chain,
-    and Z Y taken as the transpose of Y Z in the backward (38 -> 34 launches).  Same tolerances as the full products."""
+@pytest.mark.parametrize('b,d,itn', [(3, 70, 5), (2, 128, 5), (9, 64, 3), (2, 33, 2), (3, 200, 3), (2, 256, 2),
+                                     (2, 128, 1), (2, 40, 1)])
+def test_ns_grouped_products(F, b, d, itn):
+    """The Newton-Schulz chain on the grouped kernel (hk_nsmm.h): both tile widths (64 / 128 columns; the automatic
+    choice depends on the batch size), aligned fast path (d % 128 == 0) and guarded path (any d), every iterN branch of
+    the reference (MPNCOV.py:149-161,177-194).  Same tolerances as round 1's one-GEMM-per-launch chain; the two tile
+    widths accumulate in the same k order, so they agree bit for bit."""
+    from hawkeye_amd import _lib
     x = torch.relu(torch.randn(b, d, 6, 7, generator=torch.Generator().manual_seed(d))) + 0.01
     xo = x.clone().requires_grad_(True)
     yo = O.triuvec(O.sqrtm(O.covpool(xo), itn))
     wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))
     (yo * wt).sum().backward()
     res = []
-    for flag in ('0', '1'):
-        monkeypatch.setenv('HK_NS_SYM', flag)
-        xg = x.clone().to(DEV).requires_grad_(True)
-        cov = F.covpool(xg)
-        s = F.sqrtm(cov, itn)
-        yg = F.triuvec(s)
-        (yg * wt.to(DEV)).sum().backward()
-        assert rel(yg, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
-        if flag == '1':
-            assert rel(s, s.transpose(1, 2)) < 1e-6            # off-diagonal tiles mirrored, diagonal tiles computed
-        res.append((yg.detach(), xg.grad))
-    assert rel(res[1][0], res[0][0]) < 5e-6 and rel(res[1][1], res[0][1]) < 5e-5
-
-
-@pytest.mark.parametrize('b,d,itn', [(2, 128, 5), (3, 200, 3), (9, 256, 2), (3, 70, 4)])
-def test_ns_128_tile_gemm_variant(F, b, d, itn, monkeypatch):
-    """HK_NS_GEMM=4: the Newton-Schulz products on bgemm128_kernel (128x128 tile, 8 waves, two-chunk prefetch through
-    two register sets).  Same k order as the 64x64 kernel, so results agree to rounding of the tile boundaries only."""
-    x = torch.relu(torch.randn(b, d, 5, 6, generator=torch.Generator().manual_seed(d + 1))) + 0.01
-    xo = x.clone().requires_grad_(True)
-    yo = O.sqrtm(O.covpool(xo), itn)
-    wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(2))
-    (yo * wt).sum().backward()
-    res = []
-    for flag in ('0', '4', '5'):                         # 5: the same two-chunk prefetch on the 64x64 tile
-        monkeypatch.setenv('HK_NS_GEMM', flag)
-        xg = x.clone().to(DEV).requires_grad_(True)
-        yg = F.sqrtm(F.covpool(xg), itn)
-        (yg * wt.to(DEV)).sum().backward()
+    for tn in (64, 128):
+        with _lib.tuning(ns_tn=tn):
+            xg = x.clone().to(DEV).requires_grad_(True)
+            yg = F.triuvec(F.sqrtm(F.covpool(xg), itn))
+            (yg * wt.to(DEV)).sum().backward()
         assert rel(yg, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
         res.append((yg.detach(), xg.grad))
-    assert rel(res[1][0], res[0][0]) < 2e-6 and rel(res[1][1], res[0][1]) < 2e-5
-    assert torch.equal(res[2][0], res[0][0]) and torch.equal(res[2][1], res[0][1])    # same tile, same k order: bit-identical
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize('b,d,itn', [(2, 128, 5), (3, 70, 3), (2, 200, 4)])
-def test_ns_bf16_split_products(F, b, d, itn, monkeypatch):
-    """HK_NS_GEMM=6 / 7: the fp32 products of the Newton-Schulz chain computed on the bf16 matrix pipe from operands
-    split exactly into three bf16 pieces - six piece products reproduce fp32 to its own rounding level (same bounds as
-    the f32-MFMA path), three keep 1e-5 (inside the 1e-4 parity budget).  On the device this also confirms the
-    operand layout assumed for v_mfma_f32_32x32x16_bf16: a wrong one cannot pass."""
-    x = torch.relu(torch.randn(b, d, 6, 7, generator=torch.Generator().manual_seed(d + 3))) + 0.01
+def test_ns_nonsymmetric_upstream_gradient(F):
+    """The backward takes Z Y from the Y Z product (the iterates commute); that must hold for ANY upstream gradient, also
+    a non-symmetric one (Triuvec's backward hands over an upper-triangular matrix)."""
+    b, d, itn = 2, 96, 5
+    x = torch.relu(torch.randn(b, d, 5, 5, generator=torch.Generator().manual_seed(77))) + 0.01
+    wt = torch.randn(b, d, d, generator=torch.Generator().manual_seed(78)).triu()
     xo = x.clone().requires_grad_(True)
-    yo = O.sqrtm(O.covpool(xo), itn)
-    wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(4))
-    (yo * wt).sum().backward()
-    flags = (('6', 1e-5, 1e-4), ('7', 1e-4, 1e-3))
-    if d >= 128:                                            # the same on the 128x128 / 8-wave tile
-        flags += (('8', 1e-5, 1e-4), ('9', 1e-4, 1e-3))
-    for flag, tol_f, tol_b in flags:
-        monkeypatch.setenv('HK_NS_GEMM', flag)
-        xg = x.clone().to(DEV).requires_grad_(True)
-        yg = F.sqrtm(F.covpool(xg), itn)
-        (yg * wt.to(DEV)).sum().backward()
-        assert rel(yg, yo) < tol_f and rel(xg.grad, xo.grad) < tol_b, flag
-        if flag in ('6', '8'):
-            assert rel(yg, yo) < 4e-6 and rel(xg.grad, xo.grad) < 4e-6       # fp32-equivalent in practice
+    (O.sqrtm(O.covpool(xo), itn) * wt).sum().backward()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    (F.sqrtm(F.covpool(xg), itn) * wt.to(DEV)).sum().backward()
+    assert rel(xg.grad, xo.grad) < 1e-4
 
 
 _MODEL_CFG = {
@@ -377,10 +342,58 @@ _MODEL_CFG = {
 }
 
 
+@pytest.mark.parametrize('b,j,k', [(2, 6000, 200), (2, 32896, 200), (3, 262144, 200), (16, 6000, 8142)])
+def test_linear_bwd_direct_at_classifier_shapes(F, b, j, k):
+    """hk_linear_bwd on its own at the three classifier widths of the plugins (CBCNN 6000: not a multiple of 64, so the
+    48-column / 8-deep tails of the tile kernel are exercised; MPN 32896; BCNN 262144) and the iNat class count:
+    dy = g W, dW = g^T y, db = sum_b g against fp64.  Nothing but the kernel is between the inputs and the check, so a
+    failure here is the kernel's."""
+    gen = torch.Generator().manual_seed(j + k)
+    y = torch.randn(b, j, generator=gen)
+    w = torch.randn(k, j, generator=gen) / j ** 0.5
+    bias = torch.randn(k, generator=gen)
+    g = torch.randn(b, k, generator=gen)
+    yg, wg, bg = (v.clone().to(DEV).requires_grad_(True) for v in (y, w, bias))
+    og = F.linear(yg, wg, bg)
+    (og * g.to(DEV)).sum().backward()
+    assert rel(og, torch.nn.functional.linear(y.double(), w.double(), bias.double())) < 2e-6
+    assert rel(yg.grad, g.double() @ w.double()) < 2e-6
+    assert rel(wg.grad, g.double().t() @ y.double()) < 2e-6
+    assert rel(bg.grad, g.double().sum(0)) < 2e-6
+    # element-wise as well: a wrong tail column hides in a norm
+    assert float((yg.grad.double().cpu() - g.double() @ w.double()).abs().max()) < 1e-5 * float((g.double() @ w.double()).abs().max())
+
+
+def _head64(name, m, feats):
+    """fp64 CPU evaluation of everything behind the backbone (oracle pool + Linear): the yardstick for the gradient at
+    the pool input."""
+    import copy
+    f64 = feats.detach().double().cpu().requires_grad_(True)
+    if name == 'BCNN':
+        pooled = O.bilinear_pool(f64)
+    elif name == 'CBCNN':
+        pooled = O.compact_bilinear_pool_gram(f64, 6000)
+    else:
+        dr = copy.deepcopy(m.pool.conv_dr_block).cpu().double().eval()
+        pooled = O.mpncov_pool(dr(f64), 5).reshape(f64.shape[0], -1)
+    logits = torch.nn.functional.linear(pooled, m.classifier.weight.detach().double().cpu(),
+                                        m.classifier.bias.detach().double().cpu())
+    torch.nn.functional.cross_entropy(logits, torch.tensor([3, 77])).backward()
+    return f64.grad
+
+
 @pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN'])
 def test_models_with_hip_classifier(F, name, monkeypatch):
-    """HAWKEYE_HIP_LINEAR=1: the classifier on the pooled vector runs on hk_linear_* - logits still match the REFERENCE
-    model's (tests/golden/model_logits.npz) and a train step gives the same classifier gradient as torch's Linear."""
+    """HAWKEYE_HIP_LINEAR=1: the classifier on the pooled vector runs on hk_linear_*.  Checked in three separate places so
+    that a failure says where it comes from:
+      (a) logits vs the REFERENCE model (tests/golden/model_logits.npz) and the classifier's own gradients vs torch's;
+      (b) the gradient at the POOL INPUT (backbone output) of both paths against an fp64 evaluation of the head - the
+          HIP-classifier path has to be as close to fp64 as torch's Linear is;
+      (c) the trunk gradient.  The backbone's backward is the same linear map in both runs, so the difference of the
+          two trunk gradients must be that map applied to the difference of the two pool-input gradients; what is left
+          over is MIOpen's run-to-run noise (weight-gradient kernels with atomics), measured from two torch-only runs.
+    Round 1's version compared the trunk gradients of the two paths directly at 1e-4 and failed for CBCNN on the
+    MI355X (GPUTEST_r01); DESIGN.md section 4 has the diagnosis."""
     import os
 
     import hawkeye_amd.model  # noqa: F401
@@ -392,18 +405,43 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
     seeded_init(m, 900)
     m = m.to(DEV).eval()
     x = torch.from_numpy(np.ascontiguousarray(rs_randn(901, (2, 3, 64, 64)))).to(DEV)
-    grads = []
-    for flag in ('0', '1'):
+    w0 = next(m.backbone.parameters())
+    feats_seen = []
+
+    def keep(mod, inp, out):                                 # (returning something would replace the module's output)
+        out.retain_grad()
+        feats_seen.append(out)
+    hook = m.backbone.register_forward_hook(keep)
+    runs = []
+    for flag in ('0', '0', '1'):
         monkeypatch.setenv('HAWKEYE_HIP_LINEAR', flag)
         m.zero_grad()
         y = m(x)
         assert rel(y, g[name]) < 1e-4 and y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
-        torch.nn.functional.cross_entropy(y, torch.tensor([3, 77], device=y.device)).backward()
-        grads.append((m.classifier.weight.grad.clone(), m.classifier.bias.grad.clone(),
-                      next(m.backbone.parameters()).grad.clone()))
-    # the trunk gradient goes through MIOpen's weight-gradient kernels (split-K with atomics: not bitwise repeatable)
-    for (p, q), tol in zip(zip(grads[0], grads[1]), (1e-5, 1e-5, 1e-4)):
-        assert rel(q, p) < tol
+        torch.nn.functional.cross_entropy(y, torch.tensor([3, 77], device=y.device)).backward(retain_graph=True)
+        runs.append(dict(cw=m.classifier.weight.grad.clone(), cb=m.classifier.bias.grad.clone(), trunk=w0.grad.clone(),
+                         feats=feats_seen[-1], fgrad=feats_seen[-1].grad.clone()))
+    hook.remove()
+    t0, t0b, t1 = runs
+    # (a) the classifier's own gradients
+    assert rel(t1['cw'], t0['cw']) < 1e-5 and rel(t1['cb'], t0['cb']) < 1e-5
+    # (b) pool-input gradient vs fp64
+    f64 = _head64(name, m, t0['feats'])
+    e0, e1 = rel(t0['fgrad'], f64), rel(t1['fgrad'], f64)
+    d01 = rel(t1['fgrad'], t0['fgrad'])
+    # (c) trunk: noise floor of the torch-only path, then the linearity residual
+    noise = rel(t0b['trunk'], t0['trunk'])
+    lin = torch.autograd.grad(t0['feats'], w0, grad_outputs=t1['fgrad'] - t0['fgrad'], retain_graph=False)[0]
+    resid = float(((t1['trunk'] - t0['trunk']) - lin).double().norm() / t0['trunk'].double().norm())
+    direct = rel(t1['trunk'], t0['trunk'])
+    print(f'[hip classifier {name}] pool-input grad vs fp64: torch {e0:.2e} hip {e1:.2e} (hip vs torch {d01:.2e}); '
+          f'trunk: hip vs torch {direct:.2e}, MIOpen run-to-run {noise:.2e}, linearity residual {resid:.2e}, '
+          f'amplification {direct / max(d01, 1e-30):.1f}x')
+    assert e1 < 2 * e0 + 1e-6, (e0, e1)
+    assert d01 < 1e-5, d01                                  # the two heads hand the backbone the same gradient
+    # what the linear propagation of that head difference does not explain must be run-to-run noise or the rounding of
+    # evaluating the backward map itself (which scales with the same amplification as `direct`)
+    assert resid < max(20 * noise, 0.5 * direct, 2e-6), (resid, noise, direct)
 
 
 def test_cin_model_matches_reference(F):

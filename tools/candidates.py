@@ -35,6 +35,13 @@ else:
 rows = []
 
 
+def knob(name, value):
+    """A/B lever of the library (hk_tuning_set); every function below restores what it touches."""
+    rc = lib.hk_tuning_set(name.encode(), int(value))
+    if rc != 0:
+        raise RuntimeError(f'hk_tuning_set({name}) returned {rc}')
+
+
 def sz(full, tiny):
     return tiny if TINY else full
 
@@ -102,16 +109,16 @@ def linear():
         rows[-4]['rel_err_vs_torch'] = err
         if tag.startswith('bcnn'):                      # slab-count sweep for the split-K forward (auto = 384 here)
             for slabs in sz((64, 128, 256, 768, 1024), (2, 3)):
-                os.environ['HK_LINEAR_SLABS'] = str(slabs)
+                knob('linear_slabs', slabs)
                 n2 = lib.hk_linear_ws_bytes(B, J, K)
                 ws2 = torch.empty(n2, dtype=torch.uint8, device=dev)
-                row(f'linear fwd {tag}', f'hk_linear_fwd HK_LINEAR_SLABS={slabs}',
+                row(f'linear fwd {tag}', f'hk_linear_fwd linear_slabs={slabs}',
                     timeit(lambda: lib.hk_linear_fwd(ptr(y), ptr(w), ptr(b), ptr(out), B, J, K, ptr(ws2), n2, stream())), fl,
                     4.0 * (B * J + K * J))
-            del os.environ['HK_LINEAR_SLABS']
+            knob('linear_slabs', 0)
 
 
-def ns_sym():
+def ns_chain():
     B, d = sz(64, 2), sz(256, 128)
     x = torch.relu(torch.randn(B, d, 196, device=dev))
     cov, mu = torch.empty(B, d, d, device=dev), torch.empty(B, d, device=dev)
@@ -122,12 +129,12 @@ def ns_sym():
     nwf, nwb = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 0), lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 1)
     wf, wb = torch.empty(nwf, dtype=torch.uint8, device=dev), torch.empty(nwb, dtype=torch.uint8, device=dev)
     ref = None
-    for sym, gemm in (('0', '0'), ('1', '0'), ('0', '4'), ('1', '4'), ('0', '5'), ('0', '6'), ('0', '7'), ('0', '8'), ('0', '9')):
-        os.environ['HK_NS_SYM'], os.environ['HK_NS_GEMM'] = sym, gemm
+    for tn in (0, 64, 128):
+        knob('ns_tn', tn)
         f = timeit(lambda: lib.hk_ns_sqrtm_fwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), B, d, 5, ptr(wf), nwf, stream()))
         b = timeit(lambda: lib.hk_ns_sqrtm_bwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), ptr(g), ptr(da), B, d, 5,
                                                ptr(wb), nwb, stream()))
-        tag = f'HK_NS_SYM={sym} HK_NS_GEMM={gemm}' + (' (round-1 default)' if (sym, gemm) == ('0', '0') else '')
+        tag = 'grouped products, ' + ('automatic tile width (default)' if tn == 0 else f'ns_tn={tn}')
         row('ns_sqrtm fwd B=64 d=256 it=5', tag, f, 12 * 2.0 * B * d ** 3)
         row('ns_sqrtm bwd B=64 d=256 it=5', tag, b, 38 * 2.0 * B * d ** 3)
         if ref is None:
@@ -135,7 +142,7 @@ def ns_sym():
         else:
             rows[-2]['rel_vs_default'] = float((out - ref[0]).norm() / ref[0].norm())
             rows[-1]['rel_vs_default'] = float((da - ref[1]).norm() / ref[1].norm())
-    os.environ['HK_NS_SYM'], os.environ['HK_NS_GEMM'] = '0', '0'
+    knob('ns_tn', 0)
 
 
 def npairs():
@@ -179,8 +186,8 @@ def cbp():
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         ref = None
         for flag, tag in (('0', 'row-sketch binning (round-1 default at B=64)'), ('1', 'CSR gather binning (round-1 default at B=16)'),
-                          ('2', 'row-scatter binning (bins in LDS, one barrier per row)')):
-            os.environ['HK_CBP_CSR'] = flag
+                          ('2', 'row-scatter binning (bins in LDS, one barrier per row; round-2 default)')):
+            knob('cbp_bin', flag)
             row(f'cbp fwd B={B}', tag,
                 timeit(lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws,
                                               stream())), 2.0 * B * C * C * HW)
@@ -188,7 +195,7 @@ def cbp():
                 ref = y.clone()
             elif flag == '2':
                 rows[-1]['bit_identical_to_default'] = bool(torch.equal(y, ref))
-    del os.environ['HK_CBP_CSR']
+    knob('cbp_bin', -1)
 
 
 def bwd_variants():
@@ -205,7 +212,7 @@ def bwd_variants():
     mu, g, dxm = torch.zeros(B, dc, device=dev), torch.randn(B, dc, dc, device=dev), torch.empty_like(xm)
     ref = None
     for flag in ('0', '4', '3'):
-        os.environ['HK_BWD_V'] = flag
+        knob('bwd_v', flag)
         tag = {'0': 'HK_BWD_V=0 four barriers per K-block (round-1 default)', '4': 'HK_BWD_V=4 two barriers, direct transposed loads',
                '3': 'HK_BWD_V=3 raw tiles, 3 WGs/CU'}[flag]
         row('bcnn bwd_gemm B=64 C=512', tag,
@@ -219,7 +226,7 @@ def bwd_variants():
             row('cov_pool bwd B=64 C=256', tag,
                 timeit(lambda: lib.hk_cov_pool_bwd(ptr(xm), ptr(mu), ptr(g), ptr(dxm), B, dc, HW, stream()), iters=40),
                 2.0 * B * dc * dc * HW)
-    os.environ['HK_BWD_V'] = '0'
+    knob('bwd_v', 0)
 
 
 def roi_bwd():
@@ -229,7 +236,7 @@ def roi_bwd():
     drop = torch.tensor([[10., 12., 20., 30.]] * B, device=dev)
     ref = None
     for flag in ('0', '2'):
-        os.environ['HK_ROI_BWD'] = flag
+        knob('roi_bwd', flag)
         row(f'roi_crop_resize bwd B={B} C={C} 56x56', 'default table kernel' if flag == '0' else 'HK_ROI_BWD=2 LDS-staged, 4 maps / WG',
             timeit(lambda: lib.hk_roi_crop_resize_bwd(ptr(dy), ptr(box), ptr(drop), ptr(dx), B, C, 56, 56, 1, stream())), 0.0,
             8.0 * B * C * 3136)
@@ -237,7 +244,7 @@ def roi_bwd():
             ref = dx.clone()
         else:
             rows[-1]['bit_identical_to_default'] = bool(torch.equal(dx, ref))
-    os.environ['HK_ROI_BWD'] = '0'
+    knob('roi_bwd', 0)
 
 
 def cin():
@@ -302,7 +309,7 @@ def bcnn_step_with_hip_linear():
 
 
 if __name__ == '__main__':
-    for f in (bwd_variants, roi_bwd, linear, ns_sym, npairs, cbp, cin):
+    for f in (bwd_variants, roi_bwd, linear, ns_chain, npairs, cbp, cin):
         guarded(f)
     if '--step' in sys.argv and not TINY:
         guarded(bcnn_step_with_hip_linear)

@@ -1,0 +1,160 @@
+"""The other BASELINE.json configs on ONE MI355X (configs[2..4] at their single-GPU shapes), next to the headline:
+    MPN   (Fast MPN-COV, ResNet-50, 448x448, batch 64)            configs/MPN.yaml
+    CBCNN (VGG-16, 448x448, D = 6000, batch 64 and the yaml's 16)  configs/CBCNN_S2.yaml
+    APCNN (ResNet-50 + FPN, 448x448, batch 16, 8142 classes = iNat2018 shape: hidden_num 256, border 0.1-0.9,
+           model/methods/APCNN.py:360-363,451-454)                 configs/APCNN.yaml
+For each: ms per full train step (forward, loss, backward, SGD step; synthetic batch resident in HBM) and the
+HIP-event time + roofline fraction of every hand-written kernel of its pooling head at that batch size.
+bench.py runs this in a subprocess after the headline measurement and attaches the list as `other_models`.
+    python tools/model_rows.py [--quick]      # prints one JSON list
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import bench                      # build_model, time_events, peaks (also points MIOpen at the in-tree cache)
+import hawkeye_amd.functional as F
+from hawkeye_amd import _lib
+from hawkeye_amd._lib import ptr, stream
+
+QUICK = '--quick' in sys.argv
+dev = torch.device('cuda:0')
+lib = _lib.load()
+rows = []
+
+
+def E(*shape, dtype=torch.float32):
+    return torch.empty(*shape, dtype=dtype, device=dev)
+
+
+def R(*shape):
+    return torch.randn(*shape, device=dev)
+
+
+def kernel_row(model, name, fn, flops=0.0, bytes_=0.0, iters=30):
+    us = bench.time_events(fn, iters) * 1e3
+    tf, gbs = flops / us / 1e6, bytes_ / us / 1e3
+    mfma = flops > 0 and flops / max(bytes_, 1.0) > bench.PEAK_MFMA_F32_TF * 1e3 / bench.PEAK_HBM_GBS
+    rows.append({'model': model, 'kernel': name, 'us': round(us, 1), 'bound': 'mfma' if mfma else 'hbm',
+                 'achieved': round(tf if mfma else gbs, 1), 'unit': 'TFLOP/s' if mfma else 'GB/s',
+                 'frac': round(tf / bench.PEAK_MFMA_F32_TF if mfma else gbs / bench.PEAK_HBM_GBS, 3)})
+
+
+def train_row(model_name, batch, classes, image=448, steps=6, warmup=3):
+    torch.manual_seed(0)
+    model = bench.build_model(model_name, classes).to(dev).to(memory_format=torch.channels_last)
+    model.train()
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.005, momentum=0.9, weight_decay=1e-5)
+    images = torch.randn(batch, 3, image, image, device=dev).contiguous(memory_format=torch.channels_last)
+    labels = torch.randint(0, classes, (batch,), device=dev)
+
+    def step():
+        out = model(images, labels) if model_name == 'APCNN' else model(images)
+        loss = sum(crit(o, labels) for o in out[1]) if model_name == 'APCNN' else crit(out, labels)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+    t_first = time.perf_counter()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t_warm = time.perf_counter() - t_first
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    rows.append({'model': model_name, 'train_step': f'{image}x{image} batch {batch}, {classes} classes, fp32, channels_last',
+                 'ms_per_step': round(ms, 2), 'images_per_sec': round(batch / ms * 1e3, 1), 'warmup_s': round(t_warm, 1),
+                 'loss_finite': bool(torch.isfinite(loss).item())})
+    del model, opt, images
+    torch.cuda.empty_cache()
+
+
+def mpn_kernels(B=64, d=256, HW=196):
+    x = torch.relu(R(B, d, HW)); cov = E(B, d, d); mu = E(B, d); g = R(B, d, d).triu(); dx = E(B, d, HW)
+    kernel_row('MPN', 'cov_pool fwd (row means + centred Gram)', lambda: lib.hk_cov_pool_fwd(ptr(x), ptr(cov), ptr(mu), B, d, HW, stream()),
+               2.0 * B * d * d * HW, 4.0 * B * (d * HW + d * d))
+    kernel_row('MPN', 'cov_pool bwd', lambda: lib.hk_cov_pool_bwd(ptr(x), ptr(mu), ptr(g), ptr(dx), B, d, HW, stream()),
+               2.0 * B * d * d * HW, 4.0 * B * (2 * d * HW + d * d))
+    out = E(B, d, d); na = E(B); ys = E(B, 4, d, d); zs = E(B, 4, d, d); da = E(B, d, d)
+    nwf = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 0); nwb = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 1)
+    wsf = E(nwf, dtype=torch.uint8); wsb = E(nwb, dtype=torch.uint8)
+    kernel_row('MPN', 'ns_sqrtm fwd chain (12 products of 256^3 per sample, 11 launches)',
+               lambda: lib.hk_ns_sqrtm_fwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), B, d, 5, ptr(wsf), nwf, stream()),
+               12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10)
+    kernel_row('MPN', 'ns_sqrtm bwd chain (38 products of 256^3 per sample, 13 launches)',
+               lambda: lib.hk_ns_sqrtm_bwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), ptr(g), ptr(da), B, d, 5, ptr(wsb),
+                                           nwb, stream()), 38 * 2.0 * B * d ** 3, 4.0 * B * d * d * 12)
+    tv = E(B, d * (d + 1) // 2)
+    kernel_row('MPN', 'triu_vec fwd', lambda: lib.hk_triu_vec_fwd(ptr(out), ptr(tv), B, d, stream()), 0, 4.0 * B * 32896 * 2)
+    kernel_row('MPN', 'triu_vec bwd', lambda: lib.hk_triu_vec_bwd(ptr(tv), ptr(da), B, d, stream()), 0, 4.0 * B * (32896 + 65536))
+
+
+def cbp_kernels(C=512, HW=196, D=6000):
+    plan = F.CbpPlan(*F.sketch_hashes(C, C, D), D, dev)
+    for B in (64, 16):
+        x = torch.relu(R(B, C, HW)); y = E(B, D); craw = E(B, D); inv = E(B); dy = R(B, D); dx = E(B, C, HW)
+        nws = lib.hk_cbp_ws_bytes(B, C, HW, D); ws = E(nws, dtype=torch.uint8)
+        fl = 2.0 * B * C * C * HW
+        kernel_row('CBCNN', f'cbp fwd B={B} (raw Gram + binning + norm)',
+                   lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws, stream()),
+                   fl, 4.0 * B * (C * HW + D))
+        kernel_row('CBCNN', f'cbp bwd B={B}',
+                   lambda: lib.hk_cbp_bwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), ptr(dy), ptr(dx), B, C, HW, D,
+                                          ptr(ws), nws, stream()), fl, 4.0 * B * (2 * C * HW + 2 * D))
+
+
+def apcnn_kernels(B=16, classes=8142):
+    for hw in (56, 28, 14):
+        n = hw * hw
+        ff = R(B, 256, n); aa = torch.rand(B, n, device=dev); gp = E(B, 256); sg = E(B, 256)
+        dgp = R(B, 256); dsg = R(B, 256); dff = E(B, 256, n); daa = E(B, n)
+        kernel_row('APCNN', f'att_pool fwd {hw}x{hw}', lambda: lib.hk_att_pool_fwd(ptr(ff), ptr(aa), ptr(gp), ptr(sg), B, 256, n, stream()),
+                   0, 4.0 * B * 256 * n)
+        kernel_row('APCNN', f'att_pool bwd {hw}x{hw}',
+                   lambda: lib.hk_att_pool_bwd(ptr(ff), ptr(aa), ptr(dgp), ptr(dsg), ptr(dff), ptr(daa), B, 256, n, stream()),
+                   0, 8.0 * B * 256 * n)
+    masks = [torch.rand(B, 1, s, s, device=dev) for s in (56, 28, 14)]
+    lv = [(8, 64., 5), (16, 128., 3), (32, 256., 1)]
+    tabs = []
+
+    def roi_all():                                     # border kept for != 200 classes: [0.1 h, 0.9 h)  (APCNN.py:451-454)
+        tabs.clear()
+        for m, (s, a, k) in zip(masks, lv):
+            tabs.append(F.att_roi_select(m, s, a, 448, 448, classes, 0.05, k))
+    kernel_row('APCNN', f'att_roi_select x3 levels ({classes}-class border)', roi_all)
+    u = torch.rand(B, 2, device=dev)
+    box, drop = F.roi_boxes(tabs, u, 8.0)
+    x2 = R(B, 512, 56, 56); y2 = E(B, 512, 56, 56)
+    kernel_row('APCNN', 'roi_crop_resize fwd', lambda: lib.hk_roi_crop_resize_fwd(ptr(x2), ptr(box), ptr(drop), ptr(y2), B, 512, 56, 56, 1, stream()),
+               0, 8.0 * B * 512 * 3136)
+    kernel_row('APCNN', 'roi_crop_resize bwd', lambda: lib.hk_roi_crop_resize_bwd(ptr(y2), ptr(box), ptr(drop), ptr(x2), B, 512, 56, 56, 1, stream()),
+               0, 8.0 * B * 512 * 3136)
+
+
+def guarded(fn, *args):
+    try:
+        fn(*args)
+    except Exception as e:  # noqa: BLE001
+        rows.append({'stage': getattr(fn, '__name__', str(fn)) + str(args), 'error': repr(e)[:300]})
+        torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    guarded(mpn_kernels)
+    guarded(cbp_kernels)
+    guarded(apcnn_kernels)
+    steps = 3 if QUICK else 6
+    guarded(train_row, 'MPN', 64, 200, 448, steps)
+    guarded(train_row, 'CBCNN', 64, 200, 448, steps)
+    guarded(train_row, 'CBCNN', 16, 200, 448, steps)
+    guarded(train_row, 'APCNN', 16, 8142, 448, steps)
+    print(json.dumps(rows), flush=True)
