@@ -23,6 +23,7 @@
 //   68 KB of LDS per workgroup -> 2 workgroups per CU overlap each other's phases.
 #include <cstdlib>
 #include "hk_common.h"
+#include "hk_bwd128.h"
 
 namespace hk {
 
@@ -217,15 +218,6 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
 // MODE 0 BCNN: P = (dy + dy^T) / y * coef          (ry, rd, rt loaded)
 // MODE 1 COV : P = (g + g^T) / M, X centred          (rd, rt loaded; rx -= mu[k])
 // MODE 2 CBP : P = dG + dG^T gathered from dc         (rd computed; nothing to transpose)
-struct BwdExtra {
-    const float* mu;     // [B][C]      (COV)
-    const int* h1;       // [C]         (CBP)
-    const int* h2;
-    const float* s1;
-    const float* s2;
-    const float* dc;     // [B][D]
-    int D;
-};
 
 template <int HW, int NSX, int MODE, bool LOAD_T = true>
 __device__ __forceinline__ void bwd_load(f32x4 (&ry)[4], f32x4 (&rd)[4], f32x4 (&rt)[4], f32x4 (&rx)[NSX],
@@ -238,7 +230,7 @@ __device__ __forceinline__ void bwd_load(f32x4 (&ry)[4], f32x4 (&rd)[4], f32x4 (
         const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
         const long long o1 = cc + (long long)(I * 64 + r) * C + kb * 64 + c4;
         const long long o2 = cc + (long long)(kb * 64 + r) * C + I * 64 + c4;
-        if (MODE == 0) ry[u] = *reinterpret_cast<const f32x4*>(y + o1);
+        if (MODE == 0 || MODE == 3) ry[u] = *reinterpret_cast<const f32x4*>(y + o1);
         if (MODE != 2) {
             rd[u] = *reinterpret_cast<const f32x4*>(dy + o1);
             if (LOAD_T) rt[u] = *reinterpret_cast<const f32x4*>(dy + o2);
@@ -288,10 +280,11 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     const long long cc = (long long)b * C * C;
     const float* xb = x + (long long)b * C * HW;
     float coef = 1.0f / (float)HW;                         // COV
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 3) {
         const float in = inv_norm[b];
         coef = in * in / (2.0f * (float)HW);
     }
+    const float t2 = MODE == 3 ? 2.0f * bwd_t_of(ex, b) : 0.f;
 
     f32x4 acc[NT];
 #pragma unroll
@@ -331,6 +324,12 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
                 p[1] = (rd[u][1] + tp[1]) * coef;
                 p[2] = (rd[u][2] + tp[2]) * coef;
                 p[3] = (rd[u][3] + tp[3]) * coef;
+            } else if (MODE == 3) {                        // signed sqrt: (dy_ij + dy_ji - 2 t y_ij) / |y_ij|, 0 at y = 0
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float yv = ry[u][t];
+                    p[t] = yv == 0.f ? 0.f : (rd[u][t] + tp[t] - t2 * yv) * (__builtin_amdgcn_rcpf(fabsf(yv)) * coef);
+                }
             } else {
                 p = rd[u];
             }
@@ -377,275 +376,6 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     }
 }
 
-// ----------------------------------------------------------------------------- backward v4: two barriers per K-block
-// Same tiling, same LDS budget and bit-identical arithmetic as bcnn_bwd_panel_kernel, but the transposed operand
-// dy(K,I)^T is not staged through an LDS scratch: every thread fetches the four dy[k][i] it needs for its own P
-// elements straight from global memory (16 dword loads per K-block instead of 4 dwordx4 - four times the L1 requests
-// for that one operand, the same HBM/L2 sectors, issued a whole K-block ahead like the other operands).  That removes
-// the scatter (11 % LDS bank conflicts) and two of the four barriers of a K-block:
-//     barrier -> P tile from registers -> sP ; X block -> sX -> barrier -> next loads in flight, MFMA phase.
-// MODE 2 (CBP) has no transposition to begin with and simply loses its redundant barrier.
-// Opt-in (HK_BWD_V=4): written after round 1's GPU budget was spent; validated on the CPU emulation tier only.
-template <int HW, int NSX, int MODE>
-__device__ __forceinline__ void bwd_load_v4(f32x4 (&ry)[4], f32x4 (&rd)[4], f32x4 (&rt)[4], f32x4 (&rx)[NSX],
-                                            const float* __restrict__ y, const float* __restrict__ dy,
-                                            const float* __restrict__ xb, long long cc, int C, int I, int kb, int tid,
-                                            const BwdExtra& ex, int b) {
-    bwd_load<HW, NSX, MODE, false>(ry, rd, rt, rx, y, dy, xb, cc, C, I, kb, tid, ex, b);    // y, dy(I,K) (or the CBP gather), X
-    if (MODE != 2) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
-            const float* col = dy + cc + (long long)(kb * 64 + c4) * C + I * 64 + r;     // dy[k = c4 + t][i = r]
-#pragma unroll
-            for (int t = 0; t < 4; ++t) rt[u][t] = col[(long long)t * C];
-        }
-    }
-}
-
-template <int HW, int MODE>
-__global__ __launch_bounds__(256, 2) void bcnn_bwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                             const float* __restrict__ dy,
-                                                             const float* __restrict__ inv_norm, float* __restrict__ dx,
-                                                             float* __restrict__ tpart, int C, int nb, int B, BwdExtra ex) {
-    constexpr int NT = (HW + 15) / 16;
-    constexpr int XN4 = 64 * HW / 4;
-    constexpr int NSX = (XN4 + 255) / 256;
-    constexpr int PP = 68;
-    __shared__ __attribute__((aligned(16))) float lds[64 * PP + 64 * HW + 16];
-    float* sP = lds;
-    float* sX = lds + 64 * PP;
-
-    int b, I;
-    if (!xcd_map(blockIdx.x, B, nb, b, I)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const long long cc = (long long)b * C * C;
-    const float* xb = x + (long long)b * C * HW;
-    float coef = 1.0f / (float)HW;
-    if (MODE == 0) {
-        const float in = inv_norm[b];
-        coef = in * in / (2.0f * (float)HW);
-    }
-
-    f32x4 acc[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float tacc = 0.f;
-
-    f32x4 ry[4], rd[4], rt[4], rx[NSX];
-    bwd_load_v4<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, 0, tid, ex, b);
-    for (int kb = 0; kb < nb; ++kb) {
-        __syncthreads();                                   // previous MFMA phase finished with sP / sX
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {                      // P tile, straight from registers
-            const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
-            f32x4 p;
-            if (MODE == 0) {
-                p[0] = (rd[u][0] + rt[u][0]) * (__builtin_amdgcn_rcpf(ry[u][0]) * coef);
-                p[1] = (rd[u][1] + rt[u][1]) * (__builtin_amdgcn_rcpf(ry[u][1]) * coef);
-                p[2] = (rd[u][2] + rt[u][2]) * (__builtin_amdgcn_rcpf(ry[u][2]) * coef);
-                p[3] = (rd[u][3] + rt[u][3]) * (__builtin_amdgcn_rcpf(ry[u][3]) * coef);
-                tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
-            } else if (MODE == 1) {
-                p[0] = (rd[u][0] + rt[u][0]) * coef;
-                p[1] = (rd[u][1] + rt[u][1]) * coef;
-                p[2] = (rd[u][2] + rt[u][2]) * coef;
-                p[3] = (rd[u][3] + rt[u][3]) * coef;
-            } else {
-                p = rd[u];
-            }
-            *reinterpret_cast<f32x4*>(&sP[r * PP + c4]) = p;
-        }
-#pragma unroll
-        for (int u = 0; u < NSX; ++u) {                    // X block next to it (its own region: no barrier in between)
-            const int f = tid + 256 * u;
-            if (f < XN4) reinterpret_cast<f32x4*>(sX)[f] = rx[u];
-        }
-        __syncthreads();
-        bwd_load_v4<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, (kb + 1 < nb ? kb + 1 : kb), tid, ex, b);
-
-        const float* ap = sP + (wave * 16 + l15) * PP + 4 * lq;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * s);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float* bp = sX + (16 * s + 4 * lq + t) * HW + l15;
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bp[16 * n], acc[n], 0, 0, 0);
-            }
-        }
-    }
-
-    float* dxb = dx + (long long)b * C * HW + (long long)(I * 64 + wave * 16 + lq * 4) * HW;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = 16 * n + l15;
-        if (col < HW) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dxb[(long long)r * HW + col] = acc[n][r];
-        }
-    }
-    if (MODE == 0) {
-        __syncthreads();
-        const float tsum = block_sum<4>(tacc, lds);
-        if (tid == 0) tpart[(long long)b * nb + I] = tsum;
-    }
-}
-
-// ----------------------------------------------------------------------------- backward v3: no transposition, 3 WGs / CU
-// dX[I] = sum_K P(I,K) X(K),  P[i][k] = (dy[i][k] + dy[k][i]) * w[i][k]   (w = coef / y for BCNN, 1/M for COV).
-// Instead of building P in LDS (transposing dy(K,I) through a scratch: 4 barriers per K-block, 11 % bank conflicts),
-// the RAW tiles go to LDS exactly as they sit in HBM - y(I,K), dy(I,K) row-major [i][k] and dy(K,I) row-major
-// [k][i] - and the MFMA A-fragment is assembled per lane when it is read: the 16x16x4 A layout wants
-// A[i = lane & 15][k = lane >> 4], which is one ds_read_b128 along k from the [i][k] tiles and four conflict-free
-// ds_read_b32 (lanes along i) from the [k][i] tile; 4 v_rcp + 8 VALU per 52 MFMAs.  y is bitwise symmetric (the forward
-// writes mirrored tiles from one accumulator), so y[k][i] is never loaded.  K-blocks of 32 rows: 51 KB of LDS and
-// ~130 VGPRs per workgroup -> THREE workgroups per CU, two barriers per K-block.
-template <int HW, int MODE>
-__global__ __launch_bounds__(256, 3) void bcnn_bwd_v3_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                             const float* __restrict__ dy,
-                                                             const float* __restrict__ inv_norm,
-                                                             float* __restrict__ dx, float* __restrict__ tpart, int C,
-                                                             int nb, int B, BwdExtra ex) {
-    constexpr int KB = 32;                       // K rows per block
-    constexpr int NT = (HW + 15) / 16;
-    constexpr int XN4 = KB * HW / 4;             // float4 of an X block
-    constexpr int NSX = (XN4 + 255) / 256;
-    constexpr int PD = KB + 4;                   // pitch of the [i][k] tiles (36: 9 x 16 B, odd -> b128 conflict-free)
-    constexpr int PT = 64 + 4;                   // pitch of the [k][i] tile
-    constexpr int XS = KB * HW + 16;
-    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * PD + KB * PT + XS];
-    float* sY = lds;                             // y(I,K)   [64][PD]   (BCNN only)
-    float* sD = lds + 64 * PD;                   // dy(I,K)  [64][PD]   (COV: g(I,K); CBP: gathered dG + dG^T)
-    float* sDt = sD + 64 * PD;                   // dy(K,I)  [KB][PT]
-    float* sX = sDt + KB * PT;                   // X(K)     [KB][HW]
-
-    int b, I;
-    if (!xcd_map(blockIdx.x, B, nb, b, I)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const long long cc = (long long)b * C * C;
-    const float* xb = x + (long long)b * C * HW;
-    float coef = 1.0f / (float)HW;
-    if (MODE == 0) {
-        const float in = inv_norm[b];
-        coef = in * in / (2.0f * (float)HW);
-    }
-    const int nkb = C / KB;
-
-    f32x4 acc[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float tacc = 0.f;
-
-    // staging registers: 2 float4 of each 64x32 / 32x64 tile, NSX float4 of the X block
-    f32x4 ry[2], rd[2], rt[2], rx[NSX];
-    auto load = [&](int kb) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int f = tid + 256 * u;
-            const int r = f >> 3, c4 = (f & 7) * 4;                 // [i][k] tiles: 64 rows x 8 float4
-            const long long o1 = cc + (long long)(I * 64 + r) * C + kb * KB + c4;
-            if (MODE == 0) ry[u] = *reinterpret_cast<const f32x4*>(y + o1);
-            if (MODE != 2) {
-                rd[u] = *reinterpret_cast<const f32x4*>(dy + o1);
-                const int rk = f >> 4, ci = (f & 15) * 4;           // [k][i] tile: 32 rows x 16 float4
-                rt[u] = *reinterpret_cast<const f32x4*>(dy + cc + (long long)(kb * KB + rk) * C + I * 64 + ci);
-            } else {
-                const int i = I * 64 + r;
-                const int h1i = ex.h1[i], h2i = ex.h2[i];
-                const float s1i = ex.s1[i], s2i = ex.s2[i];
-                const float* d = ex.dc + (long long)b * ex.D;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int k = kb * KB + c4 + t;
-                    int ba = h1i + ex.h2[k]; if (ba >= ex.D) ba -= ex.D;
-                    int bb = ex.h1[k] + h2i; if (bb >= ex.D) bb -= ex.D;
-                    rd[u][t] = s1i * ex.s2[k] * d[ba] + ex.s1[k] * s2i * d[bb];
-                }
-            }
-        }
-        const f32x4* xs = reinterpret_cast<const f32x4*>(xb + (long long)kb * KB * HW);
-#pragma unroll
-        for (int u = 0; u < NSX; ++u) {
-            const int f = tid + 256 * u, fc = f < XN4 ? f : XN4 - 1;
-            rx[u] = xs[fc];
-            if (MODE == 1) rx[u] -= ex.mu[(long long)b * C + kb * KB + (4 * fc) / HW];
-        }
-    };
-
-    load(0);
-    for (int kb = 0; kb < nkb; ++kb) {
-        __syncthreads();                                   // previous MFMA phase finished with the LDS tiles
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int f = tid + 256 * u;
-            const int r = f >> 3, c4 = (f & 7) * 4;
-            if (MODE == 0) {
-                *reinterpret_cast<f32x4*>(&sY[r * PD + c4]) = ry[u];
-                tacc += (ry[u][0] * rd[u][0] + ry[u][1] * rd[u][1]) + (ry[u][2] * rd[u][2] + ry[u][3] * rd[u][3]);
-            }
-            *reinterpret_cast<f32x4*>(&sD[r * PD + c4]) = rd[u];
-            if (MODE != 2) {
-                const int rk = f >> 4, ci = (f & 15) * 4;
-                *reinterpret_cast<f32x4*>(&sDt[rk * PT + ci]) = rt[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NSX; ++u) {
-            const int f = tid + 256 * u;
-            if (f < XN4) reinterpret_cast<f32x4*>(sX)[f] = rx[u];
-        }
-        __syncthreads();
-        load(kb + 1 < nkb ? kb + 1 : kb);                  // in flight during the MFMA phase (last: harmless re-read)
-
-        const int arow = (wave * 16 + l15) * PD + 4 * lq;
-#pragma unroll
-        for (int s = 0; s < KB / 16; ++s) {
-            f32x4 av = *reinterpret_cast<const f32x4*>(&sD[arow + 16 * s]);
-            if (MODE != 2) {
-                f32x4 tv;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) tv[t] = sDt[(16 * s + 4 * lq + t) * PT + wave * 16 + l15];
-                av += tv;
-            }
-            if (MODE == 0) {
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(&sY[arow + 16 * s]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) av[t] *= __builtin_amdgcn_rcpf(yv[t]) * coef;
-            } else if (MODE == 1) {
-                av *= coef;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float* bp = sX + (16 * s + 4 * lq + t) * HW + l15;
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bp[16 * n], acc[n], 0, 0, 0);
-            }
-        }
-    }
-
-    float* dxb = dx + (long long)b * C * HW + (long long)(I * 64 + wave * 16 + lq * 4) * HW;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = 16 * n + l15;
-        if (col < HW) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dxb[(long long)r * HW + col] = acc[n][r];
-        }
-    }
-    if (MODE == 0) {
-        __syncthreads();
-        const float tsum = block_sum<4>(tacc, lds);
-        if (tid == 0) tpart[(long long)b * nb + I] = tsum;
-    }
-}
-
-// ----------------------------------------------------------------------------- dispatch
 template <int HW, int MODE, bool CENTER>
 static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, const float* mu, float alpha,
                        hipStream_t st) {
@@ -662,23 +392,18 @@ template <int HW, int MODE>
 static int bwd_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
                       int B, int C, const BwdExtra& ex, hipStream_t st) {
     const int nb = C / 64;
-    // Three structures were measured at B=64, C=512, HW=196 (all bit-compatible):
-    //   bcnn_bwd_panel_kernel (below, default)   64-row K-blocks, P built in LDS, 2 WGs/CU          85-88 us
-    //   bcnn_bwd_v3_kernel    (HK_BWD_V=3)       32-row K-blocks, raw tiles, no transposition, 3/CU  92 us
-    //   producer/consumer 512-thread variant     (removed)                94 us
-    // All sit at ~65 % matrix-pipe occupancy at the ~1.9 GHz DVFS clock; the backward moves 235 MB per launch.
-    const int v = tuning().bwd_v;
-    if (v == 4) {   // two-barrier variant (direct transposed loads): not yet timed on the GPU
-        hipLaunchKernelGGL((bcnn_bwd_v4_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
-                           tpart, C, nb, B, ex);
-        HK_LAUNCH_CHECK();
-        return HK_OK;
-    }
-    if (v == 3) {
-        hipLaunchKernelGGL((bcnn_bwd_v3_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
-                           tpart, C, nb, B, ex);
-        HK_LAUNCH_CHECK();
-        return HK_OK;
+    // Structures measured at B=64, C=512, HW=196 (round 1 + profiles/r2_candidates.json):
+    //   bcnn_bwd_panel_kernel   64-row blocks, P built in LDS, four barriers per K-block, 2 WGs/CU    85-88 us
+    //   two-barrier variant     (transposed dy fetched directly: 4x the L1 requests)                  93 us  (removed)
+    //   raw 32-row K-blocks     (3 WGs/CU)                                                            89-92 us  (removed)
+    //   producer / consumer     (512 threads)                                                         94 us  (removed)
+    //   bcnn_bwd128_kernel      hk_bwd128.h: 128-row blocks, raw tiles, one barrier per K-block, 1 WG/CU  94 us
+    // The 128-row kernel (tuning().bwd_v == 5, needs C % 128 == 0) measured 94.3 us against 87.5 us for the 64-row kernel
+    // at this shape (profiles/r2_candidates.json): with ONE wave per SIMD its staging instructions sit in the MFMA
+    // issue stream (matrix pipe 53 % busy, 27 % of the wave time parked), so the 64-row kernel stays the default.
+    if (tuning().bwd_v == 5 && C % 128 == 0) {
+        const int rc = bwd128_launch<HW, MODE>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
     }
     hipLaunchKernelGGL((bcnn_bwd_panel_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
                        tpart, C, nb, B, ex);
@@ -721,6 +446,17 @@ int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* 
     if (C % 64 != 0 || !aligned16(x) || !aligned16(y) || !aligned16(dy) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
     BwdExtra ex = {};
 #define CALL(H) bwd_launch<H, 0>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
+// signed-sqrt variant (BCNN.py:23-24): P = (dy + dy^T - 2 t y) / |y| * inv^2 / (2M), t from its partial sums
+int bcnn_ssqrt_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, const float* tpart, int nt,
+                        float* dx, int B, int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(y) || !aligned16(dy) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+    BwdExtra ex = {};
+    ex.tb = tpart; ex.nt = nt;
+#define CALL(H) bwd_launch<H, 3>(x, y, dy, inv_norm, dx, nullptr, B, C, ex, st)
     HK_HW_SWITCH(CALL)
 #undef CALL
 }

@@ -24,6 +24,9 @@ namespace hk {
 int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C, int HW, hipStream_t st);
 int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart, int B,
                   int C, int HW, hipStream_t st);
+int gram_fast_raw(const float* x, const float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
+int bcnn_ssqrt_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, const float* tpart, int nt,
+                        float* dx, int B, int C, int HW, hipStream_t st);
 static inline bool force_generic() { return tuning().bcnn_generic == 1; }   // A/B lever (hk_tuning_set)
 
 // colsum[b,hw] = sum_c x[b,c,hw];  inv_norm[b] = 1 / max(sqrt(sum_hw colsum^2 / M + C*C*1e-5), 1e-12)
@@ -132,11 +135,19 @@ struct LdBcnnP {
     float coef;
     float tacc;
     int active;
+    const float* tsum;   // signed-sqrt variant: partial sums of t = <y, dy> [B][nt]; nullptr = the sqrt(x + 1e-5) variant
+    int nt;
+    float t2;
     __device__ __forceinline__ void begin(int b, int, int tn) {
         const float in = inv_norm[b];
         coef = in * in * inv2m;
         tacc = 0.f;
-        active = (tn == 0);
+        active = (tn == 0) && !tsum;
+        t2 = 0.f;
+        if (tsum) {
+            for (int c = 0; c < nt; ++c) t2 += tsum[(long long)b * nt + c];
+            t2 *= 2.0f;
+        }
     }
     __device__ __forceinline__ float4 ld4(int b, int r, int c) {
         float p[4] = {0.f, 0.f, 0.f, 0.f};
@@ -159,7 +170,8 @@ struct LdBcnnP {
             for (int t = 0; t < 4; ++t) {
                 if (c + t < C) {
                     const float dt = dy[base + (long long)(c + t) * C + r];
-                    p[t] = (dv[t] + dt) / yv[t] * coef;
+                    if (tsum) p[t] = yv[t] == 0.f ? 0.f : (dv[t] + dt - t2 * yv[t]) / fabsf(yv[t]) * coef;
+                    else p[t] = (dv[t] + dt) / yv[t] * coef;
                     if (active) tacc += yv[t] * dv[t];
                 }
             }
@@ -167,7 +179,7 @@ struct LdBcnnP {
         return make_float4(p[0], p[1], p[2], p[3]);
     }
     __device__ __forceinline__ void finish(int b, int tm, int tn, int tilesM, float* red) {
-        if (tn != 0) return;  // uniform per workgroup
+        if (tn != 0 || tsum) return;  // uniform per workgroup
         const float s = block_sum<4>(tacc, red);
         if (threadIdx.x == 0) tpart[(long long)b * tilesM + tm] = s;
     }
@@ -187,6 +199,60 @@ __global__ __launch_bounds__(256) void bcnn_rank1_fix_kernel(float* __restrict__
     const float* cs = colsum + (long long)b * HW;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < per_sample; e += (long long)gridDim.x * 256)
         d[e] -= k * cs[e % HW];
+}
+
+// ----------------------------------------------------------------------------- signed-sqrt variant (BCNN.py:23-24)
+// The reference keeps a second normalisation commented out next to the one it runs:
+//     x = torch.sign(x) * torch.sqrt(torch.abs(x) + 1e-10)        (BCNN.py:23-24; the form CBCNN.py:132 applies)
+// Its norm has no closed form from the column sums (sum |G_ij| is not a function of them once features can be
+// negative), so it takes two elementwise passes after the raw Gram: u in place + partial sums of u^2, then the scale.
+constexpr int SS_CHUNKS = 64;          // partial sums per image
+
+// in place: u = sign(g) sqrt(|g| + 1e-10)  (sign(0) = 0);  part[b][chunk] = sum of u^2 over the chunk (fixed order)
+__global__ __launch_bounds__(256) void ssqrt_apply_kernel(float* __restrict__ y, float* __restrict__ part, long long n) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const long long len = (n + SS_CHUNKS - 1) / SS_CHUNKS, e0 = (long long)blockIdx.x * len;
+    const long long e1 = e0 + len < n ? e0 + len : n;
+    float* p = y + (long long)b * n;
+    float s = 0.f;
+    for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const float g = p[e];
+        const float u = g == 0.f ? 0.f : copysignf(sqrtf(fabsf(g) + 1e-10f), g);
+        p[e] = u;
+        s += u * u;
+    }
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) part[(long long)b * SS_CHUNKS + blockIdx.x] = s;
+}
+
+// y *= inv_norm[b],  inv_norm[b] = 1 / max(sqrt(sum of the partials), 1e-12)   (F.normalize defaults)
+__global__ __launch_bounds__(256) void ssqrt_scale_kernel(float* __restrict__ y, const float* __restrict__ part,
+                                                          float* __restrict__ inv_norm, long long n) {
+    const int b = blockIdx.y;
+    float s = 0.f;
+    for (int c = 0; c < SS_CHUNKS; ++c) s += part[(long long)b * SS_CHUNKS + c];
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv_norm[b] = inv;
+    const long long len = (n + SS_CHUNKS - 1) / SS_CHUNKS, e0 = (long long)blockIdx.x * len;
+    const long long e1 = e0 + len < n ? e0 + len : n;
+    float* p = y + (long long)b * n;
+    for (long long e = e0 + threadIdx.x; e < e1; e += 256) p[e] *= inv;
+}
+
+// part[b][chunk] = sum y * dy over the chunk (t = <y, dy> of the l2-normalisation backward)
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                          float* __restrict__ part, long long n) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const long long len = (n + SS_CHUNKS - 1) / SS_CHUNKS, e0 = (long long)blockIdx.x * len;
+    const long long e1 = e0 + len < n ? e0 + len : n;
+    const float* p = y + (long long)b * n;
+    const float* q = dy + (long long)b * n;
+    float s = 0.f;
+    for (long long e = e0 + threadIdx.x; e < e1; e += 256) s += p[e] * q[e];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) part[(long long)b * SS_CHUNKS + blockIdx.x] = s;
 }
 
 }  // namespace hk
@@ -253,6 +319,7 @@ extern "C" int hk_bcnn_bwd_gemm(const float* x, const float* y, const float* dy,
     pa.inv2m = 1.0f / (2.0f * (float)HW);
     pa.vec = (aligned16(y) && aligned16(dy) && (C % 4 == 0)) ? 1 : 0;
     pa.coef = 0.f; pa.tacc = 0.f; pa.active = 0;
+    pa.tsum = nullptr; pa.nt = 0; pa.t2 = 0.f;
     const LdPlain xb = make_plain(x, (long long)C * HW, HW, C, HW);  // K x N, N contiguous
     const EpAffine ep = make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f);
     // 64-row tiles only: tpart is indexed by 64-row block (hk_bcnn_bwd_rank1 sums ceil(C/64) partials)
@@ -280,4 +347,52 @@ extern "C" int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy,
     int rc = hk_bcnn_bwd_gemm(x, y, dy, inv_norm, dx, (float*)ws, B, C, HW, stream);
     if (rc != HK_OK) return rc;
     return hk_bcnn_bwd_rank1(dx, (const float*)ws, inv_norm, colsum, B, C, HW, stream);
+}
+
+// ------------------------------------------------------------------ signed-sqrt variant
+extern "C" size_t hk_bcnn_ssqrt_ws_bytes(int B, int C, int HW) {
+    (void)C; (void)HW;
+    return (size_t)B * SS_CHUNKS * sizeof(float) + 256;
+}
+
+extern "C" int hk_bcnn_ssqrt_pool_fwd(const float* x, float* y, float* inv_norm, int B, int C, int HW, void* ws,
+                                      size_t ws_bytes, hk_stream_t stream) {
+    if (!x || !y || !inv_norm || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    if (!ws || ws_bytes < hk_bcnn_ssqrt_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = force_generic() ? HK_ERR_UNSUPPORTED : gram_fast_raw(x, nullptr, 1.0f / (float)HW, y, B, C, HW, st);
+    if (rc == HK_ERR_UNSUPPORTED) {
+        const LdPlain xa = make_plain(x, (long long)C * HW, HW, C, HW);
+        rc = bgemm_launch<true, true>(xa, xa, make_affine(y, (long long)C * C, C, 1.0f / (float)HW, nullptr, 0.f, 0.f), C, C,
+                                      HW, B, st);
+    }
+    if (rc != HK_OK) return rc;
+    const long long n = (long long)C * C;
+    hipLaunchKernelGGL(ssqrt_apply_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (float*)ws, n);
+    HK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ssqrt_scale_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (const float*)ws, inv_norm, n);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_bcnn_ssqrt_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx,
+                                      int B, int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    if (!x || !y || !dy || !inv_norm || !dx || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    if (!ws || ws_bytes < hk_bcnn_ssqrt_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* tpart = (float*)ws;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, dy, tpart, (long long)C * C);
+    HK_LAUNCH_CHECK();
+    if (!force_generic()) {
+        const int rc = bcnn_ssqrt_fast_bwd(x, y, dy, inv_norm, tpart, SS_CHUNKS, dx, B, C, HW, st);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
+    LdBcnnP pa;
+    pa.y = y; pa.dy = dy; pa.inv_norm = inv_norm; pa.tpart = nullptr; pa.C = C;
+    pa.inv2m = 1.0f / (2.0f * (float)HW);
+    pa.vec = (aligned16(y) && aligned16(dy) && (C % 4 == 0)) ? 1 : 0;
+    pa.coef = 0.f; pa.tacc = 0.f; pa.active = 0;
+    pa.tsum = tpart; pa.nt = SS_CHUNKS; pa.t2 = 0.f;
+    const LdPlain xb = make_plain(x, (long long)C * HW, HW, C, HW);
+    return bgemm_launch<true, false>(pa, xb, make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f), C, HW, C, B, st);
 }

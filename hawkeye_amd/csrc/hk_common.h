@@ -44,7 +44,8 @@ struct Tuning {
     int roi_bwd = 0;        // HK_ROI_BWD       0: default ROI-refinement backward, 1: the other variant
     int linear_slabs = 0;   // HK_LINEAR_SLABS  0: automatic split-K slab count of hk_linear_fwd
     int ns_tn = 0;          // HK_NS_TN         0: automatic, 64 / 128: forced tile width of the Newton-Schulz products
-    int bwd_v = 0;          // HK_BWD_V         variant of the Gram backward kernel (bcnn_fast.hip)
+    int bwd_v = 0;          // HK_BWD_V         Gram backward: 0 / 1 the 64-row kernel (bcnn_fast.hip), 5 the 128-row kernel (hk_bwd128.h)
+    int ns_streams = 1;     // HK_NS_STREAMS    1: the two halves of the batch run the Newton-Schulz chain on two HIP queues (default), 0: one queue
 };
 Tuning& tuning();           // api.hip
 

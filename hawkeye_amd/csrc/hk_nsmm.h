@@ -59,7 +59,7 @@ struct NsGroup {
 // TN = columns of the workgroup tile (128 or 64; rows are always 128).  EDGE = true: any d / alignment (guarded scalar
 // loads and stores); false: d % 128 == 0, 16-byte aligned operands.
 template <int TN, bool EDGE>
-__global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, int nb, int tilesM, int tilesN) {
+__global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, int nb, int b0, int tilesM, int tilesN) {
     constexpr int TM = 128, BK = 32;
     constexpr int NJ = TN / 64;                 // 32-column MFMA tiles per wave (wave tile = 64 x TN/2)
     constexpr int PA = BK + 4;                  // A chunk [128][32] k-contiguous: pitch 36 (pitch/4 odd: ds_read_b128 conflict-free)
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
     const int tiles = tilesM * tilesN;
     int b, t_;
     if (!xcd_map(blockIdx.x, nb, g.np * tiles, b, t_)) return;
+    b += b0;                                    // this launch covers samples b0 .. b0 + nb - 1
     const int pi = t_ / tiles, tile = t_ % tiles;
     const NsProb& P = g.p[pi];
     const int m0 = (tile / tilesN) * TM, n0 = (tile % tilesN) * TN;
@@ -90,12 +91,14 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
     const int ar = tid >> 3, ac = 4 * (tid & 7);             // A staging: row ar + 32 u, k offset ac
     const int br = tid / B4, bc = 4 * (tid % B4);             // B staging: k row br + BRS u, column bc
     constexpr int BRS = 256 / B4;
-    const int nkt = (d + BK - 1) / BK;                        // chunks per term
+    // chunks per term, rounded up to an even count (the loop below handles chunks in pairs; an extra chunk exists only
+    // for d % 64 in 1..32 on the guarded path, where it stages zeros)
+    const int nkt = (((d + BK - 1) / BK) + 1) & ~1;
     const int nk = P.nt * nkt;
 
     // running per-thread operand pointers of the term being staged (advanced by one chunk per gload)
     const float *pa = nullptr, *pb = nullptr;
-    float sg_term = 1.f, sg_regs = 1.f;                       // sign of the term being staged / of the chunk in ra
+    float sg_term = 1.f;                                      // sign of the term being staged
     int k0 = 0;                                               // k offset of the next chunk to stage (EDGE guards)
     auto set_term = [&](int ti) {
         const NsTerm& T = ti == 0 ? P.t[0] : (ti == 1 ? P.t[1] : P.t[2]);   // (a dynamic index would spill the table to scratch)
@@ -104,10 +107,18 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
         sg_term = T.sign;
         k0 = 0;
     };
-    // staging registers as named scalars (an indexed array here is not promoted to registers by the compiler once the
-    // loads and the LDS stores sit in different conditional blocks: it ends up in scratch)
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Staging registers: TWO sets of named vectors (an indexed array here is not promoted to registers by the compiler
+    // once the loads and the LDS stores sit in different conditional blocks: it ends up in scratch).  Chunk c + 2 is
+    // requested while chunk c is computed, so a load has two chunk-times (2 x 2048-4096 matrix-pipe cycles) to arrive -
+    // and the prologue has chunks 0 AND 1 in flight at once: one memory latency per launch instead of two.
+    struct Regs {
+        float4 a0, a1, a2, a3, b0, b1, b2, b3;
+        float sg;                                             // sign of the term the chunk belongs to
+    };
+    Regs R0, R1;
+    R0.a0 = R0.a1 = R0.a2 = R0.a3 = R0.b0 = R0.b1 = R0.b2 = R0.b3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    R0.sg = 1.f;
+    R1 = R0;
     auto lda = [&](int u) -> float4 {
         const float* q = pa + (long long)(32 * u) * d;
         if (!EDGE) return *reinterpret_cast<const float4*>(q);
@@ -134,46 +145,39 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
         }
         return v;
     };
-#define HK_NS_GLOAD()                                  \
-    do {                                               \
-        ra0 = lda(0); ra1 = lda(1); ra2 = lda(2); ra3 = lda(3); \
-        rb0 = ldb(0); rb1 = ldb(1);                    \
-        if (NLB == 4) { rb2 = ldb(2); rb3 = ldb(3); }  \
-        pa += BK;                                      \
-        pb += (long long)BK * d;                       \
-        k0 += BK;                                      \
-        sg_regs = sg_term;                             \
+    int ti = 0, kc = 0;                                       // term being staged / chunks of it already requested
+    set_term(0);
+    // request the next chunk (in chunk order) into register set R
+#define HK_NS_GLOAD(R)                                                     \
+    do {                                                                   \
+        if (kc == nkt) { set_term(++ti); kc = 0; }                         \
+        R.a0 = lda(0); R.a1 = lda(1); R.a2 = lda(2); R.a3 = lda(3);        \
+        R.b0 = ldb(0); R.b1 = ldb(1);                                      \
+        if (NLB == 4) { R.b2 = ldb(2); R.b3 = ldb(3); }                    \
+        pa += BK;                                                          \
+        pb += (long long)BK * d;                                           \
+        k0 += BK;                                                          \
+        R.sg = sg_term;                                                    \
+        ++kc;                                                              \
     } while (0)
     // registers -> LDS stage `buf`; the term's sign is applied here (exact), i.e. AFTER the chunk's MFMAs were issued:
     // touching the loaded values any earlier would park the wave on the global loads at the top of the chunk
-    auto sta = [&](float* As, int u, float4 v) {
-        v.x *= sg_regs; v.y *= sg_regs; v.z *= sg_regs; v.w *= sg_regs;
+    auto sta = [&](float* As, int u, float4 v, float sg) {
+        v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
         *reinterpret_cast<float4*>(&As[(ar + 32 * u) * PA + ac]) = v;
     };
-#define HK_NS_SSTORE(buf)                                                                  \
+#define HK_NS_SSTORE(R, buf)                                                               \
     do {                                                                                   \
         float* As_ = lds + (buf) * (SA + SB);                                              \
         float* Bs_ = As_ + SA;                                                             \
-        sta(As_, 0, ra0); sta(As_, 1, ra1); sta(As_, 2, ra2); sta(As_, 3, ra3);            \
-        *reinterpret_cast<float4*>(&Bs_[(br + BRS * 0) * PB + bc]) = rb0;                  \
-        *reinterpret_cast<float4*>(&Bs_[(br + BRS * 1) * PB + bc]) = rb1;                  \
+        sta(As_, 0, R.a0, R.sg); sta(As_, 1, R.a1, R.sg); sta(As_, 2, R.a2, R.sg); sta(As_, 3, R.a3, R.sg); \
+        *reinterpret_cast<float4*>(&Bs_[(br + BRS * 0) * PB + bc]) = R.b0;                 \
+        *reinterpret_cast<float4*>(&Bs_[(br + BRS * 1) * PB + bc]) = R.b1;                 \
         if (NLB == 4) {                                                                    \
-            *reinterpret_cast<float4*>(&Bs_[(br + BRS * 2) * PB + bc]) = rb2;              \
-            *reinterpret_cast<float4*>(&Bs_[(br + BRS * 3) * PB + bc]) = rb3;              \
+            *reinterpret_cast<float4*>(&Bs_[(br + BRS * 2) * PB + bc]) = R.b2;             \
+            *reinterpret_cast<float4*>(&Bs_[(br + BRS * 3) * PB + bc]) = R.b3;             \
         }                                                                                  \
     } while (0)
-
-    int ti = 0, kc = 1;                                       // term / chunks of it already requested
-    set_term(0);
-    HK_NS_GLOAD();
-    HK_NS_SSTORE(0);
-    __syncthreads();
-
-    for (int c = 0; c < nk; ++c) {
-        const int cur = c & 1;
-        const float* As = lds + cur * (SA + SB) + (wm * 64 + l31) * PA + 4 * lh;
-        const float* Bs = lds + cur * (SA + SB) + SA + (4 * lh) * PB + wn * (TN / 2) + l31;
-        float a[2][4], bb[NJ][4];
 #define HK_NS_FRAG(s_, A_, B_)                                                                        \
         do {                                                                                              \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
@@ -183,86 +187,141 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
             _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                \
                 _Pragma("unroll") for (int t = 0; t < 4; ++t) B_[j][t] = Bs[(8 * (s_) + t) * PB + 32 * j]; \
         } while (0)
-        // order inside a chunk (fenced with sched_barrier so that it survives the scheduler): fragments of step 0, then
-        // the global loads of the NEXT chunk (their address arithmetic runs in the shadow of the LDS latency), then per
-        // 8-deep step: fragments of step s + 1, 16 (8) MFMAs of step s.  The loaded chunk goes to the other LDS stage
-        // before the LAST step's MFMAs, which cover the store; one barrier per chunk.
-        HK_NS_FRAG(0, a, bb);
-        const bool more = c + 1 < nk;
-        if (more) {
-            if (kc == nkt) { set_term(++ti); kc = 0; }
-            HK_NS_GLOAD();
-            ++kc;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            float an[2][4], bn[NJ][4];
-            if (s + 1 < BK / 8) {
-                HK_NS_FRAG(s + 1, an, bn);
-            } else if (more) {
-                HK_NS_SSTORE(cur ^ 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < BK / 8) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) a[i][t] = an[i][t];
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) bb[j][t] = bn[j][t];
-                }
-            }
-        }
-#undef HK_NS_FRAG
-        __syncthreads();
+    // One chunk.  Order (fenced with sched_barrier so that it survives the scheduler): fragments of step 0, then the
+    // global loads of chunk c + 2 into RLOAD (its previous content, chunk c, is in LDS), then per 8-deep step:
+    // fragments of step s + 1, 16 (8) MFMAs of step s.  Chunk c + 1 (in RSTORE, requested a chunk ago) goes to the
+    // other LDS stage before the LAST step's MFMAs, which cover the store; one barrier per chunk.
+    // LOAD_ / STORE_ are compile-time: a branch around the global loads would make the compiler's s_waitcnt vmcnt
+    // accounting conservative at the join (it then waits for the NEWEST loads before every LDS store - the two-deep
+    // prefetch is gone and the wait lands at the end of the chunk).
+#define HK_NS_CHUNK(c_, RLOAD, RSTORE, LOAD_, STORE_)                                                             \
+    do {                                                                                                          \
+        const int cur = (c_) & 1;                                                                                 \
+        const float* As = lds + cur * (SA + SB) + (wm * 64 + l31) * PA + 4 * lh;                                  \
+        const float* Bs = lds + cur * (SA + SB) + SA + (4 * lh) * PB + wn * (TN / 2) + l31;                       \
+        float a[2][4], bb[NJ][4];                                                                                 \
+        HK_NS_FRAG(0, a, bb);                                                                                     \
+        if (LOAD_) HK_NS_GLOAD(RLOAD);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        _Pragma("unroll") for (int s = 0; s < BK / 8; ++s) {                                                      \
+            float an[2][4], bn[NJ][4];                                                                            \
+            if (s + 1 < BK / 8) {                                                                                 \
+                HK_NS_FRAG(s + 1, an, bn);                                                                        \
+            } else if (STORE_) {                                                                                  \
+                HK_NS_SSTORE(RSTORE, cur ^ 1);                                                                    \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
+                    _Pragma("unroll") for (int j = 0; j < NJ; ++j)       /* operands swapped: see the epilogue */ \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[j][t], a[i][t], acc[i][j], 0, 0, 0);  \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if (s + 1 < BK / 8) {                                                                                 \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i) a[i][t] = an[i][t];                             \
+                    _Pragma("unroll") for (int j = 0; j < NJ; ++j) bb[j][t] = bn[j][t];                           \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        __syncthreads();                                                                                          \
+    } while (0)
+
+    HK_NS_GLOAD(R0);                                          // chunk 0
+    HK_NS_GLOAD(R1);                                          // chunk 1 (nk >= 2): both in flight before any wait
+    HK_NS_SSTORE(R0, 0);
+    __syncthreads();
+    int c = 0;
+    for (; c + 2 < nk; c += 2) {                              // steady state
+        HK_NS_CHUNK(c, R0, R1, true, true);                   // even chunk: R0 <- chunk c + 2, R1 (chunk c + 1) -> LDS
+        HK_NS_CHUNK(c + 1, R1, R0, true, true);               // odd chunk : R1 <- chunk c + 3, R0 (chunk c + 2) -> LDS
     }
+    HK_NS_CHUNK(c, R0, R1, false, true);                      // last pair: nothing left to request
+    HK_NS_CHUNK(c + 1, R1, R0, false, false);
+#undef HK_NS_CHUNK
+#undef HK_NS_FRAG
 #undef HK_NS_GLOAD
 #undef HK_NS_SSTORE
 
-    // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // epilogue.  The MFMAs above were issued with the operands SWAPPED (B fragment first), so an accumulator holds the
+    // transposed tile: lane & 31 = row m of C, (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = column n.  The four registers
+    // of a group are four consecutive columns of one row: one 16-byte load / store per group instead of four 4-byte
+    // ones (16 store instructions per wave for a 64 x 64 sub-tile instead of 64 - the launch's store burst is
+    // issue-bound: every workgroup of a launch reaches its epilogue at the same time).
+    // Explicit fmaf everywhere: both tile widths must round identically (a contraction left to the compiler differs
+    // between instantiations).
+    // every field of the problem descriptor is read ONCE into a scalar here (P lives in the kernarg segment behind a
+    // dynamic index: each mention is a scalar load, and a mention inside a per-element condition becomes a branch)
     const float sb_ = P.bscale ? P.bscale[b] : 1.0f;
-    const float al = P.alpha * sb_;
-    const float e1 = P.e1_scaled ? P.e1 * sb_ : P.e1;
+    const float al = P.alpha * sb_, diag = P.diag, alpha2 = P.alpha2, diag2 = P.diag2;
     float* Cb = P.C + (long long)b * P.sc;
     const float* E1b = P.E1 ? P.E1 + (long long)b * P.se1 : nullptr;
     const float* E2b = P.E2 ? P.E2 + (long long)b * P.se2 : nullptr;
     float* C2b = P.C2 ? P.C2 + (long long)b * P.sc2 : nullptr;
+    const bool has1 = E1b != nullptr, has2 = E2b != nullptr, has_c2 = C2b != nullptr;
+    const float e1 = has1 ? (P.e1_scaled ? P.e1 * sb_ : P.e1) : 0.f;      // (a missing term: 0 * 0 added, exact)
+    const float e2 = has2 ? P.e2 : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int col = n0 + wn * (TN / 2) + j * 32 + l31;
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * lh;
-            float x1[16], x2[16];
+            const int row = m0 + wm * 64 + i * 32 + l31;
+            const int cbase = n0 + wn * (TN / 2) + j * 32 + 4 * lh;
+            const long long orow = (long long)row * d;
+            float4 x1[4], x2[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                const long long o = (long long)row * d + col;
-                const bool ok = !EDGE || (row < d && col < d);
-                x1[r] = (E1b && ok) ? E1b[o] : 0.f;
-                x2[r] = (E2b && ok) ? E2b[o] : 0.f;
+            for (int gq = 0; gq < 4; ++gq) x1[gq] = x2[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has1) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int col = cbase + 8 * gq;
+                    if (!EDGE) {
+                        x1[gq] = *reinterpret_cast<const float4*>(E1b + orow + col);
+                    } else if (row < d) {
+                        float* u1 = reinterpret_cast<float*>(&x1[gq]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (col + t < d) u1[t] = E1b[orow + col + t];
+                    }
+                }
+            }
+            if (has2) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int col = cbase + 8 * gq;
+                    if (!EDGE) {
+                        x2[gq] = *reinterpret_cast<const float4*>(E2b + orow + col);
+                    } else if (row < d) {
+                        float* u2 = reinterpret_cast<float*>(&x2[gq]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (col + t < d) u2[t] = E2b[orow + col + t];
+                    }
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                const long long o = (long long)row * d + col;
-                if (EDGE && !(row < d && col < d)) continue;
-                const float v = acc[i][j][r];
-                float out = al * v;
-                if (row == col) out += P.diag;
-                if (E1b) out += e1 * x1[r];
-                if (E2b) out += P.e2 * x2[r];
-                Cb[o] = out;
-                if (C2b) C2b[o] = P.alpha2 * v + (row == col ? P.diag2 : 0.f);
+            for (int gq = 0; gq < 4; ++gq) {
+                const int col = cbase + 8 * gq;
+                float o1[4], o2[4];
+                const float xs1[4] = {x1[gq].x, x1[gq].y, x1[gq].z, x1[gq].w};
+                const float xs2[4] = {x2[gq].x, x2[gq].y, x2[gq].z, x2[gq].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float v = acc[i][j][4 * gq + t];
+                    const bool dg = row == col + t;
+                    o1[t] = fmaf(e2, xs2[t], fmaf(e1, xs1[t], fmaf(al, v, dg ? diag : 0.f)));
+                    o2[t] = fmaf(alpha2, v, dg ? diag2 : 0.f);
+                }
+                if (!EDGE) {
+                    *reinterpret_cast<float4*>(Cb + orow + col) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+                    if (has_c2) *reinterpret_cast<float4*>(C2b + orow + col) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                } else if (row < d) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (col + t < d) {
+                            Cb[orow + col + t] = o1[t];
+                            if (has_c2) C2b[orow + col + t] = o2[t];
+                        }
+                }
             }
         }
 }
@@ -298,7 +357,7 @@ static inline bool ns_prob_aligned(const NsProb& p) {
 }
 
 // tn: 0 = choose (128-wide tiles when that still gives two workgroups per CU, else 64-wide), 64 / 128 = forced
-static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, int tn = 0) {
+static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, int tn = 0, int b0 = 0) {
     if (g.np < 1 || g.np > 4 || d <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
     bool fast = d % 128 == 0;
     for (int i = 0; i < g.np; ++i) {
@@ -307,15 +366,17 @@ static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, i
     }
     const int tm = (d + 127) / 128;
     if (tn == 0) tn = tuning().ns_tn;
-    if (tn != 64 && tn != 128) tn = ((long long)g.np * tm * tm * nb >= 512) ? 128 : 64;
+    // 64-wide tiles unless that would put more than 8 workgroups on every CU: measured at B = 64, d = 256 (ns_bench):
+    // forced 64 -> 291 / 750 us (fwd / bwd), forced 128 -> 297 / 770, mixed (128 for the multi-problem launches) 291 / 768
+    if (tn != 64 && tn != 128) tn = ((long long)g.np * tm * tm * 2 * nb > 2048) ? 128 : 64;
     const int tnn = (d + tn - 1) / tn;
     const dim3 grid(xcd_grid(nb, g.np * tm * tnn));
     if (tn == 128) {
-        if (fast) hipLaunchKernelGGL((nsmm_kernel<128, false>), grid, dim3(256), 0, st, g, d, nb, tm, tnn);
-        else hipLaunchKernelGGL((nsmm_kernel<128, true>), grid, dim3(256), 0, st, g, d, nb, tm, tnn);
+        if (fast) hipLaunchKernelGGL((nsmm_kernel<128, false>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+        else hipLaunchKernelGGL((nsmm_kernel<128, true>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
     } else {
-        if (fast) hipLaunchKernelGGL((nsmm_kernel<64, false>), grid, dim3(256), 0, st, g, d, nb, tm, tnn);
-        else hipLaunchKernelGGL((nsmm_kernel<64, true>), grid, dim3(256), 0, st, g, d, nb, tm, tnn);
+        if (fast) hipLaunchKernelGGL((nsmm_kernel<64, false>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+        else hipLaunchKernelGGL((nsmm_kernel<64, true>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
     }
     HK_LAUNCH_CHECK();
     return HK_OK;

@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __re
 
 static inline void slab_plan(int B, int J, int K, int& KS, int& S) {
     const long long tiles = (long long)((B + 63) / 64) * ((K + 63) / 64);
-    long long want = (1536 + tiles - 1) / tiles;                 // ~6 workgroups per CU over the 256 CUs
+    // exactly ONE wave of workgroups over the chip: 256 CUs x 4 resident 64x64x32 workgroups = 1024.  Measured at the BCNN
+    // shape (4 tiles; BENCH_r01 sweep): 256 slabs = 1024 workgroups 132 us; 128 -> 170, 384 (1.5 waves: the round-1
+    // choice) 171, 768 -> 152, 1024 -> 162
+    long long want = 1024 / tiles;
     if (tuning().linear_slabs > 0) want = tuning().linear_slabs;
     const long long max_s = (J + 255) / 256;                       // at least 256 features (8 K-chunks) per slab
     if (want > max_s) want = max_s;

@@ -33,29 +33,28 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__
 }
 
 // ----------------------------------------------------------------- Newton-Schulz glue
-// norm_a[b] = trace(a[b]) ; sq[b] = sqrt(norm_a[b])
-__global__ __launch_bounds__(256) void ns_trace_kernel(const float* __restrict__ a, float* __restrict__ norm_a,
-                                                       float* __restrict__ sq, int d) {
+// One pass over a:  norm_a[b] = trace(a[b]) (computed here when TRACE, else read), sq[b] = sqrt(norm_a[b]),
+// A = a / norm_a, Z0 = 0.5 (3I - A)      (MPNCOV.py:144-146,150/153).  Every workgroup of a sample recomputes the
+// trace itself (d diagonal elements, fixed-order block sum: identical in all of them) instead of waiting for a
+// separate trace kernel.
+template <bool TRACE>
+__global__ __launch_bounds__(256) void ns_scale_kernel(const float* __restrict__ a, float* __restrict__ norm_a,
+                                                       float* __restrict__ sq, float* __restrict__ A,
+                                                       float* __restrict__ z0, long long z0_bs, int d) {
     __shared__ float red[4];
-    const int b = blockIdx.x;
-    const float* p = a + (long long)b * d * d;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < d; i += 256) s += p[(long long)i * d + i];
-    s = block_sum<4>(s, red);
-    if (threadIdx.x == 0) {
-        if (norm_a) norm_a[b] = s;
-        sq[b] = sqrtf(s);
-    }
-}
-
-// A = a / norm_a ; Z0 = 0.5 (3I - A)      (MPNCOV.py:146,150/153)
-__global__ __launch_bounds__(256) void ns_scale_kernel(const float* __restrict__ a, const float* __restrict__ norm_a,
-                                                       float* __restrict__ A, float* __restrict__ z0,
-                                                       long long z0_bs, int d) {
     const int b = blockIdx.y;
     const long long n = (long long)d * d;
-    const float na = norm_a[b];
     const float* p = a + b * n;
+    float na;
+    if (TRACE) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < d; i += 256) s += p[(long long)i * d + i];
+        na = block_sum<4>(s, red);
+        if (blockIdx.x == 0 && threadIdx.x == 0) norm_a[b] = na;
+    } else {
+        na = norm_a[b];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sq[b] = sqrtf(na);
     float* q = A + b * n;
     float* z = z0 ? z0 + b * z0_bs : nullptr;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
@@ -68,34 +67,60 @@ __global__ __launch_bounds__(256) void ns_scale_kernel(const float* __restrict__
     }
 }
 
-// red0[b] = sum(g o out) ; red1[b] = sum(D^T o a)   (MPNCOV.py:175,197) - one workgroup per sample
-__global__ __launch_bounds__(1024) void ns_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ out,
-                                                             const float* __restrict__ D, const float* __restrict__ a,
-                                                             float* __restrict__ red0, float* __restrict__ red1, int d) {
-    __shared__ float red[16];
-    const int b = blockIdx.x;
+// Partial sums of  red0 = sum(g o out)  and  red1 = sum(D^T o a)   (MPNCOV.py:175,197): one workgroup per 32x32
+// tile, the transposed operand read coalesced and turned through LDS; part[b][tile][0/1].  (Round 1 ran this as ONE
+// workgroup per sample with a strided read of D: 114 us of the 927 us backward, profiles/r2_ns_kernel_trace.csv.)
+__global__ __launch_bounds__(256) void ns_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                            const float* __restrict__ D, const float* __restrict__ a,
+                                                            float* __restrict__ part, int d, int nt) {
+    __shared__ float tile[32][33];
+    __shared__ float red[4];
+    const int b = blockIdx.y, ti = blockIdx.x / nt, tj = blockIdx.x % nt;
     const long long n = (long long)d * d;
-    const float *gp = g + b * n, *op = out + b * n, *Dp = D + b * n, *ap = a + b * n;
-    float s0 = 0.f, s1 = 0.f;
-    for (long long e = threadIdx.x; e < n; e += 1024) {
-        s0 += gp[e] * op[e];
-        const int i = (int)(e / d), j = (int)(e % d);
-        s1 += Dp[(long long)j * d + i] * ap[e];
+    const int i0 = ti * 32, j0 = tj * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {                        // D[j0 + r][i0 + tx]
+        const int jj = j0 + r, ii = i0 + tx;
+        tile[r][tx] = (jj < d && ii < d) ? D[b * n + (long long)jj * d + ii] : 0.f;
     }
-    s0 = block_sum<16>(s0, red);
-    s1 = block_sum<16>(s1, red);
-    if (threadIdx.x == 0) { red0[b] = s0; red1[b] = s1; }
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f;
+    for (int r = ty; r < 32; r += 8) {                        // element (i0 + r, j0 + tx)
+        const int ii = i0 + r, jj = j0 + tx;
+        if (ii < d && jj < d) {
+            const long long e = b * n + (long long)ii * d + jj;
+            s0 += g[e] * out[e];
+            s1 += tile[tx][r] * a[e];
+        }
+    }
+    s0 = block_sum<4>(s0, red);
+    s1 = block_sum<4>(s1, red);
+    if (threadIdx.x == 0) {
+        part[((long long)b * nt * nt + blockIdx.x) * 2] = s0;
+        part[((long long)b * nt * nt + blockIdx.x) * 2 + 1] = s1;
+    }
 }
 
-// da = D^T / norm_a + (red0/(2 norm_a) - red1/norm_a^2) I      (MPNCOV.py:195-201)
+// da = D^T / norm_a + (red0/(2 norm_a) - red1/norm_a^2) I      (MPNCOV.py:195-201); red0 / red1 = the tile partials
+// above added in tile order (every workgroup does it for itself: nt^2 <= 64 values at d = 256)
 __global__ __launch_bounds__(256) void ns_bwd_final_kernel(const float* __restrict__ D, const float* __restrict__ norm_a,
-                                                           const float* __restrict__ red0, const float* __restrict__ red1,
+                                                           const float* __restrict__ part, int nt,
                                                            float* __restrict__ da, int d) {
     __shared__ float tile[32][33];
+    __shared__ float red[4];
     const int b = blockIdx.z;
     const long long n = (long long)d * d;
     const float na = norm_a[b];
-    const float coef = red0[b] / (2.0f * na) - red1[b] / (na * na);
+    // the tile partials, one per thread, then the fixed-order block sum (a serial loop over them in every one of the
+    // 4096 workgroups doubled this kernel's time)
+    float r0 = 0.f, r1 = 0.f;
+    for (int t = threadIdx.x; t < nt * nt; t += 256) {
+        r0 += part[((long long)b * nt * nt + t) * 2];
+        r1 += part[((long long)b * nt * nt + t) * 2 + 1];
+    }
+    r0 = block_sum<4>(r0, red);
+    r1 = block_sum<4>(r1, red);
+    const float coef = r0 / (2.0f * na) - r1 / (na * na);
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     // read D[j0.., i0..] (rows j, cols i) coalesced, write da[i][j]
@@ -159,11 +184,68 @@ static inline NsProb ns_yz_pair(const float* Y, const float* Z, long long sbs, f
     return p;
 }
 
-static inline dim3 ew_grid(long long n, int B) {
-    long long g = (n + 255) / 256;
-    if (g > 256) g = 256;
+// Dispatch of one group launch of the chain.  With tuning().ns_streams == 1 and a batch of >= 16 samples the two
+// halves of the batch run the SAME chain on two HIP queues (the caller's stream and a library-owned one, joined before
+// the entry point returns).  Why: every workgroup of a launch is resident at once (512 workgroups = 2 per CU), so all
+// of them are in their prologue (first operand chunk: nothing for the matrix pipe to do) and in their epilogue (the
+// store burst) at the same time - 8-12 us per launch of a 30-120 us launch (profiles/r2_ns_*).  Two independent chains
+// on two queues drift apart, and one's fill / drain is covered by the other's main loop.
+struct NsDispatch {
+    int d, B, h;
+    hipStream_t st, aux;
+    int operator()(const NsGroup& g) const {
+        if (!aux) return nsmm_launch(g, d, B, st);
+        const int rc = nsmm_launch(g, d, h, st, 0, 0);
+        if (rc != HK_OK) return rc;
+        return nsmm_launch(g, d, B - h, aux, 0, h);
+    }
+};
+
+struct NsAux {
+    hipStream_t aux = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+// one helper queue per device, created on first use and kept for the life of the process
+static NsAux* ns_aux() {
+    static NsAux tab[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    NsAux& a = tab[dev];
+    if (!a.aux) {
+        if (hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking) != hipSuccess) { a.aux = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &a;
+}
+// fork: everything enqueued on `st` so far happens before the helper queue's work; returns the dispatcher
+static inline NsDispatch ns_fork(int d, int B, hipStream_t st) {
+    NsDispatch L{d, B, B / 2, st, nullptr};
+    if (tuning().ns_streams != 1 || B < 16) return L;
+    NsAux* a = ns_aux();
+    if (!a) return L;
+    if (hipEventRecord(a->fork, st) != hipSuccess || hipStreamWaitEvent(a->aux, a->fork, 0) != hipSuccess) return L;
+    L.aux = a->aux;
+    return L;
+}
+// join: the helper queue's work happens before whatever is enqueued on `st` next
+static inline int ns_join(const NsDispatch& L) {
+    if (!L.aux) return HK_OK;
+    NsAux* a = ns_aux();
+    hipError_t e = hipEventRecord(a->join, L.aux);
+    if (e == hipSuccess) e = hipStreamWaitEvent(L.st, a->join, 0);
+    return e == hipSuccess ? HK_OK : (int)e;
+}
+
+// grid of ns_scale_kernel: a few workgroups per sample (each one recomputes the trace before it starts: with the
+// 256-per-sample grid of an elementwise kernel that prologue costs more than the scaling, 26 us instead of ~8)
+static inline dim3 ns_scale_grid(long long n, int B) {
+    long long g = n / 4096;
+    if (g < 1) g = 1;
+    if (g > 16) g = 16;
     return dim3((unsigned)g, (unsigned)B);
 }
+
 
 }  // namespace hk
 
@@ -214,7 +296,8 @@ extern "C" int hk_cov_pool_bwd(const float* x, const float* mu, const float* dco
 extern "C" size_t hk_ns_sqrtm_ws_bytes(int B, int d, int iter_n, int backward) {
     (void)iter_n;
     const size_t mat = (size_t)B * d * d * sizeof(float);
-    const size_t small = (size_t)4 * B * sizeof(float) + 256;
+    const size_t nt = (size_t)(d + 31) / 32;
+    const size_t small = ((size_t)B + (backward ? 2 * (size_t)B * nt * nt : 0)) * sizeof(float) + 256;
     return (backward ? 10 * mat : 2 * mat) + small;
 }
 
@@ -233,28 +316,28 @@ extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float*
     const int S = iter_n >= 2 ? iter_n - 1 : 1;   // slots in ysave / zsave
     const long long sbs = (long long)S * n;
 
-    hipLaunchKernelGGL(ns_trace_kernel, dim3(B), dim3(256), 0, st, a, norm_a, sq, d);
-    HK_LAUNCH_CHECK();
     if (iter_n < 2) {
-        hipLaunchKernelGGL(ns_scale_kernel, ew_grid(n, B), dim3(256), 0, st, a, (const float*)norm_a, A, T, n, d);
+        hipLaunchKernelGGL(ns_scale_kernel<true>, ns_scale_grid(n, B), dim3(256), 0, st, a, norm_a, sq, A, T, n, d);
         HK_LAUNCH_CHECK();
         return nsmm_launch(ns_group(ns_single(A, n, T, n, out, n, 1.0f, 0.f, sq)), d, B, st);   // :151,:161
     }
-    hipLaunchKernelGGL(ns_scale_kernel, ew_grid(n, B), dim3(256), 0, st, a, (const float*)norm_a, A, zsave, sbs, d);
+    hipLaunchKernelGGL(ns_scale_kernel<true>, ns_scale_grid(n, B), dim3(256), 0, st, a, norm_a, sq, A, zsave, sbs, d);
     HK_LAUNCH_CHECK();
-    HK_TRY(nsmm_launch(ns_group(ns_single(A, n, zsave, sbs, ysave, sbs, 1.f, 0.f)), d, B, st));   // Y0 = A ZY   :154
+    const NsDispatch L = ns_fork(d, B, st);
+    HK_TRY(L(ns_group(ns_single(A, n, zsave, sbs, ysave, sbs, 1.f, 0.f))));                        // Y0 = A ZY   :154
     for (int i = 1; i < iter_n - 1; ++i) {                                                          // :156-159
         const float* Yp = ysave + (long long)(i - 1) * n;
         const float* Zp = zsave + (long long)(i - 1) * n;
-        HK_TRY(nsmm_launch(ns_group(ns_single(Zp, sbs, Yp, sbs, T, n, -0.5f, 1.5f)), d, B, st));   // ZY = .5(3I - Z Y)
+        HK_TRY(L(ns_group(ns_single(Zp, sbs, Yp, sbs, T, n, -0.5f, 1.5f))));                       // ZY = .5(3I - Z Y)
         NsGroup g = ns_group(ns_single(Yp, sbs, T, n, ysave + (long long)i * n, sbs, 1.f, 0.f));   // Y' = Y ZY
         g += ns_single(T, n, Zp, sbs, zsave + (long long)i * n, sbs, 1.f, 0.f);                    // Z' = ZY Z
-        HK_TRY(nsmm_launch(g, d, B, st));
+        HK_TRY(L(g));
     }
     const float* Yl = ysave + (long long)(iter_n - 2) * n;
     const float* Zl = zsave + (long long)(iter_n - 2) * n;
-    HK_TRY(nsmm_launch(ns_group(ns_single(Zl, sbs, Yl, sbs, T, n, -1.f, 3.f)), d, B, st));         // 3I - Z Y      :160
-    return nsmm_launch(ns_group(ns_single(Yl, sbs, T, n, out, n, 0.5f, 0.f, sq)), d, B, st);       // .5 Y (.) sqrt(normA)
+    HK_TRY(L(ns_group(ns_single(Zl, sbs, Yl, sbs, T, n, -1.f, 3.f))));                             // 3I - Z Y      :160
+    HK_TRY(L(ns_group(ns_single(Yl, sbs, T, n, out, n, 0.5f, 0.f, sq))));                          // .5 Y (.) sqrt(normA)
+    return ns_join(L);
 }
 
 // Backward schedule at iterN = 5 (MPNCOV.py:166-202): the reference's 38 products as 34 in 9 launches -
@@ -271,30 +354,31 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
     float *W1 = A + bn, *W2 = W1 + bn, *W3 = W2 + bn, *W4 = W3 + bn;
     float *dY = W4 + bn, *dZ = dY + bn, *dYn = dZ + bn, *dZn = dYn + bn, *D = dZn + bn;
     float* sq = D + bn;
-    float *red0 = sq + B, *red1 = red0 + B;
+    float* part = sq + B;                            // [B][nt * nt][2] partial sums of the two trace terms
+    const int nt = (d + 31) / 32;
     const int S = iter_n >= 2 ? iter_n - 1 : 1;
     const long long sbs = (long long)S * n;
     const float* g = dout;
 
-    hipLaunchKernelGGL(ns_trace_kernel, dim3(B), dim3(256), 0, st, a, (float*)nullptr, sq, d);
-    HK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ns_scale_kernel, ew_grid(n, B), dim3(256), 0, st, a, norm_a, A, (float*)nullptr, n, d);
+    hipLaunchKernelGGL(ns_scale_kernel<false>, ns_scale_grid(n, B), dim3(256), 0, st, a, const_cast<float*>(norm_a), sq, A,
+                       (float*)nullptr, n, d);        // sq = sqrt(norm_a): the trace the forward saved
     HK_LAUNCH_CHECK();
 
+    const NsDispatch L = ns_fork(d, B, st);
     if (iter_n < 2) {
         // der = .5 (dpc (3I - A) - A dpc) = sq (1.5 g - .5 (g A + A g)),  dpc = sq g                 :178
         NsProb p = ns_prob(D, n, -0.5f, 0.f, sq);
         p += ns_term(g, n, A, n);
         p += ns_term(A, n, g, n);
         p.E1 = g; p.se1 = n; p.e1 = 1.5f; p.e1_scaled = 1;
-        HK_TRY(nsmm_launch(ns_group(p), d, B, st));
+        HK_TRY(L(ns_group(p)));
     } else {
         const float* Yl = ysave + (long long)(iter_n - 2) * n;
         const float* Zl = zsave + (long long)(iter_n - 2) * n;
         {   // W1 = 3I - Yl Zl, W2 = Zl Yl (= Yl Zl), W3 = Yl g
             NsGroup gr = ns_group(ns_yz_pair(Yl, Zl, sbs, W1, W2, n));
             gr += ns_single(Yl, sbs, g, n, W3, n, 1.f, 0.f);
-            HK_TRY(nsmm_launch(gr, d, B, st));
+            HK_TRY(L(gr));
         }
         {   // dldY = .5 sq (g (3I - Yl Zl) - Zl Yl g)   :180-181 ;  dldZ = -.5 sq (Yl g) Yl   :182
             NsProb py = ns_prob(dY, n, 0.5f, 0.f, sq);
@@ -302,7 +386,7 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
             py += ns_term(W2, n, g, n, -1.f);
             NsGroup gr = ns_group(py);
             gr += ns_single(W3, n, Yl, sbs, dZ, n, -0.5f, 0.f, sq);
-            HK_TRY(nsmm_launch(gr, d, B, st));
+            HK_TRY(L(gr));
         }
         for (int i = iter_n - 3; i >= 0; --i) {                                                      // :183-193
             const float* Yi = ysave + (long long)i * n;
@@ -311,7 +395,7 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
                 NsGroup gr = ns_group(ns_yz_pair(Yi, Zi, sbs, W1, W2, n));
                 gr += ns_single(Zi, sbs, dZ, n, W3, n, 1.f, 0.f);
                 gr += ns_single(Yi, sbs, dY, n, W4, n, 1.f, 0.f);
-                HK_TRY(nsmm_launch(gr, d, B, st));
+                HK_TRY(L(gr));
             }
             {   // dldY' = .5 (dldY YZ - (Z dldZ) Z - ZY dldY) ;  dldZ' = .5 (YZ dldZ - (Y dldY) Y - dldZ ZY)
                 NsProb py = ns_prob(dYn, n, 0.5f, 0.f);
@@ -324,7 +408,7 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
                 pz += ns_term(dZ, n, W2, n, -1.f);
                 NsGroup gr = ns_group(py);
                 gr += pz;
-                HK_TRY(nsmm_launch(gr, d, B, st));
+                HK_TRY(L(gr));
             }
             float* t = dY; dY = dYn; dYn = t;
             t = dZ; dZ = dZn; dZn = t;
@@ -335,12 +419,13 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
         p += ns_term(A, n, dY, n);
         p.E1 = dY; p.se1 = n; p.e1 = 1.5f;
         p.E2 = dZ; p.se2 = n; p.e2 = -0.5f;
-        HK_TRY(nsmm_launch(ns_group(p), d, B, st));
+        HK_TRY(L(ns_group(p)));
     }
-    hipLaunchKernelGGL(ns_bwd_reduce_kernel, dim3(B), dim3(1024), 0, st, g, out, (const float*)D, a, red0, red1, d);
+    HK_TRY(ns_join(L));
+    hipLaunchKernelGGL(ns_bwd_reduce_kernel, dim3(nt * nt, B), dim3(256), 0, st, g, out, (const float*)D, a, part, d, nt);
     HK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ns_bwd_final_kernel, dim3((d + 31) / 32, (d + 31) / 32, B), dim3(256), 0, st, (const float*)D,
-                       norm_a, (const float*)red0, (const float*)red1, da, d);
+    hipLaunchKernelGGL(ns_bwd_final_kernel, dim3(nt, nt, B), dim3(256), 0, st, (const float*)D, norm_a,
+                       (const float*)part, nt, da, d);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

@@ -111,7 +111,10 @@ class GradientAllReducer:
         for p in reversed(params):                      # reverse registration ~ backward production order
             nbytes = p.numel() * p.element_size()
             same = (not cur) or (cur[0].dtype == p.dtype and cur[0].device == p.device)
-            if cur and (cur_bytes + nbytes > limit or not same):
+            # a bucket is closed when the next parameter would overflow it - unless it is still tiny (< 1 MiB and < a quarter of the limit): a bias must
+            # not become a collective of its own in front of its 210 MB weight (BCNN: classifier.bias + classifier.weight
+            # form bucket 0 together, the first thing backward produces)
+            if cur and (not same or (cur_bytes + nbytes > limit and cur_bytes >= min(1 << 20, limit // 4))):
                 groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)

@@ -63,9 +63,44 @@ class _BilinearPool(torch.autograd.Function):
         return dx
 
 
-def bilinear_pool(x):
-    """[B,C,H,W] -> [B,C*C]:  sqrt(X X^T / HW + 1e-5), l2-normalised."""
-    return _BilinearPool.apply(x)
+class _BilinearPoolSignedSqrt(torch.autograd.Function):
+    """The reference's alternative normalisation (commented out at model/methods/BCNN.py:23-24):
+    sign(G) sqrt(|G| + 1e-10), l2-normalised."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x)
+        b, c, h, w = x.shape
+        hw = h * w
+        y = torch.empty(b, c * c, dtype=torch.float32, device=x.device)
+        inv_norm = torch.empty(b, dtype=torch.float32, device=x.device)
+        nws = lib.hk_bcnn_ssqrt_ws_bytes(b, c, hw)
+        ws = _ws(nws, x.device)
+        check(lib.hk_bcnn_ssqrt_pool_fwd(ptr(x), ptr(y), ptr(inv_norm), b, c, hw, ptr(ws), nws, stream()),
+              'hk_bcnn_ssqrt_pool_fwd')
+        ctx.save_for_backward(x, y, inv_norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, inv_norm = ctx.saved_tensors
+        b, c, h, w = x.shape
+        hw = h * w
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        nws = lib.hk_bcnn_ssqrt_ws_bytes(b, c, hw)
+        ws = _ws(nws, x.device)
+        check(lib.hk_bcnn_ssqrt_pool_bwd(ptr(x), ptr(y), ptr(dy), ptr(inv_norm), ptr(dx), b, c, hw, ptr(ws), nws,
+                                         stream()), 'hk_bcnn_ssqrt_pool_bwd')
+        return dx
+
+
+def bilinear_pool(x, signed_sqrt=False):
+    """[B,C,H,W] -> [B,C*C]:  sqrt(X X^T / HW + 1e-5), l2-normalised (what the reference runs, BCNN.py:21);
+    signed_sqrt=True: sign(G) sqrt(|G| + 1e-10) instead (its commented alternative, BCNN.py:23-24)."""
+    return _BilinearPoolSignedSqrt.apply(x) if signed_sqrt else _BilinearPool.apply(x)
 
 
 # --------------------------------------------------------------------- MPN-COV
@@ -519,6 +554,10 @@ def npairs_loss(parts, targets):
 
 
 # --------------------------------------------------------------------- classifier
+_LINEAR_BWD_HIP_MAX = 16 * 1024 * 1024      # features x outputs up to which hk_linear_bwd beats rocBLAS (see backward)
+_FORCE_HIP_LINEAR_BWD = False                # tests / benchmarks: always take hk_linear_bwd
+
+
 class _Linear(torch.autograd.Function):
     """replaces nn.Linear on the pooled vector (model/methods/BCNN.py:42,54 and the other heads' classifiers)."""
 
@@ -547,6 +586,14 @@ class _Linear(torch.autograd.Function):
         g = _f32c(g)
         b, j = y.shape
         k = weight.shape[0]
+        if j * k > _LINEAR_BWD_HIP_MAX and not _FORCE_HIP_LINEAR_BWD:
+            # measured on the MI355X (BENCH_r01 / profiles/r2_candidates.json): hk_linear_bwd wins at the MPN shape
+            # (32896 -> 200: 56.8 vs 73.6 us) and loses to rocBLAS at the two widest ones (BCNN 262144 -> 200: 320 vs
+            # 205 us, OSME 100352 -> 1024: 386 vs 295 us) - those keep the library GEMMs for dy / dW
+            dy = g @ weight if ctx.needs_input_grad[0] else None
+            dw = g.t() @ y if ctx.needs_input_grad[1] else None
+            db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return dy, dw, db
         dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
         db = torch.empty(k, dtype=torch.float32, device=y.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None

@@ -22,8 +22,14 @@ class BilinearPooling(nn.Module):
     + one Gram launch whose epilogue writes the final y; backward = one GEMM-shaped launch + one rank-1 fix-up
     (hawkeye_amd/csrc/bcnn_fast.hip, bcnn_pool.hip)."""
 
+    def __init__(self, signed_sqrt=False):
+        """signed_sqrt=True selects the normalisation the reference keeps commented out (BCNN.py:23-24):
+        sign(G) sqrt(|G| + 1e-10) instead of sqrt(G + 1e-5).  Default = what the reference runs."""
+        super().__init__()
+        self.signed_sqrt = signed_sqrt
+
     def forward(self, x):
-        return HF.bilinear_pool(x)
+        return HF.bilinear_pool(x, self.signed_sqrt)
 
 
 def _frozen(module):

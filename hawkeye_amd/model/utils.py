@@ -45,12 +45,12 @@ def load_state_dict(model, state_dict):
 
 def wide_linear(layer, x):
     """`layer(x)` for the classifier / part FCs that sit directly on a pooled vector (tens of thousands of features,
-    a few hundred outputs).  HAWKEYE_HIP_LINEAR=1 routes it through the split-K f32-MFMA kernels
-    (hk_linear_fwd/bwd); the `nn.Linear` stays the parameter holder, so `state_dict` keys, initialisers
-    and optimiser groups are untouched.  Off by default until it has a measured number on the GPU (rocBLAS picks a
-    16x64 macro-tile for the BCNN shape: 400 us for a 45 us HBM-bound product, profiles/r1d_bench_bcnn_kernel_stats.csv).
-    """
-    if os.environ.get('HAWKEYE_HIP_LINEAR') == '1':
+    a few hundred outputs): the split-K f32-MFMA kernel hk_linear_fwd - 134 us against rocBLAS' 385 us at
+    the BCNN shape (it picks a 16x64 macro-tile for a 45 us HBM-bound product), 30 vs 79 us at MPN's, 203 vs 266 us at
+    OSME's; the backward takes hk_linear_bwd where that wins and the library GEMMs elsewhere (functional._Linear).  The
+    `nn.Linear` stays the parameter holder, so `state_dict` keys, initialisers and optimiser groups are untouched.
+    HAWKEYE_HIP_LINEAR=0 switches back to `layer(x)` (A/B lever)."""
+    if os.environ.get('HAWKEYE_HIP_LINEAR', '1') != '0':
         from .. import functional as F        # hawkeye_amd.functional
         return F.linear(x, layer.weight, layer.bias)
     return layer(x)

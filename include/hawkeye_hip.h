@@ -70,6 +70,19 @@ int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy, const floa
                      const float* colsum, float* dx, int B, int C, int HW, void* ws, size_t ws_bytes,
                      hk_stream_t stream);
 
+/* Signed-sqrt variant - the second normalisation the reference keeps (commented out) next to the one it runs:
+ *     G = X X^T / HW ; u = sign(G) sqrt(|G| + 1e-10) ; y = u / max(|u|_2, 1e-12)
+ * replaces model/methods/BCNN.py:18,23-26 (the `sign * sqrt(abs + 1e-10)` alternative; = CBCNN.py:132 on the 512x512
+ * Gram) and its autograd backward.  Raw Gram on the panel kernel, then two elementwise passes (the norm of u has no
+ * closed form from column sums); backward: t = <y, dy> partials, then the same GEMM-shaped launch as the default
+ * variant with P = (dy + dy^T - 2 t y) / |y| * inv_norm^2 / (2 HW), zero where y = 0 (torch: sign'(0) = abs'(0) = 0).
+ *   inv_norm [B]  saved for backward ;  ws: hk_bcnn_ssqrt_ws_bytes */
+size_t hk_bcnn_ssqrt_ws_bytes(int B, int C, int HW);
+int hk_bcnn_ssqrt_pool_fwd(const float* x, float* y, float* inv_norm, int B, int C, int HW, void* ws, size_t ws_bytes,
+                           hk_stream_t stream);
+int hk_bcnn_ssqrt_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, int B, int C,
+                           int HW, void* ws, size_t ws_bytes, hk_stream_t stream);
+
 /* The two stages of each direction, individually callable (hk_bcnn_pool_fwd = colsum_norm + gram_norm,
  * hk_bcnn_pool_bwd = bwd_gemm + bwd_rank1); bench.py times them separately.
  *   tpart [B, ceil(C/64)] partial sums of <y,dy> written by bwd_gemm, consumed by bwd_rank1 */

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(HERE, '_stubs'))
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
-from inputs import rs_randn, rs_relu_randn, sub  # noqa: E402  (tests/golden/inputs.py)
+from inputs import rs_randn, rs_relu_randn, rs_signed_channels, sub  # noqa: E402  (tests/golden/inputs.py)
 
 torch.manual_seed(0)
 torch.set_num_threads(8)
@@ -70,6 +70,30 @@ def gen_bcnn():
     save('bcnn_512', y_sub=sub(y), y_sum=y.double().sum(), y_argmax=y.argmax(dim=1),
          y_rownorm=y.norm(dim=1), dx_sub=sub(x.grad), dx_sum=x.grad.double().sum(),
          dx_abs=x.grad.double().abs().sum())
+
+
+def gen_bcnn_ssqrt():
+    """The reference's OTHER normalisation: BCNN.py:23-24 are commented out next to the `sqrt(x + 1e-5)` of :21.  The
+    class is rebuilt from the reference's own source text with that pair of lines swapped in, then run."""
+    import inspect
+    src = inspect.getsource(M_BCNN.BilinearPooling)
+    live, dead = '        x = torch.sqrt(x + 1e-5)\n', '        # x = torch.sign(x) * torch.sqrt(torch.abs(x) + 1e-10)\n'
+    assert live in src and dead in src, 'reference BCNN.py changed'
+    src = src.replace(live, '').replace(dead, dead.replace('# ', '', 1))
+    ns = {'torch': torch}
+    exec(src, ns)
+    pool = ns['BilinearPooling']()
+    x = t(rs_signed_channels(15, (3, 32, 5, 7))).requires_grad_(True)  # signed channels: negative Gram entries, none near 0
+    y = pool(x)
+    w = t(rs_randn(16, tuple(y.shape)))
+    (y * w).sum().backward()
+    save('bcnn_ssqrt_small', y=y, dx=x.grad)
+    x = t(rs_signed_channels(1240, (2, 512, 14, 14))).requires_grad_(True)
+    y = pool(x)
+    w = t(rs_randn(1241, tuple(y.shape)))
+    (y * w).sum().backward()
+    save('bcnn_ssqrt_512', y_sub=sub(y), y_sum=y.double().sum(), y_abs=y.double().abs().sum(), y_rownorm=y.norm(dim=1),
+         dx_sub=sub(x.grad), dx_sum=x.grad.double().sum(), dx_abs=x.grad.double().abs().sum())
 
 
 # ---------------------------------------------------------------- CBP
@@ -381,6 +405,7 @@ if __name__ == '__main__':
         sys.exit(0)
     gen_mamc()
     gen_bcnn()
+    gen_bcnn_ssqrt()
     gen_cbp()
     gen_mpn()
     gen_apcnn()

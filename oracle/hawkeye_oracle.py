@@ -37,6 +37,18 @@ def bilinear_pool(x):
     return F.normalize(z)                                # BCNN.py:26 (p=2, dim=1, eps=1e-12)
 
 
+def bilinear_pool_signed_sqrt(x):
+    """BilinearPooling.forward with the normalisation the reference keeps commented out (BCNN.py:23-24) in place of
+    the `sqrt(x + 1e-5)` of :21 - the same torch ops, just the other line enabled."""
+    b, c, h, w = x.shape
+    m = h * w
+    xm = x.reshape(b, c, m)                                      # :17
+    g = torch.bmm(xm, xm.transpose(1, 2)) / m                    # :18
+    g = g.reshape(b, -1)                                         # :23
+    u = torch.sign(g) * torch.sqrt(torch.abs(g) + 1e-10)         # :24
+    return F.normalize(u)                                        # :26
+
+
 # ----------------------------------------------------------------------------
 # Compact bilinear pooling  (model/methods/CBCNN.py:68-164)
 # ----------------------------------------------------------------------------

@@ -6,6 +6,7 @@ hawkeye_amd.functional.  Outside the context the product behaviour (HIP tensors 
 """
 import contextlib
 import ctypes
+import os
 
 
 from hawkeye_amd import _lib
@@ -40,7 +41,14 @@ def emulated():
     lib = load_emu()
     saved = (_lib._lib, F.ptr, F.stream, F._on)
     _lib._lib, F.ptr, F.stream, F._on = lib, _cpu_ptr, (lambda: None), (lambda device: contextlib.nullcontext())
+    # the plugins route their wide classifier through hk_linear_fwd by default; emulating a 262144-feature split-K
+    # GEMM takes minutes, so whole-model cases keep nn.Linear here unless a test asks for the kernel explicitly
+    had = os.environ.get('HAWKEYE_HIP_LINEAR')
+    if had is None:
+        os.environ['HAWKEYE_HIP_LINEAR'] = '0'
     try:
         yield F
     finally:
         _lib._lib, F.ptr, F.stream, F._on = saved
+        if had is None:
+            os.environ.pop('HAWKEYE_HIP_LINEAR', None)

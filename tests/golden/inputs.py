@@ -13,6 +13,16 @@ def rs_relu_randn(seed, shape):
     return np.maximum(rs_randn(seed, shape), 0.0)
 
 
+def rs_signed_channels(seed, shape):
+    """|N(0,1)| + 0.1 with a random sign per CHANNEL ([B,C,H,W]): every Gram entry X_i . X_j is bounded away from zero
+    with mixed signs - a well-conditioned input for sign(G) sqrt(|G| + eps), whose slope 1 / (2 sqrt(|G| + eps)) blows up
+    at G = 0 (with zero-mean features a few of the C*C entries land within fp32 rounding of 0 and dominate any fp32
+    vs fp32 comparison of the gradient)."""
+    a = np.abs(rs_randn(seed, shape)) + np.float32(0.1)
+    sign = np.random.RandomState(seed + 1000).choice(np.array([-1.0, 1.0], dtype=np.float32), size=shape[1])
+    return (a * sign[None, :, None, None]).astype(np.float32)
+
+
 def sub(a, stride=1009):
     """Strided subsample of a flattened tensor (stride prime, offset 0)."""
     if torch.is_tensor(a):

@@ -79,7 +79,7 @@ def test_two_rank_gloo_allreduce(tmp_path):
         opt.step()
     for a, p in zip(got['params'], model.parameters()):
         torch.testing.assert_close(a, p.detach(), rtol=1e-5, atol=1e-6)
-    assert len(got['buckets']) >= 3                # tiny bucket limit -> several buckets, last layer first
+    assert len(got['buckets']) >= 2                # tiny bucket limit -> several buckets, last layer first
     assert got['buckets'][0][0] >= 1
 
 
@@ -125,3 +125,16 @@ def test_bucket_views_follow_parameter_memory_format():
         o2.step()
     for a, b in zip(net.parameters(), ref.parameters()):
         assert torch.allclose(a, b, atol=1e-6)
+
+
+def test_tiny_parameter_joins_the_next_bucket():
+    """A bias in front of a weight far above the bucket limit must not become a collective of its own."""
+    from hawkeye_amd import ddp
+    net = nn.Sequential(nn.Linear(64, 8), nn.ReLU(), nn.Linear(8, 600000))     # last layer: 2.4 MB bias, 19 MB weight
+    red = ddp.GradientAllReducer(net, bucket_mb=4.0, broadcast=False)
+    sizes = red.describe()
+    assert sizes[0][0] == 1 and sizes[0][1] > 2.0            # the 2.4 MB bias alone is big enough to stand alone
+    net2 = nn.Sequential(nn.Linear(64, 8), nn.ReLU(), nn.Linear(8, 1000))       # 4 KB bias: joins its 32 KB weight
+    red2 = ddp.GradientAllReducer(net2, bucket_mb=0.03, broadcast=False)
+    first = red2.describe()[0]
+    assert first[0] == 2

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import hawkeye_oracle as O
-from inputs import rs_randn, rs_relu_randn, sub
+from inputs import rs_randn, rs_relu_randn, rs_signed_channels, sub
 
 pytestmark = pytest.mark.gpu
 
@@ -95,6 +95,46 @@ def test_bcnn_512_vs_golden(F):
     np.testing.assert_allclose(yg.detach().norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
     assert rel(xg.grad, x.grad) < 1e-5
     np.testing.assert_allclose(sub(xg.grad.cpu()).numpy(), g['dx_sub'], rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('shape,seed', [((3, 32, 5, 7), 15), ((2, 128, 14, 14), 31), ((2, 64, 10, 10), 32), ((3, 100, 4, 6), 33)])
+def test_bcnn_signed_sqrt_variant(F, shape, seed, tune):
+    """sign(G) sqrt(|G| + 1e-10), l2-normalised - the normalisation the reference keeps commented out next to the one
+    it runs (BCNN.py:23-24): hk_bcnn_ssqrt_pool_fwd/bwd vs the oracle on features with a sign per channel (negative Gram entries, none near
+    zero: tests/golden/inputs.py::rs_signed_channels says why), vs
+    the golden produced from the reference's own source with those lines enabled, on the panel kernels (64- and
+    128-row backward), the generic path, and a ragged shape."""
+    b, c = shape[0], shape[1]
+    xn, wn = rs_signed_channels(seed, shape), rs_randn(seed + 1, (b, c * c))
+    x = t(xn).requires_grad_(True)
+    y = O.bilinear_pool_signed_sqrt(x)
+    (y * t(wn)).sum().backward()
+    outs = []
+    for generic, bwd_v in ((0, 1), (0, 5), (1, 0)):
+        tune('bcnn_generic', generic)
+        tune('bwd_v', bwd_v)
+        xg = t(xn).to(DEV).requires_grad_(True)
+        yg = F.bilinear_pool(xg, signed_sqrt=True)
+        (yg * t(wn).to(DEV)).sum().backward()
+        assert rel(yg, y) < 2e-6 and rel(xg.grad, x.grad) < 5e-5, (generic, bwd_v)
+        np.testing.assert_allclose(yg.detach().norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
+        outs.append(xg.grad)
+    if seed == 15:
+        g = load('bcnn_ssqrt_small')
+        assert rel(yg, g['y']) < 2e-6 and rel(xg.grad, g['dx']) < 5e-5
+
+
+def test_bcnn_signed_sqrt_512_vs_golden(F):
+    g = load('bcnn_ssqrt_512')
+    xn, wn = rs_signed_channels(1240, (2, 512, 14, 14)), rs_randn(1241, (2, 512 * 512))
+    xg = t(xn).to(DEV).requires_grad_(True)
+    yg = F.bilinear_pool(xg, signed_sqrt=True)
+    (yg * t(wn).to(DEV)).sum().backward()
+    np.testing.assert_allclose(sub(yg.detach().cpu()).numpy(), g['y_sub'], rtol=2e-5, atol=2e-9)
+    assert abs(float(yg.double().abs().sum()) / float(g['y_abs']) - 1) < 1e-6
+    np.testing.assert_allclose(yg.detach().norm(dim=1).cpu().numpy(), g['y_rownorm'], rtol=1e-5)
+    assert rel(sub(xg.grad.cpu()), g['dx_sub']) < 1e-4
+    assert abs(float(xg.grad.double().abs().sum()) / float(g['dx_abs']) - 1) < 1e-5
 
 
 @pytest.mark.parametrize('shape', [(1, 8, 1, 1), (2, 13, 3, 3), (5, 64, 7, 7), (9, 100, 4, 6)])

@@ -211,21 +211,20 @@ def bwd_variants():
     xm = torch.relu(torch.randn(B, dc, HW, device=dev))
     mu, g, dxm = torch.zeros(B, dc, device=dev), torch.randn(B, dc, dc, device=dev), torch.empty_like(xm)
     ref = None
-    for flag in ('0', '4', '3'):
+    for flag in (1, 5):
         knob('bwd_v', flag)
-        tag = {'0': 'HK_BWD_V=0 four barriers per K-block (round-1 default)', '4': 'HK_BWD_V=4 two barriers, direct transposed loads',
-               '3': 'HK_BWD_V=3 raw tiles, 3 WGs/CU'}[flag]
+        tag = {1: 'bwd_v=1: 64-row blocks, P tile built in LDS, 2 WGs/CU (round-1 kernel)',
+               5: 'bwd_v=5: 128-row blocks, raw tiles, one barrier per K-block, 1 WG/CU (hk_bwd128.h)'}[flag]
         row('bcnn bwd_gemm B=64 C=512', tag,
             timeit(lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream()), iters=40),
             2.0 * B * C * C * HW, 8.0 * B * (C * C + C * HW))
         if ref is None:
             ref = dx.clone()
         else:
-            rows[-1]['bit_identical_to_default'] = bool(torch.equal(dx, ref))
-        if flag != '3':
-            row('cov_pool bwd B=64 C=256', tag,
-                timeit(lambda: lib.hk_cov_pool_bwd(ptr(xm), ptr(mu), ptr(g), ptr(dxm), B, dc, HW, stream()), iters=40),
-                2.0 * B * dc * dc * HW)
+            rows[-1]['rel_vs_64row'] = float((dx - ref).norm() / ref.norm())
+        row('cov_pool bwd B=64 C=256', tag,
+            timeit(lambda: lib.hk_cov_pool_bwd(ptr(xm), ptr(mu), ptr(g), ptr(dxm), B, dc, HW, stream()), iters=40),
+            2.0 * B * dc * dc * HW)
     knob('bwd_v', 0)
 
 
@@ -305,7 +304,7 @@ def bcnn_step_with_hip_linear():
         ms = (time.perf_counter() - t0) / 8 * 1e3
         rows.append({'op': 'BCNN bs64 448^2 train step', 'variant': f'HAWKEYE_HIP_LINEAR={flag}', 'ms_per_step': round(ms, 2),
                      'images_per_sec': round(64 / ms * 1e3, 1)})
-    os.environ['HAWKEYE_HIP_LINEAR'] = '0'
+    os.environ.pop('HAWKEYE_HIP_LINEAR', None)
 
 
 if __name__ == '__main__':
