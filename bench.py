@@ -64,6 +64,9 @@ def parse():
                          'one-GPU box (adds `ddp_timeline` to the JSON line)')
     ap.add_argument('--ddp-trace', action='store_true', help='N > 1: add `ddp_timeline` (where in the backward each '
                                                              'gradient bucket\'s all-reduce was issued)')
+    ap.add_argument('--kernels-first', action='store_true',
+                    help='also time the pooling-head kernels BEFORE the training loop (`kernels_before`): the same kernels read '
+                         '1.2-1.4x slower right after 25 conv-bound steps (power-limited clocks) than on a cool chip')
     ap.add_argument('--no-other-models', action='store_true',
                     help='skip the subprocess that times the other BASELINE.json configs (MPN, CBCNN, APCNN-8142)')
     return ap.parse_args()
@@ -317,6 +320,9 @@ def main():
         opt.step()
         return loss
 
+    kernels_before = None
+    if a.kernels_first and world == 1:
+        kernels_before = kernel_rooflines(a.batch, 512, (a.image // 32) ** 2, dev)
     for i in range(a.warmup):
         tw = time.perf_counter()
         step()
@@ -365,6 +371,8 @@ def main():
                                                                    if 'bwd' in dom['kernel'] else
                                                                    4.0 * a.batch * (512 * 512 + 512 * (a.image // 32) ** 2))}
             res['kernels'] = ks
+            if kernels_before is not None:
+                res['kernels_before'] = kernels_before
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.image, a.classes)
         if reducer is not None and reducer.trace:

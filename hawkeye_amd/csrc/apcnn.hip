@@ -468,7 +468,7 @@ extern "C" int hk_roi_crop_resize_fwd(const float* x, const float* box, const fl
 extern "C" int hk_roi_crop_resize_bwd(const float* dy, const float* box, const float* drop, float* dx, int B, int C,
                                       int H, int W, int training, hk_stream_t stream) {
     if (!dy || !box || !drop || !dx || B <= 0 || C <= 0 || H <= 0 || W <= 0) return HK_ERR_BAD_ARG;
-    if (tuning().roi_bwd == 2) {                            // LDS-staged variant (apcnn_roi2.hip)
+    if (tuning().roi_bwd != 1) {                            // default: uniform-window kernel (apcnn_roi2.hip); 1 = the round-1 kernel below
         const int rc = roi_crop_bwd_v2(dy, box, drop, dx, B, C, H, W, training, (hipStream_t)stream);
         if (rc != HK_ERR_UNSUPPORTED) return rc;
     }

@@ -41,7 +41,7 @@ namespace hk {
 struct Tuning {
     int bcnn_generic = 0;   // HK_BCNN_GENERIC  1: generic GEMM path instead of the panel-resident Gram / backward kernels
     int cbp_bin = -1;       // HK_CBP_BIN      -1: by batch size, 0: row-sketch, 1: CSR gather, 2: row-scatter
-    int roi_bwd = 0;        // HK_ROI_BWD       0: default ROI-refinement backward, 1: the other variant
+    int roi_bwd = 0;        // HK_ROI_BWD       0: uniform-window ROI-refinement backward (apcnn_roi2.hip), 1: the round-1 table kernel
     int linear_slabs = 0;   // HK_LINEAR_SLABS  0: automatic split-K slab count of hk_linear_fwd
     int ns_tn = 0;          // HK_NS_TN         0: automatic, 64 / 128: forced tile width of the Newton-Schulz products
     int bwd_v = 0;          // HK_BWD_V         Gram backward: 0 / 1 the 64-row kernel (bcnn_fast.hip), 5 the 128-row kernel (hk_bwd128.h)

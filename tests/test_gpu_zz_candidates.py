@@ -76,16 +76,18 @@ def test_backward_128_row_kernel(F, b, c, hw, tune):
 
 @pytest.mark.parametrize('mode', ['train', 'eval'])
 def test_roi_crop_backward_lds_variant_bit_identical(F, mode, tune):
-    """roi_bwd=2 (tables shared by 4 channel maps, dY map staged in LDS) adds the same taps in the same order as the
-    default table-driven backward: bit-identical dX, for several boxes including a dropped block and a tiny crop."""
+    """The uniform-window ROI-refinement backward (apcnn_roi2.hip, the default: one tap-window size per workgroup, four
+    pixels per thread in flight, geometry computed once for 8 channel maps, map staged in LDS) adds the same taps in
+    the same order as the round-1 table kernel (roi_bwd=1): bit-identical dX, for several boxes including a dropped
+    block, a tiny crop (large windows) and a full-size one."""
     gen = torch.Generator().manual_seed(9)
     x = torch.randn(4, 10, 56, 56, generator=gen)                         # 10 channels: 2 full groups of 4 + a ragged one
     wt = torch.randn(4, 10, 56, 56, generator=gen)
     box = torch.tensor([[3.2, 5.9, 40.1, 33.3], [0., 0., 56., 56.], [20.5, 21.5, 24.4, 25.9], [10., 2., 55.9, 17.2]])
     drop = torch.tensor([[10., 12., 20., 30.], [0., 0., -1., -1.], [0., 0., -1., -1.], [12., 3., 30., 9.]])
     res = []
-    for flag in ('0', '2'):
-        tune('roi_bwd', int(flag))
+    for flag in (1, 0):
+        tune('roi_bwd', flag)
         xg = x.clone().to(DEV).requires_grad_(True)
         y = F.roi_crop_resize(xg, box.to(DEV), drop.to(DEV), mode == 'train')
         (y * wt.to(DEV)).sum().backward()

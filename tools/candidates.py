@@ -234,9 +234,9 @@ def roi_bwd():
     box = torch.tensor([[3.2, 5.9, 40.1, 33.3]] * B, device=dev)
     drop = torch.tensor([[10., 12., 20., 30.]] * B, device=dev)
     ref = None
-    for flag in ('0', '2'):
+    for flag in (1, 0):
         knob('roi_bwd', flag)
-        row(f'roi_crop_resize bwd B={B} C={C} 56x56', 'default table kernel' if flag == '0' else 'HK_ROI_BWD=2 LDS-staged, 4 maps / WG',
+        row(f'roi_crop_resize bwd B={B} C={C} 56x56', 'roi_bwd=1: round-1 table kernel' if flag == 1 else 'uniform-window kernel, 8 maps / WG, 4 pixels in flight (default)',
             timeit(lambda: lib.hk_roi_crop_resize_bwd(ptr(dy), ptr(box), ptr(drop), ptr(dx), B, C, 56, 56, 1, stream())), 0.0,
             8.0 * B * C * 3136)
         if ref is None:
