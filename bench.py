@@ -151,7 +151,8 @@ def kernel_rooflines(B, C, HW, dev):
          0.0, 4.0 * B * C * HW),
         ('bcnn_gram_panel_kernel<196>', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
          flops, 4.0 * B * C * HW + 4.0 * B * C * C),
-        ('bcnn_bwd_panel_kernel<196>', lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp),
+        ('bcnn_bwd128_kernel<196>' if (C % 128 == 0 and B * (C // 128) >= 192) else 'bcnn_bwd_panel_kernel<196>',
+         lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp),
                                                                    B, C, HW, stream()),
          flops, 8.0 * B * C * C + 8.0 * B * C * HW),
         ('bcnn_rank1_fix_kernel', lambda: lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream()),
@@ -176,14 +177,15 @@ def pmc_traffic(kernel_prefix):
     FETCH_SIZE / WRITE_SIZE in KiB, separate passes; FETCH_SIZE doubled - gfx950 reports half of the bytes of
     16-B-per-lane streaming reads, MI355X_MICROARCH.md section HBM).  PMC cannot be sampled from inside this
     process, so this is the last profiled value, or None when the file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r1b_pool_kernels_pmc.csv')
-    try:
-        import csv
-        vals = {r['Counter']: float(r['MeanValue']) for r in csv.DictReader(open(path))
-                if r['Kernel'].startswith(kernel_prefix) and r['Counter'] in ('FETCH_SIZE', 'WRITE_SIZE')}
-        return round((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0)
-    except Exception:
-        return None
+    import csv
+    for name in ('r2_pool_kernels_pmc.csv', 'r1b_pool_kernels_pmc.csv'):
+        try:
+            vals = {r['Counter']: float(r['MeanValue']) for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', name)))
+                    if r['Kernel'].replace('void ', '').startswith(kernel_prefix) and r['Counter'] in ('FETCH_SIZE', 'WRITE_SIZE')}
+            return round((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0), 'profiles/' + name
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(image, classes):
@@ -364,8 +366,11 @@ def main():
             res['roofline'] = {k: dom[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
             res['roofline']['kernel'] = dom['kernel']
             res['roofline']['us'] = dom['us']
-            res['roofline']['traffic'] = pmc_traffic('hk::' + dom['kernel'].split('<')[0])
-            res['roofline']['traffic_source'] = 'profiles/r1b_pool_kernels_pmc.csv (rocprofv3 --pmc, bytes per launch)'
+            tr_bytes, tr_src = pmc_traffic('hk::' + dom['kernel'].split('<')[0])
+            res['roofline']['traffic'] = tr_bytes
+            res['roofline']['traffic_source'] = (tr_src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, '
+                                                 'FETCH doubled per MI355X_MICROARCH.md)') if tr_src else None
+
             res['roofline']['algorithmic'] = {'flops_per_launch': 2.0 * a.batch * 512 * 512 * (a.image // 32) ** 2,
                                               'bytes_per_launch': (8.0 * a.batch * (512 * 512 + 512 * (a.image // 32) ** 2)
                                                                    if 'bwd' in dom['kernel'] else

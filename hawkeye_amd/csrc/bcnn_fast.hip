@@ -27,6 +27,10 @@
 
 namespace hk {
 
+#ifdef HK_LAB
+__device__ long long* g_lab_stamps = nullptr;
+#endif
+
 // ----------------------------------------------------------------------------- forward
 // MODE 0: BCNN  y = sqrt(acc / M + 1e-5) * inv_norm[b]        MODE 1: raw  y = alpha * acc  (CBP Gram, covariance)
 template <int MODE>
@@ -295,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, 0, tid, ex, b);
     for (int kb = 0; kb < nb; ++kb) {
         __syncthreads();                                   // previous MFMA phase finished with sP / sX
+        HK_STAMP(kb, 0);
         if (MODE != 2) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                  // dy(K,I) transposed into the scratch: T[i][k] = dy[k][i]
@@ -306,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
             }
             __syncthreads();
         }
+        HK_STAMP(kb, 1);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                      // P tile
             const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
@@ -336,14 +342,17 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
             *reinterpret_cast<f32x4*>(&sP[r * PP + c4]) = p;
         }
         __syncthreads();                                   // scratch reads done: X block may overwrite it
+        HK_STAMP(kb, 2);
 #pragma unroll
         for (int u = 0; u < NSX; ++u) {
             const int f = tid + 256 * u;
             if (f < XN4) reinterpret_cast<f32x4*>(sX)[f] = rx[u];
         }
         __syncthreads();
+        HK_STAMP(kb, 3);
         // next K-block's operands: in flight during the MFMA phase (last iteration: harmless re-read)
         bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, (kb + 1 < nb ? kb + 1 : kb), tid, ex, b);
+        HK_STAMP(kb, 4);
 
         const float* ap = sP + (wave * 16 + l15) * PP + 4 * lq;
 #pragma unroll
@@ -357,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bp[16 * n], acc[n], 0, 0, 0);
             }
         }
+        HK_STAMP(kb, 5);
     }
 
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -397,11 +407,12 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
     //   two-barrier variant     (transposed dy fetched directly: 4x the L1 requests)                  93 us  (removed)
     //   raw 32-row K-blocks     (3 WGs/CU)                                                            89-92 us  (removed)
     //   producer / consumer     (512 threads)                                                         94 us  (removed)
-    //   bcnn_bwd128_kernel      hk_bwd128.h: 128-row blocks, raw tiles, one barrier per K-block, 1 WG/CU  94 us
-    // The 128-row kernel (tuning().bwd_v == 5, needs C % 128 == 0) measured 94.3 us against 87.5 us for the 64-row kernel
-    // at this shape (profiles/r2_candidates.json): with ONE wave per SIMD its staging instructions sit in the MFMA
-    // issue stream (matrix pipe 53 % busy, 27 % of the wave time parked), so the 64-row kernel stays the default.
-    if (tuning().bwd_v == 5 && C % 128 == 0) {
+    //   bcnn_bwd128_kernel      hk_bwd128.h: 128-row blocks, raw tiles, one barrier per K-block, 8 waves  77-80 us
+    // The 128-row kernel needs C % 128 == 0 and enough row blocks to fill the chip (one workgroup per CU:
+    // B * C / 128 >= 192); the covariance at B = 64, C = 256 (128 row blocks) is faster on the 64-row kernel
+    // (30 vs 39 us).  tuning().bwd_v: 0 automatic, 1 force the 64-row kernel, 5 force the 128-row one.
+    const int v = tuning().bwd_v;
+    if (v != 1 && C % 128 == 0 && (v >= 5 || (long long)B * (C / 128) >= 192)) {
         const int rc = bwd128_launch<HW, MODE>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
         if (rc != HK_ERR_UNSUPPORTED) return rc;
     }
@@ -483,3 +494,9 @@ int cbp_fast_bwd(const float* x, const int* h1, const int* h2, const float* s1, 
 }
 
 }  // namespace hk
+
+#ifdef HK_LAB
+extern "C" int hk_lab_set_stamps(long long* dev_buffer) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hk::g_lab_stamps), &dev_buffer, sizeof(dev_buffer));
+}
+#endif

@@ -1,27 +1,45 @@
-// Gram backward, second structure:  dX[I rows] = sum_K P(I,K) X(K)  for 128-row blocks I on ONE workgroup per CU.
+// Gram backward, second structure:  dX[I rows] = sum_K P(I,K) X(K)  for 128-row blocks I, one 8-wave workgroup per CU.
 //
-// Why (profiles/r1c_sq_wait_counters.csv, BENCH_r01, profiles/r2_candidates.json): the 64-row kernel
-// (bcnn_bwd_panel_kernel) and its two variants all sit at 85-93 us = 0.45-0.49 of the fp32 MFMA peak with the matrix
-// pipe 66 % busy.  What they share:  (1) a P-tile BUILD phase between MFMA phases (transposing scatter of dy(K,I), 16
-// v_rcp, three or four workgroup barriers per K-block),  (2) one ds_read_b32 of the X operand per MFMA (each wave
-// owns only 16 rows), i.e. ~1 LDS wave-instruction per 32 matrix-pipe cycles from each of 8 waves,  (3) every X block
-// is staged by 8 workgroups per image.  This kernel removes all three:
+// Why (profiles/r1c_sq_wait_counters.csv, BENCH_r01, profiles/r2_bwd_lab.json): the 64-row kernel
+// (bcnn_bwd_panel_kernel) sits at 85-88 us = 0.48-0.49 of the fp32 MFMA peak.  Cycle stamps inside it (tools/bwd_lab.py)
+// give 18.3k cycles per K-block of which 11.2k are the MFMA phase (6.7k when alone on the SIMD) and 7.1k are phases
+// that issue no MFMA - transposing scatter of dy(K,I) 0.9k, P-tile build 1.6k, X store 1.0k, issuing the next block's
+// 25 loads 2.7k, four barriers - more than the partner workgroup's MFMA phase can cover.  This kernel:
 //   * no P tile: LDS holds the RAW tiles  S1 = dy(I,K) [i][k],  S2 = dy(K,I) [k][i],  W = coef / y(I,K) [i][k]  exactly
 //     as they lie in HBM (coalesced 16-byte loads, 16-byte LDS stores, no transposition), and the MFMA A operand is
 //     formed when the fragment is read:  a = (S1[i][k] + S2[k][i]) * W[i][k]  - for the 16x16x4 A layout lanes run
 //     along i, so the "transposed" read of S2 is a conflict-free ds_read_b32 of consecutive addresses;
-//   * each wave owns 32 rows x 13 column tiles (26 accumulators): an X fragment feeds two MFMAs, half the LDS reads;
-//   * 128-row blocks: X is staged by 4 workgroups per image instead of 8;
-//   * K-blocks of 32 channels, two LDS stages (2 x 77 KB), ONE barrier per K-block; the next block's global loads are
-//     issued before the MFMAs of the current one and land in the other stage between its two halves.
-// Same arithmetic per element as the 64-row kernel (sum, rcp, coef folded into W) - dX agrees to rounding, not bit for
-// bit (W = rcp(y) * coef is rounded before the multiplication).
+//   * each wave owns 32 rows x 7 (6) column tiles: an X fragment feeds two MFMAs, half the LDS reads per MFMA;
+//   * 128-row blocks: X is staged by 4 workgroups per image instead of 8 (the vector-memory pipe of a CU moves
+//     73 KB per K-block instead of 98 KB per 64 channels);
+//   * K-blocks of 32 channels, two LDS stages (2 x 77 KB), ONE barrier per K-block; 8 waves = two per SIMD, the next
+//     block's loads / LDS stores cut into four parts each and placed between the eight MFMA groups of a block, operand
+//     fragments double-buffered one group ahead.
+// Measured (B = 64, C = 512, 14x14; same box, alternating): 64-row 85.3 us, this kernel 77.5 us; with the staging
+// removed from the loop 66.2 us, with the per-group fragment reads removed as well 62.7 us (timing-only builds) - the
+// MFMA stream + 16 barriers + prologue / epilogue of this tiling is 0.66 of the peak, the staging costs another 0.12.
+// A first version with ONE wave per SIMD (256 threads) ran 94-111 us: every staging instruction sat in the MFMA issue
+// stream (15.1k cycles per K-block for 6.7k cycles of MFMAs).
+// Same arithmetic per element as the 64-row kernel ((dy + dy^T) * (rcp(y) * coef)): bit-identical dX.
 // MODE 0 BCNN   P = (dy + dy^T) / y * inv^2 / (2M)          MODE 1 COV   P = (g + g^T) / M, X centred
 // MODE 2 CBP    P = dG + dG^T gathered from dc               MODE 3 signed-sqrt BCNN (BCNN.py:23-24): see bcnn_pool.hip
 #pragma once
 #include "hk_common.h"
 
 namespace hk {
+
+// HK_LAB builds only (make lab -> libhawkeye_hip_lab.so, tools/bwd_lab.py): cycle stamps of wave 0 of the first 64
+// workgroups at the phase boundaries of every K-block.  Compiled out of the product library.
+#ifdef HK_LAB
+extern __device__ long long* g_lab_stamps;               // [64 workgroups][32 K-blocks][8 stamps]
+#define HK_STAMP(kb_, slot_)                                                                          \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 64 && g_lab_stamps)                                      \
+            g_lab_stamps[((long long)blockIdx.x * 32 + (kb_)) * 8 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define HK_STAMP(kb_, slot_) do { } while (0)
+#endif
 
 struct BwdExtra {
     const float* mu;     // [B][C]      (COV)
@@ -42,13 +60,22 @@ __device__ __forceinline__ float bwd_t_of(const BwdExtra& ex, int b) {
     return t;
 }
 
-template <int HW, int MODE>
-__global__ __launch_bounds__(256, 1) void bcnn_bwd128_kernel(const float* __restrict__ x, const float* __restrict__ y,
+// 512 threads = 8 waves = TWO waves per SIMD: wave w owns rows 32 (w & 3) .. + 31 and the column tiles of half w >> 2
+// (7 + 6 of the 13 tiles at HW = 196), so both waves of a SIMD run the same stream half a tile-group apart and one's
+// staging / fragment reads issue in the shadow of the other's MFMAs (a single wave per SIMD exposed all of them: the lab
+// build measured 15.1k cycles per K-block for 6.7k cycles of MFMAs, tools/bwd_lab.py).  Global loads run TWO K-blocks
+// ahead through two register sets; the loads and the LDS stores of a K-block are cut into four parts each and placed
+// between the eight MFMA groups of the block.
+// LABV (HK_LAB builds, timing only - results are wrong): 1 = no staging inside the loop (MFMA + fragment stream alone),
+// 2 = staging but the fragments are read once per K-block only (no per-group LDS reads), 3 = both removed
+template <int HW, int MODE, int LABV = 0>
+__global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ dy,
                                                              const float* __restrict__ inv_norm, float* __restrict__ dx,
                                                              float* __restrict__ tpart, int C, int nI, int B,
                                                              BwdExtra ex) {
     constexpr int NT = (HW + 15) / 16;          // 16-column output tiles
+    constexpr int NH = (NT + 1) / 2;            // tiles of the first column half (the second has NT - NH)
     constexpr int KB = 32;                      // channels per K-block
     constexpr int P1 = KB + 4;                  // pitch of the [i][k] tiles (ds_read_b128: pitch / 4 odd)
     constexpr int P2 = 128 + 4;                 // pitch of the [k][i] tile
@@ -56,51 +83,66 @@ __global__ __launch_bounds__(256, 1) void bcnn_bwd128_kernel(const float* __rest
     constexpr bool HAS_S2 = MODE != 2;
     constexpr int S1_SZ = 128 * P1, W_SZ = HAS_W ? 128 * P1 : 0, S2_SZ = HAS_S2 ? KB * P2 : 0;
     constexpr int XN4 = KB * HW / 4;            // float4 of one X block
-    constexpr int NSX = (XN4 + 255) / 256;
+    constexpr int NSX = (XN4 + 511) / 512;      // (<= 4)
     constexpr int X_SZ = (XN4 + 3) / 4 * 16;    // floats, rounded to 64 B
     constexpr int STAGE = S1_SZ + W_SZ + S2_SZ + X_SZ;
+    static_assert(NSX <= 4, "X block staging assumes at most four 16-byte vectors per thread");
     HK_DYN_LDS16(lds);
 
     int b, I;
     if (!xcd_map(blockIdx.x, B, nI, b, I)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
+    const int wrow = (wave & 3) * 32;
+    const int half = __builtin_amdgcn_readfirstlane(wave) >> 2;   // wave-uniform: the tile guards below must be scalar branches
+    const int nt0 = half * NH, nloc = half ? NT - NH : NH;      // this wave's column tiles: nt0 .. nt0 + nloc - 1
     const long long cc = (long long)b * C * C;
     const float* xb = x + (long long)b * C * HW;
-    const int nkb = C / KB;
-    float coef = 1.0f / (float)HW;                         // COV
+    const int nkb = C / KB;                                     // even (C % 128 == 0)
+    float coef = 1.0f / (float)HW;                              // COV
     if (HAS_W) {
         const float in = inv_norm[b];
         coef = in * in / (2.0f * (float)HW);
     }
     const float t2 = MODE == 3 ? 2.0f * bwd_t_of(ex, b) : 0.f;
 
-    f32x4 acc[2][NT];
+    f32x4 acc[2][NH];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NH; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float tacc = 0.f;
 
-    // staging registers: named (an indexed array that is loaded and stored in different conditional blocks is not
-    // promoted to registers)
-    f32x4 ry0, ry1, ry2, ry3, rd0, rd1, rd2, rd3, rt0, rt1, rt2, rt3;
-    f32x4 rx[NSX];
-    float rmu[NSX];                                            // COV: channel mean of each staged X vector
+    // staging registers of the NEXT K-block (requested during the first half of the current block, stored to the other
+    // LDS stage during its second half); named members: an indexed array that is loaded and stored in different
+    // blocks is not promoted to registers
+    struct Regs {
+        f32x4 y0, y1, d0, d1, t0, t1, x0, x1, x2, x3;
+        float m0, m1, m2, m3;                                   // COV: channel mean of each staged X vector
+    };
+    Regs R0;
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    ry0 = ry1 = ry2 = ry3 = rd0 = rd1 = rd2 = rd3 = rt0 = rt1 = rt2 = rt3 = z4;
+    R0.y0 = R0.y1 = R0.d0 = R0.d1 = R0.t0 = R0.t1 = R0.x0 = R0.x1 = R0.x2 = R0.x3 = z4;
+    R0.m0 = R0.m1 = R0.m2 = R0.m3 = 0.f;
 
-    const int r1 = tid >> 3, c1 = 4 * (tid & 7);           // [i][k] tiles: row r1 + 32 u, k offset c1
-    const int r2 = tid >> 5, c2 = 4 * (tid & 31);          // [k][i] tile : k row r2 + 8 u, i offset c2
+    const int r1 = tid >> 3, c1 = 4 * (tid & 7);           // [i][k] tiles: row r1 + 64 u, k offset c1
+    const int r2 = tid >> 5, c2 = 4 * (tid & 31);          // [k][i] tile : k row r2 + 16 u, i offset c2
 
+    // addresses = wave-uniform base (advances with the K-block, lives in SGPRs) + a loop-invariant 32-bit offset per
+    // thread: ten 64-bit per-thread pointers would not fit next to two staging register sets
+    const int o1[2] = {r1 * C + c1, (r1 + 64) * C + c1};
+    const int o2[2] = {r2 * C + c2, (r2 + 16) * C + c2};
+    const float* ybase = y + cc + (long long)I * 128 * C;      // + kb * KB
+    const float* dbase = dy + cc + (long long)I * 128 * C;     // + kb * KB
+    const float* tbase = dy + cc + I * 128;                    // + kb * KB * C
     auto ld1 = [&](const float* base, int kb, int u) -> f32x4 {
-        return *reinterpret_cast<const f32x4*>(base + cc + (long long)(I * 128 + r1 + 32 * u) * C + kb * KB + c1);
+        return *reinterpret_cast<const f32x4*>(base + kb * KB + o1[u]);
     };
     auto ld2 = [&](int kb, int u) -> f32x4 {
-        return *reinterpret_cast<const f32x4*>(dy + cc + (long long)(kb * KB + r2 + 8 * u) * C + I * 128 + c2);
+        return *reinterpret_cast<const f32x4*>(tbase + (long long)kb * KB * C + o2[u]);
     };
     auto gather = [&](int kb, int u) -> f32x4 {               // CBP: P(I,K) from the dc vector (CBCNN.py backward)
-        const int i = I * 128 + r1 + 32 * u;
+        const int i = I * 128 + r1 + 64 * u;
         const int h1i = ex.h1[i], h2i = ex.h2[i];
         const float s1i = ex.s1[i], s2i = ex.s2[i];
         const float* dcb = ex.dc + (long long)b * ex.D;
@@ -114,21 +156,23 @@ __global__ __launch_bounds__(256, 1) void bcnn_bwd128_kernel(const float* __rest
         }
         return p;
     };
-#define HK_BW_GLOAD(kb)                                                                                        \
+    int ox[4];                                                  // clamped float4 index of this thread's X vectors
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ox[u] = (tid + 512 * u < XN4) ? tid + 512 * u : XN4 - 1;
+    auto ldx = [&](int kb, int u, float& mean) -> f32x4 {
+        mean = MODE == 1 ? ex.mu[(long long)b * C + kb * KB + (4 * ox[u]) / HW] : 0.f;
+        return reinterpret_cast<const f32x4*>(xb + (long long)kb * KB * HW)[ox[u]];
+    };
+    // the loads of one K-block in four parts (placed between MFMA groups)
+#define HK_BW_GLOAD(R, kb, part)                                                                               \
     do {                                                                                                       \
-        if (HAS_W) { ry0 = ld1(y, kb, 0); ry1 = ld1(y, kb, 1); ry2 = ld1(y, kb, 2); ry3 = ld1(y, kb, 3); }     \
-        if (MODE != 2) {                                                                                       \
-            rd0 = ld1(dy, kb, 0); rd1 = ld1(dy, kb, 1); rd2 = ld1(dy, kb, 2); rd3 = ld1(dy, kb, 3);            \
-            rt0 = ld2(kb, 0); rt1 = ld2(kb, 1); rt2 = ld2(kb, 2); rt3 = ld2(kb, 3);                            \
-        } else {                                                                                               \
-            rd0 = gather(kb, 0); rd1 = gather(kb, 1); rd2 = gather(kb, 2); rd3 = gather(kb, 3);                \
-        }                                                                                                      \
-        const f32x4* xs_ = reinterpret_cast<const f32x4*>(xb + (long long)(kb) * KB * HW);                     \
-        _Pragma("unroll") for (int u = 0; u < NSX; ++u) {                                                      \
-            const int f_ = tid + 256 * u, fc_ = f_ < XN4 ? f_ : XN4 - 1;                                       \
-            rx[u] = xs_[fc_];                                                                                  \
-            rmu[u] = MODE == 1 ? ex.mu[(long long)b * C + (kb) * KB + (4 * fc_) / HW] : 0.f;                   \
-        }                                                                                                      \
+        if ((part) == 0) { if (HAS_W) { R.y0 = ld1(ybase, kb, 0); R.y1 = ld1(ybase, kb, 1); } }                 \
+        if ((part) == 1) { if (MODE != 2) { R.d0 = ld1(dbase, kb, 0); R.d1 = ld1(dbase, kb, 1); }              \
+                           else { R.d0 = gather(kb, 0); R.d1 = gather(kb, 1); } }                              \
+        if ((part) == 2) { if (HAS_S2) { R.t0 = ld2(kb, 0); R.t1 = ld2(kb, 1); } }                              \
+        if ((part) == 3) { R.x0 = ldx(kb, 0, R.m0); R.x1 = ldx(kb, 1, R.m1);                                   \
+                           if (NSX > 2) R.x2 = ldx(kb, 2, R.m2);                                               \
+                           if (NSX > 3) R.x3 = ldx(kb, 3, R.m3); }                                             \
     } while (0)
 
     // W = coef / y (v_rcp_f32, 1 ulp: parity budget 1e-4);  signed sqrt: |y| in the denominator, 0 where y == 0
@@ -142,93 +186,131 @@ __global__ __launch_bounds__(256, 1) void bcnn_bwd128_kernel(const float* __rest
         return w;
     };
     auto sst1 = [&](float* S1, float* Wt, int u, f32x4 yv, f32x4 dv) {
-        const int o = (r1 + 32 * u) * P1 + c1;
+        const int o = (r1 + 64 * u) * P1 + c1;
+        if (MODE == 0) tacc += (yv[0] * dv[0] + yv[1] * dv[1]) + (yv[2] * dv[2] + yv[3] * dv[3]);
         if (MODE == 1) dv *= coef;
         if (MODE == 3) dv -= t2 * yv;                          // (dy_ij + dy_ji - 2 t y_ij) / |y_ij|: the whole -2 t y term here
         *reinterpret_cast<f32x4*>(S1 + o) = dv;
         if (HAS_W) *reinterpret_cast<f32x4*>(Wt + o) = wof(yv);
-        if (MODE == 0) tacc += (yv[0] * dv[0] + yv[1] * dv[1]) + (yv[2] * dv[2] + yv[3] * dv[3]);
     };
-#define HK_BW_SSTORE(st)                                                                                       \
+    auto sstx = [&](float* X_, int u, f32x4 v, float mean) {
+        const int f = tid + 512 * u;
+        // the mean is subtracted HERE, not after the load: touching the value there parks the wave on it
+        if (f < XN4) reinterpret_cast<f32x4*>(X_)[f] = MODE == 1 ? v - mean : v;
+    };
+    // the LDS stores of one K-block (registers R -> stage st), in four parts
+#define HK_BW_SSTORE(R, st, part)                                                                              \
     do {                                                                                                       \
         float* S1_ = lds + (st) * STAGE;                                                                       \
         float* W_ = S1_ + S1_SZ;                                                                               \
         float* S2_ = W_ + W_SZ;                                                                                \
         float* X_ = S2_ + S2_SZ;                                                                               \
-        sst1(S1_, W_, 0, ry0, rd0); sst1(S1_, W_, 1, ry1, rd1); sst1(S1_, W_, 2, ry2, rd2); sst1(S1_, W_, 3, ry3, rd3); \
-        if (HAS_S2) {                                                                                          \
+        if ((part) == 0) sst1(S1_, W_, 0, R.y0, R.d0);                                                         \
+        if ((part) == 1) sst1(S1_, W_, 1, R.y1, R.d1);                                                         \
+        if ((part) == 2 && HAS_S2) {                                                                           \
             const float sc_ = MODE == 1 ? coef : 1.0f;                                                         \
-            *reinterpret_cast<f32x4*>(S2_ + (r2 + 0) * P2 + c2) = rt0 * sc_;                                   \
-            *reinterpret_cast<f32x4*>(S2_ + (r2 + 8) * P2 + c2) = rt1 * sc_;                                   \
-            *reinterpret_cast<f32x4*>(S2_ + (r2 + 16) * P2 + c2) = rt2 * sc_;                                  \
-            *reinterpret_cast<f32x4*>(S2_ + (r2 + 24) * P2 + c2) = rt3 * sc_;                                  \
+            *reinterpret_cast<f32x4*>(S2_ + (r2 + 0) * P2 + c2) = R.t0 * sc_;                                  \
+            *reinterpret_cast<f32x4*>(S2_ + (r2 + 16) * P2 + c2) = R.t1 * sc_;                                 \
         }                                                                                                      \
-        _Pragma("unroll") for (int u = 0; u < NSX; ++u) {                                                      \
-            const int f_ = tid + 256 * u;                                                                      \
-            /* the mean is subtracted HERE, not after the load: touching the value there parks the wave on it */ \
-            if (f_ < XN4) reinterpret_cast<f32x4*>(X_)[f_] = MODE == 1 ? rx[u] - rmu[u] : rx[u];               \
-        }                                                                                                      \
+        if ((part) == 3) { sstx(X_, 0, R.x0, R.m0); sstx(X_, 1, R.x1, R.m1);                                   \
+                           if (NSX > 2) sstx(X_, 2, R.x2, R.m2);                                               \
+                           if (NSX > 3) sstx(X_, 3, R.x3, R.m3); }                                             \
     } while (0)
 
-    HK_BW_GLOAD(0);
-    HK_BW_SSTORE(0);
-    __syncthreads();
+    // A fragments of the wave's two 16-row blocks for k = 16 s + 4 lq + t, formed from the raw tiles
+#define HK_BW_AFRAG(A_, s_)                                                                                    \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+            const int row_ = wrow + i * 16 + l15;                                                              \
+            const f32x4 d1_ = *reinterpret_cast<const f32x4*>(S1 + row_ * P1 + 16 * (s_) + 4 * lq);            \
+            f32x4 wv_ = (f32x4){1.f, 1.f, 1.f, 1.f};                                                           \
+            if (HAS_W) wv_ = *reinterpret_cast<const f32x4*>(Wt + row_ * P1 + 16 * (s_) + 4 * lq);             \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+                float v_ = d1_[t];                                                                             \
+                if (HAS_S2) v_ += S2[(16 * (s_) + 4 * lq + t) * P2 + row_];                                    \
+                A_[i][t] = HAS_W ? v_ * wv_[t] : v_;                                                           \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+#define HK_BW_BFRAG(B_, s_, t_)                                                                                \
+    do {                                                                                                       \
+        if ((LABV & 2) && ((s_) != 0 || (t_) > 1)) break;                                                      \
+        const float* bp_ = X + (16 * (s_) + 4 * lq + (t_)) * HW + 16 * nt0 + l15;                              \
+        _Pragma("unroll") for (int n = 0; n < NH; ++n) B_[n] = (n < nloc) ? bp_[16 * n] : 0.f;                 \
+    } while (0)
+#define HK_BW_MFMA(A_, B_, t_)                                                                                 \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int n = 0; n < NH; ++n) {                                                       \
+            if (n < NH - 1 || n < nloc) {                                                                      \
+                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[0][t_], B_[n], acc[0][n], 0, 0, 0);        \
+                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[1][t_], B_[n], acc[1][n], 0, 0, 0);        \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+    // One K-block: eight MFMA groups (s = 0, 1; t = 0..3).  The operand fragments of a group are read while the
+    // previous group's MFMAs run (explicit double buffering: bA / bB); the loads of K-block kb_ + 1 are requested in four
+    // parts behind groups 0-3 and stored to the other LDS stage in four parts behind groups 4-7 (each part has four
+    // groups = >3000 matrix-pipe cycles to arrive).  MORE_ is compile-time: no branch around the loads.
+#define HK_BW_KBLOCK(kb_, RL, RS, LOAD_, STORE_)                                                               \
+    do {                                                                                                       \
+        const int cur = (kb_) & 1;                                                                             \
+        const float* S1 = lds + cur * STAGE;                                                                   \
+        const float* Wt = S1 + S1_SZ;                                                                          \
+        const float* S2 = Wt + W_SZ;                                                                           \
+        const float* X = S2 + S2_SZ;                                                                           \
+        HK_STAMP(kb_, 0);                                                                                      \
+        float a0[2][4], a1[2][4], bA[NH], bB[NH];                                                              \
+        HK_BW_AFRAG(a0, 0);                                                                                    \
+        HK_BW_BFRAG(bA, 0, 0);                                                                                 \
+        HK_STAMP(kb_, 1);                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        HK_BW_BFRAG(bB, 0, 1); HK_BW_MFMA(a0, bA, 0); if (LOAD_) HK_BW_GLOAD(RL, (kb_) + 1, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        HK_BW_BFRAG(bA, 0, 2); HK_BW_MFMA(a0, bB, 1); if (LOAD_) HK_BW_GLOAD(RL, (kb_) + 1, 1);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        HK_BW_BFRAG(bB, 0, 3); HK_BW_MFMA(a0, bA, 2); if (LOAD_) HK_BW_GLOAD(RL, (kb_) + 1, 2);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (LABV & 2) { _Pragma("unroll") for (int t = 0; t < 4; ++t) { a1[0][t] = a0[0][t]; a1[1][t] = a0[1][t]; } }   \
+        else HK_BW_AFRAG(a1, 1);                                                                               \
+        HK_BW_BFRAG(bA, 1, 0); HK_BW_MFMA(a0, bB, 3); if (LOAD_) HK_BW_GLOAD(RL, (kb_) + 1, 3);                \
+        HK_STAMP(kb_, 2);                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        HK_BW_BFRAG(bB, 1, 1); HK_BW_MFMA(a1, bA, 0); if (STORE_) HK_BW_SSTORE(RS, cur ^ 1, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        HK_BW_BFRAG(bA, 1, 2); HK_BW_MFMA(a1, bB, 1); if (STORE_) HK_BW_SSTORE(RS, cur ^ 1, 1);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        HK_BW_BFRAG(bB, 1, 3); HK_BW_MFMA(a1, bA, 2); if (STORE_) HK_BW_SSTORE(RS, cur ^ 1, 2);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        HK_BW_MFMA(a1, bB, 3); if (STORE_) HK_BW_SSTORE(RS, cur ^ 1, 3);                                       \
+        HK_STAMP(kb_, 3);                                                                                      \
+        __syncthreads();                                                                                       \
+        HK_STAMP(kb_, 4);                                                                                      \
+    } while (0)
 
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = kb & 1;
-        const bool more = kb + 1 < nkb;
-        if (more) HK_BW_GLOAD(kb + 1);
-        const float* S1 = lds + cur * STAGE;
-        const float* Wt = S1 + S1_SZ;
-        const float* S2 = Wt + W_SZ;
-        const float* X = S2 + S2_SZ;
-        __builtin_amdgcn_sched_barrier(0);
+    // prologue: K-block 0 staged
 #pragma unroll
-        for (int s = 0; s < KB / 16; ++s) {
-            // A fragments of the wave's two 16-row blocks for k = 16 s + 4 lq + t
-            float a[2][4];
+    for (int part = 0; part < 4; ++part) HK_BW_GLOAD(R0, 0, part);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wave * 32 + i * 16 + l15;
-                const f32x4 d1 = *reinterpret_cast<const f32x4*>(S1 + row * P1 + 16 * s + 4 * lq);
-                f32x4 wv = (f32x4){1.f, 1.f, 1.f, 1.f};
-                if (HAS_W) wv = *reinterpret_cast<const f32x4*>(Wt + row * P1 + 16 * s + 4 * lq);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float v = d1[t];
-                    if (HAS_S2) v += S2[(16 * s + 4 * lq + t) * P2 + row];
-                    a[i][t] = HAS_W ? v * wv[t] : v;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float* bp = X + (16 * s + 4 * lq + t) * HW + l15;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const float bv = bp[16 * n];
-                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][t], bv, acc[0][n], 0, 0, 0);
-                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][t], bv, acc[1][n], 0, 0, 0);
-                }
-            }
-            if (s == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) HK_BW_SSTORE(cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
-    }
+    for (int part = 0; part < 4; ++part) HK_BW_SSTORE(R0, 0, part);
+    __syncthreads();
+    int kb = 0;
+    for (; kb + 1 < nkb; ++kb) HK_BW_KBLOCK(kb, R0, R0, !(LABV & 1), !(LABV & 1));     // steady state
+    HK_BW_KBLOCK(kb, R0, R0, false, false);                             // last block: nothing left to stage
+#undef HK_BW_KBLOCK
+#undef HK_BW_MFMA
+#undef HK_BW_BFRAG
+#undef HK_BW_AFRAG
 #undef HK_BW_GLOAD
 #undef HK_BW_SSTORE
 
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        float* dxb = dx + (long long)b * C * HW + (long long)(I * 128 + wave * 32 + i * 16 + lq * 4) * HW;
+        float* dxb = dx + (long long)b * C * HW + (long long)(I * 128 + wrow + i * 16 + lq * 4) * HW;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int col = 16 * n + l15;
-            if (col < HW) {
+        for (int n = 0; n < NH; ++n) {
+            const int col = 16 * (nt0 + n) + l15;
+            if (n < nloc && col < HW) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dxb[(long long)r * HW + col] = acc[i][n][r];
             }
@@ -236,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_bwd128_kernel(const float* __rest
     }
     if (MODE == 0) {                                           // t partials: slot 2I (+ a zero in 2I + 1: the consumer
         __syncthreads();                                       // adds C / 64 slots per image)
-        const float tsum = block_sum<4>(tacc, lds);
+        const float tsum = block_sum<8>(tacc, lds);
         if (tid == 0) {
             tpart[(long long)b * (2 * nI) + 2 * I] = tsum;
             tpart[(long long)b * (2 * nI) + 2 * I + 1] = 0.f;
@@ -266,7 +348,24 @@ static int bwd128_launch(const float* x, const float* y, const float* dy, const 
         attr_set = true;
     }
     const int nI = C / 128;
-    hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, MODE>), dim3(xcd_grid(B, nI)), dim3(256), lds, st, x, y, dy, inv_norm, dx,
+#ifdef HK_LAB
+    if (MODE == 0 && tuning().bwd_v >= 6 && tuning().bwd_v <= 8) {
+        const int lv = tuning().bwd_v - 5;
+        static bool a2 = false;
+        if (!a2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            a2 = true;
+        }
+        if (lv == 1) hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, 0, 1>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);
+        if (lv == 2) hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, 0, 2>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);
+        if (lv == 3) hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, 0, 3>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
+#endif
+    hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, MODE>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx,
                        tpart, C, nI, B, ex);
     HK_LAUNCH_CHECK();
     return HK_OK;
