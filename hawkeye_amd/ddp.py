@@ -11,6 +11,10 @@ Design for an 8-GPU MI355X node (xGMI full mesh, 7 links x ~153 GB/s per GPU):
     gradients).  For BCNN the classifier weight (209.7 MB of the 268.6 MB total)
     is produced first and forms bucket 0 on its own: its all-reduce is in flight
     during the whole VGG backward;
+  * buckets are 16 MiB (a parameter above that is a bucket of its own): measured on the MI355X with a forced
+    single-rank RCCL group (bench.py --force-pg), the classifier bucket is issued 0.3 ms into a 140 ms backward; with
+    round 1's 64 MiB limit all 26 VGG tensors (56 MiB) formed ONE bucket that was only complete at the very end of
+    backward - nothing left to hide it behind;
   * each bucket's all-reduce is issued from a post-accumulate-grad hook the moment
     its last gradient lands (async on RCCL's stream, overlapping the rest of
     backward); `finish()` joins before `optimizer.step()`;
@@ -81,7 +85,7 @@ class GradientAllReducer:
     `.backbone` / `.classifier` / `.pool`, cf. Examples/CBCNN.py:14,21 and
     Examples/MPN.py:15-17 which break under a DataParallel wrapper)."""
 
-    def __init__(self, module, bucket_mb=64.0, process_group=None, broadcast=True, trace=False):
+    def __init__(self, module, bucket_mb=16.0, process_group=None, broadcast=True, trace=False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1

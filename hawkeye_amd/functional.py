@@ -452,6 +452,14 @@ def osme_scale(x, m):
 
 # --------------------------------------------------------------------- generic
 # --------------------------------------------------------------------- CIN channel interaction
+# hk_cin_sci_fwd (Gram + row softmax + W X on the generic 64x64 tile) measured 704-714 us against 611-616 us for rocBLAS
+# bmm + softmax + bmm at the plugin's shape (B = 20, C = 2048, HW = 49; BENCH_r01, profiles/r2_candidates.json): with
+# K = 49 the Gram is two chunks per tile and the chain is bound by writing / re-reading the 335 MB of W.  Until there is
+# a fused kernel that beats the library, the forward takes the library GEMMs (W is still produced and saved: the
+# contrastive branch and the backward kernels consume it); tests set this to True to keep the kernel covered.
+_CIN_SCI_FWD_HIP = False
+
+
 class _CinSci(torch.autograd.Function):
     """W = softmax_rows(-X X^T / HW), Y = W X.  replaces model/methods/CIN.py:31-34.  W is an output too: the
     contrastive branch (cin_cci) consumes it and sends a gradient back into it."""
@@ -461,9 +469,13 @@ class _CinSci(torch.autograd.Function):
         lib = _lib.load()
         x = _f32c(x)
         b, c, hw = x.shape
-        w = torch.empty(b, c, c, dtype=torch.float32, device=x.device)
-        y = torch.empty_like(x)
-        check(lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), b, c, hw, stream()), 'hk_cin_sci_fwd')
+        if _CIN_SCI_FWD_HIP or not x.is_cuda:
+            w = torch.empty(b, c, c, dtype=torch.float32, device=x.device)
+            y = torch.empty_like(x)
+            check(lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), b, c, hw, stream()), 'hk_cin_sci_fwd')
+        else:
+            w = torch.softmax(torch.bmm(x, x.transpose(1, 2)).mul_(-1.0 / hw), dim=2)      # CIN.py:31-33
+            y = torch.bmm(w, x)                                                            # CIN.py:34
         ctx.save_for_backward(x, w)
         ctx.set_materialize_grads(False)
         return y, w
