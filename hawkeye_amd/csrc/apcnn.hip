@@ -271,9 +271,9 @@ __global__ __launch_bounds__(256) void roi_crop_bwd_kernel(const float* __restri
                         int b0, b1; float lb0, lb1;
                         src_index(g.sw, ox, g.cw, b0, b1, lb0, lb1);
                         const float wx = (b0 == rx ? lb0 : 0.f) + (b1 == rx ? lb1 : 0.f);
-                        rowacc += wx * gp[oy * W + ox];
+                        rowacc = fmaf(wx, gp[oy * W + ox], rowacc);
                     }
-                    acc += wy * rowacc;
+                    acc = fmaf(wy, rowacc, acc);
                 }
                 acc *= g.rate;
             }
@@ -386,8 +386,9 @@ __global__ __launch_bounds__(256) void roi_crop_bwd_tab_kernel(const float* __re
                 const int oy0 = ylo[ry], oy1 = yhi[ry], ox0 = xlo[rx], ox1 = xhi[rx];
                 for (int oy = oy0; oy <= oy1; ++oy) {
                     float rowacc = 0.f;
-                    for (int ox = ox0; ox <= ox1; ++ox) rowacc += wx[rx * 65 + ox] * gp[oy * W + ox];
-                    acc += wy[ry * 65 + oy] * rowacc;
+                    // explicit fmaf: the backward kernels must agree bit for bit, whatever the compiler would contract
+                    for (int ox = ox0; ox <= ox1; ++ox) rowacc = fmaf(wx[rx * 65 + ox], gp[oy * W + ox], rowacc);
+                    acc = fmaf(wy[ry * 65 + oy], rowacc, acc);
                 }
                 acc *= g.rate;
             }

@@ -1,163 +1,304 @@
 // ROI-refinement backward for maps up to 64x64 (get_roi_crop_feat's autograd backward, model/methods/APCNN.py:478-531):
 //   dX[crop pixel] = rate * sum over the output pixels that sampled it of  ly * lx * dY      (bilinear resize, transposed)
 // History on the AP-CNN shape (16 x 512 maps of 56x56 = 205 MB read + written; HBM time ~35 us):
-//   roi_crop_bwd_tab_kernel (apcnn.hip)   tables per workgroup, taps read from global memory          187-201 us
-//   LDS-staged map, 4 maps per workgroup   same loops on LDS                                           144 us
-// Both are LATENCY bound, not bandwidth bound: every source pixel runs a doubly nested loop with data-dependent trip
-// counts (its own tap range), one dependent LDS/global read per tap, one pixel at a time per thread, and the index
-// arithmetic of all 3136 pixels is redone for every channel map.  This kernel keeps the taps and their order
-// (bit-identical dX) and removes the serialisation:
-//   * the tap window has the SAME size KY x KX for every pixel of the workgroup (the largest range of the tables;
-//     windows are shifted to stay inside the map, the extra taps carry table weight 0), so the loops are uniform and
-//     FOUR pixels per thread run through them together - four independent accumulation chains instead of one;
-//   * a pixel's geometry (table rows, window origin, inside-crop / dropped flags) is computed once per workgroup and
-//     kept in registers for all ROI2_CPB = 8 channel maps;
-//   * each map is staged into LDS with 16-byte loads, the next map's loads are issued before the current map's gather.
+//   roi_crop_bwd_tab_kernel (apcnn.hip)   tables per workgroup, taps read from global memory                  187-204 us
+//   LDS-staged map, 4 maps per workgroup   same loops on LDS                                                   144 us
+//   uniform KY x KX window, 4 pixels in flight, geometry once per 8 maps                                       132 us
+// Cycle stamps inside that third version (tools/roi_lab.py, profiles/r2_roi_lab.json) showed where the time went: the
+// gather of one map took ~8-16k cycles for a few hundred LDS reads per thread - one exposed LDS latency per tap (the tap
+// loops have data-dependent trip counts, every read sits in its own basic block behind an s_waitcnt), all H x W pixels
+// of the map walked the loops although only the crop receives gradient, and the per-workgroup prologue (tables by
+// serial scans, 13 integer divisions per thread) was another ~16k cycles.  This version:
+//   * only CROP pixels are gathered: slot k of a thread is crop pixel q = tid + 256 k (row q / cw, column q % cw);
+//     the rest of the map is zero and stays zero in an LDS image of the output map (zeroed once per workgroup), which
+//     is written to HBM with 16-byte stores after every map;
+//   * the tap window has the SAME size for every pixel of the workgroup and, when it is at most 3 x 3 or 4 x 4 (crops of
+//     at least ~28 / ~19 pixels a side of a 56-pixel map), the loops are compile-time: a pixel's KW + KW table weights
+//     live in registers for all maps of the workgroup and its KW * KW taps are unconditional LDS reads, all in flight
+//     together.  The window is shifted to stay inside the map, taps outside a pixel's true range carry table weight 0
+//     and read finite map values, so dX is bit-identical to the table kernel (x + 0 * finite = x).  Small crops (up
+//     to 512 pixels) have windows up to 8 x 8 the same way, two pixels per thread; anything else takes the table loops;
+//   * the tables' non-zero ranges come from LDS atomics while the tables are filled (no scans), pixel coordinates from
+//     a multiply-shift instead of integer division;
+//   * 8-32 maps per workgroup (chosen so that the grid is at most two workgroups per CU: one round, no tail), each map
+//     staged into LDS with 16-byte loads, the next map's loads issued before the current map's gather.
 #include "hk_roi.h"
 #include "../../include/hawkeye_hip.h"
 
 namespace hk {
 
-constexpr int ROI2_CPB = 8;      // channel maps per workgroup
-constexpr int ROI2_PPT = 13;     // pixels per thread: ceil(64 * 64 / 256) would be 16; 56 x 56 needs 13
+// HK_LAB builds only (tools/roi_lab.py): cycle stamps of thread 0 of the first 64 workgroups of image 0
+#ifdef HK_LAB
+__device__ long long* g_roi_stamps = nullptr;            // [64 workgroups][32][8]
+#define ROI_STAMP(kb_, slot_)                                                                          \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0 && (kb_) < 32 && g_roi_stamps)     \
+            g_roi_stamps[((long long)blockIdx.x * 32 + (kb_)) * 8 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define ROI_STAMP(kb_, slot_) do { } while (0)
+#endif
 
+// PPT (template): crop pixels per thread, ceil(H * W / 256) rounded up to an instance - 4 (maps up to 32 x 32), 13 (56 x 56:
+// 255 registers, two workgroups per CU), 16 (64 x 64: one workgroup per CU)
+
+struct RoiShared {
+    CropGeom g;
+    int ylo[64], yhi[64], xlo[64], xhi[64];
+    int kmax[2];
+};
+
+// One workgroup: image b, maps c0 .. c0 + nmaps - 1.  KW = 3 / 4: compile-time KW x KW window with register weights
+// (KY = KX = KW on entry); 0: table loops over the KY x KX window
+template <int KW, int ROI2_PPT>
+__device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float* __restrict__ dx, const RoiShared& sh,
+                                             const float* wy, const float* wx, float* smap, float* omap, int b, int C,
+                                             int c0, int nmaps, int H, int W, int KY, int KX, int training) {
+    constexpr bool REGW = KW > 0;
+    constexpr int KR = REGW ? KW : 1;
+    const int tid = threadIdx.x, hw = H * W;
+    const CropGeom g = sh.g;
+    const int ncrop = g.ch * g.cw;                         // (> 0 here)
+    const int nk = __builtin_amdgcn_readfirstlane((ncrop + 255) >> 8);   // slots in use (uniform: scalar branches below)
+    const int inv = ((1 << 20) + g.cw - 1) / g.cw;         // q / cw = (q * inv) >> 20, exact for q < 4096, cw <= 64
+
+    // geometry of slot k: offset of the window origin in the staged map (< 0: the pixel receives no gradient), offset of
+    // the pixel in the output map, and either the weights (REGW) or the offsets of the window origin in the tables
+    int smo[ROI2_PPT], omo[ROI2_PPT];
+    int wyo[REGW ? 1 : ROI2_PPT], wxo[REGW ? 1 : ROI2_PPT];
+    float rwy[REGW ? ROI2_PPT : 1][KR], rwx[REGW ? ROI2_PPT : 1][KR];
+#pragma unroll
+    for (int k = 0; k < ROI2_PPT; ++k) {
+        const int q = tid + 256 * k;
+        int wyo_k = 0, wxo_k = 0;
+        smo[k] = -1;
+        omo[k] = 0;
+        if (q < ncrop) {
+            const int ry = (q * inv) >> 20, rx = q - ry * g.cw;
+            const int iy = ry + g.y1, ix = rx + g.x1;
+            const bool dropped = training && iy >= g.dy1 && iy < g.dy2 && ix >= g.dx1 && ix < g.dx2;
+            if (!dropped && sh.yhi[ry] >= sh.ylo[ry] && sh.xhi[rx] >= sh.xlo[rx]) {
+                int oy0 = sh.ylo[ry], ox0 = sh.xlo[rx];
+                if (oy0 > H - KY) oy0 = H - KY;              // keep the window inside the map: the taps added on the
+                if (ox0 > W - KX) ox0 = W - KX;              // low side have table weight 0
+                wyo_k = ry * 65 + oy0;
+                wxo_k = rx * 65 + ox0;
+                smo[k] = oy0 * W + ox0;
+                omo[k] = iy * W + ix;
+            }
+        }
+        if (REGW) {                                         // (entries behind the true range are table zeros)
+#pragma unroll
+            for (int a = 0; a < KR; ++a) {
+                rwy[k][a] = wy[wyo_k + a];
+                rwx[k][a] = wx[wxo_k + a];
+            }
+        } else {
+            wyo[k] = wyo_k;
+            wxo[k] = wxo_k;
+        }
+    }
+    ROI_STAMP(31, 2);
+
+    const bool vec = (hw % 4 == 0) && ((((uintptr_t)dy) & 15) == 0) && ((((uintptr_t)dx) & 15) == 0);
+    const int n4 = hw / 4;
+    // staged next map (vec): 4 x 256 float4 >= 64 x 64 / 4.  Named registers - an array that is loaded in one block and
+    // stored in another is not promoted to registers (it went to scratch: 80 bytes per lane, a round trip per map)
+    float4 st0, st1, st2, st3;
+    st0 = st1 = st2 = st3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int f0 = tid < n4 ? tid : n4 - 1, f1 = tid + 256 < n4 ? tid + 256 : n4 - 1;
+    const int f2 = tid + 512 < n4 ? tid + 512 : n4 - 1, f3 = tid + 768 < n4 ? tid + 768 : n4 - 1;
+    auto issue = [&](int cc) {
+        const float4* gp4 = reinterpret_cast<const float4*>(dy + ((long long)b * C + c0 + cc) * hw);
+        st0 = gp4[f0]; st1 = gp4[f1]; st2 = gp4[f2]; st3 = gp4[f3];
+    };
+    if (vec) issue(0);
+    for (int cc = 0; cc < nmaps; ++cc) {
+        const float* gp = dy + ((long long)b * C + c0 + cc) * hw;
+        float* dp = dx + ((long long)b * C + c0 + cc) * hw;
+        ROI_STAMP(cc, 0);
+        __syncthreads();                                   // previous map: gathered by everyone, output image written out
+        if (vec) {
+            float4* s4 = reinterpret_cast<float4*>(smap);
+            if (tid < n4) s4[tid] = st0;
+            if (tid + 256 < n4) s4[tid + 256] = st1;
+            if (tid + 512 < n4) s4[tid + 512] = st2;
+            if (tid + 768 < n4) s4[tid + 768] = st3;
+        } else {
+            for (int p = tid; p < hw; p += 256) smap[p] = gp[p];
+        }
+        __syncthreads();
+        ROI_STAMP(cc, 1);
+        if (vec && cc + 1 < nmaps) issue(cc + 1);          // in flight during the gather below
+        if (REGW) {
+            // two slots per (uniform) block: both slots' KW * KW reads are in flight before the first is used
+#pragma unroll
+            for (int k0 = 0; k0 < ROI2_PPT; k0 += 2) {
+                if (k0 < nk) {
+                    float res[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int k = k0 + j < ROI2_PPT ? k0 + j : k0;
+                        const int so = smo[k] < 0 ? 0 : smo[k];
+                        float acc = 0.f;
+#pragma unroll
+                        for (int a = 0; a < KR; ++a) {
+                            float rowacc = 0.f;
+#pragma unroll
+                            for (int bq = 0; bq < KR; ++bq) rowacc = fmaf(rwx[k][bq], smap[so + a * W + bq], rowacc);
+                            acc = fmaf(rwy[k][a], rowacc, acc); // (explicit fmaf: bit-identical to the table kernel)
+                        }
+                        res[j] = acc * g.rate;
+                    }
+                    if (smo[k0] >= 0) omap[omo[k0]] = res[0];
+                    if (k0 + 1 < ROI2_PPT && smo[k0 + 1 < ROI2_PPT ? k0 + 1 : k0] >= 0) omap[omo[k0 + 1 < ROI2_PPT ? k0 + 1 : k0]] = res[1];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k0 = 0; k0 < ROI2_PPT; k0 += 4) {
+                if (k0 < nk) {                               // uniform
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int a = 0; a < KY; ++a) {
+                        float rowacc[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int bq = 0; bq < KX; ++bq) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int so = smo[k0 + j] < 0 ? 0 : smo[k0 + j];
+                                rowacc[j] = fmaf(wx[wxo[k0 + j] + bq], smap[so + a * W + bq], rowacc[j]);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = fmaf(wy[wyo[k0 + j] + a], rowacc[j], acc[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (smo[k0 + j] >= 0) omap[omo[k0 + j]] = acc[j] * g.rate;
+                }
+            }
+        }
+        ROI_STAMP(cc, 2);
+        __syncthreads();                                   // output image complete
+        if (vec) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = tid + 256 * u;
+                if (f < n4) reinterpret_cast<float4*>(dp)[f] = reinterpret_cast<const float4*>(omap)[f];
+            }
+        } else {
+            for (int p = tid; p < hw; p += 256) dp[p] = omap[p];
+        }
+        ROI_STAMP(cc, 3);
+    }
+}
+
+template <int PPT>
 __global__ __launch_bounds__(256) void roi_crop_bwd_tab3_kernel(const float* __restrict__ dy, const float* __restrict__ box,
                                                                 const float* __restrict__ drop, float* __restrict__ dx,
-                                                                int C, int H, int W, int training) {
-    __shared__ CropGeom g;
-    __shared__ float wy[64 * 65 + 64], wx[64 * 65 + 64];
-    __shared__ __attribute__((aligned(16))) float smap[64 * 64];
-    __shared__ int ylo[64], yhi[64], xlo[64], xhi[64];
-    const int b = blockIdx.y, c0 = blockIdx.x * ROI2_CPB, tid = threadIdx.x;
-    if (tid == 0) g = crop_geom(box + b * 4, drop + b * 4, C, H, W, training);
-    for (int e = tid; e < 64 * 65 + 64; e += 256) { wy[e] = 0.f; wx[e] = 0.f; }
+                                                                int C, int H, int W, int training, int cpb) {
+    HK_DYN_LDS16(lds);                                     // wy, wx [64 * 65 + 64], smap, omap [64 * 64]: 66.3 KB
+    __shared__ RoiShared sh;
+    float* wy = lds;
+    float* wx = wy + 64 * 65 + 64;
+    float* smap = wx + 64 * 65 + 64;
+    float* omap = smap + 64 * 64;
+    const int b = blockIdx.y, c0 = blockIdx.x * cpb, tid = threadIdx.x;
+    const int hw = H * W;
+    ROI_STAMP(31, 0);
+    if (tid == 0) {
+        sh.g = crop_geom(box + b * 4, drop + b * 4, C, H, W, training);
+        sh.kmax[0] = sh.kmax[1] = 1;
+    }
+    {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < (64 * 65 + 64) / 4; e += 256) {
+            reinterpret_cast<float4*>(wy)[e] = z;
+            reinterpret_cast<float4*>(wx)[e] = z;
+        }
+        for (int e = tid; e < 64 * 64 / 4; e += 256) reinterpret_cast<float4*>(omap)[e] = z;
+        if (tid < 64) { sh.ylo[tid] = H; sh.yhi[tid] = -1; sh.xlo[tid] = W; sh.xhi[tid] = -1; }
+    }
     __syncthreads();
+    const CropGeom g = sh.g;
+    const int nmaps = (C - c0) < cpb ? (C - c0) : cpb;
     if (g.ch > 0 && g.cw > 0) {
+        // table rows = source pixels of the crop, columns = output pixels; a row's non-zero range by LDS atomics
         if (tid < H) {                                   // output row tid contributes to source rows i0, i1
             int i0, i1; float l0, l1;
             src_index(g.sh, tid, g.ch, i0, i1, l0, l1);
             wy[i0 * 65 + tid] += l0;
             wy[i1 * 65 + tid] += l1;
+            if (l0 != 0.f) { atomicMin(&sh.ylo[i0], tid); atomicMax(&sh.yhi[i0], tid); }
+            if (l1 != 0.f) { atomicMin(&sh.ylo[i1], tid); atomicMax(&sh.yhi[i1], tid); }
         } else if (tid >= 64 && tid - 64 < W) {
             const int ox = tid - 64;
             int i0, i1; float l0, l1;
             src_index(g.sw, ox, g.cw, i0, i1, l0, l1);
             wx[i0 * 65 + ox] += l0;
             wx[i1 * 65 + ox] += l1;
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {                                       // non-zero range of each table row
-        int lo = H, hi = -1;
-        for (int o = 0; o < H; ++o)
-            if (wy[tid * 65 + o] != 0.f) { lo = o < lo ? o : lo; hi = o; }
-        ylo[tid] = lo; yhi[tid] = hi;
-    } else if (tid < 128) {
-        const int r = tid - 64;
-        int lo = W, hi = -1;
-        for (int o = 0; o < W; ++o)
-            if (wx[r * 65 + o] != 0.f) { lo = o < lo ? o : lo; hi = o; }
-        xlo[r] = lo; xhi[r] = hi;
-    }
-    __syncthreads();
-    int KY = 1, KX = 1;                                   // largest tap range of any table row (every thread for itself)
-    for (int r = 0; r < 64; ++r) {
-        const int ny = yhi[r] - ylo[r] + 1, nx = xhi[r] - xlo[r] + 1;
-        KY = ny > KY ? ny : KY;
-        KX = nx > KX ? nx : KX;
-    }
-    KY = KY < H ? KY : H;
-    KX = KX < W ? KX : W;
-    const int hw = H * W;
-
-    // geometry of this thread's pixels p = tid + 256 k : offsets of the window origin in the tables and in the map
-    int wyo[ROI2_PPT], wxo[ROI2_PPT], smo[ROI2_PPT];      // < 0 in smo: the pixel receives no gradient
-#pragma unroll
-    for (int k = 0; k < ROI2_PPT; ++k) {
-        const int p = tid + 256 * k;
-        wyo[k] = wxo[k] = 0;
-        smo[k] = -1;
-        if (p < hw) {
-            const int iy = p / W, ix = p % W;
-            const int ry = iy - g.y1, rx = ix - g.x1;
-            if (g.cw > 0 && g.ch > 0 && ry >= 0 && ry < g.ch && rx >= 0 && rx < g.cw) {
-                const bool dropped = training && iy >= g.dy1 && iy < g.dy2 && ix >= g.dx1 && ix < g.dx2;
-                if (!dropped && yhi[ry] >= ylo[ry] && xhi[rx] >= xlo[rx]) {
-                    int oy0 = ylo[ry], ox0 = xlo[rx];
-                    if (oy0 > H - KY) oy0 = H - KY;          // keep the window inside the map: the taps added on the
-                    if (ox0 > W - KX) ox0 = W - KX;          // low side have table weight 0
-                    wyo[k] = ry * 65 + oy0;
-                    wxo[k] = rx * 65 + ox0;
-                    smo[k] = oy0 * W + ox0;
-                }
-            }
-        }
-    }
-
-    const bool vec = (hw % 4 == 0) && ((((uintptr_t)dy) & 15) == 0);
-    const int n4 = hw / 4;
-    float4 st[4];                                          // staged next map (vec) - 4 x 256 float4 >= 64 x 64 / 4
-    auto issue = [&](int cc) {
-        const float4* gp4 = reinterpret_cast<const float4*>(dy + ((long long)b * C + c0 + cc) * hw);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = tid + 256 * u;
-            st[u] = gp4[f < n4 ? f : n4 - 1];
-        }
-    };
-    const int nmaps = (C - c0) < ROI2_CPB ? (C - c0) : ROI2_CPB;
-    if (vec) issue(0);
-    for (int cc = 0; cc < nmaps; ++cc) {
-        const float* gp = dy + ((long long)b * C + c0 + cc) * hw;
-        float* dp = dx + ((long long)b * C + c0 + cc) * hw;
-        __syncthreads();                                   // previous map no longer read
-        if (vec) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = tid + 256 * u;
-                if (f < n4) reinterpret_cast<float4*>(smap)[f] = st[u];
-            }
-        } else {
-            for (int p = tid; p < hw; p += 256) smap[p] = gp[p];
+            if (l0 != 0.f) { atomicMin(&sh.xlo[i0], ox); atomicMax(&sh.xhi[i0], ox); }
+            if (l1 != 0.f) { atomicMin(&sh.xlo[i1], ox); atomicMax(&sh.xhi[i1], ox); }
         }
         __syncthreads();
-        if (vec && cc + 1 < nmaps) issue(cc + 1);          // in flight during the gather below
-#pragma unroll
-        for (int k0 = 0; k0 < ROI2_PPT; k0 += 4) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int a = 0; a < KY; ++a) {
-                float rowacc[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int bq = 0; bq < KX; ++bq) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (k0 + j < ROI2_PPT) {
-                            const int so = smo[k0 + j] < 0 ? 0 : smo[k0 + j];
-                            rowacc[j] += wx[wxo[k0 + j] + bq] * smap[so + a * W + bq];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (k0 + j < ROI2_PPT) acc[j] += wy[wyo[k0 + j] + a] * rowacc[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (k0 + j < ROI2_PPT) {
-                    const int p = tid + 256 * (k0 + j);
-                    if (p < hw) dp[p] = smo[k0 + j] < 0 ? 0.f : acc[j] * g.rate;
-                }
-            }
+        if (tid < 64) atomicMax(&sh.kmax[0], sh.yhi[tid] - sh.ylo[tid] + 1);      // largest tap range of any table row
+        else if (tid < 128) atomicMax(&sh.kmax[1], sh.xhi[tid - 64] - sh.xlo[tid - 64] + 1);
+        __syncthreads();
+        int KY = sh.kmax[0], KX = sh.kmax[1];
+        KY = KY < H ? KY : H;
+        KX = KX < W ? KX : W;
+        ROI_STAMP(31, 1);
+        // (a map smaller than the compile-time window cannot take it: the window has to fit inside the map)
+        if (KY <= 3 && KX <= 3 && H >= 3 && W >= 3)
+            roi_bwd_maps<3, PPT>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, 3, 3, training);
+        else if (KY <= 4 && KX <= 4 && H >= 4 && W >= 4)
+            roi_bwd_maps<4, PPT>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, 4, 4, training);
+        else if (KY <= 8 && KX <= 8 && H >= 8 && W >= 8 && g.ch * g.cw <= 512)
+            // small crops: windows up to 8 x 8, but at most two pixels per thread
+            roi_bwd_maps<8, 2>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, 8, 8, training);
+        else
+            roi_bwd_maps<0, PPT>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, KY, KX, training);
+    } else {                                               // empty crop: the whole map is zero
+        for (int cc = 0; cc < nmaps; ++cc) {
+            float* dp = dx + ((long long)b * C + c0 + cc) * hw;
+            for (int p = tid; p < hw; p += 256) dp[p] = 0.f;
         }
     }
+    ROI_STAMP(31, 3);
 }
 
 int roi_crop_bwd_v2(const float* dy, const float* box, const float* drop, float* dx, int B, int C, int H, int W,
                     int training, hipStream_t st) {
-    if (H > 64 || W > 64 || H * W > 256 * ROI2_PPT) return HK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(roi_crop_bwd_tab3_kernel, dim3((C + ROI2_CPB - 1) / ROI2_CPB, B), dim3(256), 0, st, dy, box, drop, dx,
-                       C, H, W, training);
+    if (H > 64 || W > 64) return HK_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)(2 * (64 * 65 + 64) + 2 * 64 * 64) * sizeof(float);
+    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in
+    if (!attr_set) {
+        for (const void* f : {reinterpret_cast<const void*>(&roi_crop_bwd_tab3_kernel<4>),
+                              reinterpret_cast<const void*>(&roi_crop_bwd_tab3_kernel<13>),
+                              reinterpret_cast<const void*>(&roi_crop_bwd_tab3_kernel<16>)}) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return (int)e;
+        }
+        attr_set = true;
+    }
+    // maps per workgroup: the kernel holds 2 workgroups per CU (registers, LDS), so up to 512 run at once; a grid just
+    // above that leaves a mostly idle second round
+    int cpb = 8;
+    while (cpb < 32 && (long long)B * ((C + cpb - 1) / cpb) > 512) cpb *= 2;
+    const dim3 grid((C + cpb - 1) / cpb, B);
+    if (H * W <= 256 * 4)
+        hipLaunchKernelGGL(roi_crop_bwd_tab3_kernel<4>, grid, dim3(256), lds, st, dy, box, drop, dx, C, H, W, training, cpb);
+    else if (H * W <= 256 * 13)
+        hipLaunchKernelGGL(roi_crop_bwd_tab3_kernel<13>, grid, dim3(256), lds, st, dy, box, drop, dx, C, H, W, training, cpb);
+    else
+        hipLaunchKernelGGL(roi_crop_bwd_tab3_kernel<16>, grid, dim3(256), lds, st, dy, box, drop, dx, C, H, W, training, cpb);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
 
 }  // namespace hk
+
+#ifdef HK_LAB
+extern "C" int hk_lab_set_roi_stamps(long long* dev_buffer) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hk::g_roi_stamps), &dev_buffer, sizeof(dev_buffer));
+}
+#endif

@@ -359,50 +359,65 @@ static int rowsketch_launch(const float* G, const CbpPlan& pl, float* part, int 
     return HK_OK;
 }
 
-// c_raw[b][k] = sum over the 64-row chunks of part[b][chunk][k], in chunk order (one thread per bin: coalesced, and
-// B*D/256 workgroups - summing inside the one-workgroup-per-sample norm kernel serialised 192 loads per thread).
-__global__ __launch_bounds__(256) void cbp_partsum_kernel(const float* __restrict__ part, float* __restrict__ c_raw,
+// The finishing stage runs one thread per bin on a (ceil(D / 256), B) grid in two launches; round 1's single
+// one-workgroup-per-sample norm kernel (two dependent passes of 24 elements per thread on 64 of the 256 CUs) took 12 us
+// for 1.5 MB.
+// (1) c_raw[b][k] = sum over the 64-row chunks of part[b][chunk][k], in chunk order, and the workgroup's share of
+//     |u|^2 = sum_k (|c_k| + 1e-10 where c_k != 0) to ssq[b][blockIdx.x].  part may be c_raw itself (nchunk = 1: the
+//     CSR gather wrote c_raw directly) - no __restrict__ on the two.
+__global__ __launch_bounds__(256) void cbp_partsum_kernel(const float* part, float* c_raw, float* __restrict__ ssq,
                                                          int D, int nchunk) {
+    __shared__ float red[4];
     const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (k >= D) return;
-    const float* pp = part + (long long)b * nchunk * D + k;
     float s = 0.f;
+    if (k < D) {
+        const float* pp = part + (long long)b * nchunk * D + k;
 #pragma unroll 8
-    for (int q = 0; q < nchunk; ++q) s += pp[(long long)q * D];
-    c_raw[(long long)b * D + k] = s;
+        for (int q = 0; q < nchunk; ++q) s += pp[(long long)q * D];
+        c_raw[(long long)b * D + k] = s;
+    }
+    // u^2 = |c| + 1e-10 where c != 0; sign(0) = 0 makes u = 0 exactly there
+    const float ss = block_sum<4>(s != 0.f ? fabsf(s) + 1e-10f : 0.f, red);
+    if (threadIdx.x == 0) ssq[(long long)b * gridDim.x + blockIdx.x] = ss;
 }
 
 // u = sign(c) sqrt(|c| + 1e-10) ; y = u / max(|u|_2, 1e-12)      (CBCNN.py:132-133)
 // part != nullptr: c_raw[b,k] = sum of the nchunk row-chunk partials (fixed order) is formed here first
-__global__ __launch_bounds__(256) void cbp_norm_kernel(float* __restrict__ c_raw, float* __restrict__ y,
-                                                       float* __restrict__ inv_norm, int D) {
-    __shared__ float red[4];
-    const int b = blockIdx.x;
-    float* c = c_raw + (long long)b * D;
-    float ss = 0.f;   // u^2 = |c| + 1e-10 where c != 0; sign(0) = 0 makes u = 0 exactly there
-    for (int k = threadIdx.x; k < D; k += 256) ss += (c[k] != 0.f) ? fabsf(c[k]) + 1e-10f : 0.f;
-    ss = block_sum<4>(ss, red);
+// (2) every thread adds the sample's gridDim.x partial sums in the same order (so all agree on n) and writes its bin
+__global__ __launch_bounds__(256) void cbp_norm_kernel(const float* __restrict__ c_raw, const float* __restrict__ ssq,
+                                                       float* __restrict__ y, float* __restrict__ inv_norm, int D) {
+    const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    float ss = 0.f;
+    for (int q = 0; q < (int)gridDim.x; ++q) ss += ssq[(long long)b * gridDim.x + q];
     const float n = fmaxf(sqrtf(ss), 1e-12f);
-    for (int k = threadIdx.x; k < D; k += 256) {
-        const float v = c[k];
+    if (k < D) {
+        const float v = c_raw[(long long)b * D + k];
         const float sg = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
         y[(long long)b * D + k] = sg * sqrtf(fabsf(v) + 1e-10f) / n;
     }
-    if (threadIdx.x == 0) inv_norm[b] = 1.0f / n;
+    if (k == 0) inv_norm[b] = 1.0f / n;
+}
+
+// backward of the finishing stage, same two-launch shape:  tp[b][blockIdx.x] = the workgroup's share of <y, dy>
+__global__ __launch_bounds__(256) void cbp_dot_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ tp, int D) {
+    __shared__ float red[4];
+    const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    const long long o = (long long)b * D;
+    const float t = block_sum<4>(k < D ? y[o + k] * dy[o + k] : 0.f, red);
+    if (threadIdx.x == 0) tp[(long long)b * gridDim.x + blockIdx.x] = t;
 }
 
 // dc = ((dy - y <y,dy>) / n) / (2 sqrt(|c| + 1e-10))
 __global__ __launch_bounds__(256) void cbp_dc_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                      const float* __restrict__ c_raw, const float* __restrict__ inv_norm,
-                                                     float* __restrict__ dc, int D) {
-    __shared__ float red[4];
-    const int b = blockIdx.x;
+                                                     const float* __restrict__ tp, float* __restrict__ dc, int D) {
+    const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     const long long o = (long long)b * D;
     float t = 0.f;
-    for (int k = threadIdx.x; k < D; k += 256) t += y[o + k] * dy[o + k];
-    t = block_sum<4>(t, red);
+    for (int q = 0; q < (int)gridDim.x; ++q) t += tp[(long long)b * gridDim.x + q];
     const float in = inv_norm[b];
-    for (int k = threadIdx.x; k < D; k += 256) {
+    if (k < D) {
         const float c = c_raw[o + k];
         const float du = (dy[o + k] - y[o + k] * t) * in;
         // c == 0 exactly (a bin whose Gram entries are all exactly 0): torch's autograd of sign(c)*sqrt(|c|+1e-10)
@@ -504,8 +519,9 @@ extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32
 
 extern "C" size_t hk_cbp_ws_bytes(int B, int C, int HW, int D) {
     (void)HW;
-    const size_t g = (size_t)B * C * C * sizeof(float) + (size_t)B * ((C + 63) / 64) * D * sizeof(float);  // G + row-chunk partials
-    const size_t dc = (size_t)B * D * sizeof(float);
+    const size_t fin = (size_t)B * ((D + 255) / 256) * sizeof(float);            // per-workgroup sums of the finishing stage
+    const size_t g = (size_t)B * C * C * sizeof(float) + (size_t)B * ((C + 63) / 64) * D * sizeof(float) + fin;  // G + row-chunk partials
+    const size_t dc = (size_t)B * D * sizeof(float) + fin;
     return (g > dc ? g : dc) + 256;
 }
 
@@ -516,11 +532,6 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
     hipStream_t st = (hipStream_t)stream;
     const CbpPlan pl = cbp_view(plan, C, D);
     float* G = (float*)ws;
-    const LdPlain xa = make_plain(x, (long long)C * HW, HW, C, HW);
-    const EpAffine ep = make_affine(G, (long long)C * C, C, 1.0f, nullptr, 0.f, 0.f);
-    int rc = force_generic() ? HK_ERR_UNSUPPORTED : gram_fast_raw(x, nullptr, 1.0f, G, B, C, HW, st);
-    if (rc == HK_ERR_UNSUPPORTED) rc = bgemm_launch<true, true>(xa, xa, ep, C, C, HW, B, st);      // raw Gram, no 1/HW
-    if (rc != HK_OK) return rc;
     const int nchunk = (C + 63) / 64;
     float* part = G + (long long)B * C * C;
     // Binning stage, measured at C=512, D=6000 (whole hk_cbp_fwd, HIP events, BENCH_r01): row-scatter 89.0 us @B=64 /
@@ -533,31 +544,51 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
                            (bin >= 0 ? bin == 0 : B * nchunk >= 256);
     const bool scatter = (bin < 0 || bin == 2) && C <= 512 && C % 4 == 0 && pl.emax <= CBP_EMAX &&
                          rowscatter_lds(C, D) <= 150 * 1024;
-    if (scatter) {
-        const int rc2 = C <= 256 ? rowscatter_launch<1>(G, pl, part, B, C, D, nchunk, st)
-                                 : rowscatter_launch<2>(G, pl, part, B, C, D, nchunk, st);
-        if (rc2 != HK_OK) return rc2;
-    } else if (rowsketch) {
-        int rc2 = HK_ERR_UNSUPPORTED;
-        const bool one = C <= 256;
-        switch (nq8) {
-            case 1: rc2 = one ? rowsketch_launch<1, 1>(G, pl, part, B, C, D, nchunk, st) : rowsketch_launch<2, 1>(G, pl, part, B, C, D, nchunk, st); break;
-            case 2: rc2 = one ? rowsketch_launch<1, 2>(G, pl, part, B, C, D, nchunk, st) : rowsketch_launch<2, 2>(G, pl, part, B, C, D, nchunk, st); break;
-            case 3: rc2 = one ? rowsketch_launch<1, 3>(G, pl, part, B, C, D, nchunk, st) : rowsketch_launch<2, 3>(G, pl, part, B, C, D, nchunk, st); break;
-            case 4: rc2 = one ? rowsketch_launch<1, 4>(G, pl, part, B, C, D, nchunk, st) : rowsketch_launch<2, 4>(G, pl, part, B, C, D, nchunk, st); break;
+    // Gram + binning of samples b0 .. b0 + nb - 1 on queue q
+    auto gram_and_bin = [&](int b0, int nb, hipStream_t q) -> int {
+        const float* xh = x + (long long)b0 * C * HW;
+        float* Gh = G + (long long)b0 * C * C;
+        float* ph = part + (long long)b0 * nchunk * D;
+        int rc = force_generic() ? HK_ERR_UNSUPPORTED : gram_fast_raw(xh, nullptr, 1.0f, Gh, nb, C, HW, q);
+        if (rc == HK_ERR_UNSUPPORTED) {                                                            // raw Gram, no 1/HW
+            const LdPlain xa = make_plain(xh, (long long)C * HW, HW, C, HW);
+            const EpAffine ep = make_affine(Gh, (long long)C * C, C, 1.0f, nullptr, 0.f, 0.f);
+            rc = bgemm_launch<true, true>(xa, xa, ep, C, C, HW, nb, q);
         }
-        if (rc2 != HK_OK) return rc2;
-    } else {
-        hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 3) / 4, B), dim3(256), 0, st, (const float*)G, pl.off, pl.ent, c_raw,
-                           C * C, D);
-    }
-    HK_LAUNCH_CHECK();
-    if (rowsketch || scatter) {
-        hipLaunchKernelGGL(cbp_partsum_kernel, dim3((D + 255) / 256, B), dim3(256), 0, st, (const float*)part, c_raw, D,
-                           nchunk);
+        if (rc != HK_OK) return rc;
+        if (scatter)
+            return C <= 256 ? rowscatter_launch<1>(Gh, pl, ph, nb, C, D, nchunk, q)
+                            : rowscatter_launch<2>(Gh, pl, ph, nb, C, D, nchunk, q);
+        if (rowsketch) {
+            const bool one = C <= 256;
+            switch (nq8) {
+                case 1: return one ? rowsketch_launch<1, 1>(Gh, pl, ph, nb, C, D, nchunk, q) : rowsketch_launch<2, 1>(Gh, pl, ph, nb, C, D, nchunk, q);
+                case 2: return one ? rowsketch_launch<1, 2>(Gh, pl, ph, nb, C, D, nchunk, q) : rowsketch_launch<2, 2>(Gh, pl, ph, nb, C, D, nchunk, q);
+                case 3: return one ? rowsketch_launch<1, 3>(Gh, pl, ph, nb, C, D, nchunk, q) : rowsketch_launch<2, 3>(Gh, pl, ph, nb, C, D, nchunk, q);
+                case 4: return one ? rowsketch_launch<1, 4>(Gh, pl, ph, nb, C, D, nchunk, q) : rowsketch_launch<2, 4>(Gh, pl, ph, nb, C, D, nchunk, q);
+            }
+            return HK_ERR_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 3) / 4, nb), dim3(256), 0, q, (const float*)Gh, pl.off, pl.ent,
+                           c_raw + (long long)b0 * D, C * C, D);
         HK_LAUNCH_CHECK();
+        return HK_OK;
+    };
+    // (Running the two halves of the batch on two HIP queues, so that one half's binning overlaps the other's Gram - what
+    //  pays for the Newton-Schulz chain - was measured here and is NOT done: 121.9 us against 81.5 us on one queue at
+    //  B = 64; both kernels want most of a CU's LDS and each half-batch Gram fills only half the CUs.)
+    {
+        const int rc = gram_and_bin(0, B, st);
+        if (rc != HK_OK) return rc;
     }
-    hipLaunchKernelGGL(cbp_norm_kernel, dim3(B), dim3(256), 0, st, c_raw, y, inv_norm, D);
+    float* ssq = part + (long long)B * nchunk * D;
+    const dim3 fgrid((D + 255) / 256, B);
+    if (rowsketch || scatter)
+        hipLaunchKernelGGL(cbp_partsum_kernel, fgrid, dim3(256), 0, st, (const float*)part, c_raw, ssq, D, nchunk);
+    else
+        hipLaunchKernelGGL(cbp_partsum_kernel, fgrid, dim3(256), 0, st, (const float*)c_raw, c_raw, ssq, D, 1);
+    HK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cbp_norm_kernel, fgrid, dim3(256), 0, st, (const float*)c_raw, (const float*)ssq, y, inv_norm, D);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
@@ -570,7 +601,11 @@ extern "C" int hk_cbp_bwd(const float* x, const void* plan, const float* y, cons
     if (!ws || ws_bytes < hk_cbp_ws_bytes(B, C, HW, D)) return HK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* dc = (float*)ws;
-    hipLaunchKernelGGL(cbp_dc_kernel, dim3(B), dim3(256), 0, st, y, dy, c_raw, inv_norm, dc, D);
+    float* tp = dc + (long long)B * D;
+    const dim3 fgrid((D + 255) / 256, B);
+    hipLaunchKernelGGL(cbp_dot_kernel, fgrid, dim3(256), 0, st, y, dy, tp, D);
+    HK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cbp_dc_kernel, fgrid, dim3(256), 0, st, y, dy, c_raw, inv_norm, (const float*)tp, dc, D);
     HK_LAUNCH_CHECK();
     if (!force_generic()) {
         const CbpPlan pv = cbp_view(plan, C, D);

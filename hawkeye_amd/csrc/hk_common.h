@@ -49,6 +49,41 @@ struct Tuning {
 };
 Tuning& tuning();           // api.hip
 
+// One helper HIP queue per device (created on first use, kept for the life of the process) for entry points that run
+// two independent halves of a batch side by side: fork = everything enqueued on `st` so far happens before the helper
+// queue's work; join = the helper queue's work happens before whatever is enqueued on `st` next.  Event record / wait
+// pairs only - no host synchronisation, capturable in a hipGraph like any fork / join.
+struct AuxQueue {
+    hipStream_t aux = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+inline AuxQueue* aux_queue() {
+    static AuxQueue tab[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    AuxQueue& a = tab[dev];
+    if (!a.aux) {
+        if (hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking) != hipSuccess) { a.aux = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &a;
+}
+// the helper queue, ordered after `st`; nullptr when it cannot be had (the caller then stays on `st`)
+inline hipStream_t aux_fork(hipStream_t st) {
+    AuxQueue* a = aux_queue();
+    if (!a) return nullptr;
+    if (hipEventRecord(a->fork, st) != hipSuccess || hipStreamWaitEvent(a->aux, a->fork, 0) != hipSuccess) return nullptr;
+    return a->aux;
+}
+inline int aux_join(hipStream_t aux, hipStream_t st) {
+    if (!aux) return HK_OK;
+    AuxQueue* a = aux_queue();
+    hipError_t e = hipEventRecord(a->join, aux);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, a->join, 0);
+    return e == hipSuccess ? HK_OK : (int)e;
+}
+
 constexpr int WAVE = 64;
 constexpr int NXCD = 8;
 

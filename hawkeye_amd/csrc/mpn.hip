@@ -201,41 +201,15 @@ struct NsDispatch {
     }
 };
 
-struct NsAux {
-    hipStream_t aux = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-// one helper queue per device, created on first use and kept for the life of the process
-static NsAux* ns_aux() {
-    static NsAux tab[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    NsAux& a = tab[dev];
-    if (!a.aux) {
-        if (hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking) != hipSuccess) { a.aux = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    }
-    return &a;
-}
 // fork: everything enqueued on `st` so far happens before the helper queue's work; returns the dispatcher
 static inline NsDispatch ns_fork(int d, int B, hipStream_t st) {
     NsDispatch L{d, B, B / 2, st, nullptr};
     if (tuning().ns_streams != 1 || B < 16) return L;
-    NsAux* a = ns_aux();
-    if (!a) return L;
-    if (hipEventRecord(a->fork, st) != hipSuccess || hipStreamWaitEvent(a->aux, a->fork, 0) != hipSuccess) return L;
-    L.aux = a->aux;
+    L.aux = aux_fork(st);
     return L;
 }
 // join: the helper queue's work happens before whatever is enqueued on `st` next
-static inline int ns_join(const NsDispatch& L) {
-    if (!L.aux) return HK_OK;
-    NsAux* a = ns_aux();
-    hipError_t e = hipEventRecord(a->join, L.aux);
-    if (e == hipSuccess) e = hipStreamWaitEvent(L.st, a->join, 0);
-    return e == hipSuccess ? HK_OK : (int)e;
-}
+static inline int ns_join(const NsDispatch& L) { return aux_join(L.aux, L.st); }
 
 // grid of ns_scale_kernel: a few workgroups per sample (each one recomputes the trace before it starts: with the
 // 256-per-sample grid of an elementwise kernel that prologue costs more than the scaling, 26 us instead of ~8)

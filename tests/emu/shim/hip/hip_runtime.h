@@ -371,6 +371,11 @@ inline v16f mfma_f32_32x32x16_bf16(v8bf a, v8bf b, v16f c, int, int, int) {
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_f32_16x16x4
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_f32_32x32x16_bf16
 
+// LDS / global integer atomics: the fibers of a workgroup are switched only at barriers and wave-wide collectives, so a
+// read-modify-write between two switch points is atomic by construction (and min / max do not depend on the order)
+inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
+inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+
 template <class T>
 inline T __shfl_xor(T v, int mask, int = 64) {
     return hipemu::wave_exchange(v, [mask](int lane) { return lane ^ mask; });

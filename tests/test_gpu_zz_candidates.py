@@ -95,6 +95,38 @@ def test_roi_crop_backward_lds_variant_bit_identical(F, mode, tune):
     assert torch.equal(res[0], res[1]) and float(res[0].abs().sum()) > 0
 
 
+@pytest.mark.parametrize('h,w', [(14, 14), (28, 28), (64, 64), (33, 47), (5, 7), (3, 60)])
+def test_roi_crop_backward_other_map_sizes(F, h, w, tune):
+    """The ROI-refinement backward on maps other than AP-CNN's 56 x 56: the three pixels-per-thread instances (maps up
+    to 32 x 32, up to 3328 pixels, 64 x 64), odd sizes (no 16-byte path), maps smaller than the compile-time windows;
+    boxes that give 3 x 3, 4 x 4 and larger tap windows, an empty crop and a full one.  Bit-identical to the round-1
+    table kernel, and equal to autograd through torch's own crop + bilinear resize."""
+    gen = torch.Generator().manual_seed(h * 100 + w)
+    x = torch.randn(5, 3, h, w, generator=gen)
+    wt = torch.randn(5, 3, h, w, generator=gen)
+    box = torch.tensor([[0., 0., w, h], [w * 0.2, h * 0.1, w * 0.8, h * 0.75], [w * 0.3, h * 0.3, w * 0.3 + 2.2, h * 0.3 + 1.5],
+                        [1.2, 0.4, w * 0.45, h - 0.3], [w * 0.6, h * 0.6, w * 0.6, h * 0.9]])
+    drop = torch.tensor([[0., 0., -1., -1.]] * 5)
+    res = []
+    for flag in (1, 0):
+        tune('roi_bwd', flag)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        y = F.roi_crop_resize(xg, box.to(DEV), drop.to(DEV), False)
+        (y * wt.to(DEV)).sum().backward()
+        res.append((y.detach().cpu(), xg.grad.cpu()))
+    assert torch.equal(res[0][1], res[1][1])
+    xo = x.clone().requires_grad_(True)
+    ys = []
+    for i in range(5):
+        x1, y1, x2, y2 = [int(v) for v in box[i]]
+        crop = xo[i:i + 1, :, y1:y2, x1:x2]
+        ys.append(torch.nn.functional.interpolate(crop, size=(h, w), mode='bilinear', align_corners=False)
+                  if crop.numel() else torch.zeros(1, 3, h, w))
+    yo = torch.cat(ys, 0)
+    (yo * wt).sum().backward()
+    assert rel(res[1][0], yo) < 1e-6 and rel(res[1][1], xo.grad) < 1e-6
+
+
 @pytest.mark.parametrize('c,d,b', [(128, 1024, 3), (256, 2048, 2), (512, 6000, 2), (512, 8192, 2), (64, 50, 3), (96, 333, 2)])
 def test_cbp_row_scatter_binning(F, c, d, b, tune):
     """cbp_bin=2 (the default wherever its bins fit the LDS): the chunk's bins live in LDS and every row adds its <= C non-zero sketch entries into them (one

@@ -195,6 +195,11 @@ def cbp():
                 ref = y.clone()
             elif flag == '2':
                 rows[-1]['bit_identical_to_default'] = bool(torch.equal(y, ref))
+        knob('cbp_bin', -1)
+        dy, dx = torch.randn(B, D, device=dev), torch.empty_like(x)
+        row(f'cbp bwd B={B}', 'dot + dc kernels, Gram backward MODE 2',
+            timeit(lambda: lib.hk_cbp_bwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), ptr(dy), ptr(dx), B, C, HW, D,
+                                          ptr(ws), nws, stream())), 2.0 * B * C * C * HW)
     knob('cbp_bin', -1)
 
 
@@ -231,18 +236,21 @@ def bwd_variants():
 def roi_bwd():
     B, C = sz(16, 2), sz(512, 8)
     dy, dx = torch.randn(B, C, 56, 56, device=dev), torch.empty(B, C, 56, 56, device=dev)
-    box = torch.tensor([[3.2, 5.9, 40.1, 33.3]] * B, device=dev)
     drop = torch.tensor([[10., 12., 20., 30.]] * B, device=dev)
-    ref = None
-    for flag in (1, 0):
-        knob('roi_bwd', flag)
-        row(f'roi_crop_resize bwd B={B} C={C} 56x56', 'roi_bwd=1: round-1 table kernel' if flag == 1 else 'uniform-window kernel, 8 maps / WG, 4 pixels in flight (default)',
-            timeit(lambda: lib.hk_roi_crop_resize_bwd(ptr(dy), ptr(box), ptr(drop), ptr(dx), B, C, 56, 56, 1, stream())), 0.0,
-            8.0 * B * C * 3136)
-        if ref is None:
-            ref = dx.clone()
-        else:
-            rows[-1]['bit_identical_to_default'] = bool(torch.equal(dx, ref))
+    # a 37 x 28 crop (tap windows up to 3 x 3), a 23 x 21 one (4 x 4) and a 9 x 11 one (table loops)
+    for bx, tag in (([3.2, 5.9, 40.1, 33.3], '37x28 crop'), ([20.2, 14.9, 43.1, 35.3], '23x21 crop'), ([20.2, 14.9, 29.1, 25.3], '9x11 crop')):
+        box = torch.tensor([bx] * B, device=dev)
+        ref = None
+        for flag in (1, 0):
+            knob('roi_bwd', flag)
+            row(f'roi_crop_resize bwd B={B} C={C} 56x56, {tag}', 'roi_bwd=1: round-1 table kernel' if flag == 1 else
+                'crop-only gather, compile-time 3x3 / 4x4 windows with register weights, LDS output image (default)',
+                timeit(lambda: lib.hk_roi_crop_resize_bwd(ptr(dy), ptr(box), ptr(drop), ptr(dx), B, C, 56, 56, 1, stream())), 0.0,
+                8.0 * B * C * 3136)
+            if ref is None:
+                ref = dx.clone()
+            else:
+                rows[-1]['bit_identical_to_default'] = bool(torch.equal(dx, ref))
     knob('roi_bwd', 0)
 
 
