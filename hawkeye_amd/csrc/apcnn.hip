@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void roi_crop_fwd_kernel(const float* __restri
                 }
                 v[i][j] = t;
             }
-        yp[o] = la0 * (lb0 * v[0][0] + lb1 * v[0][1]) + la1 * (lb0 * v[1][0] + lb1 * v[1][1]);
+        const float r0 = fmaf(lb1, v[0][1], lb0 * v[0][0]), r1 = fmaf(lb1, v[1][1], lb0 * v[1][0]);
+        yp[o] = fmaf(la1, r1, la0 * r0);
     }
 }
 
@@ -327,7 +328,9 @@ __global__ __launch_bounds__(256) void roi_crop_fwd_tab_kernel(const float* __re
                 }
                 v[i][j] = t;
             }
-        yp[o] = a.l0 * (q.l0 * v[0][0] + q.l1 * v[0][1]) + a.l1 * (q.l0 * v[1][0] + q.l1 * v[1][1]);
+        // (explicit fmaf: the same bits as roi_crop_fwd_tab2_kernel, whatever the compiler would contract)
+        const float r0 = fmaf(q.l1, v[0][1], q.l0 * v[0][0]), r1 = fmaf(q.l1, v[1][1], q.l0 * v[1][0]);
+        yp[o] = fmaf(a.l1, r1, a.l0 * r0);
     }
     }
 }
@@ -452,6 +455,10 @@ extern "C" int hk_roi_boxes(const float* rois3, const int32_t* cnt3, int k3, con
 extern "C" int hk_roi_crop_resize_fwd(const float* x, const float* box, const float* drop, float* y, int B, int C, int H,
                                       int W, int training, hk_stream_t stream) {
     if (!x || !box || !drop || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return HK_ERR_BAD_ARG;
+    if (tuning().roi_bwd != 1) {                            // default: apcnn_roi2.hip; roi_bwd = 1 keeps the round-1 kernels (both directions)
+        const int rc = roi_crop_fwd_v2(x, box, drop, y, B, C, H, W, training, (hipStream_t)stream);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
     if (H <= 64 && W <= 64) {
         hipLaunchKernelGGL(roi_crop_fwd_tab_kernel, dim3((C + ROI_CPB - 1) / ROI_CPB, B), dim3(256), 0, (hipStream_t)stream, x, box, drop, y, C, H, W,
                            training);

@@ -17,7 +17,8 @@
 //     live in registers for all maps of the workgroup and its KW * KW taps are unconditional LDS reads, all in flight
 //     together.  The window is shifted to stay inside the map, taps outside a pixel's true range carry table weight 0
 //     and read finite map values, so dX is bit-identical to the table kernel (x + 0 * finite = x).  Small crops (up
-//     to 512 pixels) have windows up to 8 x 8 the same way, two pixels per thread; anything else takes the table loops;
+//     to 512 pixels) have windows up to 8 x 8 the same way, two pixels per thread; anything else takes the table loops
+//     (a 12 x 12 instance was tried: its 288 reads in flight push the whole kernel to one workgroup per CU);
 //   * the tables' non-zero ranges come from LDS atomics while the tables are filled (no scans), pixel coordinates from
 //     a multiply-shift instead of integer division;
 //   * 8-32 maps per workgroup (chosen so that the grid is at most two workgroups per CU: one round, no tail), each map
@@ -291,6 +292,119 @@ int roi_crop_bwd_v2(const float* dy, const float* box, const float* drop, float*
         hipLaunchKernelGGL(roi_crop_bwd_tab3_kernel<13>, grid, dim3(256), lds, st, dy, box, drop, dx, C, H, W, training, cpb);
     else
         hipLaunchKernelGGL(roi_crop_bwd_tab3_kernel<16>, grid, dim3(256), lds, st, dy, box, drop, dx, C, H, W, training, cpb);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward (crop + bilinear resize to H x W + drop mask), same recipe: 8-32 maps per workgroup, the map staged in LDS with
+// 16-byte loads one map ahead, an output pixel's geometry (two row offsets, column step, four weights, drop bits) in
+// registers for all maps of the workgroup, its four taps unconditional LDS reads.  The round-1 kernel
+// (roi_crop_fwd_tab_kernel: one map per workgroup, four 4-byte global gathers and an integer division per pixel) ran
+// 73-75 us on the AP-CNN shape.  Same expression, explicit fmaf in both: bit-identical.
+template <int PPT>
+__global__ __launch_bounds__(256) void roi_crop_fwd_tab2_kernel(const float* __restrict__ x, const float* __restrict__ box,
+                                                                const float* __restrict__ drop, float* __restrict__ y,
+                                                                int C, int H, int W, int training, int cpb) {
+    __shared__ CropGeom gs;
+    __shared__ int ti0[2][64], ti1[2][64];                 // [0] rows, [1] columns: source taps of an output coordinate
+    __shared__ float tl0[2][64], tl1[2][64];
+    __shared__ __attribute__((aligned(16))) float smap[64 * 64];
+    const int b = blockIdx.y, c0 = blockIdx.x * cpb, tid = threadIdx.x;
+    const int hw = H * W;
+    if (tid == 0) gs = crop_geom(box + b * 4, drop + b * 4, C, H, W, training);
+    __syncthreads();
+    const CropGeom g = gs;
+    const int nmaps = (C - c0) < cpb ? (C - c0) : cpb;
+    if (g.cw <= 0 || g.ch <= 0) {                          // empty crop: zeros
+        for (int cc = 0; cc < nmaps; ++cc) {
+            float* yp = y + ((long long)b * C + c0 + cc) * hw;
+            for (int p = tid; p < hw; p += 256) yp[p] = 0.f;
+        }
+        return;
+    }
+    if (tid < H) src_index(g.sh, tid, g.ch, ti0[0][tid], ti1[0][tid], tl0[0][tid], tl1[0][tid]);
+    else if (tid >= 64 && tid - 64 < W) src_index(g.sw, tid - 64, g.cw, ti0[1][tid - 64], ti1[1][tid - 64], tl0[1][tid - 64], tl1[1][tid - 64]);
+    __syncthreads();
+
+    // slot k = output pixel o = tid + 256 k
+    const int inv = ((1 << 20) + W - 1) / W;               // o / W = (o * inv) >> 20, exact for o < 4096, W <= 64
+    int so0[PPT];                                           // offset of tap (0, 0) in the map
+    unsigned pk[PPT];                                       // bit 0: column step (0 / 1), bit 1: row step (0 / W), bits 2-5: tap (i, j) not dropped
+    float la0[PPT], la1[PPT], lb0[PPT], lb1[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        int o = tid + 256 * k;
+        if (o >= hw) o = hw - 1;
+        const int oy = (o * inv) >> 20, ox = o - oy * W;
+        const int ys0 = g.y1 + ti0[0][oy], ys1 = g.y1 + ti1[0][oy], xs0 = g.x1 + ti0[1][ox], xs1 = g.x1 + ti1[1][ox];
+        la0[k] = tl0[0][oy]; la1[k] = tl1[0][oy]; lb0[k] = tl0[1][ox]; lb1[k] = tl1[1][ox];
+        so0[k] = ys0 * W + xs0;
+        unsigned m = 15u;
+        if (training) {
+            const bool dy0 = ys0 >= g.dy1 && ys0 < g.dy2, dy1 = ys1 >= g.dy1 && ys1 < g.dy2;
+            const bool dx0 = xs0 >= g.dx1 && xs0 < g.dx2, dx1 = xs1 >= g.dx1 && xs1 < g.dx2;
+            m = (dy0 && dx0 ? 0u : 1u) | (dy0 && dx1 ? 0u : 2u) | (dy1 && dx0 ? 0u : 4u) | (dy1 && dx1 ? 0u : 8u);
+        }
+        pk[k] = (unsigned)(xs1 - xs0) | ((unsigned)(ys1 - ys0) << 1) | (m << 2);
+    }
+
+    const bool vec = (hw % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+    const int n4 = hw / 4;
+    float4 st0, st1, st2, st3;                             // named: see the backward
+    st0 = st1 = st2 = st3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int f0 = tid < n4 ? tid : n4 - 1, f1 = tid + 256 < n4 ? tid + 256 : n4 - 1;
+    const int f2 = tid + 512 < n4 ? tid + 512 : n4 - 1, f3 = tid + 768 < n4 ? tid + 768 : n4 - 1;
+    auto issue = [&](int cc) {
+        const float4* gp4 = reinterpret_cast<const float4*>(x + ((long long)b * C + c0 + cc) * hw);
+        st0 = gp4[f0]; st1 = gp4[f1]; st2 = gp4[f2]; st3 = gp4[f3];
+    };
+    if (vec) issue(0);
+    for (int cc = 0; cc < nmaps; ++cc) {
+        const float* xp = x + ((long long)b * C + c0 + cc) * hw;
+        float* yp = y + ((long long)b * C + c0 + cc) * hw;
+        __syncthreads();                                   // previous map no longer read
+        if (vec) {
+            float4* s4 = reinterpret_cast<float4*>(smap);
+            if (tid < n4) s4[tid] = st0;
+            if (tid + 256 < n4) s4[tid + 256] = st1;
+            if (tid + 512 < n4) s4[tid + 512] = st2;
+            if (tid + 768 < n4) s4[tid + 768] = st3;
+        } else {
+            for (int p = tid; p < hw; p += 256) smap[p] = xp[p];
+        }
+        __syncthreads();
+        if (vec && cc + 1 < nmaps) issue(cc + 1);          // in flight during the gather below
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int o = tid + 256 * k;
+            const int dxs = pk[k] & 1u, so1 = so0[k] + ((pk[k] & 2u) ? W : 0);
+            float v00 = smap[so0[k]], v01 = smap[so0[k] + dxs], v10 = smap[so1], v11 = smap[so1 + dxs];
+            if (training) {
+                v00 = ((pk[k] & 4u) ? v00 : 0.f) * g.rate;
+                v01 = ((pk[k] & 8u) ? v01 : 0.f) * g.rate;
+                v10 = ((pk[k] & 16u) ? v10 : 0.f) * g.rate;
+                v11 = ((pk[k] & 32u) ? v11 : 0.f) * g.rate;
+            }
+            const float r0 = fmaf(lb1[k], v01, lb0[k] * v00), r1 = fmaf(lb1[k], v11, lb0[k] * v10);
+            if (o < hw) yp[o] = fmaf(la1[k], r1, la0[k] * r0);
+        }
+    }
+}
+
+int roi_crop_fwd_v2(const float* x, const float* box, const float* drop, float* y, int B, int C, int H, int W, int training,
+                    hipStream_t st) {
+    if (H > 64 || W > 64) return HK_ERR_UNSUPPORTED;
+    int cpb = 8;                                            // (190 registers at 56 x 56: two workgroups per CU, 512 run at once)
+    while (cpb < 32 && (long long)B * ((C + cpb - 1) / cpb) > 512) cpb *= 2;
+    const dim3 grid((C + cpb - 1) / cpb, B);
+    if (H * W <= 256 * 4)
+        hipLaunchKernelGGL(roi_crop_fwd_tab2_kernel<4>, grid, dim3(256), 0, st, x, box, drop, y, C, H, W, training, cpb);
+    else if (H * W <= 256 * 13)
+        hipLaunchKernelGGL(roi_crop_fwd_tab2_kernel<13>, grid, dim3(256), 0, st, x, box, drop, y, C, H, W, training, cpb);
+    else
+        hipLaunchKernelGGL(roi_crop_fwd_tab2_kernel<16>, grid, dim3(256), 0, st, x, box, drop, y, C, H, W, training, cpb);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

@@ -49,7 +49,10 @@ __device__ __forceinline__ void src_index(float scale, int dst, int in, int& i0,
     l0 = 1.f - l1;
 }
 
-// apcnn_roi2.hip: LDS-staged, 4 channel maps per workgroup (HK_ROI_BWD=2); HK_ERR_UNSUPPORTED for maps above 64x64
+// apcnn_roi2.hip: LDS-staged maps, 8-32 channel maps per workgroup, per-pixel geometry in registers; HK_ERR_UNSUPPORTED for
+// maps above 64x64
+int roi_crop_fwd_v2(const float* x, const float* box, const float* drop, float* y, int B, int C, int H, int W, int training,
+                    hipStream_t st);
 int roi_crop_bwd_v2(const float* dy, const float* box, const float* drop, float* dx, int B, int C, int H, int W, int training,
                     hipStream_t st);
 

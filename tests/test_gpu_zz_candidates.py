@@ -91,8 +91,9 @@ def test_roi_crop_backward_lds_variant_bit_identical(F, mode, tune):
         xg = x.clone().to(DEV).requires_grad_(True)
         y = F.roi_crop_resize(xg, box.to(DEV), drop.to(DEV), mode == 'train')
         (y * wt.to(DEV)).sum().backward()
-        res.append(xg.grad.clone())
-    assert torch.equal(res[0], res[1]) and float(res[0].abs().sum()) > 0
+        res.append((xg.grad.clone(), y.detach().clone()))
+    assert torch.equal(res[0][0], res[1][0]) and float(res[0][0].abs().sum()) > 0
+    assert torch.equal(res[0][1], res[1][1])               # the forward kernels too (roi_bwd=1 keeps both round-1 kernels)
 
 
 @pytest.mark.parametrize('h,w', [(14, 14), (28, 28), (64, 64), (33, 47), (5, 7), (3, 60)])
@@ -114,7 +115,7 @@ def test_roi_crop_backward_other_map_sizes(F, h, w, tune):
         y = F.roi_crop_resize(xg, box.to(DEV), drop.to(DEV), False)
         (y * wt.to(DEV)).sum().backward()
         res.append((y.detach().cpu(), xg.grad.cpu()))
-    assert torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])       # backward and forward kernels
     xo = x.clone().requires_grad_(True)
     ys = []
     for i in range(5):

@@ -251,6 +251,17 @@ def roi_bwd():
                 ref = dx.clone()
             else:
                 rows[-1]['bit_identical_to_default'] = bool(torch.equal(dx, ref))
+        ref = None
+        for flag in (1, 0):                                 # (the knob keeps the round-1 kernels of both directions)
+            knob('roi_bwd', flag)
+            row(f'roi_crop_resize fwd B={B} C={C} 56x56, {tag}', 'roi_bwd=1: round-1 kernel, one map per workgroup, taps from global memory' if flag == 1 else
+                'LDS-staged maps, 16 maps per workgroup, per-pixel geometry in registers (default)',
+                timeit(lambda: lib.hk_roi_crop_resize_fwd(ptr(dy), ptr(box), ptr(drop), ptr(dx), B, C, 56, 56, 1, stream())), 0.0,
+                8.0 * B * C * 3136)
+            if ref is None:
+                ref = dx.clone()
+            else:
+                rows[-1]['bit_identical_to_default'] = bool(torch.equal(dx, ref))
     knob('roi_bwd', 0)
 
 
