@@ -23,7 +23,7 @@
 //   68 KB of LDS per workgroup -> 2 workgroups per CU overlap each other's phases.
 #include <cstdlib>
 #include "hk_common.h"
-#include "hk_bwd128.h"
+#include "hk_bwd128d.h"
 
 namespace hk {
 
@@ -413,6 +413,12 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
     // (30 vs 39 us).  tuning().bwd_v: 0 automatic, 1 force the 64-row kernel, 5 force the 128-row one.
     const int v = tuning().bwd_v;
     if (v != 1 && C % 128 == 0 && (v >= 5 || (long long)B * (C / 128) >= 192)) {
+        if constexpr (MODE == 0 || MODE == 3) {             // LDS-DMA staging (hk_bwd128d.h; forced by bwd_v = 9); bwd_v = 5 asks for the register-staged kernel
+            if (v == 0 || v >= 9) {
+                const int rc = bwd128d_launch<HW, MODE>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
+                if (rc != HK_ERR_UNSUPPORTED) return rc;
+            }
+        }
         const int rc = bwd128_launch<HW, MODE>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
         if (rc != HK_ERR_UNSUPPORTED) return rc;
     }

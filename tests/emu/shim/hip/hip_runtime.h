@@ -365,11 +365,22 @@ inline v16f mfma_f32_32x32x16_bf16(v8bf a, v8bf b, v16f c, int, int, int) {
 
 #define __syncthreads() hipemu::block_barrier()
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)   /* memory operations of a fiber complete at once */
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_f32_32x32x2
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_f32_16x16x4
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_f32_32x32x16_bf16
+
+// LDS-DMA (global_load_lds_dwordx4 ...): lane l of the wave copies `size` bytes from ITS global address to the
+// wave-uniform LDS base + size * l.  Executed at once by each fiber (the real copy is asynchronous and is waited for by
+// the barrier; the kernels only ever target an LDS stage nobody reads before the next barrier).
+namespace hipemu {
+inline void global_load_lds(const void* g, void* l, unsigned size, int off) {
+    memcpy((char*)l + off + (size_t)size * (cur->tid.x & 63), (const char*)g + off, size);
+}
+}  // namespace hipemu
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipemu::global_load_lds((const void*)(g), (void*)(l), size, off)
 
 // LDS / global integer atomics: the fibers of a workgroup are switched only at barriers and wave-wide collectives, so a
 // read-modify-write between two switch points is atomic by construction (and min / max do not depend on the order)

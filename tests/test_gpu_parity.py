@@ -110,7 +110,7 @@ def test_bcnn_signed_sqrt_variant(F, shape, seed, tune):
     y = O.bilinear_pool_signed_sqrt(x)
     (y * t(wn)).sum().backward()
     outs = []
-    for generic, bwd_v in ((0, 1), (0, 5), (1, 0)):
+    for generic, bwd_v in ((0, 1), (0, 5), (0, 9), (1, 0)):
         tune('bcnn_generic', generic)
         tune('bwd_v', bwd_v)
         xg = t(xn).to(DEV).requires_grad_(True)

@@ -39,13 +39,14 @@ def test_backward_128_row_kernel(F, b, c, hw, tune):
     """The two structures of the Gram backward - 64-row blocks with a P tile built in LDS (bwd_v=1) and 128-row blocks
     with raw tiles and the operand formed at fragment-read time (bwd_v=5, hk_bwd128.h; the default once B*C/128 fills
     the chip) - give the same dX for the BCNN, covariance and CBP modes (to rounding: the 128-row kernel rounds
-    coef/y before the product), and both agree with the oracle."""
+    coef/y before the product), and both agree with the oracle.  bwd_v=9: the 128-row kernel staged by LDS-DMA
+    (hk_bwd128d.h, BCNN and signed-sqrt modes; swizzled source / read addresses) - the same arithmetic as bwd_v=5."""
     gen = torch.Generator().manual_seed(c + hw)
     x = torch.relu(torch.randn(b, c, hw, hw, generator=gen))
     plan = F.CbpPlan(*F.sketch_hashes(c, c, 2048), 2048, torch.device(DEV) if DEV != 'cuda'
                      else torch.device('cuda', torch.cuda.current_device()))
     res = []
-    for flag in (1, 5):
+    for flag in (1, 5, 9):
         tune('bwd_v', flag)
         out = []
         xg = x.clone().to(DEV).requires_grad_(True)
@@ -60,10 +61,20 @@ def test_backward_128_row_kernel(F, b, c, hw, tune):
         yc = F.compact_bilinear_pool(xg, plan)
         (yc * torch.randn(yc.shape, generator=torch.Generator().manual_seed(3)).to(DEV)).sum().backward()
         out.append(xg.grad.clone())
+        xg = x.clone().to(DEV).requires_grad_(True)
+        ys = F.bilinear_pool(xg, signed_sqrt=True)
+        (ys * torch.randn(ys.shape, generator=torch.Generator().manual_seed(4)).to(DEV)).sum().backward()
+        out.append(xg.grad.clone())
         res.append(out)
-    for p, q, tol in zip(res[0], res[1], (2e-6, 2e-6, 2e-6)):
+    for p, q, tol in zip(res[0], res[1], (2e-6, 2e-6, 2e-6, 2e-5)):
         assert rel(q, p) < tol
     assert torch.equal(res[0][2], res[1][2])               # CBP: P is gathered, nothing is rounded differently
+    # LDS-DMA staging: the same products.  dX of the GEMM itself is bit-identical (tools/bwd_ab.py compares it); through
+    # the whole backward the scalar t = <y, dy> differs in its last bits (BCNN mode: summed inside the GEMM kernel in a
+    # different order; signed sqrt: t comes from its own kernel, but d - t2 * y is contracted per kernel)
+    for k in (2,):
+        assert rel(res[k][0], res[1][0]) < 1e-6, (k, float(rel(res[k][0], res[1][0])))
+        assert rel(res[k][3], res[1][3]) < 1e-6, (k, float(rel(res[k][3], res[1][3])))
     xo = x.clone().requires_grad_(True)                    # and both agree with the oracle
     yo = O.bilinear_pool(xo)
     (yo * torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))).sum().backward()

@@ -24,7 +24,8 @@ lib.hk_bcnn_colsum_norm(p(x), p(cs), p(inv), B, C, HW, p(ws), nws, st)
 lib.hk_bcnn_gram_norm(p(x), p(inv), p(y), B, C, HW, st)
 out = {}
 for rnd in range(2):
-    for v, tag in ((1, '64-row kernel'), (5, '128-row kernel'), (6, '128-row, no staging in the loop'), (7, '128-row, fragments read once per K-block'), (8, '128-row, neither')):
+    for v, tag in ((1, '64-row kernel'), (5, '128-row kernel'), (6, '128-row, no staging in the loop'), (7, '128-row, fragments read once per K-block'), (8, '128-row, neither'),
+                   (9, '128-row staged by LDS-DMA'), (10, '128-row LDS-DMA, every K-block staged from the addresses of K-block 0 (L2 hits)')):
         lib.hk_tuning_set(b'bwd_v', v)
         for _ in range(3):
             lib.hk_bcnn_bwd_gemm(p(x), p(y), p(dy), p(inv), p(dx), p(tp), B, C, HW, st)
