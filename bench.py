@@ -151,7 +151,7 @@ def kernel_rooflines(B, C, HW, dev):
          0.0, 4.0 * B * C * HW),
         ('bcnn_gram_panel_kernel<196>', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
          flops, 4.0 * B * C * HW + 4.0 * B * C * C),
-        ('bcnn_bwd128_kernel<196>' if (C % 128 == 0 and B * (C // 128) >= 192) else 'bcnn_bwd_panel_kernel<196>',
+        ('bcnn_bwd128d_kernel<196>' if (C % 128 == 0 and B * (C // 128) >= 192) else 'bcnn_bwd_panel_kernel<196>',
          lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp),
                                                                    B, C, HW, stream()),
          flops, 8.0 * B * C * C + 8.0 * B * C * HW),

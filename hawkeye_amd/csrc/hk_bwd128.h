@@ -51,6 +51,7 @@ struct BwdExtra {
     int D;
     const float* tb;     // [B][nt]     (signed sqrt: partial sums of t = <y, dy>, added in order)
     int nt;
+    int dc_lds;          // CBP, 128-row kernel: the sample's dc vector and the hash / sign tables are copied to LDS once
 };
 
 // t = <y, dy> of sample b from its partial sums (every workgroup adds them itself, fixed order)
@@ -141,18 +142,59 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
     auto ld2 = [&](int kb, int u) -> f32x4 {
         return *reinterpret_cast<const f32x4*>(tbase + (long long)kb * KB * C + o2[u]);
     };
-    auto gather = [&](int kb, int u) -> f32x4 {               // CBP: P(I,K) from the dc vector (CBCNN.py backward)
-        const int i = I * 128 + r1 + 64 * u;
-        const int h1i = ex.h1[i], h2i = ex.h2[i];
-        const float s1i = ex.s1[i], s2i = ex.s2[i];
-        const float* dcb = ex.dc + (long long)b * ex.D;
-        f32x4 p;
+    // CBP: P(I,K) from the dc vector (CBCNN.py backward).  Every element costs two gathers from dc and the hashes /
+    // signs of its column: from global memory that was 32 dependent loads per thread and K-block (L2 hits, but the
+    // vector-memory pipe and their latency sat in front of the LDS stores).  The sample's dc (D floats) and the four
+    // tables (C entries each) are copied to LDS once per workgroup behind the two stages when they fit (ex.dc_lds);
+    // the row's own hash / sign values are loop-invariant registers.
+    const float* dcl = lds + 2 * STAGE;                        // [D], then h1, h2 (int), s1, s2 [C]
+    int hi1[2] = {0, 0}, hi2[2] = {0, 0};
+    float si1[2] = {0.f, 0.f}, si2[2] = {0.f, 0.f};
+    if (MODE == 2) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k = kb * KB + c1 + t;
-            int ba = h1i + ex.h2[k]; if (ba >= ex.D) ba -= ex.D;
-            int bb = ex.h1[k] + h2i; if (bb >= ex.D) bb -= ex.D;
-            p[t] = s1i * ex.s2[k] * dcb[ba] + ex.s1[k] * s2i * dcb[bb];
+        for (int u = 0; u < 2; ++u) {
+            const int i = I * 128 + r1 + 64 * u;
+            hi1[u] = ex.h1[i]; hi2[u] = ex.h2[i]; si1[u] = ex.s1[i]; si2[u] = ex.s2[i];
+        }
+        if (ex.dc_lds) {
+            float* dw = lds + 2 * STAGE;
+            const float* dcb = ex.dc + (long long)b * ex.D;
+            for (int e = tid; e < ex.D; e += 512) dw[e] = dcb[e];
+            int* tw = reinterpret_cast<int*>(dw + ex.D);
+            for (int e = tid; e < C; e += 512) {
+                tw[e] = ex.h1[e];
+                tw[C + e] = ex.h2[e];
+                reinterpret_cast<float*>(tw)[2 * C + e] = ex.s1[e];
+                reinterpret_cast<float*>(tw)[3 * C + e] = ex.s2[e];
+            }
+            __syncthreads();
+        }
+    }
+    auto gather = [&](int kb, int u) -> f32x4 {
+        const int h1i = hi1[u], h2i = hi2[u];
+        const float s1i = si1[u], s2i = si2[u];
+        f32x4 p;
+        if (ex.dc_lds) {
+            const int* th1 = reinterpret_cast<const int*>(dcl + ex.D);
+            const int* th2 = th1 + C;
+            const float* ts1 = reinterpret_cast<const float*>(th1) + 2 * C;
+            const float* ts2 = ts1 + C;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = kb * KB + c1 + t;
+                int ba = h1i + th2[k]; if (ba >= ex.D) ba -= ex.D;
+                int bb = th1[k] + h2i; if (bb >= ex.D) bb -= ex.D;
+                p[t] = s1i * ts2[k] * dcl[ba] + ts1[k] * s2i * dcl[bb];
+            }
+        } else {
+            const float* dcb = ex.dc + (long long)b * ex.D;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = kb * KB + c1 + t;
+                int ba = h1i + ex.h2[k]; if (ba >= ex.D) ba -= ex.D;
+                int bb = ex.h1[k] + h2i; if (bb >= ex.D) bb -= ex.D;
+                p[t] = s1i * ex.s2[k] * dcb[ba] + ex.s1[k] * s2i * dcb[bb];
+            }
         }
         return p;
     };
@@ -337,9 +379,15 @@ static inline size_t bwd128_lds_bytes() {
 // HK_ERR_UNSUPPORTED unless C % 128 == 0 (the caller then takes the 64-row kernel)
 template <int HW, int MODE>
 static int bwd128_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
-                         int B, int C, const BwdExtra& ex, hipStream_t st) {
+                         int B, int C, const BwdExtra& ex_in, hipStream_t st) {
     if (C % 128 != 0) return HK_ERR_UNSUPPORTED;
-    const size_t lds = bwd128_lds_bytes<HW, MODE>();
+    size_t lds = bwd128_lds_bytes<HW, MODE>();
+    BwdExtra ex = ex_in;
+    ex.dc_lds = 0;
+    if (MODE == 2) {                                        // dc + tables behind the two stages when they fit
+        const size_t extra = ((size_t)ex.D + 4 * (size_t)C) * sizeof(float);
+        if (lds + extra <= 160 * 1024) { lds += extra; ex.dc_lds = 1; }
+    }
     static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, MODE>),

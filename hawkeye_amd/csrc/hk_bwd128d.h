@@ -29,7 +29,10 @@
 // Tried and removed: FOUR stages of 16 channels with the pieces issued three K-blocks ahead, an explicit
 // s_waitcnt vmcnt(n) + s_barrier instead of __syncthreads (so that only the pieces needed next are waited for) and the
 // next K-block's first fragments read before the barrier: 69.9 us / 66.5 us from L2 - the same; the barrier was not
-// waiting for HBM.
+// waiting for HBM.  A diagonal walk of the column blocks (row block I at column block (S - I) mod nI, so that the
+// partner row blocks of an image read dy(I, J) and dy(J, I) within the same four K-blocks): 70.5 us against 69.4 us and
+// MORE L2 misses (FETCH_SIZE x 2 = 253 MB against 208 MB, profiles/r2_bwd_diag1_fetch.csv) - the four row blocks of an
+// image no longer read the same X block at the same time.
 #pragma once
 #include "hk_bwd128.h"
 

@@ -249,6 +249,8 @@ class _CompactBilinearPool(torch.autograd.Function):
         x = _f32c(x)
         b, c, h, w = x.shape
         hw, d = h * w, plan.D
+        if plan.C != c:
+            raise _lib.HawkeyeHipError(f'compact_bilinear_pool: the plan was built for {plan.C} channels, input has {c}')
         y = torch.empty(b, d, dtype=torch.float32, device=x.device)
         c_raw = torch.empty(b, d, dtype=torch.float32, device=x.device)
         inv_norm = torch.empty(b, dtype=torch.float32, device=x.device)
@@ -297,6 +299,8 @@ class _AttPool(torch.autograd.Function):
             ctx.has_att = False
             return gap, None
         a_s = _f32c(a_s)
+        if a_s.numel() != b * h * w:
+            raise _lib.HawkeyeHipError(f'att_pool: spatial attention must have {b} x {h} x {w} elements, got {tuple(a_s.shape)}')
         sgap = torch.empty(b, c, dtype=torch.float32, device=f.device)
         check(lib.hk_att_pool_fwd(ptr(f), ptr(a_s), ptr(gap), ptr(sgap), b, c, h * w, stream()), 'hk_att_pool_fwd')
         ctx.save_for_backward(f, a_s)
@@ -370,6 +374,8 @@ class _RoiCropResize(torch.autograd.Function):
         x = _f32c(x)
         b, c, h, w = x.shape
         box, drop = _f32c(box), _f32c(drop)
+        if tuple(box.shape) != (b, 4) or tuple(drop.shape) != (b, 4):
+            raise _lib.HawkeyeHipError(f'roi_crop_resize: box and drop must be [{b}, 4], got {tuple(box.shape)} and {tuple(drop.shape)}')
         y = torch.empty_like(x)
         check(lib.hk_roi_crop_resize_fwd(ptr(x), ptr(box), ptr(drop), ptr(y), b, c, h, w, int(training), stream()),
               'hk_roi_crop_resize_fwd')
@@ -421,6 +427,8 @@ class _OsmeScale(torch.autograd.Function):
         lib = _lib.load()
         x, m = _f32c(x), _f32c(m)
         n, c, h, w = x.shape
+        if m.dim() != 3 or tuple(m.shape[1:]) != (n, c):
+            raise _lib.HawkeyeHipError(f'osme_scale: gates must be [P, N, C] = [P, {n}, {c}], got {tuple(m.shape)}')
         p = m.shape[0]
         s = torch.empty(p, n, c, h, w, dtype=torch.float32, device=x.device)
         check(lib.hk_osme_scale_fwd(ptr(x), ptr(m), ptr(s), p, n, c, h * w, stream()), 'hk_osme_scale_fwd')

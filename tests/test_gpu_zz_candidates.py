@@ -107,6 +107,28 @@ def test_roi_crop_backward_lds_variant_bit_identical(F, mode, tune):
     assert torch.equal(res[0][1], res[1][1])               # the forward kernels too (roi_bwd=1 keeps both round-1 kernels)
 
 
+def test_wrappers_refuse_mismatched_shapes(F):
+    """The C ABI takes raw pointers and sizes: a tensor of the wrong shape would be read out of bounds (a [N, C] gate
+    vector handed to osme_scale as if it were [P, N, C] faulted the GPU in a profiling script).  The host wrappers
+    check what the kernels cannot."""
+    from hawkeye_amd._lib import HawkeyeHipError
+    x = torch.randn(2, 8, 5, 5).to(DEV)
+    with pytest.raises(HawkeyeHipError):
+        F.osme_scale(x, torch.rand(2, 8).to(DEV))
+    with pytest.raises(HawkeyeHipError):
+        F.att_pool(x, torch.rand(2, 1, 4, 4).to(DEV))
+    with pytest.raises(HawkeyeHipError):
+        F.roi_crop_resize(x, torch.zeros(3, 4).to(DEV), torch.zeros(2, 4).to(DEV), False)
+    plan = F.CbpPlan(*F.sketch_hashes(16, 16, 64), 64, torch.device(DEV) if DEV != 'cuda'
+                     else torch.device('cuda', torch.cuda.current_device()))
+    with pytest.raises(HawkeyeHipError):
+        F.compact_bilinear_pool(x, plan)
+    with pytest.raises(HawkeyeHipError):
+        F.linear(torch.randn(2, 10).to(DEV), torch.randn(3, 11).to(DEV))
+    with pytest.raises(HawkeyeHipError):
+        F.npairs_loss(torch.randn(4, 2, 8).to(DEV), torch.zeros(3, dtype=torch.long).to(DEV))
+
+
 @pytest.mark.parametrize('h,w', [(14, 14), (28, 28), (64, 64), (33, 47), (5, 7), (3, 60)])
 def test_roi_crop_backward_other_map_sizes(F, h, w, tune):
     """The ROI-refinement backward on maps other than AP-CNN's 56 x 56: the three pixels-per-thread instances (maps up

@@ -19,10 +19,11 @@ st = P(torch.cuda.current_stream().cuda_stream)
 p = lambda t: P(t.data_ptr())
 assert lib.hk_bcnn_colsum_norm(p(x), p(cs), p(inv), B, C, HW, p(ws), nws, st) == 0
 assert lib.hk_bcnn_gram_norm(p(x), p(inv), p(y), B, C, HW, st) == 0
-names = {1: '64-row kernel (bwd_v=1)', 5: '128-row, register-staged (bwd_v=5)', 9: '128-row, LDS-DMA (bwd_v=9, default)'}
+names = {(1, 0): '64-row kernel (bwd_v=1)', (5, 0): '128-row, register-staged (bwd_v=5)',
+         (9, 0): '128-row, LDS-DMA (bwd_v=9, default)'}
 out = {n: [] for n in names.values()}
 for rnd in range(5):
-    for v, tag in names.items():
+    for (v, dg), tag in names.items():
         lib.hk_tuning_set(b'bwd_v', v)
         for _ in range(3):
             assert lib.hk_bcnn_bwd_gemm(p(x), p(y), p(dy), p(inv), p(dx), p(tp), B, C, HW, st) == 0

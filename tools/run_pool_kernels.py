@@ -27,12 +27,53 @@ for _ in range(reps):
     lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream())
     lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream())
 torch.cuda.synchronize()
-print('ok')
+print('ok', flush=True)
 
-if len(sys.argv) > 2 and sys.argv[2] == 'ns':          # also the Newton-Schulz chain (generic bgemm_kernel, 256^3 x 64)
+mode = sys.argv[2] if len(sys.argv) > 2 else ''
+if mode in ('ns', 'all'):          # the Newton-Schulz chain (grouped nsmm_kernel launches, 256^3 x 64), forward and backward
     import hawkeye_amd.functional as F
-    cov = F.covpool(torch.relu(torch.randn(64, 256, 14, 14, device=dev)))
+    xc = torch.relu(torch.randn(64, 256, 14, 14, device=dev)).requires_grad_(True)
+    wt = torch.randn(64, 256, 256, device=dev)
     for _ in range(2):
-        F.sqrtm(cov, 5)
+        xc.grad = None
+        (F.sqrtm(F.covpool(xc), 5) * wt).sum().backward()      # covariance fwd / bwd kernels as well
     torch.cuda.synchronize()
-    print('ns ok')
+    print('ns ok', flush=True)
+
+if mode == 'all':                  # the other heads at the BASELINE config shapes (SURVEY 8a rows A2, A7, A9, A10 + 8f)
+    import hawkeye_amd.functional as F
+    # A2 compact bilinear pooling, B = 64, C = 512, D = 6000
+    plan = F.CbpPlan(*F.sketch_hashes(512, 512, 6000), 6000, dev)
+    xb = torch.relu(torch.randn(64, 512, 14, 14, device=dev)).requires_grad_(True)
+    wc = torch.randn(64, 6000, device=dev)
+    # signed-sqrt Gram (BCNN.py:23-24)
+    ws = torch.randn(64, 512 * 512, device=dev)
+    # A7 attention pooling (AP-CNN level 3: 16 x 512 x 56 x 56, 200 classes) / A9 ROI refinement / A10 OSME (2 x 16 x 2048 x 7 x 7)
+    f3 = torch.randn(16, 512, 56, 56, device=dev, requires_grad=True)
+    a3 = torch.rand(16, 1, 56, 56, device=dev)
+    box = torch.tensor([[3.2, 5.9, 40.1, 33.3]] * 8 + [[20.2, 14.9, 43.1, 35.3]] * 8, device=dev)
+    drop = torch.tensor([[10., 12., 20., 30.]] * 16, device=dev)
+    xo = torch.relu(torch.randn(16, 2048, 7, 7, device=dev)).requires_grad_(True)
+    # 8f: classifier (262144 -> 200), n-pairs loss
+    yl = torch.randn(64, 262144, device=dev)
+    wl, bl = torch.randn(200, 262144, device=dev) * 0.01, torch.zeros(200, device=dev)
+    parts = torch.randn(32, 2, 1024, device=dev, requires_grad=True)
+    tg = torch.arange(16, device=dev).repeat_interleave(2)
+    for _ in range(reps):
+        xb.grad = None
+        (F.compact_bilinear_pool(xb, plan) * wc).sum().backward()
+        xb.grad = None
+        (F.bilinear_pool(xb, signed_sqrt=True) * ws).sum().backward()
+        f3.grad = None
+        g, sg = F.att_pool(f3, a3)
+        (g.sum() + sg.sum()).backward()
+        f3.grad = None
+        F.roi_crop_resize(f3, box, drop, True).sum().backward()
+        xo.grad = None
+        z = F.osme_gap(xo)
+        (F.osme_scale(xo, torch.sigmoid(torch.stack([z, 0.5 * z]))).sum()).backward()      # P = 2 gates [P, N, C]
+        F.linear(yl, wl, bl)
+        parts.grad = None
+        F.npairs_loss(parts, tg).backward()
+    torch.cuda.synchronize()
+    print('all ok', flush=True)
