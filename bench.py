@@ -111,19 +111,25 @@ def build_model(name, classes):
     return MODEL.get(name)(cfg)
 
 
-def time_events(fn, iters, warm=3):
+def time_events(fn, iters, warm=3, rounds=1):
     """Average duration (ms) of fn() measured with HIP events on torch's current stream - the stream the
-    C ABI launches on (functional.stream())."""
+    C ABI launches on (functional.stream()).  rounds > 1: that many back-to-back rounds of `iters` launches with no
+    host synchronisation in between; returns (last round, first round).  Under a sustained fp32-MFMA load the chip's
+    clock settles only after ~10 ms (tools/bwd_ab.py: 77 -> 72 -> 69.5 us over the first three rounds of the same
+    kernel), so a kernel timed cold is 8-10 % slower than the same kernel inside a busy training step."""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(rounds + 1)]
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
+    ev[0].record()
+    for r in range(rounds):
+        for _ in range(iters):
+            fn()
+        ev[r + 1].record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    if rounds == 1:
+        return ev[0].elapsed_time(ev[1]) / iters
+    return ev[rounds - 1].elapsed_time(ev[rounds]) / iters, ev[0].elapsed_time(ev[1]) / iters
 
 
 def kernel_rooflines(B, C, HW, dev):
@@ -160,10 +166,10 @@ def kernel_rooflines(B, C, HW, dev):
     ]
     out = []
     for name, fn, fl, by in stages:
-        ms = time_events(fn, 50)
+        ms, ms_first = time_events(fn, 50, rounds=4)       # steady state: the fourth back-to-back round of 50 launches
         tf, gbs = fl / ms / 1e9, by / ms / 1e6
         bound = 'mfma' if fl > 0 and fl / by > PEAK_MFMA_F32_TF * 1e3 / PEAK_HBM_GBS else 'hbm'
-        out.append({'kernel': name, 'us': round(ms * 1e3, 2), 'bound': bound,
+        out.append({'kernel': name, 'us': round(ms * 1e3, 2), 'us_first_round': round(ms_first * 1e3, 2), 'bound': bound,
                     'achieved': round(tf if bound == 'mfma' else gbs, 2),
                     'peak': PEAK_MFMA_F32_TF if bound == 'mfma' else PEAK_HBM_GBS,
                     'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',

@@ -8,6 +8,11 @@ RandomResizedCrop scale (0.08, 1) / ratio (3/4, 4/3) with ten attempts and a cen
 one of 14 operations drawn uniformly, its strength one of 31 bins drawn uniformly, nearest-neighbour geometry, no
 fill; RandomErasing scale (0.02, 0.33) / ratio (0.3, 3.3), value 0).  Host-side plumbing on the CPU data workers
 (SURVEY 8f-3); randomness comes from python's `random`, which the DataLoader seeds per worker.
+
+PARITY UNPINNED: torchvision is neither in the build container nor on the GPU box (no wheel, no network), so the
+reference's presets cannot be executed to generate fixtures.  tests/test_transforms_cpu.py checks this file against the
+published definitions only; the device tail `hk_image_finalize` is pinned bit-exactly against this file's own CPU path
+(tests/test_gpu_zz_candidates.py::test_image_finalize_bit_exact).
 """
 import math
 import random
