@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "hk_bgemm.h"
+#include "hk_bwd128d.h"      // glds16 (LDS-DMA)
 #include "../../include/hawkeye_hip.h"
 
 namespace hk {
@@ -69,7 +70,178 @@ __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __re
     db[k] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward for the WIDE classifiers (BCNN 262 144 -> 200, OSME 100 352 -> 1024): a workgroup owns one slab of features and
+// ALL of its (up to 64) samples x a group of NT 16-column class tiles, so y is read once and W once, through LDS-DMA.
+// The generic split-K path above runs at 133-144 us on the BCNN shape = 1.95 TB/s (profiles/r2_pool_kernels_pmc.csv:
+// 53 % of its wave time parked on loads, y fetched by four class tiles, one chunk of register prefetch); the product is
+// balanced between the matrix pipe and HBM (24 FLOP/B), so both have to be kept busy:
+//   * 512 threads = 8 waves: wave w owns samples 16 (w & 3) .. + 15 and the class tiles of half w >> 2 (7 + 6 of 13, or
+//     8 + 8 of 16), 16x16x4 MFMA, A operand = y rows, B operand = W rows - both tiles are [row][32 features] exactly as
+//     they lie in memory, read back with ds_read_b128 through the XOR swizzle of hk_bwd128d.h (slot row * 8 + (k4 ^ (row & 7)));
+//   * chunks of 32 features, FOUR LDS stages (4 x 34.8 KB for 13 class tiles, 4 x 38.9 KB for 15), the pieces of chunk
+//     c + 3 are issued during chunk c; the barrier that ends a chunk waits with s_waitcnt vmcnt(n) for everything but
+//     the n pieces the wave has just issued, so a piece has two whole chunks to arrive;
+//   * the fragments of chunk c + 1 (complete one barrier earlier) are read behind the last MFMAs of chunk c.
+// Partial results [S][B][K] as before, added in slab order by linear_reduce_kernel: deterministic.
+#define HK_VMCNT_IMM(n) (((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))     /* gfx9 s_waitcnt: vmcnt only */
+#define HK_VM_BARRIER(n)                                                                                       \
+    do {                                                                                                       \
+        asm volatile("" ::: "memory");                 /* no LDS access moves across */                        \
+        __builtin_amdgcn_s_waitcnt(HK_VMCNT_IMM(n));                                                           \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        asm volatile("" ::: "memory");                                                                         \
+    } while (0)
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __restrict__ y, const float* __restrict__ w,
+                                                               float* __restrict__ part, int B, int J, int K, int KS,
+                                                               int S, int ngrp) {
+    constexpr int NH = (NT + 1) / 2;
+    constexpr int NS = 4;                                // LDS stages (chunk c + 1 must be complete one barrier early: >= 4)
+    constexpr int CH = 32;                               // features per chunk
+    constexpr int A_SZ = 64 * CH, B_SZ = NT * 16 * CH;   // floats
+    constexpr int STAGE = A_SZ + B_SZ;
+    constexpr int NPA = 8, NPB = NT * 2, NP = NPA + NPB; // 1 KB pieces per chunk: 8 rows x 32 floats each
+    constexpr int PPW = (NP + 7) / 8;                    // pieces per wave (at most)
+    HK_DYN_LDS16(lds);
+
+    int slab, grp;
+    if (!xcd_map(blockIdx.x, S, ngrp, slab, grp)) return;
+    const int rg = blockIdx.y;                                  // group of 64 samples
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int rb = wave & 3, half = wave >> 2;
+    const int nt0 = half * NH, nloc = half ? NT - NH : NH;
+    const long long f0 = (long long)slab * KS;                  // first feature of the slab
+    const int nfeat = (J - f0) < KS ? (int)(J - f0) : KS;       // (a multiple of 32: J % 32 == 0, KS % 32 == 0)
+    const int nch = nfeat / CH;
+
+    // this lane's source offsets (floats, from y / w + f0 + 32 c) in the pieces its wave issues: piece p = wave + 8 u;
+    // p < 8: sample rows 8 p .. 8 p + 7 (clamped to the last sample), else class rows 8 (p - 8) .. (clamped to K - 1);
+    // LDS slot j = lane & 7 of row r holds the feature quad j ^ (r & 7)
+    long long src[PPW];
+    int npc = 0;
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+        const int p = wave + 8 * u;
+        const int r8 = lane >> 3, q4 = 4 * ((lane & 7) ^ (r8 & 7));
+        if (p < NPA) {
+            int row = rg * 64 + 8 * p + r8;
+            row = row < B ? row : B - 1;
+            src[u] = (long long)row * J + q4;
+        } else {
+            int n = grp * (NT * 16) + 8 * (p - NPA) + r8;
+            n = n < K ? n : K - 1;
+            src[u] = (long long)n * J + q4;
+        }
+        if (p < NP) ++npc;
+    }
+    // pieces of chunk c into stage st (float offset); part 0 / 1: first / second half of the wave's pieces
+    auto dma = [&](int c, int st, int part) {
+        const long long fo = f0 + (long long)c * CH;
+#pragma unroll
+        for (int u = 0; u < PPW; ++u) {
+            if ((u < (PPW + 1) / 2) != (part == 0)) continue;
+            const int p = wave + 8 * u;
+            if (p < NP) glds16((p < NPA ? y : w) + src[u] + fo, lds + st + 256 * p);
+        }
+    };
+    auto vm_barrier = [&](bool all) {
+        if (all) HK_VM_BARRIER(0);
+        else if (npc == 6) HK_VM_BARRIER(6);
+        else if (npc == 5) HK_VM_BARRIER(5);
+        else if (npc == 4) HK_VM_BARRIER(4);
+        else if (npc == 3) HK_VM_BARRIER(3);
+        else HK_VM_BARRIER(0);
+    };
+
+    f32x4 acc[NH];
+#pragma unroll
+    for (int n = 0; n < NH; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragments of feature step s (0 / 1) of the chunk in stage st: a = y[16 rb + l15][16 s + 4 lq ..+3],
+    // b[n] = W[16 (nt0 + n) + l15][same features]
+    const int arow = 16 * rb + l15;
+    const int aoff = arow * CH, asw = arow & 7;
+    const int boff = A_SZ + (16 * nt0 + l15) * CH, bsw = l15 & 7;      // (16 (nt0 + n) is a multiple of 8)
+    auto frag = [&](int st, int s, f32x4& a, f32x4 (&b)[NH]) {
+        const float* base = lds + st;
+        a = *reinterpret_cast<const f32x4*>(base + aoff + (((4 * s + lq) ^ asw) << 2));
+#pragma unroll
+        for (int n = 0; n < NH; ++n)
+            b[n] = (n < nloc) ? *reinterpret_cast<const f32x4*>(base + boff + n * 16 * CH + (((4 * s + lq) ^ bsw) << 2))
+                              : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto mma = [&](const f32x4& a, const f32x4 (&b)[NH]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int n = 0; n < NH; ++n)
+                if (n < NH - 1 || n < nloc) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n][t], acc[n], 0, 0, 0);
+    };
+
+    // prologue: chunks 0 .. NS - 2 into stages 0 .. NS - 2
+    for (int c = 0; c < NS - 1 && c < nch; ++c) { dma(c, c * STAGE, 0); dma(c, c * STAGE, 1); }
+    vm_barrier(true);
+    f32x4 a0, a1, b0[NH], b1[NH];
+    frag(0, 0, a0, b0);
+    int cur = 0;                                                 // stage of chunk c (float offset), nxt = chunk c + 1
+    for (int c = 0; c < nch; ++c) {
+        const int nxt = cur + STAGE < NS * STAGE ? cur + STAGE : 0;
+        const int dst = cur >= STAGE ? cur - STAGE : (NS - 1) * STAGE;      // stage of chunk c - 1 = chunk c + NS - 1
+        const bool load = c + NS - 1 < nch;                      // uniform
+        frag(cur, 1, a1, b1);
+        mma(a0, b0);
+        if (load) dma(c + NS - 1, dst, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nch) frag(nxt, 0, a0, b0);                   // complete and published by the previous barrier
+        mma(a1, b1);
+        if (load) dma(c + NS - 1, dst, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        vm_barrier(!load);
+        cur = nxt;
+    }
+
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+    float* pb = part + (long long)slab * B * K;
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
+        const int col = grp * (NT * 16) + 16 * (nt0 + n) + l15;
+        if (n < nloc && col < K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rg * 64 + 16 * rb + 4 * lq + r;
+                if (row < B) pb[(long long)row * K + col] = acc[n][r];
+            }
+        }
+    }
+}
+
+// the wide-classifier plan: slabs of KS features for linear_skinny_kernel; false when the generic path serves the shape
+static inline bool skinny_plan(int B, int J, int K, int& KS, int& S, int& nt, int& ngrp, int& nrg) {
+    if (tuning().linear_slabs < 0) return false;                 // knob: -1 forces the generic split-K path
+    if (J % 32 != 0) return false;
+    nt = K <= 208 ? 13 : 15;
+    ngrp = (K + nt * 16 - 1) / (nt * 16);
+    nrg = (B + 63) / 64;
+    const long long chunks = (long long)(J / 32) * ngrp * nrg;   // chunk-tasks in all
+    // Not for: too little work to amortise a 4-stage pipeline per workgroup; fewer than half of the 64 sample rows of the
+    // MFMA tiles in use (OSME, N = 10: 273 us here against 203 us on the generic path - the rows are wasted matrix-pipe
+    // time and the product is a pure stream of W).  A forced slab count also forces this path (tests).
+    if ((chunks < 256 * 16 || B < 33) && tuning().linear_slabs <= 0) return false;
+    long long want = 256 / ((long long)ngrp * nrg);              // one workgroup per CU
+    if (want < 1) want = 1;
+    if (tuning().linear_slabs > 0) want = tuning().linear_slabs;
+    KS = (int)(((J / 32 + want - 1) / want) * 32);
+    S = (J + KS - 1) / KS;
+    return true;
+}
+
 static inline void slab_plan(int B, int J, int K, int& KS, int& S) {
+    int nt, ngrp, nrg;
+    if (skinny_plan(B, J, K, KS, S, nt, ngrp, nrg)) return;
     const long long tiles = (long long)((B + 63) / 64) * ((K + 63) / 64);
     // exactly ONE wave of workgroups over the chip: 256 CUs x 4 resident 64x64x32 workgroups = 1024.  Measured at the BCNN
     // shape (4 tiles; BENCH_r01 sweep): 256 slabs = 1024 workgroups 132 us; 128 -> 170, 384 (1.5 waves: the round-1
@@ -102,6 +274,29 @@ extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, 
     int KS, S;
     slab_plan(B, J, K, KS, S);
     float* part = (float*)ws;
+    int nt, ngrp, nrg;
+    if (aligned16(y) && aligned16(w) && skinny_plan(B, J, K, KS, S, nt, ngrp, nrg)) {
+        const dim3 grid(xcd_grid(S, ngrp), nrg);
+        const void* fn = nt == 13 ? reinterpret_cast<const void*>(&linear_skinny_kernel<13>)
+                                  : reinterpret_cast<const void*>(&linear_skinny_kernel<15>);
+        const size_t lds = (size_t)4 * (64 * 32 + nt * 16 * 32) * sizeof(float);
+        static bool attr13 = false, attr15 = false;             // > 64 KB of dynamic LDS needs the opt-in
+        bool& attr = nt == 13 ? attr13 : attr15;
+        if (!attr) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr = true;
+        }
+        if (nt == 13)
+            hipLaunchKernelGGL((linear_skinny_kernel<13>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
+        else
+            hipLaunchKernelGGL((linear_skinny_kernel<15>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
+        HK_LAUNCH_CHECK();
+        const int BK = B * K;
+        hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, out, BK, K, S);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     LdSlab la, lb;
     la.p = y; la.ld = J; la.R = B; la.J = J; la.KS = KS; la.vec = (aligned16(y) && J % 4 == 0) ? 1 : 0;
     lb.p = w; lb.ld = J; lb.R = K; lb.J = J; lb.KS = KS; lb.vec = (aligned16(w) && J % 4 == 0) ? 1 : 0;

@@ -255,6 +255,27 @@ def test_linear_split_k(F, b, j, k, bias, tune):
             assert rel(bg.grad, b64.grad) < 2e-6
 
 
+@pytest.mark.parametrize('b,j,k,slabs', [(70, 2048, 250, 4), (10, 3200, 500, 2), (64, 1024, 200, 1), (3, 640, 13, 5),
+                                         (64, 8192, 200, 0)])
+def test_linear_wide_classifier_kernel(F, b, j, k, slabs, tune):
+    """linear_skinny_kernel (the forward of the wide classifiers: a workgroup owns a slab of features, all samples and a
+    group of 13 / 15 class tiles; LDS-DMA staging, four stages, explicit vmcnt(n) barriers): more than 64 samples (two
+    row groups), more than 208 classes (several class groups, the last one ragged), a single slab, slabs with fewer
+    chunks than pipeline stages, and the automatic plan - against fp64 and against the generic split-K path
+    (linear_slabs = -1)."""
+    gen = torch.Generator().manual_seed(b + j + k)
+    y = torch.randn(b, j, generator=gen)
+    w = torch.randn(k, j, generator=gen) / j ** 0.5
+    bv = torch.randn(k, generator=gen)
+    o64 = torch.nn.functional.linear(y.double(), w.double(), bv.double())
+    outs = []
+    for s in (slabs, -1):
+        tune('linear_slabs', s)
+        outs.append(F.linear(y.to(DEV), w.to(DEV), bv.to(DEV)).cpu())
+        assert rel(outs[-1], o64) < 2e-6, s
+    assert rel(outs[0], outs[1]) < 2e-6
+
+
 def test_mamc_npairs_loss_vs_reference_goldens(F):
     """hk_npairs_loss vs the REFERENCE's NPairsLoss / MAMCLoss (tests/golden/mamc_loss.npz) and the
     oracle, including empty positive / negative sets."""

@@ -95,7 +95,7 @@ def linear():
         nws = lib.hk_linear_ws_bytes(B, J, K)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         fl = 2.0 * B * J * K
-        row(f'linear fwd {tag}', 'hk_linear_fwd (split-K MFMA)',
+        row(f'linear fwd {tag}', 'hk_linear_fwd (automatic: wide-classifier kernel where it applies)',
             timeit(lambda: lib.hk_linear_fwd(ptr(y), ptr(w), ptr(b), ptr(out), B, J, K, ptr(ws), nws, stream())), fl,
             4.0 * (B * J + K * J))
         row(f'linear fwd {tag}', 'torch F.linear (rocBLAS/hipBLASLt)', timeit(lambda: TF.linear(y, w, b)), fl,
@@ -107,8 +107,8 @@ def linear():
             4.0 * (2 * B * J + 2 * K * J))
         err = float((out - TF.linear(y, w, b)).norm() / TF.linear(y, w, b).norm())
         rows[-4]['rel_err_vs_torch'] = err
-        if tag.startswith('bcnn'):                      # slab-count sweep for the split-K forward (auto = 384 here)
-            for slabs in sz((64, 128, 256, 768, 1024), (2, 3)):
+        if tag.startswith('bcnn'):                      # -1: the generic split-K path (round-2a default, 256 slabs); then a
+            for slabs in sz((-1, 128, 192, 256, 512), (2, 3)):      # slab-count sweep of the wide-classifier kernel (auto = 256)
                 knob('linear_slabs', slabs)
                 n2 = lib.hk_linear_ws_bytes(B, J, K)
                 ws2 = torch.empty(n2, dtype=torch.uint8, device=dev)
