@@ -397,6 +397,46 @@ def gen_models(models):
     save('model_osme', logits=logits, parts=parts)
 
 
+APCNN_TRAIN_BATCH = 8
+
+
+def gen_apcnn_train():
+    """AP-CNN in TRAIN mode (BatchNorm on batch statistics, the python-`random` drop block of APCNN.py:485-504 with a
+    fixed seed): logits of both stages and a few gradients of  sum(out_mean * wt)  - the whole two-stage model with the
+    ROI refinement's backward, as the reference's own autograd computes it.
+    BatchNorm over a batch of TWO samples divides by the difference of two nearly equal pooled features: rounding
+    differences of 1e-7 in a feature come out as 1e-3 in a logit.  The reference is therefore run twice, in float64
+    (the pinned values) and in float32 (what it actually executes); the float32 run's own distance from the float64
+    one is stored per tensor (`e32_*`) and is the yardstick of the test's tolerances."""
+    import random
+    from inputs import seeded_init
+    runs = {}
+    for dt in (torch.float64, torch.float32):
+        m = M_AP.resnet50(200)
+        seeded_init(m, 910)
+        m = m.to(dt).train()
+        x = t(rs_randn(911, (APCNN_TRAIN_BATCH, 3, 224, 224))).to(dt)
+        wt = t(rs_randn(912, (APCNN_TRAIN_BATCH, 200))).to(dt)
+        random.seed(3)
+        out_mean, out_list, mask_cat, roi_list = m(x, None)
+        (out_mean * wt).sum().backward()
+        runs[dt] = (out_mean.detach(), torch.stack(out_list).detach(), roi_list,
+                    {n: p.grad for n, p in m.named_parameters() if p.grad is not None})
+    om, ol, rois, grads = runs[torch.float64]
+    om32, ol32, rois32, grads32 = runs[torch.float32]
+    assert all(torch.equal(a[:, :5].float(), b[:, :5]) for a, b in zip(rois, rois32)), 'fp32 / fp64 picked different ROIs'
+    keep = ['conv1.weight', 'layer2.0.conv1.weight', 'layer4.2.conv3.weight', 'cls_concate.1.weight']
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    stride = lambda k: max(7, grads[k].numel() // 2000 | 1)
+    save('model_apcnn_train', out_mean=om, out_list=ol, roi3=rois[0].float(), roi4=rois[1].float(), roi5=rois[2].float(),
+         e32_out_list=np.array([rel(ol32[i], ol[i]) for i in range(8)]), e32_out_mean=np.array([rel(om32, om)]),
+         grad_names=np.array(keep), **{'g%d' % i: sub(grads[k], stride(k)) for i, k in enumerate(keep)},
+         **{'gn%d' % i: grads[k].norm().reshape(1) for i, k in enumerate(keep)},
+         e32_g=np.array([rel(grads32[k], grads[k]) for k in keep]))
+    print('fp32 reference vs fp64 reference: out_list', [rel(ol32[i], ol[i]) for i in range(8)],
+          'grads', [rel(grads32[k], grads[k]) for k in keep])
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:                       # regenerate selected fixtures only, e.g. `gen_golden.py mamc`

@@ -140,6 +140,44 @@ def test_train_step_runs_and_updates(name, size):
     assert changed > 0.9 * len(before)
 
 
+def test_apcnn_train_mode_matches_reference():
+    """AP-CNN in TRAIN mode against the reference (tests/golden/model_apcnn_train.npz, oracle/gen_golden.py
+    gen_apcnn_train; batch 8): BatchNorm on batch statistics, the drop block of APCNN.py:485-504 driven by python
+    `random` with the same seed (exact_random_stream replays the reference's draws), both stages' logits, and the
+    gradient of sum(out_mean * wt) at four depths of the network - i.e. through hk_roi_crop_resize_bwd,
+    hk_att_pool_bwd and the ROI selection, as the reference's own autograd computes it.  The pinned values are the
+    reference run in float64; the tolerances are multiples of the distance of the reference's OWN float32 run from
+    them (`e32_*`: 1e-5 on the logits, 4e-3 on the first convolution's gradient - train-mode BatchNorm amplifies
+    rounding; at batch 2 the reference's float32 gradients are 18 % away from its float64 ones)."""
+    import random
+    g = load('model_apcnn_train')
+    n = g['out_mean'].shape[0]
+    m = build('APCNN', num_classes=200)
+    seeded_init(m, 910)
+    m = m.to(DEV).train()
+    m.exact_random_stream = True
+    x = t(rs_randn(911, (n, 3, 224, 224))).to(DEV)
+    wt = t(rs_randn(912, (n, 200))).to(DEV)
+    random.seed(3)
+    out_mean, out_list, _mask, rois = m(x, None)
+    (out_mean * wt).sum().backward()
+    for got, key in zip(rois, ('roi3', 'roi4', 'roi5')):       # same cells picked
+        got = got.cpu().numpy()
+        assert got.shape == g[key].shape
+        np.testing.assert_array_equal(got[:, :5], g[key][:, :5])
+    k = 5.0 if DEV == 'cpu' else 20.0                          # (GPU: MIOpen convolutions in a different summation order)
+    for i, o in enumerate(out_list):
+        r = float(rel(o, g['out_list'][i]))
+        assert r < k * max(float(g['e32_out_list'][i]), 1e-5), (i, r, float(g['e32_out_list'][i]))
+    assert rel(out_mean, g['out_mean']) < k * max(float(g['e32_out_mean'][0]), 1e-5)
+    grads = dict(m.named_parameters())
+    for i, name in enumerate(g['grad_names']):
+        gr = grads[str(name)].grad
+        r = float(rel(sub(gr.cpu(), max(7, gr.numel() // 2000 | 1)), g['g%d' % i]))
+        assert r < k * max(float(g['e32_g'][i]), 1e-5), (str(name), r, float(g['e32_g'][i]))
+        assert abs(float(gr.double().norm()) / float(g['gn%d' % i][0]) - 1) < k * max(float(g['e32_g'][i]), 1e-5), str(name)
+
+
 def test_apcnn_exact_random_stream_mode():
     """exact_random_stream=True consumes python `random` exactly like the reference (APCNN.py:494-501):
     random() per image, then randint(0, n-1) on the level-3 / level-4 ROI count."""
