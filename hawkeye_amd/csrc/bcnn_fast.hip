@@ -168,12 +168,21 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     for (int i = 0; i < 16; ++i) prev[i] = 0.f;
     bool has_prev = false;
 
+    // Column blocks of a row block.  Paired rows (pair_mode 1: rows w and nb - 1 - w, nb + 1 tiles per workgroup) walk
+    // J = I .. nb - 1.  A single row (pair_mode 0) walks CYCLICALLY, J = I, I + 1, .. (mod nb), nb / 2 + 1 columns for
+    // the first half of the rows and nb / 2 for the second ((nb + 1) / 2 for odd nb): every unordered pair {I, J} is
+    // produced once (tile (I, J) and its mirror are both written) and no workgroup has more than nb / 2 + 1 tiles -
+    // the triangular walk gave row 0 nb tiles and row nb - 1 one.
+    const int cyc = pair_mode ? 0 : ((nb & 1) ? (nb + 1) / 2 : (rb0 < nb / 2 ? nb / 2 + 1 : nb / 2));
     for (int ri = 0; ri < nrb; ++ri) {
         const int I = ri == 0 ? rb0 : rb1;
-        for (int J = I; J < nb; ++J) {
+        const int cnt = pair_mode ? nb - I : cyc;
+        for (int tt = 0; tt < cnt; ++tt) {
+            int J = I + tt;
+            if (J >= nb) J -= nb;
             int next_blk = -1;
             bool newrow = false;
-            if (J + 1 < nb) next_blk = J + 1;
+            if (tt + 1 < cnt) next_blk = (J + 1 < nb) ? J + 1 : 0;
             else if (ri + 1 < nrb) { next_blk = rb1; newrow = true; }
             const int n_idx = (a_idx == b_idx) ? (a_idx + 1) % 3 : 3 - a_idx - b_idx;
 

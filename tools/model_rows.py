@@ -6,7 +6,7 @@
 For each: ms per full train step (forward, loss, backward, SGD step; synthetic batch resident in HBM) and the
 HIP-event time + roofline fraction of every hand-written kernel of its pooling head at that batch size.
 bench.py runs this in a subprocess after the headline measurement and attaches the list as `other_models`.
-    python tools/model_rows.py [--quick]      # prints one JSON list
+    python tools/model_rows.py [--quick | --kernels-only]      # prints one JSON list
 """
 import json
 import os
@@ -152,6 +152,9 @@ if __name__ == '__main__':
     guarded(mpn_kernels)
     guarded(cbp_kernels)
     guarded(apcnn_kernels)
+    if '--kernels-only' in sys.argv:
+        print(json.dumps(rows), flush=True)
+        sys.exit(0)
     steps = 3 if QUICK else 6
     guarded(train_row, 'MPN', 64, 200, 448, steps)
     guarded(train_row, 'CBCNN', 64, 200, 448, steps)
