@@ -431,6 +431,13 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
         const int rc = bwd128_launch<HW, MODE>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
         if (rc != HK_ERR_UNSUPPORTED) return rc;
     }
+    // 64-row blocks on the eight-wave kernel (two waves per SIMD): where the 128-row blocks would not fill the chip but
+    // the 64-row ones do with ONE workgroup per CU (the covariance at C = 256, B = 64: 256 row blocks) - the 4-wave
+    // panel kernel then has one wave per SIMD and nothing covers its staging phases.  bwd_v = 4 forces it.
+    if (v == 4 || (v == 0 && MODE == 1 && (long long)B * nb >= 192 && (long long)B * nb <= 320)) {
+        const int rc = bwd128_launch<HW, MODE, 1>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
     hipLaunchKernelGGL((bcnn_bwd_panel_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
                        tpart, C, nb, B, ex);
     HK_LAUNCH_CHECK();

@@ -69,7 +69,10 @@ __device__ __forceinline__ float bwd_t_of(const BwdExtra& ex, int b) {
 // between the eight MFMA groups of the block.
 // LABV (HK_LAB builds, timing only - results are wrong): 1 = no staging inside the loop (MFMA + fragment stream alone),
 // 2 = staging but the fragments are read once per K-block only (no per-group LDS reads), 3 = both removed
-template <int HW, int MODE, int LABV = 0>
+// RB: 16-row blocks per wave = 2 (128-row blocks, the structure described above) or 1 (64-row blocks with the same eight
+// waves: for shapes whose 128-row blocks would not fill the chip, e.g. the covariance at C = 256, B = 64 - the 4-wave
+// panel kernel holds ONE wave per SIMD there and nothing covers its staging phases)
+template <int HW, int MODE, int LABV = 0, int RB = 2>
 __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ dy,
                                                              const float* __restrict__ inv_norm, float* __restrict__ dx,
@@ -79,10 +82,11 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
     constexpr int NH = (NT + 1) / 2;            // tiles of the first column half (the second has NT - NH)
     constexpr int KB = 32;                      // channels per K-block
     constexpr int P1 = KB + 4;                  // pitch of the [i][k] tiles (ds_read_b128: pitch / 4 odd)
-    constexpr int P2 = 128 + 4;                 // pitch of the [k][i] tile
+    constexpr int IB = 64 * RB;                 // rows of a block
+    constexpr int P2 = IB + 4;                  // pitch of the [k][i] tile
     constexpr bool HAS_W = MODE == 0 || MODE == 3;
     constexpr bool HAS_S2 = MODE != 2;
-    constexpr int S1_SZ = 128 * P1, W_SZ = HAS_W ? 128 * P1 : 0, S2_SZ = HAS_S2 ? KB * P2 : 0;
+    constexpr int S1_SZ = IB * P1, W_SZ = HAS_W ? IB * P1 : 0, S2_SZ = HAS_S2 ? KB * P2 : 0;
     constexpr int XN4 = KB * HW / 4;            // float4 of one X block
     constexpr int NSX = (XN4 + 511) / 512;      // (<= 4)
     constexpr int X_SZ = (XN4 + 3) / 4 * 16;    // floats, rounded to 64 B
@@ -94,12 +98,12 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
     if (!xcd_map(blockIdx.x, B, nI, b, I)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int wrow = (wave & 3) * 32;
+    const int wrow = (wave & 3) * (16 * RB);
     const int half = __builtin_amdgcn_readfirstlane(wave) >> 2;   // wave-uniform: the tile guards below must be scalar branches
     const int nt0 = half * NH, nloc = half ? NT - NH : NH;      // this wave's column tiles: nt0 .. nt0 + nloc - 1
     const long long cc = (long long)b * C * C;
     const float* xb = x + (long long)b * C * HW;
-    const int nkb = C / KB;                                     // even (C % 128 == 0)
+    const int nkb = C / KB;                                     // even (C % 64 == 0)
     float coef = 1.0f / (float)HW;                              // COV
     if (HAS_W) {
         const float in = inv_norm[b];
@@ -107,9 +111,9 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
     }
     const float t2 = MODE == 3 ? 2.0f * bwd_t_of(ex, b) : 0.f;
 
-    f32x4 acc[2][NH];
+    f32x4 acc[RB][NH];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int n = 0; n < NH; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float tacc = 0.f;
@@ -126,16 +130,17 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
     R0.y0 = R0.y1 = R0.d0 = R0.d1 = R0.t0 = R0.t1 = R0.x0 = R0.x1 = R0.x2 = R0.x3 = z4;
     R0.m0 = R0.m1 = R0.m2 = R0.m3 = 0.f;
 
-    const int r1 = tid >> 3, c1 = 4 * (tid & 7);           // [i][k] tiles: row r1 + 64 u, k offset c1
-    const int r2 = tid >> 5, c2 = 4 * (tid & 31);          // [k][i] tile : k row r2 + 16 u, i offset c2
+    const int r1 = tid >> 3, c1 = 4 * (tid & 7);           // [i][k] tiles: row r1 + 64 u (u < RB), k offset c1
+    // [k][i] tile: RB = 2: k row r2 + 16 u, 32 float4 per row; RB = 1: k row r2 (32 rows at once), 16 float4 per row
+    const int r2 = RB == 2 ? tid >> 5 : tid >> 4, c2 = RB == 2 ? 4 * (tid & 31) : 4 * (tid & 15);
 
     // addresses = wave-uniform base (advances with the K-block, lives in SGPRs) + a loop-invariant 32-bit offset per
     // thread: ten 64-bit per-thread pointers would not fit next to two staging register sets
     const int o1[2] = {r1 * C + c1, (r1 + 64) * C + c1};
     const int o2[2] = {r2 * C + c2, (r2 + 16) * C + c2};
-    const float* ybase = y + cc + (long long)I * 128 * C;      // + kb * KB
-    const float* dbase = dy + cc + (long long)I * 128 * C;     // + kb * KB
-    const float* tbase = dy + cc + I * 128;                    // + kb * KB * C
+    const float* ybase = y + cc + (long long)I * IB * C;       // + kb * KB
+    const float* dbase = dy + cc + (long long)I * IB * C;      // + kb * KB
+    const float* tbase = dy + cc + I * IB;                     // + kb * KB * C
     auto ld1 = [&](const float* base, int kb, int u) -> f32x4 {
         return *reinterpret_cast<const f32x4*>(base + kb * KB + o1[u]);
     };
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
     if (MODE == 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = I * 128 + r1 + 64 * u;
+            const int i = I * IB + r1 + 64 * (u < RB ? u : 0);
             hi1[u] = ex.h1[i]; hi2[u] = ex.h2[i]; si1[u] = ex.s1[i]; si2[u] = ex.s2[i];
         }
         if (ex.dc_lds) {
@@ -208,10 +213,10 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
     // the loads of one K-block in four parts (placed between MFMA groups)
 #define HK_BW_GLOAD(R, kb, part)                                                                               \
     do {                                                                                                       \
-        if ((part) == 0) { if (HAS_W) { R.y0 = ld1(ybase, kb, 0); R.y1 = ld1(ybase, kb, 1); } }                 \
-        if ((part) == 1) { if (MODE != 2) { R.d0 = ld1(dbase, kb, 0); R.d1 = ld1(dbase, kb, 1); }              \
-                           else { R.d0 = gather(kb, 0); R.d1 = gather(kb, 1); } }                              \
-        if ((part) == 2) { if (HAS_S2) { R.t0 = ld2(kb, 0); R.t1 = ld2(kb, 1); } }                              \
+        if ((part) == 0) { if (HAS_W) { R.y0 = ld1(ybase, kb, 0); if (RB == 2) R.y1 = ld1(ybase, kb, 1); } }    \
+        if ((part) == 1) { if (MODE != 2) { R.d0 = ld1(dbase, kb, 0); if (RB == 2) R.d1 = ld1(dbase, kb, 1); } \
+                           else { R.d0 = gather(kb, 0); if (RB == 2) R.d1 = gather(kb, 1); } }                 \
+        if ((part) == 2) { if (HAS_S2) { R.t0 = ld2(kb, 0); if (RB == 2) R.t1 = ld2(kb, 1); } }                 \
         if ((part) == 3) { R.x0 = ldx(kb, 0, R.m0); R.x1 = ldx(kb, 1, R.m1);                                   \
                            if (NSX > 2) R.x2 = ldx(kb, 2, R.m2);                                               \
                            if (NSX > 3) R.x3 = ldx(kb, 3, R.m3); }                                             \
@@ -248,11 +253,11 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
         float* S2_ = W_ + W_SZ;                                                                                \
         float* X_ = S2_ + S2_SZ;                                                                               \
         if ((part) == 0) sst1(S1_, W_, 0, R.y0, R.d0);                                                         \
-        if ((part) == 1) sst1(S1_, W_, 1, R.y1, R.d1);                                                         \
+        if ((part) == 1 && RB == 2) sst1(S1_, W_, 1, R.y1, R.d1);                                              \
         if ((part) == 2 && HAS_S2) {                                                                           \
             const float sc_ = MODE == 1 ? coef : 1.0f;                                                         \
             *reinterpret_cast<f32x4*>(S2_ + (r2 + 0) * P2 + c2) = R.t0 * sc_;                                  \
-            *reinterpret_cast<f32x4*>(S2_ + (r2 + 16) * P2 + c2) = R.t1 * sc_;                                 \
+            if (RB == 2) *reinterpret_cast<f32x4*>(S2_ + (r2 + 16) * P2 + c2) = R.t1 * sc_;                    \
         }                                                                                                      \
         if ((part) == 3) { sstx(X_, 0, R.x0, R.m0); sstx(X_, 1, R.x1, R.m1);                                   \
                            if (NSX > 2) sstx(X_, 2, R.x2, R.m2);                                               \
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
     // A fragments of the wave's two 16-row blocks for k = 16 s + 4 lq + t, formed from the raw tiles
 #define HK_BW_AFRAG(A_, s_)                                                                                    \
     do {                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                       \
             const int row_ = wrow + i * 16 + l15;                                                              \
             const f32x4 d1_ = *reinterpret_cast<const f32x4*>(S1 + row_ * P1 + 16 * (s_) + 4 * lq);            \
             f32x4 wv_ = (f32x4){1.f, 1.f, 1.f, 1.f};                                                           \
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
         _Pragma("unroll") for (int n = 0; n < NH; ++n) {                                                       \
             if (n < NH - 1 || n < nloc) {                                                                      \
                 acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[0][t_], B_[n], acc[0][n], 0, 0, 0);        \
-                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[1][t_], B_[n], acc[1][n], 0, 0, 0);        \
+                if (RB == 2) acc[RB - 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[RB - 1][t_], B_[n], acc[RB - 1][n], 0, 0, 0); \
             }                                                                                                  \
         }                                                                                                      \
     } while (0)
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
         const float* S2 = Wt + W_SZ;                                                                           \
         const float* X = S2 + S2_SZ;                                                                           \
         HK_STAMP(kb_, 0);                                                                                      \
-        float a0[2][4], a1[2][4], bA[NH], bB[NH];                                                              \
+        float a0[RB][4], a1[RB][4], bA[NH], bB[NH];                                                            \
         HK_BW_AFRAG(a0, 0);                                                                                    \
         HK_BW_BFRAG(bA, 0, 0);                                                                                 \
         HK_STAMP(kb_, 1);                                                                                      \
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         HK_BW_BFRAG(bB, 0, 3); HK_BW_MFMA(a0, bA, 2); if (LOAD_) HK_BW_GLOAD(RL, (kb_) + 1, 2);                \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if (LABV & 2) { _Pragma("unroll") for (int t = 0; t < 4; ++t) { a1[0][t] = a0[0][t]; a1[1][t] = a0[1][t]; } }   \
+        if (LABV & 2) { _Pragma("unroll") for (int t = 0; t < 4; ++t) { a1[0][t] = a0[0][t]; a1[RB - 1][t] = a0[RB - 1][t]; } }   \
         else HK_BW_AFRAG(a1, 1);                                                                               \
         HK_BW_BFRAG(bA, 1, 0); HK_BW_MFMA(a0, bB, 3); if (LOAD_) HK_BW_GLOAD(RL, (kb_) + 1, 3);                \
         HK_STAMP(kb_, 2);                                                                                      \
@@ -347,8 +352,8 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
 
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float* dxb = dx + (long long)b * C * HW + (long long)(I * 128 + wrow + i * 16 + lq * 4) * HW;
+    for (int i = 0; i < RB; ++i) {
+        float* dxb = dx + (long long)b * C * HW + (long long)(I * IB + wrow + i * 16 + lq * 4) * HW;
 #pragma unroll
         for (int n = 0; n < NH; ++n) {
             const int col = 16 * (nt0 + n) + l15;
@@ -362,26 +367,31 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
         __syncthreads();                                       // adds C / 64 slots per image)
         const float tsum = block_sum<8>(tacc, lds);
         if (tid == 0) {
-            tpart[(long long)b * (2 * nI) + 2 * I] = tsum;
-            tpart[(long long)b * (2 * nI) + 2 * I + 1] = 0.f;
+            if (RB == 2) {
+                tpart[(long long)b * (2 * nI) + 2 * I] = tsum;
+                tpart[(long long)b * (2 * nI) + 2 * I + 1] = 0.f;
+            } else {
+                tpart[(long long)b * nI + I] = tsum;
+            }
         }
     }
 }
 
-template <int HW, int MODE>
+template <int HW, int MODE, int RB = 2>
 static inline size_t bwd128_lds_bytes() {
     constexpr bool HAS_W = MODE == 0 || MODE == 3;
     constexpr bool HAS_S2 = MODE != 2;
-    constexpr int stage = 128 * 36 + (HAS_W ? 128 * 36 : 0) + (HAS_S2 ? 32 * 132 : 0) + ((32 * HW / 4 + 3) / 4 * 16);
+    constexpr int IB = 64 * RB;
+    constexpr int stage = IB * 36 + (HAS_W ? IB * 36 : 0) + (HAS_S2 ? 32 * (IB + 4) : 0) + ((32 * HW / 4 + 3) / 4 * 16);
     return (size_t)2 * stage * sizeof(float);
 }
 
-// HK_ERR_UNSUPPORTED unless C % 128 == 0 (the caller then takes the 64-row kernel)
-template <int HW, int MODE>
+// HK_ERR_UNSUPPORTED unless C % (64 RB) == 0 (the caller then takes the 4-wave 64-row kernel)
+template <int HW, int MODE, int RB = 2>
 static int bwd128_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
                          int B, int C, const BwdExtra& ex_in, hipStream_t st) {
-    if (C % 128 != 0) return HK_ERR_UNSUPPORTED;
-    size_t lds = bwd128_lds_bytes<HW, MODE>();
+    if (C % (64 * RB) != 0) return HK_ERR_UNSUPPORTED;
+    size_t lds = bwd128_lds_bytes<HW, MODE, RB>();
     BwdExtra ex = ex_in;
     ex.dc_lds = 0;
     if (MODE == 2) {                                        // dc + tables behind the two stages when they fit
@@ -390,14 +400,14 @@ static int bwd128_launch(const float* x, const float* y, const float* dy, const 
     }
     static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, MODE>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, MODE, 0, RB>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int nI = C / 128;
+    const int nI = C / (64 * RB);
 #ifdef HK_LAB
-    if (MODE == 0 && tuning().bwd_v >= 6 && tuning().bwd_v <= 8) {
+    if (MODE == 0 && RB == 2 && tuning().bwd_v >= 6 && tuning().bwd_v <= 8) {
         const int lv = tuning().bwd_v - 5;
         static bool a2 = false;
         if (!a2) {
@@ -413,8 +423,8 @@ static int bwd128_launch(const float* x, const float* y, const float* dy, const 
         return HK_OK;
     }
 #endif
-    hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, MODE>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx,
-                       tpart, C, nI, B, ex);
+    hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, MODE, 0, RB>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm,
+                       dx, tpart, C, nI, B, ex);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

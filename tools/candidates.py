@@ -216,9 +216,10 @@ def bwd_variants():
     xm = torch.relu(torch.randn(B, dc, HW, device=dev))
     mu, g, dxm = torch.zeros(B, dc, device=dev), torch.randn(B, dc, dc, device=dev), torch.empty_like(xm)
     ref = None
-    for flag in (1, 5, 9):
+    for flag in (1, 4, 5, 9):
         knob('bwd_v', flag)
         tag = {1: 'bwd_v=1: 64-row blocks, P tile built in LDS, 2 WGs/CU (round-1 kernel)',
+               4: 'bwd_v=4: 64-row blocks on the eight-wave raw-tile kernel (default for the covariance at C=256, B=64)',
                5: 'bwd_v=5: 128-row blocks, raw tiles, one barrier per K-block, 1 WG/CU (hk_bwd128.h)',
                9: 'bwd_v=9: 128-row blocks staged by LDS-DMA, swizzled tiles (hk_bwd128d.h; BCNN mode only, default)'}[flag]
         row('bcnn bwd_gemm B=64 C=512', tag,

@@ -37,7 +37,7 @@ def R(*shape):
 
 
 def kernel_row(model, name, fn, flops=0.0, bytes_=0.0, iters=30):
-    us = bench.time_events(fn, iters) * 1e3
+    us = bench.time_events(fn, iters, rounds=3)[0] * 1e3           # third back-to-back round: settled clocks (bench.py)
     tf, gbs = flops / us / 1e6, bytes_ / us / 1e3
     mfma = flops > 0 and flops / max(bytes_, 1.0) > bench.PEAK_MFMA_F32_TF * 1e3 / bench.PEAK_HBM_GBS
     rows.append({'model': model, 'kernel': name, 'us': round(us, 1), 'bound': 'mfma' if mfma else 'hbm',
