@@ -93,27 +93,32 @@ __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __re
         asm volatile("" ::: "memory");                                                                         \
     } while (0)
 
-template <int NT>
+// MT: 16-sample row tiles per workgroup.  4: up to 64 samples, wave w owns row tile w & 3 and one half of the NT class tiles.
+// 1: up to 16 samples (OSME: N = 10) - every wave owns the same 16 rows and NT / 8 of the class tiles; the product is then
+// a pure stream of W (2 KB of LDS-DMA pieces per MFMA-cycle-pair), the matrix pipe idles.
+template <int NT, int MT>
 __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __restrict__ y, const float* __restrict__ w,
                                                                float* __restrict__ part, int B, int J, int K, int KS,
                                                                int S, int ngrp) {
-    constexpr int NH = (NT + 1) / 2;
+    static_assert(MT == 4 || (MT == 1 && NT % 8 == 0), "one row tile: the class tiles are dealt to the eight waves");
+    constexpr int NH = MT == 4 ? (NT + 1) / 2 : NT / 8;   // class tiles per wave (at most)
     constexpr int NS = 4;                                // LDS stages (chunk c + 1 must be complete one barrier early: >= 4)
     constexpr int CH = 32;                               // features per chunk
-    constexpr int A_SZ = 64 * CH, B_SZ = NT * 16 * CH;   // floats
+    constexpr int MR = 16 * MT;                          // sample rows per workgroup
+    constexpr int A_SZ = MR * CH, B_SZ = NT * 16 * CH;   // floats
     constexpr int STAGE = A_SZ + B_SZ;
-    constexpr int NPA = 8, NPB = NT * 2, NP = NPA + NPB; // 1 KB pieces per chunk: 8 rows x 32 floats each
+    constexpr int NPA = 2 * MT, NPB = NT * 2, NP = NPA + NPB; // 1 KB pieces per chunk: 8 rows x 32 floats each
     constexpr int PPW = (NP + 7) / 8;                    // pieces per wave (at most)
     HK_DYN_LDS16(lds);
 
     int slab, grp;
     if (!xcd_map(blockIdx.x, S, ngrp, slab, grp)) return;
-    const int rg = blockIdx.y;                                  // group of 64 samples
+    const int rg = blockIdx.y;                                  // group of MR samples
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
-    const int rb = wave & 3, half = wave >> 2;
-    const int nt0 = half * NH, nloc = half ? NT - NH : NH;
+    const int rb = MT == 4 ? (wave & 3) : 0, half = wave >> 2;
+    const int nt0 = MT == 4 ? half * NH : wave * NH, nloc = MT == 4 ? (half ? NT - NH : NH) : NH;
     const long long f0 = (long long)slab * KS;                  // first feature of the slab
     const int nfeat = (J - f0) < KS ? (int)(J - f0) : KS;       // (a multiple of 32: J % 32 == 0, KS % 32 == 0)
     const int nch = nfeat / CH;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
         const int p = wave + 8 * u;
         const int r8 = lane >> 3, q4 = 4 * ((lane & 7) ^ (r8 & 7));
         if (p < NPA) {
-            int row = rg * 64 + 8 * p + r8;
+            int row = rg * MR + 8 * p + r8;
             row = row < B ? row : B - 1;
             src[u] = (long long)row * J + q4;
         } else {
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
         if (n < nloc && col < K) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = rg * 64 + 16 * rb + 4 * lq + r;
+                const int row = rg * MR + 16 * rb + 4 * lq + r;
                 if (row < B) pb[(long long)row * K + col] = acc[n][r];
             }
         }
@@ -223,14 +228,16 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
 static inline bool skinny_plan(int B, int J, int K, int& KS, int& S, int& nt, int& ngrp, int& nrg) {
     if (tuning().linear_slabs < 0) return false;                 // knob: -1 forces the generic split-K path
     if (J % 32 != 0) return false;
-    nt = K <= 208 ? 13 : 15;
+    // up to 16 samples (OSME, N = 10): one 16-row tile and 16 class tiles per workgroup (with the 64-row instance the
+    // idle rows are matrix-pipe time: 273 us against 203 us on the generic path).  17-32 samples: generic path.
+    const bool small = B <= 16;
+    nt = small ? 16 : (K <= 208 ? 13 : 15);
     ngrp = (K + nt * 16 - 1) / (nt * 16);
-    nrg = (B + 63) / 64;
+    nrg = small ? 1 : (B + 63) / 64;
     const long long chunks = (long long)(J / 32) * ngrp * nrg;   // chunk-tasks in all
-    // Not for: too little work to amortise a 4-stage pipeline per workgroup; fewer than half of the 64 sample rows of the
-    // MFMA tiles in use (OSME, N = 10: 273 us here against 203 us on the generic path - the rows are wasted matrix-pipe
-    // time and the product is a pure stream of W).  A forced slab count also forces this path (tests).
-    if ((chunks < 256 * 16 || B < 33) && tuning().linear_slabs <= 0) return false;
+    // Not for: too little work to amortise a 4-stage pipeline per workgroup; 17-32 samples (fewer than half of the 64
+    // sample rows in use).  A forced slab count also forces this path (tests).
+    if ((chunks < 256 * 16 || (B > 16 && B < 33)) && tuning().linear_slabs <= 0) return false;
     long long want = 256 / ((long long)ngrp * nrg);              // one workgroup per CU
     if (want < 1) want = 1;
     if (tuning().linear_slabs > 0) want = tuning().linear_slabs;
@@ -277,20 +284,23 @@ extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, 
     int nt, ngrp, nrg;
     if (aligned16(y) && aligned16(w) && skinny_plan(B, J, K, KS, S, nt, ngrp, nrg)) {
         const dim3 grid(xcd_grid(S, ngrp), nrg);
-        const void* fn = nt == 13 ? reinterpret_cast<const void*>(&linear_skinny_kernel<13>)
-                                  : reinterpret_cast<const void*>(&linear_skinny_kernel<15>);
-        const size_t lds = (size_t)4 * (64 * 32 + nt * 16 * 32) * sizeof(float);
-        static bool attr13 = false, attr15 = false;             // > 64 KB of dynamic LDS needs the opt-in
-        bool& attr = nt == 13 ? attr13 : attr15;
+        const void* fn = nt == 13 ? reinterpret_cast<const void*>(&linear_skinny_kernel<13, 4>)
+                       : nt == 15 ? reinterpret_cast<const void*>(&linear_skinny_kernel<15, 4>)
+                                  : reinterpret_cast<const void*>(&linear_skinny_kernel<16, 1>);
+        const size_t lds = (size_t)4 * ((nt == 16 ? 16 : 64) * 32 + nt * 16 * 32) * sizeof(float);
+        static bool attr13 = false, attr15 = false, attr16 = false;   // > 64 KB of dynamic LDS needs the opt-in
+        bool& attr = nt == 13 ? attr13 : (nt == 15 ? attr15 : attr16);
         if (!attr) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
             attr = true;
         }
         if (nt == 13)
-            hipLaunchKernelGGL((linear_skinny_kernel<13>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
+            hipLaunchKernelGGL((linear_skinny_kernel<13, 4>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
+        else if (nt == 15)
+            hipLaunchKernelGGL((linear_skinny_kernel<15, 4>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
         else
-            hipLaunchKernelGGL((linear_skinny_kernel<15>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
+            hipLaunchKernelGGL((linear_skinny_kernel<16, 1>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
         HK_LAUNCH_CHECK();
         const int BK = B * K;
         hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, out, BK, K, S);
