@@ -61,13 +61,16 @@ __global__ __launch_bounds__(256) void linear_reduce_kernel(const float* __restr
     if (g == 0 && e < BK) out[e] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) + (bias ? bias[e % K] : 0.f);
 }
 
+// db[k] = sum_b g[b][k]: one wave per class, lanes over the samples, fixed shuffle tree (one thread per class looping over
+// 64 dependent loads took 17 us)
 __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __restrict__ g, float* __restrict__ db, int B,
                                                               int K) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= K) return;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += g[(long long)b * K + k];
-    db[k] = s;
+    for (int b = lane; b < B; b += 64) s += g[(long long)b * K + k];
+    s = wave_sum(s);
+    if (lane == 0) db[k] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -224,6 +227,223 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the wide classifier (up to 64 samples, up to 208 classes: BCNN / CBCNN heads).  Both products stream their
+// large operand once through LDS-DMA and write their large result once; the small operand g [B][K] (51 KB) never
+// changes along the feature axis, so every wave keeps ITS fragments of g in registers for the whole kernel:
+//   dy [B][J] = g W      per 32-feature chunk: W tile [208 classes][32] by DMA (26 pieces); wave w owns the output tile
+//                        (sample tile w & 3, feature half w >> 2): 52 MFMAs, A = g rows (registers), B = W[c][j] read with
+//                        ds_read_b32 (lanes along j)
+//   dW [K][J] = g^T y    per chunk: y tile [64 samples][32] by DMA (8 pieces); the 13 x 2 output tiles are dealt to the
+//                        eight waves (3-4 each, all with the same feature half): 16 MFMAs per tile, A = g^T (registers,
+//                        lanes along the class), B = y[b][j] read once per chunk and reused by the wave's tiles
+// LDS stages with the pieces two / three chunks ahead and explicit vmcnt(n) barriers, as in the forward.  Measured at the
+// BCNN shape (B = 64, 262 144 -> 200; rocprofv3): dy 106-113 us, dW 96-103 us, db 4.8 us = 213 us for hk_linear_bwd
+// against 315 us on the generic tiles (64x64 tiles with K = 200 / 64 are all prologue) and 200-205 us for the three
+// rocBLAS calls - on par with the library, which is why hawkeye_amd/functional.py keeps `g @ W`, `g^T @ y` for the widest
+// shapes; callers of the C ABI get these kernels.  Both products sit at ~2.5 TB/s / ~61 TF/s, like the library's.
+__global__ __launch_bounds__(512, 2) void linear_dy_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                           float* __restrict__ dy, int B, int J, int K, int KS, int S) {
+    // Chunks are processed in PAIRS: waves 0-3 take the even chunk, waves 4-7 the odd one; a wave owns the 16 samples
+    // bt = wave & 3 and BOTH 16-feature halves of its chunk (two independent accumulation chains, and the two halves of
+    // every 128-byte line of dy are written by the same wave back to back).  Three LDS stages of a chunk pair each.
+    constexpr int NT = 13, NS = 3, CH = 32;
+    constexpr int TILE = NT * 16 * CH;                   // W tile [208][32] floats
+    constexpr int STAGE = 2 * TILE;
+    constexpr int NP = 2 * NT * 2;                       // 1 KB pieces per chunk pair
+    constexpr int PPW = (NP + 7) / 8;
+    HK_DYN_LDS16(lds);
+    const int slab = blockIdx.x;
+    if (slab >= S) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int bt = wave & 3, grp = wave >> 2;
+    const long long f0 = (long long)slab * KS;
+    const int nfeat = (J - f0) < KS ? (int)(J - f0) : KS;
+    const int nch = nfeat / CH, npair = (nch + 1) / 2;
+
+    // A fragments, resident: ga[s][t] = g[16 bt + l15][16 s + 4 lq + t]  (zero beyond B samples / K classes)
+    float ga[NT][4];
+    {
+        const int b = 16 * bt + l15;
+#pragma unroll
+        for (int s_ = 0; s_ < NT; ++s_)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = 16 * s_ + 4 * lq + t;
+                ga[s_][t] = (b < B && c < K) ? g[(long long)b * K + c] : 0.f;
+            }
+    }
+    // piece p = wave + 8 u of a pair: chunk half h = p / 26, class rows 8 q .. 8 q + 7 (q = p % 26, clamped to K - 1)
+    long long src[PPW];
+    int npc = 0;
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+        const int p = wave + 8 * u, q = p % (2 * NT), r8 = lane >> 3;
+        int c = 8 * q + r8;
+        c = c < K ? c : K - 1;
+        src[u] = (long long)c * J + 4 * ((lane & 7) ^ (r8 & 7));
+        if (p < NP) ++npc;
+    }
+    auto dma = [&](int pair, int st) {
+#pragma unroll
+        for (int u = 0; u < PPW; ++u) {
+            const int p = wave + 8 * u;
+            if (p < NP) {
+                const int h = p / (2 * NT), q = p % (2 * NT);
+                int ch = 2 * pair + h;
+                ch = ch < nch ? ch : nch - 1;                   // (odd chunk count: the last pair re-reads its first chunk)
+                glds16(w + src[u] + f0 + (long long)ch * CH, lds + st + h * TILE + 256 * q);
+            }
+        }
+    };
+    auto vm_barrier = [&](bool all) {
+        if (all) HK_VM_BARRIER(0);
+        else if (npc == 7) HK_VM_BARRIER(7);
+        else HK_VM_BARRIER(6);
+    };
+    for (int c = 0; c < NS - 1 && c < npair; ++c) dma(c, c * STAGE);
+    vm_barrier(true);
+    int cur = 0;
+    const int jq = l15 >> 2, j3 = l15 & 3;               // feature quad (of the first half) / element of this lane's column
+    for (int pr = 0; pr < npair; ++pr) {
+        const int dst = cur >= STAGE ? cur - STAGE : (NS - 1) * STAGE;
+        const bool load = pr + NS - 1 < npair;
+        if (load) dma(pr + NS - 1, dst);
+        const int ch = 2 * pr + grp;
+        const float* Wt = lds + cur + grp * TILE;
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        if (ch < nch) {                                         // uniform
+#pragma unroll
+            for (int s_ = 0; s_ < NT; ++s_) {
+                float b0[4], b1[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int cr = 16 * s_ + 4 * lq + t;        // class row of the tile; slot (q ^ (cr & 7)) holds quad q
+                    b0[t] = Wt[cr * CH + ((jq ^ (cr & 7)) << 2) + j3];
+                    b1[t] = Wt[cr * CH + (((jq + 4) ^ (cr & 7)) << 2) + j3];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s_][t], b0[t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s_][t], b1[t], acc1, 0, 0, 0);
+                }
+            }
+        }
+        // The barrier comes BEFORE this pair's stores: stores count in vmcnt too, and with the stores just issued
+        // vmcnt(n) would wait for the pieces issued a moment ago.  Behind the barrier they have a whole pair to retire.
+        vm_barrier(!load);
+        if (ch < nch) {
+            // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+            const long long col = f0 + (long long)ch * CH + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = 16 * bt + 4 * lq + r;
+                if (b < B) {
+                    dy[(long long)b * J + col] = acc0[r];
+                    dy[(long long)b * J + col + 16] = acc1[r];
+                }
+            }
+        }
+        cur = cur + STAGE < NS * STAGE ? cur + STAGE : 0;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void linear_dw_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                           float* __restrict__ dw, int B, int J, int K, int KS, int S) {
+    // 64-feature chunks; wave w owns the class tiles w and w + 8 (< 13) and all four 16-feature quarters of the chunk, so
+    // it writes whole 256-byte runs of a dW row.
+    constexpr int NT = 13, NS = 4, CH = 64;
+    constexpr int STAGE = 64 * CH;                       // y tile [64 samples][64] floats = 16 pieces, two per wave
+    HK_DYN_LDS16(lds);
+    const int slab = blockIdx.x;
+    if (slab >= S) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const long long f0 = (long long)slab * KS;
+    const int nfeat = (J - f0) < KS ? (int)(J - f0) : KS;
+    const int nch = nfeat / CH;                                 // (KS and J are multiples of 64 on this path)
+    const int nct = wave + 8 < NT ? 2 : 1;                      // class tiles of this wave
+
+    // A fragments, resident: ga[ci][s][t] = g[b = 16 s + 4 lq + t][class 16 (wave + 8 ci) + l15]
+    float ga[2][4][4];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cls = 16 * (wave + 8 * ci) + l15;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int b = 16 * s_ + 4 * lq + t;
+                ga[ci][s_][t] = (ci < nct && b < B && cls < K) ? g[(long long)b * K + cls] : 0.f;
+            }
+    }
+    // pieces 2 wave, 2 wave + 1: sample rows 4 p .. 4 p + 3 (256 bytes each); slot j = lane & 15 of row b holds quad j ^ (b & 7)
+    long long src[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r4 = lane >> 4, bb = 4 * (2 * wave + u) + r4;
+        const int b = bb < B ? bb : B - 1;
+        src[u] = (long long)b * J + 4 * ((lane & 15) ^ (bb & 7));
+    }
+    auto dma = [&](int ch, int st) {
+        const long long fo = f0 + (long long)ch * CH;
+        glds16(y + src[0] + fo, lds + st + 256 * (2 * wave));
+        glds16(y + src[1] + fo, lds + st + 256 * (2 * wave + 1));
+    };
+    for (int c = 0; c < NS - 1 && c < nch; ++c) dma(c, c * STAGE);
+    HK_VM_BARRIER(0);
+    int cur = 0;
+    const int jq = l15 >> 2, j3 = l15 & 3;
+    for (int c = 0; c < nch; ++c) {
+        const int dst = cur >= STAGE ? cur - STAGE : (NS - 1) * STAGE;
+        const bool load = c + NS - 1 < nch;
+        if (load) dma(c + NS - 1, dst);
+        const float* Yt = lds + cur;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            float bv[4][4];                              // y[b = 16 s + 4 lq + t][16 ft + l15]
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int b = 16 * s_ + 4 * lq + t;
+                    bv[s_][t] = Yt[b * CH + (((4 * ft + jq) ^ (b & 7)) << 2) + j3];
+                }
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                acc[ci][ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ci < nct) {                          // uniform
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc[ci][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ci][s_][t], bv[s_][t], acc[ci][ft], 0, 0, 0);
+                }
+            }
+        }
+        if (load) HK_VM_BARRIER(2); else HK_VM_BARRIER(0);       // before the stores: see linear_dy_kernel
+        const long long col = f0 + (long long)c * CH + l15;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+            if (ci < nct) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cls = 16 * (wave + 8 * ci) + 4 * lq + r;
+                    if (cls < K) {
+#pragma unroll
+                        for (int ft = 0; ft < 4; ++ft) dw[(long long)cls * J + col + 16 * ft] = acc[ci][ft][r];
+                    }
+                }
+            }
+        }
+        cur = cur + STAGE < NS * STAGE ? cur + STAGE : 0;
+    }
+}
+
 // the wide-classifier plan: slabs of KS features for linear_skinny_kernel; false when the generic path serves the shape
 static inline bool skinny_plan(int B, int J, int K, int& KS, int& S, int& nt, int& ngrp, int& nrg) {
     if (tuning().linear_slabs < 0) return false;                 // knob: -1 forces the generic split-K path
@@ -323,6 +543,34 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
                              int K, hk_stream_t stream) {
     if (!y || !w || !g || B <= 0 || J <= 0 || K <= 0) return HK_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    // wide classifier, up to 64 samples and 208 classes: the two streaming kernels above (bwd knob linear_slabs = -1
+    // keeps the generic tiles)
+    if (B <= 64 && K <= 208 && J % 64 == 0 && (long long)J >= 65536 && tuning().linear_slabs >= 0 && aligned16(y) &&
+        aligned16(w)) {
+        const int KS = ((J / 64 + 255) / 256) * 64, S = (J + KS - 1) / KS;      // one workgroup per CU
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_dy_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        if (dy) {
+            hipLaunchKernelGGL(linear_dy_kernel, dim3(S), dim3(512), (size_t)3 * 2 * 13 * 16 * 32 * sizeof(float), st, g, w, dy,
+                               B, J, K, KS, S);
+            HK_LAUNCH_CHECK();
+        }
+        if (dw) {
+            hipLaunchKernelGGL(linear_dw_kernel, dim3(S), dim3(512), (size_t)4 * 64 * 64 * sizeof(float), st, g, y, dw, B, J, K,
+                               KS, S);
+            HK_LAUNCH_CHECK();
+        }
+        if (db) {
+            hipLaunchKernelGGL(linear_bias_grad_kernel, dim3((K + 3) / 4), dim3(256), 0, st, g, db, B, K);
+            HK_LAUNCH_CHECK();
+        }
+        return HK_OK;
+    }
     if (dy) {      // dy [B][J] = g [B][K] W [K][J]
         const LdPlain la = make_plain(g, 0, K, B, K);
         const LdPlain lb = make_plain(w, 0, J, K, J);
@@ -347,7 +595,7 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
         if (rc != HK_OK) return rc;
     }
     if (db) {
-        hipLaunchKernelGGL(linear_bias_grad_kernel, dim3((K + 255) / 256), dim3(256), 0, st, g, db, B, K);
+        hipLaunchKernelGGL(linear_bias_grad_kernel, dim3((K + 3) / 4), dim3(256), 0, st, g, db, B, K);
         HK_LAUNCH_CHECK();
     }
     return HK_OK;

@@ -607,9 +607,10 @@ class _Linear(torch.autograd.Function):
         b, j = y.shape
         k = weight.shape[0]
         if j * k > _LINEAR_BWD_HIP_MAX and not _FORCE_HIP_LINEAR_BWD:
-            # measured on the MI355X (BENCH_r01 / profiles/r2_candidates.json): hk_linear_bwd wins at the MPN shape
-            # (32896 -> 200: 56.8 vs 73.6 us) and loses to rocBLAS at the two widest ones (BCNN 262144 -> 200: 320 vs
-            # 205 us, OSME 100352 -> 1024: 386 vs 295 us) - those keep the library GEMMs for dy / dW
+            # measured on the MI355X (profiles/r2_candidates.json): hk_linear_bwd wins at the MPN shape (32896 -> 200:
+            # 58 vs 74 us), ties with rocBLAS at BCNN's (262144 -> 200: 213 us on the streaming kernels of linear.hip
+            # against 200-205 us; 315 us on the generic tiles) and loses at OSME's (100352 -> 1024: 375 vs 303 us) -
+            # the two widest keep the library GEMMs for dy / dW
             dy = g @ weight if ctx.needs_input_grad[0] else None
             dw = g.t() @ y if ctx.needs_input_grad[1] else None
             db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None

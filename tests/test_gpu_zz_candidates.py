@@ -462,10 +462,13 @@ _MODEL_CFG = {
 }
 
 
-@pytest.mark.parametrize('b,j,k', [(2, 6000, 200), (2, 32896, 200), (3, 262144, 200), (16, 6000, 8142)])
+@pytest.mark.parametrize('b,j,k', [(2, 6000, 200), (2, 32896, 200), (3, 262144, 200), (16, 6000, 8142), (64, 65536, 200),
+                                   (37, 65728, 130)])
 def test_linear_bwd_direct_at_classifier_shapes(F, b, j, k, monkeypatch):
     """hk_linear_bwd on its own at the three classifier widths of the plugins (CBCNN 6000: not a multiple of 64, so the
-    48-column / 8-deep tails of the tile kernel are exercised; MPN 32896; BCNN 262144) and the iNat class count:
+    48-column / 8-deep tails of the tile kernel are exercised; MPN 32896; BCNN 262144: from 65536 features, up to 64
+    samples and 208 classes the streaming kernels linear_dy_kernel / linear_dw_kernel - full and ragged sample / class
+    tiles, a ragged last slab) and the iNat class count:
     dy = g W, dW = g^T y, db = sum_b g against fp64.  Nothing but the kernel is between the inputs and the check, so a
     failure here is the kernel's."""
     monkeypatch.setattr(F, '_FORCE_HIP_LINEAR_BWD', True)     # (the widest shapes default to the library GEMMs: faster)
