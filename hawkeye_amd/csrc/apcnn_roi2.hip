@@ -271,16 +271,9 @@ int roi_crop_bwd_v2(const float* dy, const float* box, const float* drop, float*
                     int training, hipStream_t st) {
     if (H > 64 || W > 64) return HK_ERR_UNSUPPORTED;
     const size_t lds = (size_t)(2 * (64 * 65 + 64) + 2 * 64 * 64) * sizeof(float);
-    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in
-    if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(&roi_crop_bwd_tab3_kernel<4>),
-                              reinterpret_cast<const void*>(&roi_crop_bwd_tab3_kernel<13>),
-                              reinterpret_cast<const void*>(&roi_crop_bwd_tab3_kernel<16>)}) {
-            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            if (e != hipSuccess) return (int)e;
-        }
-        attr_set = true;
-    }
+    HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<4>);
+    HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<13>);
+    HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<16>);
     // maps per workgroup: the kernel holds 2 workgroups per CU (registers, LDS), so up to 512 run at once; a grid just
     // above that leaves a mostly idle second round
     int cpb = 8;

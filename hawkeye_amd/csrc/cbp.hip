@@ -332,13 +332,7 @@ static int rowscatter_launch(const float* G, const CbpPlan& pl, float* part, int
                              hipStream_t st) {
     const size_t lds = rowscatter_lds(C, D);
     if (lds > 150 * 1024) return HK_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cbp_rowscatter_kernel<NBT>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    HK_ALLOW_BIG_LDS(&cbp_rowscatter_kernel<NBT>);
     hipLaunchKernelGGL((cbp_rowscatter_kernel<NBT>), dim3(nchunk, B), dim3(256), lds, st, G, pl, part, C, D, nchunk);
     return HK_OK;
 }
@@ -348,13 +342,7 @@ static int rowsketch_launch(const float* G, const CbpPlan& pl, float* part, int 
                             hipStream_t st) {
     const int RS = D + 256 * 8 * NQ8;
     const size_t lds = ((size_t)((RS + 1 + 3) / 4) * 4 + 128 + 2 * CBP_RB * (size_t)C) * sizeof(float);
-    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cbp_rowsketch_kernel<NBT, NQ8>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    HK_ALLOW_BIG_LDS((&cbp_rowsketch_kernel<NBT, NQ8>));
     hipLaunchKernelGGL((cbp_rowsketch_kernel<NBT, NQ8>), dim3(nchunk, B), dim3(256), lds, st, G, pl, part, C, D, nchunk);
     return HK_OK;
 }

@@ -398,24 +398,14 @@ static int bwd128_launch(const float* x, const float* y, const float* dy, const 
         const size_t extra = ((size_t)ex.D + 4 * (size_t)C) * sizeof(float);
         if (lds + extra <= 160 * 1024) { lds += extra; ex.dc_lds = 1; }
     }
-    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, MODE, 0, RB>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, MODE, 0, RB>));
     const int nI = C / (64 * RB);
 #ifdef HK_LAB
     if (MODE == 0 && RB == 2 && tuning().bwd_v >= 6 && tuning().bwd_v <= 8) {
         const int lv = tuning().bwd_v - 5;
-        static bool a2 = false;
-        if (!a2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128_kernel<HW, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            a2 = true;
-        }
+        HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, 0, 1>));
+        HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, 0, 2>));
+        HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, 0, 3>));
         if (lv == 1) hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, 0, 1>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);
         if (lv == 2) hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, 0, 2>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);
         if (lv == 3) hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, 0, 3>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);

@@ -241,21 +241,11 @@ static int bwd128d_launch(const float* x, const float* y, const float* dy, const
     if (C % 128 != 0 || (long long)C * C >= (1ll << 31) || !aligned16(x) || !aligned16(y) || !aligned16(dy))
         return HK_ERR_UNSUPPORTED;
     const size_t lds = bwd128d_lds_bytes<HW>();
-    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128d_kernel<HW, MODE>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    HK_ALLOW_BIG_LDS((&bcnn_bwd128d_kernel<HW, MODE>));
     const int nI = C / 128;
 #ifdef HK_LAB
     if (MODE == 0 && tuning().bwd_v == 10) {
-        static bool a2 = false;
-        if (!a2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bcnn_bwd128d_kernel<HW, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            a2 = true;
-        }
+        HK_ALLOW_BIG_LDS((&bcnn_bwd128d_kernel<HW, 0, 1>));
         hipLaunchKernelGGL((bcnn_bwd128d_kernel<HW, 0, 1>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);
         HK_LAUNCH_CHECK();
         return HK_OK;

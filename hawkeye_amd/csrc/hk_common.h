@@ -136,4 +136,20 @@ __device__ __forceinline__ bool xcd_map(int bid, int nb, int tiles, int& sample,
 
 __host__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize, and the attribute belongs to the
+// (function, device) pair.  HK_ALLOW_BIG_LDS(fn) sets it once per device for the call site's kernel (a bit per device
+// in a static of the call site) and returns the HIP error from the enclosing function otherwise.
+#define HK_ALLOW_BIG_LDS(fn)                                                                                   \
+    do {                                                                                                       \
+        static unsigned done_mask_ = 0;                                                                        \
+        int dev_ = 0;                                                                                          \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ > 31) dev_ = 0;                             \
+        if (!((done_mask_ >> dev_) & 1u)) {                                                                    \
+            const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),                      \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e_ != hipSuccess) return (int)e_;                                                              \
+            done_mask_ |= 1u << dev_;                                                                          \
+        }                                                                                                      \
+    } while (0)
+
 }  // namespace hk

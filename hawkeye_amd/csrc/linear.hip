@@ -504,17 +504,10 @@ extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, 
     int nt, ngrp, nrg;
     if (aligned16(y) && aligned16(w) && skinny_plan(B, J, K, KS, S, nt, ngrp, nrg)) {
         const dim3 grid(xcd_grid(S, ngrp), nrg);
-        const void* fn = nt == 13 ? reinterpret_cast<const void*>(&linear_skinny_kernel<13, 4>)
-                       : nt == 15 ? reinterpret_cast<const void*>(&linear_skinny_kernel<15, 4>)
-                                  : reinterpret_cast<const void*>(&linear_skinny_kernel<16, 1>);
         const size_t lds = (size_t)4 * ((nt == 16 ? 16 : 64) * 32 + nt * 16 * 32) * sizeof(float);
-        static bool attr13 = false, attr15 = false, attr16 = false;   // > 64 KB of dynamic LDS needs the opt-in
-        bool& attr = nt == 13 ? attr13 : (nt == 15 ? attr15 : attr16);
-        if (!attr) {
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr = true;
-        }
+        if (nt == 13) HK_ALLOW_BIG_LDS((&linear_skinny_kernel<13, 4>));
+        else if (nt == 15) HK_ALLOW_BIG_LDS((&linear_skinny_kernel<15, 4>));
+        else HK_ALLOW_BIG_LDS((&linear_skinny_kernel<16, 1>));
         if (nt == 13)
             hipLaunchKernelGGL((linear_skinny_kernel<13, 4>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
         else if (nt == 15)
@@ -548,13 +541,7 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
     if (B <= 64 && K <= 208 && J % 64 == 0 && (long long)J >= 65536 && tuning().linear_slabs >= 0 && aligned16(y) &&
         aligned16(w)) {
         const int KS = ((J / 64 + 255) / 256) * 64, S = (J + KS - 1) / KS;      // one workgroup per CU
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_dy_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        HK_ALLOW_BIG_LDS(&linear_dy_kernel);
         if (dy) {
             hipLaunchKernelGGL(linear_dy_kernel, dim3(S), dim3(512), (size_t)3 * 2 * 13 * 16 * 32 * sizeof(float), st, g, w, dy,
                                B, J, K, KS, S);
