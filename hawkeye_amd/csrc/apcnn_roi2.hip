@@ -271,9 +271,9 @@ int roi_crop_bwd_v2(const float* dy, const float* box, const float* drop, float*
                     int training, hipStream_t st) {
     if (H > 64 || W > 64) return HK_ERR_UNSUPPORTED;
     const size_t lds = (size_t)(2 * (64 * 65 + 64) + 2 * 64 * 64) * sizeof(float);
-    HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<4>);
-    HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<13>);
-    HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<16>);
+    HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<4>, lds);
+    HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<13>, lds);
+    HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<16>, lds);
     // maps per workgroup: the kernel holds 2 workgroups per CU (registers, LDS), so up to 512 run at once; a grid just
     // above that leaves a mostly idle second round
     int cpb = 8;

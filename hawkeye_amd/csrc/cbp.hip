@@ -332,7 +332,7 @@ static int rowscatter_launch(const float* G, const CbpPlan& pl, float* part, int
                              hipStream_t st) {
     const size_t lds = rowscatter_lds(C, D);
     if (lds > 150 * 1024) return HK_ERR_UNSUPPORTED;
-    HK_ALLOW_BIG_LDS(&cbp_rowscatter_kernel<NBT>);
+    HK_ALLOW_BIG_LDS(&cbp_rowscatter_kernel<NBT>, lds);
     hipLaunchKernelGGL((cbp_rowscatter_kernel<NBT>), dim3(nchunk, B), dim3(256), lds, st, G, pl, part, C, D, nchunk);
     return HK_OK;
 }
@@ -342,7 +342,7 @@ static int rowsketch_launch(const float* G, const CbpPlan& pl, float* part, int 
                             hipStream_t st) {
     const int RS = D + 256 * 8 * NQ8;
     const size_t lds = ((size_t)((RS + 1 + 3) / 4) * 4 + 128 + 2 * CBP_RB * (size_t)C) * sizeof(float);
-    HK_ALLOW_BIG_LDS((&cbp_rowsketch_kernel<NBT, NQ8>));
+    HK_ALLOW_BIG_LDS((&cbp_rowsketch_kernel<NBT, NQ8>), lds);
     hipLaunchKernelGGL((cbp_rowsketch_kernel<NBT, NQ8>), dim3(nchunk, B), dim3(256), lds, st, G, pl, part, C, D, nchunk);
     return HK_OK;
 }

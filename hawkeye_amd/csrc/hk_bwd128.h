@@ -398,14 +398,14 @@ static int bwd128_launch(const float* x, const float* y, const float* dy, const 
         const size_t extra = ((size_t)ex.D + 4 * (size_t)C) * sizeof(float);
         if (lds + extra <= 160 * 1024) { lds += extra; ex.dc_lds = 1; }
     }
-    HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, MODE, 0, RB>));
+    HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, MODE, 0, RB>), lds);
     const int nI = C / (64 * RB);
 #ifdef HK_LAB
     if (MODE == 0 && RB == 2 && tuning().bwd_v >= 6 && tuning().bwd_v <= 8) {
         const int lv = tuning().bwd_v - 5;
-        HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, 0, 1>));
-        HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, 0, 2>));
-        HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, 0, 3>));
+        HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, 0, 1>), lds);
+        HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, 0, 2>), lds);
+        HK_ALLOW_BIG_LDS((&bcnn_bwd128_kernel<HW, 0, 3>), lds);
         if (lv == 1) hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, 0, 1>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);
         if (lv == 2) hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, 0, 2>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);
         if (lv == 3) hipLaunchKernelGGL((bcnn_bwd128_kernel<HW, 0, 3>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);

@@ -241,11 +241,11 @@ static int bwd128d_launch(const float* x, const float* y, const float* dy, const
     if (C % 128 != 0 || (long long)C * C >= (1ll << 31) || !aligned16(x) || !aligned16(y) || !aligned16(dy))
         return HK_ERR_UNSUPPORTED;
     const size_t lds = bwd128d_lds_bytes<HW>();
-    HK_ALLOW_BIG_LDS((&bcnn_bwd128d_kernel<HW, MODE>));
+    HK_ALLOW_BIG_LDS((&bcnn_bwd128d_kernel<HW, MODE>), lds);
     const int nI = C / 128;
 #ifdef HK_LAB
     if (MODE == 0 && tuning().bwd_v == 10) {
-        HK_ALLOW_BIG_LDS((&bcnn_bwd128d_kernel<HW, 0, 1>));
+        HK_ALLOW_BIG_LDS((&bcnn_bwd128d_kernel<HW, 0, 1>), lds);
         hipLaunchKernelGGL((bcnn_bwd128d_kernel<HW, 0, 1>), dim3(xcd_grid(B, nI)), dim3(512), lds, st, x, y, dy, inv_norm, dx, tpart, C, nI, B, ex);
         HK_LAUNCH_CHECK();
         return HK_OK;

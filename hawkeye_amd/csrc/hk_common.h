@@ -137,18 +137,19 @@ __device__ __forceinline__ bool xcd_map(int bid, int nb, int tiles, int& sample,
 __host__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize, and the attribute belongs to the
-// (function, device) pair.  HK_ALLOW_BIG_LDS(fn) sets it once per device for the call site's kernel (a bit per device
-// in a static of the call site) and returns the HIP error from the enclosing function otherwise.
-#define HK_ALLOW_BIG_LDS(fn)                                                                                   \
+// (function, device) pair.  HK_ALLOW_BIG_LDS(fn, bytes) raises it to `bytes` (the launch's dynamic size; static LDS of
+// the kernel counts against the same 160 KB, so the attribute is never set higher than needed) once per device and
+// size for the call site's kernel, and returns the HIP error from the enclosing function if that fails.
+#define HK_ALLOW_BIG_LDS(fn, bytes)                                                                            \
     do {                                                                                                       \
-        static unsigned done_mask_ = 0;                                                                        \
+        static size_t have_[32] = {0};                                                                         \
         int dev_ = 0;                                                                                          \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ > 31) dev_ = 0;                             \
-        if (!((done_mask_ >> dev_) & 1u)) {                                                                    \
+        if ((size_t)(bytes) > 64 * 1024 && (size_t)(bytes) > have_[dev_]) {                                    \
             const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),                      \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
             if (e_ != hipSuccess) return (int)e_;                                                              \
-            done_mask_ |= 1u << dev_;                                                                          \
+            have_[dev_] = (size_t)(bytes);                                                                     \
         }                                                                                                      \
     } while (0)
 

@@ -505,9 +505,9 @@ extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, 
     if (aligned16(y) && aligned16(w) && skinny_plan(B, J, K, KS, S, nt, ngrp, nrg)) {
         const dim3 grid(xcd_grid(S, ngrp), nrg);
         const size_t lds = (size_t)4 * ((nt == 16 ? 16 : 64) * 32 + nt * 16 * 32) * sizeof(float);
-        if (nt == 13) HK_ALLOW_BIG_LDS((&linear_skinny_kernel<13, 4>));
-        else if (nt == 15) HK_ALLOW_BIG_LDS((&linear_skinny_kernel<15, 4>));
-        else HK_ALLOW_BIG_LDS((&linear_skinny_kernel<16, 1>));
+        if (nt == 13) HK_ALLOW_BIG_LDS((&linear_skinny_kernel<13, 4>), lds);
+        else if (nt == 15) HK_ALLOW_BIG_LDS((&linear_skinny_kernel<15, 4>), lds);
+        else HK_ALLOW_BIG_LDS((&linear_skinny_kernel<16, 1>), lds);
         if (nt == 13)
             hipLaunchKernelGGL((linear_skinny_kernel<13, 4>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
         else if (nt == 15)
@@ -541,7 +541,7 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
     if (B <= 64 && K <= 208 && J % 64 == 0 && (long long)J >= 65536 && tuning().linear_slabs >= 0 && aligned16(y) &&
         aligned16(w)) {
         const int KS = ((J / 64 + 255) / 256) * 64, S = (J + KS - 1) / KS;      // one workgroup per CU
-        HK_ALLOW_BIG_LDS(&linear_dy_kernel);
+        HK_ALLOW_BIG_LDS(&linear_dy_kernel, (size_t)3 * 2 * 13 * 16 * 32 * sizeof(float));
         if (dy) {
             hipLaunchKernelGGL(linear_dy_kernel, dim3(S), dim3(512), (size_t)3 * 2 * 13 * 16 * 32 * sizeof(float), st, g, w, dy,
                                B, J, K, KS, S);

@@ -21,15 +21,12 @@ pass pmc_write --pmc WRITE_SIZE
 pass pmc_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 pass pmc_wait --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pass pmc_lds --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-# the diagonal K-block walk of the Gram backward, for the traffic comparison
-HK_BWD_DIAG=1 timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_diag1" -- python $ROOT/tools/run_pool_kernels.py 3 > "$OUT/pmc_fetch_diag1.log" 2>&1
 python $ROOT/tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_mfma" "$OUT/pmc_wait" "$OUT/pmc_lds" --only hk:: > "$OUT/r2_pool_kernels_pmc.csv"
-python $ROOT/tools/pmc_summary.py "$OUT/pmc_fetch_diag1" --only hk::bcnn_bwd > "$OUT/r2_bwd_diag1_fetch.csv"
 find "$OUT/kt" -name "*kernel_stats.csv" | head -n 1 | xargs -I{} cp {} "$OUT/r2_head_kernel_stats.csv"
 # the BCNN training step (channels_last), kernel-trace statistics
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/step_BCNN" -- python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-candidates --no-other-models > "$OUT/step_BCNN.log" 2>&1
 find "$OUT/step_BCNN" -name "*kernel_stats.csv" | head -n 1 | xargs -I{} cp {} "$OUT/r2_step_BCNN_kernel_stats.csv"
 tail -n 1 "$OUT/step_BCNN.log" | cut -c1-400
 # keep only the summaries (the raw traces are large)
-rm -rf "$OUT"/kt "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_mfma "$OUT"/pmc_wait "$OUT"/pmc_lds "$OUT"/pmc_fetch_diag1 "$OUT"/step_BCNN 2>/dev/null
-ls -la "$OUT"; grep -E "bcnn_bwd|gram_panel|nsmm|roi_crop" "$OUT/r2_pool_kernels_pmc.csv" | head -n 60; cat "$OUT/r2_bwd_diag1_fetch.csv"; head -n 40 "$OUT/r2_head_kernel_stats.csv" | cut -c1-200
+rm -rf "$OUT"/kt "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_mfma "$OUT"/pmc_wait "$OUT"/pmc_lds "$OUT"/step_BCNN 2>/dev/null
+ls -la "$OUT"; grep -E "bcnn_bwd|gram_panel|nsmm|roi_crop" "$OUT/r2_pool_kernels_pmc.csv" | head -n 60; head -n 40 "$OUT/r2_head_kernel_stats.csv" | cut -c1-200

@@ -49,7 +49,8 @@ if mode == 'all':                  # the other heads at the BASELINE config shap
     # signed-sqrt Gram (BCNN.py:23-24)
     ws = torch.randn(64, 512 * 512, device=dev)
     # A7 attention pooling (AP-CNN level 3: 16 x 512 x 56 x 56, 200 classes) / A9 ROI refinement / A10 OSME (2 x 16 x 2048 x 7 x 7)
-    f3 = torch.randn(16, 512, 56, 56, device=dev, requires_grad=True)
+    f3 = torch.randn(16, 512, 56, 56, device=dev, requires_grad=True)            # ROI refinement input (x2: 512 channels)
+    fa = torch.randn(16, 256, 56, 56, device=dev, requires_grad=True)            # attention pooling input (FPN level 3: 256 channels)
     a3 = torch.rand(16, 1, 56, 56, device=dev)
     box = torch.tensor([[3.2, 5.9, 40.1, 33.3]] * 8 + [[20.2, 14.9, 43.1, 35.3]] * 8, device=dev)
     drop = torch.tensor([[10., 12., 20., 30.]] * 16, device=dev)
@@ -64,8 +65,8 @@ if mode == 'all':                  # the other heads at the BASELINE config shap
         (F.compact_bilinear_pool(xb, plan) * wc).sum().backward()
         xb.grad = None
         (F.bilinear_pool(xb, signed_sqrt=True) * ws).sum().backward()
-        f3.grad = None
-        g, sg = F.att_pool(f3, a3)
+        fa.grad = None
+        g, sg = F.att_pool(fa, a3)
         (g.sum() + sg.sum()).backward()
         f3.grad = None
         F.roi_crop_resize(f3, box, drop, True).sum().backward()
