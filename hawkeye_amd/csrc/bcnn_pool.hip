@@ -91,6 +91,38 @@ __global__ __launch_bounds__(256) void bcnn_colsum_partial_kernel(const float* _
     }
 }
 
+// The same stage with 16-byte loads (HW % 4 == 0, x 16-byte aligned): a 64-channel group is one contiguous block of
+// 64 * HW floats; thread t owns the column quad t % (HW / 4) and the rows t / (HW / 4), + R, + 2 R, ... (R = 256 / (HW / 4)
+// row phases), all of its loads independent and in flight together; the R partial quads of a column quad are added in
+// phase order through LDS.  (The scalar version kept 4 loads in flight per thread: 7.7 us for 25.7 MB.)
+__global__ __launch_bounds__(256) void bcnn_colsum_partial4_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                                   int C, int HW, int G) {
+    __shared__ float4 red[256];
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int c0 = g * 64, n = (c0 + 64 < C) ? 64 : C - c0;
+    const int Q = HW / 4, R = 256 / Q;                    // column quads, row phases (HW >= 4: Q <= 64 -> R >= 4)
+    const int q = tid % Q, r = tid / Q;
+    const float4* xb = reinterpret_cast<const float4*>(x + ((long long)b * C + c0) * HW);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R) {
+#pragma unroll 8
+        for (int c = r; c < n; c += R) {
+            const float4 v = xb[(long long)c * Q + q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (tid < Q) {
+        float4 t = red[tid];
+        for (int k = 1; k < R; ++k) {
+            const float4 v = red[tid + k * Q];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        reinterpret_cast<float4*>(part + ((long long)b * G + g) * HW)[tid] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void bcnn_norm_finalize_kernel(const float* __restrict__ part, float* __restrict__ colsum,
                                                                  float* __restrict__ inv_norm, int C, int HW, int G) {
     __shared__ float red[4];
@@ -270,7 +302,10 @@ extern "C" int hk_bcnn_colsum_norm(const float* x, float* colsum, float* inv_nor
     if (!x || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
     const int G = (C + 63) / 64;
     if (ws && ws_bytes >= (size_t)B * G * HW * sizeof(float) && G > 1) {      // two-stage, B*G workgroups
-        hipLaunchKernelGGL(bcnn_colsum_partial_kernel, dim3(G, B), dim3(256), 0, (hipStream_t)stream, x, (float*)ws, C, HW, G);
+        if (HW % 4 == 0 && HW / 4 <= 64 && aligned16(x) && aligned16(ws))
+            hipLaunchKernelGGL(bcnn_colsum_partial4_kernel, dim3(G, B), dim3(256), 0, (hipStream_t)stream, x, (float*)ws, C, HW, G);
+        else
+            hipLaunchKernelGGL(bcnn_colsum_partial_kernel, dim3(G, B), dim3(256), 0, (hipStream_t)stream, x, (float*)ws, C, HW, G);
         HK_LAUNCH_CHECK();
         hipLaunchKernelGGL(bcnn_norm_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, colsum,
                            inv_norm, C, HW, G);

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(512, 2) void bcnn_bwd128_kernel(const float* __rest
     constexpr int S1_SZ = IB * P1, W_SZ = HAS_W ? IB * P1 : 0, S2_SZ = HAS_S2 ? KB * P2 : 0;
     constexpr int XN4 = KB * HW / 4;            // float4 of one X block
     constexpr int NSX = (XN4 + 511) / 512;      // (<= 4)
-    constexpr int X_SZ = (XN4 + 3) / 4 * 16;    // floats, rounded to 64 B
+    // floats, rounded to 64 B, + 16: the last column tile reads columns HW .. 16 NT - 1 of every channel row (never
+    // stored); behind the last row of the block that is up to 12 floats past the X block
+    constexpr int X_SZ = (XN4 + 3) / 4 * 16 + 16;
     constexpr int STAGE = S1_SZ + W_SZ + S2_SZ + X_SZ;
     static_assert(NSX <= 4, "X block staging assumes at most four 16-byte vectors per thread");
     HK_DYN_LDS16(lds);
@@ -382,7 +384,7 @@ static inline size_t bwd128_lds_bytes() {
     constexpr bool HAS_W = MODE == 0 || MODE == 3;
     constexpr bool HAS_S2 = MODE != 2;
     constexpr int IB = 64 * RB;
-    constexpr int stage = IB * 36 + (HAS_W ? IB * 36 : 0) + (HAS_S2 ? 32 * (IB + 4) : 0) + ((32 * HW / 4 + 3) / 4 * 16);
+    constexpr int stage = IB * 36 + (HAS_W ? IB * 36 : 0) + (HAS_S2 ? 32 * (IB + 4) : 0) + ((32 * HW / 4 + 3) / 4 * 16 + 16);
     return (size_t)2 * stage * sizeof(float);
 }
 
