@@ -11,6 +11,15 @@ import hawkeye_oracle as O
 from emu.harness import emulated
 import test_gpu_parity as P
 
+_SEED = 1000 * int(os.environ.get('HK_FUZZ_SEED', '0'))      # HK_FUZZ_SEED=n: another set of random cases
+
+
+@pytest.fixture(autouse=True)
+def _seed_torch():
+    """The shapes come from numpy generators seeded per test; the DATA comes from torch.randn - seeded here so that a
+    failing case can be replayed (HK_FUZZ_SEED selects another set)."""
+    torch.manual_seed(12345 + _SEED)
+
 
 def rel(a, b):
     a, b = a.detach().double(), b.detach().double()
@@ -27,7 +36,7 @@ def F():
 
 
 def test_fuzz_bgemm(F):
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(0 + _SEED)
     for _ in range(16):
         nb, m, n, k = (int(v) for v in rng.integers(1, 150, 4))
         nb = nb % 10 + 1
@@ -42,7 +51,7 @@ def test_fuzz_bgemm(F):
 
 
 def test_fuzz_bcnn_pool(F):
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(1 + _SEED)
     for _ in range(12):
         b, h, w = int(rng.integers(1, 10)), int(rng.integers(1, 15)), int(rng.integers(1, 15))
         c = int(rng.choice([2, 3, 17, 32, 63, 64, 65, 96, 128, 130]))
@@ -53,11 +62,13 @@ def test_fuzz_bcnn_pool(F):
         xe = x.detach().clone().requires_grad_(True)
         ye = F.bilinear_pool(xe)
         (ye * wt).sum().backward()
-        assert rel(ye, y) < 1e-6 and rel(xe.grad, x.grad) < 2e-5, (b, c, h, w)
+        # (oracle and kernels are both fp32 with different summation orders: a 1-pixel, rank-1 Gram of 128 channels came
+        #  out 1.5e-6 apart under HK_FUZZ_SEED=6)
+        assert rel(ye, y) < 3e-6 and rel(xe.grad, x.grad) < 5e-5, (b, c, h, w)
 
 
 def test_fuzz_mpn_chain(F):
-    rng = np.random.default_rng(2)
+    rng = np.random.default_rng(2 + _SEED)
     for _ in range(8):
         b, h, w, itn = int(rng.integers(1, 10)), int(rng.integers(2, 9)), int(rng.integers(2, 9)), int(rng.integers(1, 7))
         d = int(rng.choice([2, 5, 16, 31, 33, 64, 70]))
@@ -73,7 +84,7 @@ def test_fuzz_mpn_chain(F):
 
 
 def test_fuzz_cbp_small(F):
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(3 + _SEED)
     for _ in range(8):
         b, h, w = int(rng.integers(1, 5)), int(rng.integers(1, 8)), int(rng.integers(1, 8))
         c, d = int(rng.choice([3, 8, 17, 32, 64, 96])), int(rng.choice([7, 16, 50, 128, 333]))
@@ -86,11 +97,16 @@ def test_fuzz_cbp_small(F):
         xe = x.clone().requires_grad_(True)
         ye = F.compact_bilinear_pool(xe, plan)
         (ye * wt).sum().backward()
-        assert rel(ye, y64) < 1e-5 and rel(xe.grad, x64.grad) < 2e-4, (b, c, d, h, w)
+        # the gradient divides by 2 sqrt|c|: a bin whose signed terms nearly cancel amplifies fp32 rounding without bound
+        # (HK_FUZZ_SEED=4: 4.5e-2 on a 3 x 1 map).  Yardstick: the ORACLE's own fp32 run against its fp64 run.
+        x32 = x.clone().requires_grad_(True)
+        (O.compact_bilinear_pool_gram(x32, d) * wt).sum().backward()
+        noise = rel(x32.grad, x64.grad)
+        assert rel(ye, y64) < 1e-5 and rel(xe.grad, x64.grad) < max(2e-4, 5 * noise), (b, c, d, h, w, noise)
 
 
 def test_fuzz_att_pool_and_osme(F):
-    rng = np.random.default_rng(4)
+    rng = np.random.default_rng(4 + _SEED)
     for _ in range(8):
         b, c, h, w = int(rng.integers(1, 6)), int(rng.integers(1, 70)), int(rng.integers(1, 30)), int(rng.integers(1, 30))
         f = torch.randn(b, c, h, w, requires_grad=True)
@@ -117,7 +133,7 @@ def test_fuzz_att_pool_and_osme(F):
 
 
 def test_fuzz_att_roi_select_bit_exact(F):
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + _SEED)
     for it in range(20):
         b, hw, s = int(rng.integers(1, 5)), int(rng.choice([7, 14, 20, 28, 56])), int(rng.choice([8, 16, 32]))
         a, k = float(rng.choice([32, 64, 128, 256])), int(rng.integers(1, 7))
@@ -131,7 +147,7 @@ def test_fuzz_att_roi_select_bit_exact(F):
 
 
 def test_fuzz_roi_crop(F):
-    rng = np.random.default_rng(6)
+    rng = np.random.default_rng(6 + _SEED)
     for _ in range(6):
         b, c, train = int(rng.integers(1, 4)), int(rng.integers(1, 6)), bool(rng.integers(2))
         rois = []
@@ -170,9 +186,13 @@ def test_fuzz_roi_crop(F):
 
 
 def test_fuzz_linear_split_k(F, tune):
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + _SEED)
     for _ in range(10):
         b, j, k = int(rng.integers(1, 70)), int(rng.integers(1, 3000)), int(rng.integers(1, 140))
+        if rng.integers(2):                                   # half of the cases: a multiple of 32 features with a forced
+            j = 32 * int(rng.integers(1, 90))                 # slab count = the wide-classifier kernels (13 / 15 / 16 class
+            k = int(rng.integers(1, 600))                     # tiles, one or four row tiles, ragged slabs and class groups)
+            b = int(rng.integers(1, 130))
         tune('linear_slabs', int(rng.integers(1, 12)))
         y, w, bias, g = torch.randn(b, j), torch.randn(k, j) / j ** 0.5, torch.randn(k), torch.randn(b, k)
         y64, w64, b64 = (v.double().requires_grad_(True) for v in (y, w, bias))
@@ -185,7 +205,7 @@ def test_fuzz_linear_split_k(F, tune):
 
 
 def test_fuzz_npairs_loss(F):
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(8 + _SEED)
     for _ in range(12):
         b, p, d, ncls = int(rng.integers(1, 20)), int(rng.integers(1, 5)), int(rng.integers(1, 300)), int(rng.integers(1, 6))
         x = torch.randn(b, p, d) * float(rng.uniform(0.1, 3))
@@ -201,7 +221,7 @@ def test_fuzz_npairs_loss(F):
 
 
 def test_fuzz_cin_interaction(F):
-    rng = np.random.default_rng(9)
+    rng = np.random.default_rng(9 + _SEED)
     for _ in range(6):
         b, c, hw = 2 * int(rng.integers(1, 4)), int(rng.integers(1, 150)), int(rng.integers(1, 60))
         x, wt = torch.relu(torch.randn(b, c, hw)), torch.randn(b)
@@ -219,7 +239,7 @@ def test_fuzz_cin_interaction(F):
 
 
 def test_fuzz_ns_variants(F, tune):
-    rng = np.random.default_rng(10)
+    rng = np.random.default_rng(10 + _SEED)
     for _ in range(3):
         b, d, itn = int(rng.integers(1, 4)), int(rng.choice([5, 40, 100, 129, 150])), int(rng.integers(1, 5))
         x = torch.relu(torch.randn(b, d, 4, 5)) + 0.02
