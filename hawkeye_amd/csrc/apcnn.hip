@@ -72,16 +72,32 @@ __global__ __launch_bounds__(256) void att_pool_bwd_kernel(const float* __restri
     const float a = a_s ? a_s[(long long)b * HW + hw] : 0.f;
     const float* fp = f + (long long)b * C * HW + hw;
     float* dp = df + (long long)b * C * HW + hw;
-    float acc = 0.f;
     if (a_s && da_s) {
-#pragma unroll 4
-        for (int c = 0; c < C; ++c) {
-            acc += ss[c] * fp[(long long)c * HW];
+        // sixteen channels per trip, their loads issued together (with four in flight the walk over 256 channels was
+        // latency bound: 22 us for 25 MB at 28 x 28); four accumulation chains combined in a fixed order
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+        int c = 0;
+        for (; c + 16 <= C; c += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = fp[(long long)(c + u) * HW];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                acc0 += ss[c + u] * v[u];
+                acc1 += ss[c + u + 1] * v[u + 1];
+                acc2 += ss[c + u + 2] * v[u + 2];
+                acc3 += ss[c + u + 3] * v[u + 3];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) dp[(long long)(c + u) * HW] = (ss[c + u] * a + sg[c + u]) * inv;
+        }
+        for (; c < C; ++c) {
+            acc0 += ss[c] * fp[(long long)c * HW];
             dp[(long long)c * HW] = (ss[c] * a + sg[c]) * inv;
         }
-        da_s[(long long)b * HW + hw] = acc * inv;
+        da_s[(long long)b * HW + hw] = ((acc0 + acc1) + (acc2 + acc3)) * inv;
     } else {
-#pragma unroll 4
+#pragma unroll 8
         for (int c = 0; c < C; ++c) dp[(long long)c * HW] = (ss[c] * a + sg[c]) * inv;
     }
 }
