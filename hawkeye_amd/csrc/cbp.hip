@@ -228,6 +228,19 @@ __global__ __launch_bounds__(256) void cbp_rowsketch_kernel(const float* __restr
 // so plain read-modify-writes are race-free, and one LDS barrier per row orders the rows - the same per-bin summation
 // order (rows ascending) and the same `c += s1 * r` expression as the row-sketch kernel, hence bit-identical partials,
 // with ~8x less LDS traffic, one barrier per row instead of two and 41 KB of LDS (3 workgroups per CU).
+// HK_LAB builds only (tools/cbp_lab.py): cycle stamps of thread 0 of the workgroups of the first eight images
+#ifdef HK_LAB
+__device__ long long* g_cbp_stamps = nullptr;            // [64 workgroups][32 blocks][8]
+#define CBP_STAMP(blk_, slot_)                                                                         \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.y < 8 && (blk_) < 32 && g_cbp_stamps)                        \
+            g_cbp_stamps[((long long)(blockIdx.y * 8 + blockIdx.x) * 32 + (blk_)) * 8 + (slot_)] =    \
+                (long long)__builtin_amdgcn_s_memtime();                                              \
+    } while (0)
+#else
+#define CBP_STAMP(blk_, slot_) do { } while (0)
+#endif
+
 template <int NBT>
 __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __restrict__ G, CbpPlan pl,
                                                              float* __restrict__ part, int C, int D, int nchunk) {
@@ -290,13 +303,24 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
     __syncthreads();
     for (int blk = 0; blk < nblk; ++blk) {
         const int cur = blk & 1;
+        CBP_STAMP(blk, 0);
         if (blk + 1 < nblk) HK_BLK_LOAD(blk + 1);
+        CBP_STAMP(blk, 1);
         const float* gcur = gb + cur * CBP_RB * C;
         const int left = nrows - blk * CBP_RB;
         const int rmax = left < CBP_RB ? left : CBP_RB;
-        for (int rr = 0; rr < rmax; ++rr) {
-            const float* grow = gcur + rr * C;
-            const int li = blk * CBP_RB + rr;
+        // Everything of the block that does not depend on the bins first - the rows' hashes and signs, the row sketches
+        // (4 x NBT x 4 gathers of staged G values) and the target bins - all LDS reads in flight together.  What is left
+        // in the ordered part is, per row, ONE dependent LDS round trip (read the bin, add, write) and the barrier; a
+        // row at a time it was three (hash -> bin address -> bin value) behind the gathers (tools/cbp_lab.py: ~1000
+        // ticks per row).  Same operations in the same order per bin: bit-identical partials.
+        float add[CBP_RB][NBT];
+        int idx[CBP_RB][NBT];
+#pragma unroll
+        for (int rr = 0; rr < CBP_RB; ++rr) {
+            const int r_ = rr < rmax ? rr : 0;
+            const float* grow = gcur + r_ * C;
+            const int li = blk * CBP_RB + r_;
             const int h1i = sh1[li];
             const float s1i = ss1[li];
 #pragma unroll
@@ -304,17 +328,26 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
                 float sacc = 0.f;                            // signed sum in channel order (padding adds 0 * x)
 #pragma unroll
                 for (int e = 0; e < CBP_EMAX; ++e) sacc += sg[u][e] * grow[jx[u][e]];
-                int idx = mb[u] + h1i;                       // bin (h1_i + h2_j) mod D of this row's entry
-                if (idx >= D) idx -= D;
-                idx = mb[u] >= 0 ? idx : D;
-                c[idx] += s1i * sacc;
+                int ix = mb[u] + h1i;                        // bin (h1_i + h2_j) mod D of this row's entry
+                if (ix >= D) ix -= D;
+                idx[rr][u] = mb[u] >= 0 ? ix : D;
+                add[rr][u] = s1i * sacc;
             }
-            HK_LDS_BARRIER();                                // the next row may hit the same bins from other lanes
+        }
+#pragma unroll
+        for (int rr = 0; rr < CBP_RB; ++rr) {
+            if (rr < rmax) {                                 // uniform
+#pragma unroll
+                for (int u = 0; u < NBT; ++u) c[idx[rr][u]] += add[rr][u];
+                HK_LDS_BARRIER();                            // the next row may hit the same bins from other lanes
+                CBP_STAMP(blk, 2 + rr);
+            }
         }
         if (blk + 1 < nblk) {
             HK_BLK_STORE(cur ^ 1);
             HK_LDS_BARRIER();
         }
+        CBP_STAMP(blk, 6);
     }
 #undef HK_BLK_LOAD
 #undef HK_BLK_STORE
@@ -607,3 +640,9 @@ extern "C" int hk_cbp_bwd(const float* x, const void* plan, const float* y, cons
     const EpAffine ep = make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f);
     return bgemm_launch<true, false>(la, xb, ep, C, HW, C, B, st);
 }
+
+#ifdef HK_LAB
+extern "C" int hk_lab_set_cbp_stamps(long long* dev_buffer) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hk::g_cbp_stamps), &dev_buffer, sizeof(dev_buffer));
+}
+#endif
