@@ -16,6 +16,7 @@
 // with dG + dG^T generated on the fly by the GEMM's A-operand loader.
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 #include "hk_bgemm.h"
 #include "../../include/hawkeye_hip.h"
@@ -241,6 +242,12 @@ __device__ long long* g_cbp_stamps = nullptr;            // [64 workgroups][32 b
 #define CBP_STAMP(blk_, slot_) do { } while (0)
 #endif
 
+// rows of G per staged block of the row-scatter kernel, and float4 per thread of one block (C <= 512).  Eight rows: the
+// block's global loads are requested one block ahead, and with four-row blocks (~1 us of work) the ~2 us of HBM latency
+// was exposed at every one of the 16 blocks of a chunk - that, not the ordered steps, was most of the kernel's 33 us.
+constexpr int CBP_SRB = 8;
+constexpr int CBP_SLD = CBP_SRB * 512 / 4 / 256;
+
 template <int NBT>
 __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __restrict__ G, CbpPlan pl,
                                                              float* __restrict__ part, int C, int D, int nchunk) {
@@ -249,11 +256,11 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
     const int poff = ((D + 1 + 3) / 4) * 4;
     int* sh1 = reinterpret_cast<int*>(smem + poff);    // [64]  h1 of the chunk's rows
     float* ss1 = smem + poff + 64;                     // [64]  s1 of the chunk's rows
-    float* gb = smem + poff + 128;                     // [2][CBP_RB * C] staged rows of G
+    float* gb = smem + poff + 128;                     // [2][CBP_SRB * C] staged rows of G
     const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
     const int i0 = ch * 64, i1 = (i0 + 64 < C) ? i0 + 64 : C;
-    const int nrows = i1 - i0, nblk = (nrows + CBP_RB - 1) / CBP_RB;
-    const int blk4 = CBP_RB * C / 4;
+    const int nrows = i1 - i0, nblk = (nrows + CBP_SRB - 1) / CBP_SRB;
+    const int blk4 = CBP_SRB * C / 4;
     const float* gbase = G + ((long long)b * C + i0) * C;
 
     for (int k = tid; k <= D; k += 256) c[k] = 0.f;
@@ -263,6 +270,7 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
     }
     int jx[NBT][CBP_EMAX], mb[NBT];
     float sg[NBT][CBP_EMAX];
+    bool one = true, one_hi = true;                        // every bin of this lane / of its units u >= 1 has one channel
 #pragma unroll
     for (int u = 0; u < NBT; ++u) {
         const int t = tid + 256 * u;
@@ -276,23 +284,30 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
             jx[u][e] = (int)(v & 0x7fffffffu);
             sg[u][e] = valid ? ((v >> 31) ? -1.f : 1.f) : 0.f;
         }
+        one = one && (hi - lo <= 1);
+        if (u > 0) one_hi = one_hi && (hi - lo <= 1);
     }
+    // no lane of this WAVE owns a bin with more than one channel (true for all but the first wave: the plan orders the
+    // bins by channel count): the sketches then take one gather per bin instead of the padded CBP_EMAX.  The kernel
+    // issues instructions 35 % of its wave cycles (profiles/r2_pool_kernels_pmc.csv) - it is bound by their number.
+    const bool single = __builtin_amdgcn_readfirstlane((int)wave_max(one ? 0.f : 1.f)) == 0;
+    const bool single_hi = __builtin_amdgcn_readfirstlane((int)wave_max(one_hi ? 0.f : 1.f)) == 0;   // (the first wave)
 
-    f32x4 st[2];
+    f32x4 st[CBP_SLD];                                  // this thread's share of one staged block
 #define HK_BLK_LOAD(blk_)                                                                            \
     do {                                                                                             \
-        const int left_ = nrows - (blk_) * CBP_RB;                                                   \
-        const int lim4_ = ((left_ < CBP_RB ? left_ : CBP_RB) * C) / 4;                               \
-        const f32x4* src_ = reinterpret_cast<const f32x4*>(gbase + (long long)(blk_) * CBP_RB * C);  \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
+        const int left_ = nrows - (blk_) * CBP_SRB;                                                   \
+        const int lim4_ = ((left_ < CBP_SRB ? left_ : CBP_SRB) * C) / 4;                               \
+        const f32x4* src_ = reinterpret_cast<const f32x4*>(gbase + (long long)(blk_) * CBP_SRB * C);  \
+        _Pragma("unroll") for (int u = 0; u < CBP_SLD; ++u) {                                              \
             const int f_ = tid + 256 * u;                                                            \
             st[u] = src_[f_ < lim4_ ? f_ : 0];                                                       \
         }                                                                                            \
     } while (0)
 #define HK_BLK_STORE(buf_)                                                                           \
     do {                                                                                             \
-        f32x4* dst_ = reinterpret_cast<f32x4*>(gb + (buf_) * CBP_RB * C);                            \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
+        f32x4* dst_ = reinterpret_cast<f32x4*>(gb + (buf_) * CBP_SRB * C);                            \
+        _Pragma("unroll") for (int u = 0; u < CBP_SLD; ++u) {                                              \
             const int f_ = tid + 256 * u;                                                            \
             if (f_ < blk4) dst_[f_] = st[u];                                                         \
         }                                                                                            \
@@ -306,41 +321,43 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
         CBP_STAMP(blk, 0);
         if (blk + 1 < nblk) HK_BLK_LOAD(blk + 1);
         CBP_STAMP(blk, 1);
-        const float* gcur = gb + cur * CBP_RB * C;
-        const int left = nrows - blk * CBP_RB;
-        const int rmax = left < CBP_RB ? left : CBP_RB;
+        const float* gcur = gb + cur * CBP_SRB * C;
+        const int left = nrows - blk * CBP_SRB;
+        const int rmax = left < CBP_SRB ? left : CBP_SRB;
         // Everything of the block that does not depend on the bins first - the rows' hashes and signs, the row sketches
         // (4 x NBT x 4 gathers of staged G values) and the target bins - all LDS reads in flight together.  What is left
         // in the ordered part is, per row, ONE dependent LDS round trip (read the bin, add, write) and the barrier; a
         // row at a time it was three (hash -> bin address -> bin value) behind the gathers (tools/cbp_lab.py: ~1000
         // ticks per row).  Same operations in the same order per bin: bit-identical partials.
-        float add[CBP_RB][NBT];
-        int idx[CBP_RB][NBT];
-#pragma unroll
-        for (int rr = 0; rr < CBP_RB; ++rr) {
-            const int r_ = rr < rmax ? rr : 0;
-            const float* grow = gcur + r_ * C;
-            const int li = blk * CBP_RB + r_;
-            const int h1i = sh1[li];
-            const float s1i = ss1[li];
-#pragma unroll
-            for (int u = 0; u < NBT; ++u) {
-                float sacc = 0.f;                            // signed sum in channel order (padding adds 0 * x)
-#pragma unroll
-                for (int e = 0; e < CBP_EMAX; ++e) sacc += sg[u][e] * grow[jx[u][e]];
-                int ix = mb[u] + h1i;                        // bin (h1_i + h2_j) mod D of this row's entry
-                if (ix >= D) ix -= D;
-                idx[rr][u] = mb[u] >= 0 ? ix : D;
-                add[rr][u] = s1i * sacc;
-            }
+        float add[CBP_SRB][NBT];
+        int idx[CBP_SRB][NBT];
+        // (the instances of the sketch loops differ in the compile-time gather counts only - of the first bin of a
+        //  lane and of its other bins; one wave-uniform branch)
+#define HK_SC_SKETCH(EN, EH)                                                                                   \
+        _Pragma("unroll") for (int rr = 0; rr < CBP_SRB; ++rr) {                                               \
+            const int r_ = rr < rmax ? rr : 0;                                                                 \
+            const float* grow = gcur + r_ * C;                                                                 \
+            const int li = blk * CBP_SRB + r_;                                                                 \
+            const int h1i = sh1[li];                                                                           \
+            const float s1i = ss1[li];                                                                         \
+            _Pragma("unroll") for (int u = 0; u < NBT; ++u) {                                                  \
+                float sacc = 0.f;                            /* signed sum in channel order (padding adds 0 * x) */ \
+                _Pragma("unroll") for (int e = 0; e < (u == 0 ? (EN) : (EH)); ++e) sacc += sg[u][e] * grow[jx[u][e]]; \
+                int ix = mb[u] + h1i;                        /* bin (h1_i + h2_j) mod D of this row's entry */ \
+                if (ix >= D) ix -= D;                                                                          \
+                idx[rr][u] = mb[u] >= 0 ? ix : D;                                                              \
+                add[rr][u] = s1i * sacc;                                                                       \
+            }                                                                                                  \
         }
+        if (single) { HK_SC_SKETCH(1, 1) } else if (single_hi) { HK_SC_SKETCH(CBP_EMAX, 1) } else { HK_SC_SKETCH(CBP_EMAX, CBP_EMAX) }
+#undef HK_SC_SKETCH
 #pragma unroll
-        for (int rr = 0; rr < CBP_RB; ++rr) {
+        for (int rr = 0; rr < CBP_SRB; ++rr) {
             if (rr < rmax) {                                 // uniform
 #pragma unroll
                 for (int u = 0; u < NBT; ++u) c[idx[rr][u]] += add[rr][u];
                 HK_LDS_BARRIER();                            // the next row may hit the same bins from other lanes
-                CBP_STAMP(blk, 2 + rr);
+                if (rr < 4) CBP_STAMP(blk, 2 + rr);          // (the first four rows of the block)
             }
         }
         if (blk + 1 < nblk) {
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
 }
 
 static inline size_t rowscatter_lds(int C, int D) {
-    return ((size_t)((D + 1 + 3) / 4) * 4 + 128 + 2 * CBP_RB * (size_t)C) * sizeof(float);
+    return ((size_t)((D + 1 + 3) / 4) * 4 + 128 + 2 * CBP_SRB * (size_t)C) * sizeof(float);
 }
 
 template <int NBT>
@@ -519,10 +536,16 @@ extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32
         unsigned* nzj = (unsigned*)((char*)nzo + cbp_align((size_t)(C + 1) * 4));
         std::vector<std::vector<int>> inv(D);
         for (int j = 0; j < C; ++j) inv[h2[j]].push_back(j);
+        // slots ordered by channel count, descending (ties: bin ascending): the few bins that two or more channels hash
+        // to (~22 of ~490 at C = 512, D = 6000) all land in the first wave of the binning kernels; every other wave has
+        // exactly one channel per bin and takes the single-gather path of cbp_rowscatter_kernel
+        std::vector<int> order;
+        for (int mbin = 0; mbin < D; ++mbin)
+            if (!inv[mbin].empty()) order.push_back(mbin);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return inv[a].size() > inv[b].size(); });
         int t = 0, e = 0;
         nzo[0] = 0;
-        for (int mbin = 0; mbin < D; ++mbin) {
-            if (inv[mbin].empty()) continue;
+        for (int mbin : order) {
             nzb[t] = mbin;
             for (int j : inv[mbin]) nzj[e++] = (unsigned)j | (s2[j] < 0.f ? 0x80000000u : 0u);
             nzo[++t] = e;
