@@ -1,4 +1,4 @@
-"""HIP-event timing of hk_cbp_fwd / hk_cbp_bwd only (C=512, 14x14, D=6000).  HK_CBP_CSR=1 selects the CSR gather."""
+"""HIP-event timing of hk_cbp_fwd / hk_cbp_bwd only (C=512, 14x14, D=6000).  HK_CBP_BIN=0|1|2 forces a binning kernel (row-sketch, CSR gather, row-scatter)."""
 import os
 import sys
 
