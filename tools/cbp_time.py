@@ -24,4 +24,4 @@ for bb in (16, 64):
     for _ in range(30):
         fn()
     e1.record(); torch.cuda.synchronize()
-    print(f'cbp fwd B={bb} csr={os.environ.get("HK_CBP_CSR", "0")}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us', flush=True)
+    print(f'cbp fwd B={bb} cbp_bin={os.environ.get("HK_CBP_BIN", "-1")}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us', flush=True)
