@@ -219,8 +219,11 @@ int hk_osme_scale_bwd(const float* x, const float* m, const float* ds, const flo
                       int P, int N, int C, int HW, hk_stream_t stream);
 
 /* ------------------------------------------------------- classifier (8f-1) ----
- * out = y W^T + bias for the wide pooled vector and its backward: split-K f32-MFMA
- * GEMM with a deterministic slab reduction (forward), plain tiles (backward).
+ * out = y W^T + bias for the wide pooled vector and its backward.  Forward: the
+ * feature axis is cut into slabs, partial results are added in slab order
+ * (deterministic); wide classifiers (J % 32 == 0, enough work) stream y and W once
+ * through LDS-DMA, other shapes take the generic f32-MFMA tiles.  Backward: streaming
+ * kernels for up to 64 samples x 208 classes from 65536 features, plain tiles otherwise.
  * replaces nn.Linear at model/methods/BCNN.py:42,54 ; CBCNN.py:26,34 ; MPNCOV.py:31 ;
  * OSME.py:34,43 (same operand layouts: W is [K][J] as in nn.Linear.weight).
  *   y [B,J] ; w [K,J] ; bias [K] or NULL ; out [B,K] ; ws: hk_linear_ws_bytes(B,J,K)
