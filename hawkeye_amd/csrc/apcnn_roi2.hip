@@ -165,16 +165,22 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
                         for (int bq = 0; bq < KX; ++bq) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const int so = smo[k0 + j] < 0 ? 0 : smo[k0 + j];
-                                rowacc[j] = fmaf(wx[wxo[k0 + j] + bq], smap[so + a * W + bq], rowacc[j]);
+                                const int k = k0 + j < ROI2_PPT ? k0 + j : k0;   // (PPT = 13: slots 13..15 do not exist)
+                                const int so = smo[k] < 0 ? 0 : smo[k];
+                                rowacc[j] = fmaf(wx[wxo[k] + bq], smap[so + a * W + bq], rowacc[j]);
                             }
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] = fmaf(wy[wyo[k0 + j] + a], rowacc[j], acc[j]);
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = k0 + j < ROI2_PPT ? k0 + j : k0;
+                            acc[j] = fmaf(wy[wyo[k] + a], rowacc[j], acc[j]);
+                        }
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (smo[k0 + j] >= 0) omap[omo[k0 + j]] = acc[j] * g.rate;
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k0 + j < ROI2_PPT ? k0 + j : k0;
+                        if (k0 + j < ROI2_PPT && smo[k] >= 0) omap[omo[k]] = acc[j] * g.rate;
+                    }
                 }
             }
         }

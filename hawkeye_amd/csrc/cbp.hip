@@ -384,6 +384,7 @@ static int rowscatter_launch(const float* G, const CbpPlan& pl, float* part, int
     if (lds > 150 * 1024) return HK_ERR_UNSUPPORTED;
     HK_ALLOW_BIG_LDS(&cbp_rowscatter_kernel<NBT>, lds);
     hipLaunchKernelGGL((cbp_rowscatter_kernel<NBT>), dim3(nchunk, B), dim3(256), lds, st, G, pl, part, C, D, nchunk);
+    HK_LAUNCH_CHECK();
     return HK_OK;
 }
 
@@ -394,6 +395,7 @@ static int rowsketch_launch(const float* G, const CbpPlan& pl, float* part, int 
     const size_t lds = ((size_t)((RS + 1 + 3) / 4) * 4 + 128 + 2 * CBP_RB * (size_t)C) * sizeof(float);
     HK_ALLOW_BIG_LDS((&cbp_rowsketch_kernel<NBT, NQ8>), lds);
     hipLaunchKernelGGL((cbp_rowsketch_kernel<NBT, NQ8>), dim3(nchunk, B), dim3(256), lds, st, G, pl, part, C, D, nchunk);
+    HK_LAUNCH_CHECK();
     return HK_OK;
 }
 

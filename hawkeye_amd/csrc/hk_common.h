@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -56,33 +57,66 @@ Tuning& tuning();           // api.hip
 struct AuxQueue {
     hipStream_t aux = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    std::mutex busy;            // held from fork to join: two host threads driving one device take turns on the helper queue
 };
 inline AuxQueue* aux_queue() {
+    // one slot per device, each created exactly once whatever thread gets there first (std::call_once); after that the
+    // slot is read-only.  A slot whose creation failed stays empty and callers fall back to the caller's stream.
     static AuxQueue tab[16];
+    static std::once_flag once[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     AuxQueue& a = tab[dev];
-    if (!a.aux) {
-        if (hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking) != hipSuccess) { a.aux = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    std::call_once(once[dev], [&a]() {
+        hipStream_t s = nullptr;
+        hipEvent_t f = nullptr, j = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
+        if (hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) {
+            if (f) (void)hipEventDestroy(f);
+            (void)hipStreamDestroy(s);
+            return;
+        }
+        a.fork = f; a.join = j; a.aux = s;
+    });
+    return a.aux ? &a : nullptr;
+}
+// Scope of one fork / join on the helper queue.  Construction (when `enable`): everything enqueued on `st` so far
+// happens before the helper queue's work; join() - or the destructor, on an early error return - makes the helper
+// queue's work happen before whatever is enqueued on `st` next, so a caller that frees or reuses its buffers on `st`
+// after a failed call is still ordered behind the half of the batch that is in flight on the helper queue.
+class AuxScope {
+  public:
+    AuxScope(hipStream_t st, bool enable) : st_(st) {
+        if (!enable) return;
+        q_ = aux_queue();
+        if (!q_) return;
+        q_->busy.lock();
+        if (hipEventRecord(q_->fork, st_) == hipSuccess && hipStreamWaitEvent(q_->aux, q_->fork, 0) == hipSuccess) {
+            aux_ = q_->aux;
+        } else {
+            q_->busy.unlock();
+            q_ = nullptr;
+        }
     }
-    return &a;
-}
-// the helper queue, ordered after `st`; nullptr when it cannot be had (the caller then stays on `st`)
-inline hipStream_t aux_fork(hipStream_t st) {
-    AuxQueue* a = aux_queue();
-    if (!a) return nullptr;
-    if (hipEventRecord(a->fork, st) != hipSuccess || hipStreamWaitEvent(a->aux, a->fork, 0) != hipSuccess) return nullptr;
-    return a->aux;
-}
-inline int aux_join(hipStream_t aux, hipStream_t st) {
-    if (!aux) return HK_OK;
-    AuxQueue* a = aux_queue();
-    hipError_t e = hipEventRecord(a->join, aux);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, a->join, 0);
-    return e == hipSuccess ? HK_OK : (int)e;
-}
+    AuxScope(const AuxScope&) = delete;
+    AuxScope& operator=(const AuxScope&) = delete;
+    ~AuxScope() { (void)join(); }
+    hipStream_t aux() const { return aux_; }        // nullptr: stay on the caller's stream
+    int join() {
+        if (!aux_) return HK_OK;
+        hipError_t e = hipEventRecord(q_->join, aux_);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st_, q_->join, 0);
+        aux_ = nullptr;
+        q_->busy.unlock();
+        q_ = nullptr;
+        return e == hipSuccess ? HK_OK : (int)e;
+    }
+
+  private:
+    hipStream_t st_, aux_ = nullptr;
+    AuxQueue* q_ = nullptr;
+};
 
 constexpr int WAVE = 64;
 constexpr int NXCD = 8;

@@ -156,10 +156,11 @@ __global__ __launch_bounds__(256) void triu_bwd_kernel(const float* __restrict__
 
 // ----------------------------------------------------------------- Newton-Schulz products (hk_nsmm.h)
 // Every product of the chain is a launch of hk::nsmm_kernel over a GROUP of independent problems.  The iterates
-// Y_i, Z_i are polynomials in the (symmetric) normalised covariance A, so they commute and Z_i Y_i = Y_i Z_i: the
-// backward takes "YZ" and "ZY" (MPNCOV.py:184-185) from ONE product (two results of the same accumulator).  This
-// needs a symmetric input - what Covpool produces and the only thing MPNCOV.forward feeds Sqrtm (MPNCOV.py:52-55);
-// measured distance from the reference's separate products: 7e-7, the distance of the reference itself from fp64.
+// Y_i, Z_i are polynomials in the normalised input A (Y_0 = A (3I - A) / 2, Z_0 = (3I - A) / 2, and every step multiplies
+// polynomials in A), so they commute and Z_i Y_i = Y_i Z_i for ANY input, symmetric or not: the backward takes "YZ"
+// and "ZY" (MPNCOV.py:184-185) from ONE product (two results of the same accumulator).  Measured distance from the
+// reference's separate products: 7e-7, the distance of the reference itself from fp64, on covariances and on
+// non-symmetric inputs alike (tests/test_gpu_zz_candidates.py::test_ns_general_input_backward).
 static inline NsGroup ns_group(const NsProb& p0) {
     NsGroup g;
     g.p[0] = p0; g.p[1] = p0; g.p[2] = p0; g.p[3] = p0;
@@ -180,7 +181,7 @@ static inline NsProb ns_single(const float* A, long long sa, const float* Bm, lo
 // P = Y Z  ->  W1 = 3 I - P ,  W2 = P      (MPNCOV.py:180,184-185)
 static inline NsProb ns_yz_pair(const float* Y, const float* Z, long long sbs, float* W1, float* W2, long long n) {
     NsProb p = ns_single(Y, sbs, Z, sbs, W1, n, -1.f, 3.f);
-    p.C2 = W2; p.sc2 = n; p.alpha2 = 1.f; p.diag2 = 0.f;
+    if (W2) { p.C2 = W2; p.sc2 = n; p.alpha2 = 1.f; p.diag2 = 0.f; }
     return p;
 }
 
@@ -192,24 +193,21 @@ static inline NsProb ns_yz_pair(const float* Y, const float* Z, long long sbs, f
 // on two queues drift apart, and one's fill / drain is covered by the other's main loop.
 struct NsDispatch {
     int d, B, h;
-    hipStream_t st, aux;
+    hipStream_t st;
+    AuxScope aux;
+    NsDispatch(int d_, int B_, hipStream_t st_)
+        : d(d_), B(B_), h(B_ / 2), st(st_), aux(st_, tuning().ns_streams == 1 && B_ >= 16) {}
     int operator()(const NsGroup& g) const {
-        if (!aux) return nsmm_launch(g, d, B, st);
+        const hipStream_t q = aux.aux();
+        if (!q) return nsmm_launch(g, d, B, st);
         const int rc = nsmm_launch(g, d, h, st, 0, 0);
         if (rc != HK_OK) return rc;
-        return nsmm_launch(g, d, B - h, aux, 0, h);
+        return nsmm_launch(g, d, B - h, q, 0, h);
     }
+    // the helper queue's work happens before whatever is enqueued on `st` next (also done by the destructor: an error
+    // return between fork and join leaves nothing running unordered on the helper queue)
+    int join() { return aux.join(); }
 };
-
-// fork: everything enqueued on `st` so far happens before the helper queue's work; returns the dispatcher
-static inline NsDispatch ns_fork(int d, int B, hipStream_t st) {
-    NsDispatch L{d, B, B / 2, st, nullptr};
-    if (tuning().ns_streams != 1 || B < 16) return L;
-    L.aux = aux_fork(st);
-    return L;
-}
-// join: the helper queue's work happens before whatever is enqueued on `st` next
-static inline int ns_join(const NsDispatch& L) { return aux_join(L.aux, L.st); }
 
 // grid of ns_scale_kernel: a few workgroups per sample (each one recomputes the trace before it starts: with the
 // 256-per-sample grid of an elementwise kernel that prologue costs more than the scaling, 26 us instead of ~8)
@@ -297,7 +295,7 @@ extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float*
     }
     hipLaunchKernelGGL(ns_scale_kernel<true>, ns_scale_grid(n, B), dim3(256), 0, st, a, norm_a, sq, A, zsave, sbs, d);
     HK_LAUNCH_CHECK();
-    const NsDispatch L = ns_fork(d, B, st);
+    NsDispatch L(d, B, st);
     HK_TRY(L(ns_group(ns_single(A, n, zsave, sbs, ysave, sbs, 1.f, 0.f))));                        // Y0 = A ZY   :154
     for (int i = 1; i < iter_n - 1; ++i) {                                                          // :156-159
         const float* Yp = ysave + (long long)(i - 1) * n;
@@ -311,14 +309,17 @@ extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float*
     const float* Zl = zsave + (long long)(iter_n - 2) * n;
     HK_TRY(L(ns_group(ns_single(Zl, sbs, Yl, sbs, T, n, -1.f, 3.f))));                             // 3I - Z Y      :160
     HK_TRY(L(ns_group(ns_single(Yl, sbs, T, n, out, n, 0.5f, 0.f, sq))));                          // .5 Y (.) sqrt(normA)
-    return ns_join(L);
+    return L.join();
 }
 
 // Backward schedule at iterN = 5 (MPNCOV.py:166-202): the reference's 38 products as 34 in 9 launches -
 //   {YZ pair, Yl g} | {dldY, dldZ} | 3 x ( {YZ pair, Z dldZ, Y dldY} | {dldY', dldZ'} as two K = 3d sums ) | der
-extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* norm_a, const float* ysave,
-                               const float* zsave, const float* dout, float* da, int B, int d, int iter_n, void* ws,
-                               size_t ws_bytes, hk_stream_t stream) {
+// general = false: Z_i Y_i is taken from the Y_i Z_i accumulator - 34 products; exact for any `a` (the iterates are
+//                  polynomials in A = a / tr(a) and commute).
+// general = true : Z_i Y_i is its own product in the same launch - the reference's 38, literally (MPNCOV.py:180-185).
+static int ns_sqrtm_bwd_impl(const float* a, const float* out, const float* norm_a, const float* ysave,
+                             const float* zsave, const float* dout, float* da, int B, int d, int iter_n, void* ws,
+                             size_t ws_bytes, hk_stream_t stream, bool general) {
     if (!a || !out || !norm_a || !dout || !da || B <= 0 || d <= 0 || iter_n < 1) return HK_ERR_BAD_ARG;
     if (iter_n >= 2 && (!ysave || !zsave)) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_ns_sqrtm_ws_bytes(B, d, iter_n, 1)) return HK_ERR_WORKSPACE;
@@ -338,7 +339,7 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
                        (float*)nullptr, n, d);        // sq = sqrt(norm_a): the trace the forward saved
     HK_LAUNCH_CHECK();
 
-    const NsDispatch L = ns_fork(d, B, st);
+    NsDispatch L(d, B, st);
     if (iter_n < 2) {
         // der = .5 (dpc (3I - A) - A dpc) = sq (1.5 g - .5 (g A + A g)),  dpc = sq g                 :178
         NsProb p = ns_prob(D, n, -0.5f, 0.f, sq);
@@ -349,8 +350,9 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
     } else {
         const float* Yl = ysave + (long long)(iter_n - 2) * n;
         const float* Zl = zsave + (long long)(iter_n - 2) * n;
-        {   // W1 = 3I - Yl Zl, W2 = Zl Yl (= Yl Zl), W3 = Yl g
-            NsGroup gr = ns_group(ns_yz_pair(Yl, Zl, sbs, W1, W2, n));
+        {   // W1 = 3I - Yl Zl, W2 = Zl Yl (= Yl Zl for a symmetric input), W3 = Yl g
+            NsGroup gr = ns_group(ns_yz_pair(Yl, Zl, sbs, W1, general ? nullptr : W2, n));
+            if (general) gr += ns_single(Zl, sbs, Yl, sbs, W2, n, 1.f, 0.f);
             gr += ns_single(Yl, sbs, g, n, W3, n, 1.f, 0.f);
             HK_TRY(L(gr));
         }
@@ -366,7 +368,8 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
             const float* Yi = ysave + (long long)i * n;
             const float* Zi = zsave + (long long)i * n;
             {   // W1 = YZ = 3I - Y Z, W2 = ZY = Z Y, W3 = Z dldZ, W4 = Y dldY
-                NsGroup gr = ns_group(ns_yz_pair(Yi, Zi, sbs, W1, W2, n));
+                NsGroup gr = ns_group(ns_yz_pair(Yi, Zi, sbs, W1, general ? nullptr : W2, n));
+                if (general) gr += ns_single(Zi, sbs, Yi, sbs, W2, n, 1.f, 0.f);
                 gr += ns_single(Zi, sbs, dZ, n, W3, n, 1.f, 0.f);
                 gr += ns_single(Yi, sbs, dY, n, W4, n, 1.f, 0.f);
                 HK_TRY(L(gr));
@@ -395,13 +398,25 @@ extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* no
         p.E2 = dZ; p.se2 = n; p.e2 = -0.5f;
         HK_TRY(L(ns_group(p)));
     }
-    HK_TRY(ns_join(L));
+    HK_TRY(L.join());
     hipLaunchKernelGGL(ns_bwd_reduce_kernel, dim3(nt * nt, B), dim3(256), 0, st, g, out, (const float*)D, a, part, d, nt);
     HK_LAUNCH_CHECK();
     hipLaunchKernelGGL(ns_bwd_final_kernel, dim3(nt, nt, B), dim3(256), 0, st, (const float*)D, norm_a,
                        (const float*)part, nt, da, d);
     HK_LAUNCH_CHECK();
     return HK_OK;
+}
+
+extern "C" int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* norm_a, const float* ysave,
+                               const float* zsave, const float* dout, float* da, int B, int d, int iter_n, void* ws,
+                               size_t ws_bytes, hk_stream_t stream) {
+    return ns_sqrtm_bwd_impl(a, out, norm_a, ysave, zsave, dout, da, B, d, iter_n, ws, ws_bytes, stream, false);
+}
+
+extern "C" int hk_ns_sqrtm_bwd_general(const float* a, const float* out, const float* norm_a, const float* ysave,
+                                       const float* zsave, const float* dout, float* da, int B, int d, int iter_n,
+                                       void* ws, size_t ws_bytes, hk_stream_t stream) {
+    return ns_sqrtm_bwd_impl(a, out, norm_a, ysave, zsave, dout, da, B, d, iter_n, ws, ws_bytes, stream, true);
 }
 
 // ------------------------------------------------------------------ triu vec

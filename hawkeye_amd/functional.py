@@ -134,7 +134,7 @@ class _Sqrtm(torch.autograd.Function):
     """replaces Sqrtm, model/methods/MPNCOV.py:137-202."""
 
     @staticmethod
-    def forward(ctx, a, iter_n):
+    def forward(ctx, a, iter_n, assume_symmetric=True):
         lib = _lib.load()
         a = _f32c(a)
         b, d, _ = a.shape
@@ -148,6 +148,7 @@ class _Sqrtm(torch.autograd.Function):
         check(lib.hk_ns_sqrtm_fwd(ptr(a), ptr(out), ptr(norm_a), ptr(ysave), ptr(zsave), b, d, iter_n,
                                   ptr(ws), nws, stream()), 'hk_ns_sqrtm_fwd')
         ctx.iter_n = iter_n
+        ctx.assume_symmetric = bool(assume_symmetric)
         ctx.save_for_backward(a, out, norm_a, ysave, zsave)
         return out
 
@@ -160,9 +161,11 @@ class _Sqrtm(torch.autograd.Function):
         da = torch.empty_like(a)
         nws = lib.hk_ns_sqrtm_ws_bytes(b, d, ctx.iter_n, 1)
         ws = _ws(nws, a.device)
-        check(lib.hk_ns_sqrtm_bwd(ptr(a), ptr(out), ptr(norm_a), ptr(ysave), ptr(zsave), ptr(g), ptr(da),
-                                  b, d, ctx.iter_n, ptr(ws), nws, stream()), 'hk_ns_sqrtm_bwd')
-        return da, None
+        # 34 products (exact for any input) or, on request, the reference's 38 literally (include/hawkeye_hip.h)
+        fn = lib.hk_ns_sqrtm_bwd if ctx.assume_symmetric else lib.hk_ns_sqrtm_bwd_general
+        check(fn(ptr(a), ptr(out), ptr(norm_a), ptr(ysave), ptr(zsave), ptr(g), ptr(da),
+                 b, d, ctx.iter_n, ptr(ws), nws, stream()), 'hk_ns_sqrtm_bwd')
+        return da, None, None
 
 
 class _Triuvec(torch.autograd.Function):
@@ -192,8 +195,11 @@ def covpool(x):
     return _Covpool.apply(x)
 
 
-def sqrtm(x, iter_n):
-    return _Sqrtm.apply(x, int(iter_n))
+def sqrtm(x, iter_n, assume_symmetric=True):
+    """Newton-Schulz square root of x [B,d,d] (any square matrices, symmetric or not).  The default backward shares one
+    product between Y_i Z_i and Z_i Y_i (the iterates are polynomials in one matrix: they commute for every input);
+    assume_symmetric=False runs the reference's 38 products literally (A/B checks)."""
+    return _Sqrtm.apply(x, int(iter_n), bool(assume_symmetric))
 
 
 def triuvec(x):

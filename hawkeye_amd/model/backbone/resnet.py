@@ -3,7 +3,7 @@ the 3x3 conv), same child order and parameter names as the reference's
 model/backbone/resnet.py:89-252 so checkpoints load both ways."""
 import torch.nn as nn
 
-from ..registry import BACKBONE
+from ..registry import BACKBONE, MODEL
 from ..utils import load_state_dict
 from . import pretrained as _pre
 
@@ -87,3 +87,15 @@ def resnet50(pretrained=False, progress=True, **kwargs):
 @BACKBONE.register
 def resnet101(pretrained=False, progress=True, **kwargs):
     return _build('resnet101', [3, 4, 23, 3], pretrained, **kwargs)
+
+
+# The plain classifiers behind the reference's default config (configs/Baseline.yaml, model.name ResNet50): registered
+# as MODELs taking the config node, like model/backbone/resnet.py:403-412.
+@MODEL.register
+def ResNet50(config):
+    return resnet50(pretrained=config.pretrained if 'pretrained' in config else True, num_classes=config.num_classes)
+
+
+@MODEL.register
+def ResNet101(config):
+    return resnet101(pretrained=config.pretrained if 'pretrained' in config else True, num_classes=config.num_classes)

@@ -186,8 +186,15 @@ class Trainer:
         from torch.utils.data.distributed import DistributedSampler
         loaders = {}
         for s in ('train', 'val'):
-            sampler = DistributedSampler(self.datasets[s], num_replicas=self.world, rank=self.rank,
-                                         shuffle=(s == 'train')) if self.world > 1 else None
+            sampler = None
+            if self.world > 1 and s == 'train':
+                sampler = DistributedSampler(self.datasets[s], num_replicas=self.world, rank=self.rank, shuffle=True)
+            elif self.world > 1:
+                # validation: indices rank, rank + world, ... with NO padding (DistributedSampler repeats samples until
+                # the set divides by the world size; the duplicates would be counted by the all-reduced meters and the
+                # accuracy that drives ReduceLROnPlateau / best_model.pth would differ from the reference's
+                # single-process number over the same set)
+                sampler = list(range(self.rank, len(self.datasets[s]), self.world))
             loaders[s] = DataLoader(self.datasets[s], config.batch_size, num_workers=config.num_workers,
                                     pin_memory=True, shuffle=(s == 'train' and sampler is None), sampler=sampler,
                                     collate_fn=self.collate_fn[s])
@@ -279,7 +286,7 @@ class Trainer:
             self.do_scheduler_step()
 
             if self.is_main:
-                if (epoch + 1) % config.save_frequence == 0:
+                if epoch != 0 and (epoch + 1) % config.save_frequence == 0:       # train.py:296
                     self.save_model()
                 if is_best:
                     self.save_model('best_model.pth')

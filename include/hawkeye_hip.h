@@ -12,9 +12,14 @@
  *  - all pointers are DEVICE pointers to contiguous fp32 (or int32 where said)
  *    buffers owned by the caller; nothing is allocated or freed by the library;
  *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream);
- *    every call only enqueues kernels on it: no host synchronisation, no
- *    global mutable state besides the test-only hk_tuning_* knobs, safe to call
- *    from one thread per device;
+ *    every call only enqueues kernels on it: no host synchronisation.  Process-wide
+ *    state is limited to (a) the test-only hk_tuning_* knobs and (b) one helper HIP
+ *    queue + event pair per device, owned by the library, created once
+ *    (std::call_once) on the first batched Newton-Schulz call and used inside
+ *    hk_ns_sqrtm_fwd / _bwd only: the two halves of the batch are forked onto it
+ *    and joined back onto `stream` before the entry point returns - also on its
+ *    error paths.  A per-device mutex is held from fork to join, so several host
+ *    threads may drive one device (they take turns on the helper queue);
  *  - scratch memory is passed in (`ws`, `ws_bytes`); the matching
  *    hk_*_ws_bytes() tells how much is needed; contents need not be preserved
  *    between calls unless stated ("saved for backward" buffers are explicit
@@ -47,7 +52,8 @@ const char* hk_version(void);
  * implementations that produce the same results (bit-identical or to rounding); the defaults are the measured winners.
  * Names: "bcnn_generic" (1 = generic GEMM path for the Gram / covariance / CBP kernels), "cbp_bin" (-1 = by batch
  * size, 0 row-sketch, 1 CSR gather, 2 row-scatter), "roi_bwd", "linear_slabs" (0 = automatic), "ns_tn" (0 = automatic,
- * 64 / 128), "bwd_v".  Values are seeded once from the environment (HK_<NAME>) when the library is first used; the
+ * 64 / 128), "bwd_v", "ns_streams" (1 = the two halves of the batch run the Newton-Schulz chain on two HIP queues,
+ * 0 = one queue).  Values are seeded once from the environment (HK_<NAME>) when the library is first used; the
  * launch paths never read the environment.  Returns HK_ERR_BAD_ARG for an unknown name.  Process-wide: set them only
  * while no other thread is launching. */
 int hk_tuning_set(const char* name, int value);
@@ -116,9 +122,19 @@ int hk_cov_pool_bwd(const float* x, const float* mu, const float* dcov, float* d
 size_t hk_ns_sqrtm_ws_bytes(int B, int d, int iter_n, int backward);
 int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
                     int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream);
+/* hk_ns_sqrtm_bwd executes 34 products instead of the reference's 38: Z_i Y_i is taken from the accumulator of Y_i Z_i.
+ * That is exact for ANY input `a`, symmetric or not: every iterate is a polynomial in the one matrix A = a / tr(a)
+ * (Y_0 = A (3I - A)/2, Z_0 = (3I - A)/2, and each step multiplies polynomials in A), and polynomials in one matrix
+ * commute.  Measured on non-symmetric inputs: 6.7e-7 from the reference, the same as the 38-product form
+ * (tests/test_gpu_zz_candidates.py::test_ns_general_input_backward).  The upstream gradient `dout` may be anything.
+ * hk_ns_sqrtm_bwd_general: same arguments, Z_i Y_i as its own product - all 38 of MPNCOV.py:174-194, literally; kept
+ * for A/B checks (it costs four more products). */
 int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* norm_a, const float* ysave,
                     const float* zsave, const float* dout, float* da, int B, int d, int iter_n, void* ws,
                     size_t ws_bytes, hk_stream_t stream);
+int hk_ns_sqrtm_bwd_general(const float* a, const float* out, const float* norm_a, const float* ysave,
+                            const float* zsave, const float* dout, float* da, int B, int d, int iter_n, void* ws,
+                            size_t ws_bytes, hk_stream_t stream);
 
 /* Row-major upper-triangle (incl. diagonal) vectorisation, index in closed form.
  * replaces model/methods/MPNCOV.py:205-218 (Triuvec.forward; index built on the

@@ -455,6 +455,27 @@ def test_ns_nonsymmetric_upstream_gradient(F):
     assert rel(xg.grad, xo.grad) < 1e-4
 
 
+@pytest.mark.parametrize('itn', [5, 2, 1])
+def test_ns_general_input_backward(F, itn):
+    """Sqrtm.backward for an input that is NOT symmetric (MPNCOV.py:166-202 works for any matrix).  Both entry points
+    must reproduce it: hk_ns_sqrtm_bwd_general (all 38 products) and the default hk_ns_sqrtm_bwd, which takes Z Y from
+    the Y Z accumulator - exact for any input, because every iterate is a polynomial in A and those commute."""
+    b, d = 3, 72
+    gen = torch.Generator().manual_seed(91)
+    r = torch.randn(b, d, d, generator=gen)
+    a = torch.eye(d).expand(b, d, d) * 1.0 + 2.0 * r / d ** 0.5           # far from symmetric, inside the Newton-Schulz basin
+    assert rel(a, a.transpose(1, 2)) > 0.5
+    wt = torch.randn(b, d, d, generator=gen)
+    ao = a.clone().requires_grad_(True)
+    (O.sqrtm(ao, itn) * wt).sum().backward()
+    for sym in (False, True):
+        ag = a.clone().to(DEV).requires_grad_(True)
+        out = F.sqrtm(ag, itn, assume_symmetric=sym)
+        (out * wt.to(DEV)).sum().backward()
+        assert rel(out, O.sqrtm(a, itn)) < 1e-5
+        assert rel(ag.grad, ao.grad) < 1e-5, sym
+
+
 _MODEL_CFG = {
     'BCNN': dict(stage=2, num_classes=200),
     'CBCNN': dict(stage=2, num_classes=200, input_channel=512, output_channel=6000),

@@ -37,7 +37,7 @@ def test_registry_semantics():
     assert r.get('foo') is foo and r['foo']() == 1
     with pytest.raises(AssertionError):
         r.register(foo)                      # uniqueness (utils/repository.py:11)
-    assert sorted(MODEL) == ['APCNN', 'BCNN', 'CBCNN', 'CIN', 'MPN', 'OSMENet']
+    assert sorted(MODEL) == ['APCNN', 'BCNN', 'CBCNN', 'CIN', 'MPN', 'OSMENet', 'ResNet101', 'ResNet50']
     ref = Repository()
     ref.register(foo)
     ref['BCNN'] = object()
@@ -121,6 +121,25 @@ def test_reference_yaml_configs_load_unchanged():
         assert cfg.is_frozen() and 'name' in cfg.model and 'experiment' in cfg
     cfg = load_config('/root/reference/configs/BCNN_S2.yaml')
     assert cfg.model.stage == 2 and cfg.dataset.transformer.image_size == 448 and cfg.experiment.cuda == [0]
+
+
+@pytest.mark.parametrize('name', ['Baseline', 'BCNN_S1', 'BCNN_S2', 'CBCNN_S2', 'MPN', 'APCNN'])
+def test_in_repo_yaml_configs(name, monkeypatch):
+    """The BASELINE configs (and the default configs/Baseline.yaml that setup_config falls back to) ship with the repo:
+    the GPU box has no /root/reference.  Each loads, names a registered plugin that constructs from its model node,
+    and - where the reference checkout exists - parses to exactly the reference's tree."""
+    from hawkeye_amd.config import load_config, setup_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_config(os.path.join(root, 'configs', name + '.yaml'))
+    assert cfg.is_frozen()
+    model = MODEL.get(cfg.model.name)(cfg.model)
+    assert sum(p.numel() for p in model.parameters()) > 1e6
+    ref = f'/root/reference/configs/{name}.yaml'
+    if os.path.exists(ref):
+        assert cfg.to_dict() == load_config(ref).to_dict()
+    if name == 'Baseline':
+        monkeypatch.chdir(root)
+        assert setup_config([]).to_dict() == cfg.to_dict()
 
 
 def test_example_trainers_keep_the_reference_optimizer_groups():
