@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include "hk_common.h"
 #include "hk_bwd128d.h"
+#include "hk_bwd3.h"
 
 namespace hk {
 
@@ -110,12 +111,44 @@ __device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x
     }
 }
 
-// CENTER: subtract the channel mean mu[b][row] while staging a panel (covariance: (X - mu)(X - mu)^T)
+// Covariance (CENTER): centre the 64 x HW row panel `p` (LDS) in place and write the 64 row means to mu_out.  Four lanes
+// per row, each sums the float4s q, q + 4, .. of its row in order, then a two-step butterfly: a fixed order, so the
+// means do not depend on which workgroup computes them.  Called between two barriers.
+template <int HW>
+__device__ __forceinline__ void center_panel(float* p, float* __restrict__ mu_out, int tid) {
+    constexpr int R4 = HW / 4;                       // float4 per row
+    constexpr int NK = (R4 + 3) / 4;
+    const int r = tid >> 2, q = tid & 3;
+    f32x4* row = reinterpret_cast<f32x4*>(p + r * HW);
+    f32x4 v[NK];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int f = q + 4 * k;
+        v[k] = f < R4 ? row[f] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float m = s / (float)HW;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int f = q + 4 * k;
+        if (f < R4) row[f] = v[k] - m;
+    }
+    if (q == 0) mu_out[r] = m;
+}
+
+// CENTER (covariance, MPNCOV.py:115-117: cov = X Ibar X^T = (1/M) (X - mu 1^T) X^T): the row panel (the A operand) is
+// centred in LDS by the workgroup that owns it - which also writes its 64 channel means to mu for the backward - and
+// the column panels stay RAW: sum_k (x_ik - mu_i)(x_jk - mu_j) = sum_k (x_ik - mu_i) x_jk because a centred row sums
+// to zero, which is exactly the reference's (X Ibar) X^T.  No separate row-mean kernel, no mean look-ups while
+// staging.  (Diagonal tiles read the centred panel on both sides: the same number to rounding.)
 template <int HW, int MODE, bool CENTER>
 __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ inv_norm,
                                                                  float* __restrict__ y, int C, int nb, int B,
-                                                                 int pair_mode, const float* __restrict__ mu,
+                                                                 int pair_mode, float* __restrict__ mu,
                                                                  float alpha) {
     constexpr int PANEL = 64 * HW;
     constexpr int N4 = PANEL / 4;
@@ -138,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     ep.yb = y + (long long)b * C * C;
     ep.C = C;
     ep.inv = MODE == 0 ? inv_norm[b] : alpha;
-    const float* mub = CENTER ? mu + (long long)b * C : nullptr;
+    float* mub = CENTER ? mu + (long long)b * C : nullptr;
     ep.inv_m = 1.0f / (float)HW;
     ep.l31 = l31;
     ep.lh = lh;
@@ -151,7 +184,6 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
         for (int u = 0; u < NST; ++u) {
             const int f = tid + 256 * u, fc = f < N4 ? f : N4 - 1;
             st0[u] = src[fc];
-            if (CENTER) st0[u] -= mub[rb0 * 64 + (4 * fc) / HW];
         }
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
 #pragma unroll
@@ -161,6 +193,10 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
         }
     }
     __syncthreads();
+    if (CENTER) {
+        center_panel<HW>(lds, mub + rb0 * 64, tid);
+        __syncthreads();
+    }
 
     int a_idx = 0, b_idx = 0;
     f32x16 prev;
@@ -194,7 +230,6 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
                 for (int u = 0; u < NST; ++u) {
                     const int f = tid + 256 * u, fc = f < N4 ? f : N4 - 1;
                     st[u] = src[fc];
-                    if (CENTER) st[u] -= mub[lb * 64 + (4 * fc) / HW];
                 }
             }
 
@@ -214,8 +249,15 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
             // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for every epilogue store of this tile
             HK_LDS_BARRIER();
             if (next_blk >= 0) {
-                if (newrow) { a_idx = n_idx; b_idx = n_idx; }
-                else b_idx = n_idx;
+                if (newrow) {
+                    a_idx = n_idx; b_idx = n_idx;
+                    if (CENTER) {                                     // the second row block of the pair: its panel just landed
+                        center_panel<HW>(lds + n_idx * PANEL, mub + rb1 * 64, tid);
+                        HK_LDS_BARRIER();
+                    }
+                } else {
+                    b_idx = n_idx;
+                }
             }
         }
     }
@@ -396,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
 }
 
 template <int HW, int MODE, bool CENTER>
-static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, const float* mu, float alpha,
+static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, float* mu, float alpha,
                        hipStream_t st) {
     const int nb = C / 64;
     const int pair_mode = ((long long)B * nb > 256) ? 1 : 0;
@@ -421,6 +463,19 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
     // B * C / 128 >= 192); the covariance at B = 64, C = 256 (128 row blocks) is faster on the 64-row kernel
     // (30 vs 39 us).  tuning().bwd_v: 0 automatic, 1 force the 64-row kernel, 5 force the 128-row one.
     const int v = tuning().bwd_v;
+    // hk_bwd3.h (bwd_v 11..14 = flags 3, 1, 2, 0: VALU remainder columns | LDS-staged epilogue): 128-row blocks where
+    // they fill the chip, else 64-row blocks
+    if constexpr (MODE == 0 || MODE == 1 || MODE == 3) {
+        if ((v >= 11 && v <= 14) || (v >= 21 && v <= 24)) {          // 21..24: the same with 128-row blocks forced
+            const int f = v % 10;
+            const int flags = f == 1 ? 3 : (f == 2 ? 1 : (f == 3 ? 2 : 0));
+            int rc = HK_ERR_UNSUPPORTED;
+            if (C % 128 == 0 && (v > 20 || (long long)B * (C / 128) >= 192))
+                rc = bwd3_launch<HW, MODE, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
+            if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, MODE, 1>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
+            if (rc != HK_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if (v != 1 && C % 128 == 0 && (v >= 5 || (long long)B * (C / 128) >= 192)) {
         if constexpr (MODE == 0 || MODE == 3) {             // LDS-DMA staging (hk_bwd128d.h; forced by bwd_v = 9); bwd_v = 5 asks for the register-staged kernel
             if (v == 0 || v >= 9) {
@@ -461,8 +516,9 @@ int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C
 #undef CALL
 }
 
-// G = alpha * X X^T (raw Gram, CBP) or alpha * (X - mu)(X - mu)^T (covariance, mu != nullptr)
-int gram_fast_raw(const float* x, const float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st) {
+// G = alpha * X X^T (raw Gram, CBP; mu == nullptr) or alpha * (X - mu 1^T) X^T (covariance; mu [B, C] is WRITTEN: the
+// channel means, computed by the kernel itself)
+int gram_fast_raw(const float* x, float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st) {
     if (C % 64 != 0 || !aligned16(x) || !aligned16(g)) return HK_ERR_UNSUPPORTED;
     if (mu) {
 #define CALL(H) gram_launch<H, 1, true>(x, nullptr, g, B, C, mu, alpha, st)

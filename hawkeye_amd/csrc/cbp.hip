@@ -23,7 +23,7 @@
 
 namespace hk {
 
-int gram_fast_raw(const float* x, const float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
+int gram_fast_raw(const float* x, float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
 int cbp_fast_bwd(const float* x, const int* h1, const int* h2, const float* s1, const float* s2, const float* dc, int D,
                  float* dx, int B, int C, int HW, hipStream_t st);
 static inline bool force_generic() { return tuning().bcnn_generic == 1; }   // A/B lever (hk_tuning_set)

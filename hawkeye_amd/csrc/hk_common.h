@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <mutex>
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -26,6 +27,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         __builtin_amdgcn_s_barrier();                      \
         asm volatile("" ::: "memory");                     \
     } while (0)
+#endif
+
+#ifndef HK_FMAC_PINNED  // acc = fma(a, b, acc) as ONE v_fmac_f32 that stays where it is written: left to the compiler, a chain of
+                        // side-product FMAs next to an MFMA stream is packed (v_pk_fma_f32) and sunk to the end of the
+                        // loop body, which keeps every operand alive until there (hk_bwd3.h: +75 live registers, spills)
+#define HK_FMAC_PINNED(acc, a, b) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
 #endif
 
 #define HK_LAUNCH_CHECK()                                 \

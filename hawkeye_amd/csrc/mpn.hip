@@ -14,7 +14,7 @@
 namespace hk {
 
 // bcnn_fast.hip (panel-resident kernels; HK_ERR_UNSUPPORTED when the shape is not covered)
-int gram_fast_raw(const float* x, const float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
+int gram_fast_raw(const float* x, float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
 int cov_fast_bwd(const float* x, const float* mu, const float* g, float* dx, int B, int C, int HW, hipStream_t st);
 static inline bool force_generic() { return tuning().bcnn_generic == 1; }   // A/B lever (hk_tuning_set)
 
@@ -233,13 +233,13 @@ using namespace hk;
 extern "C" int hk_cov_pool_fwd(const float* x, float* cov, float* mu, int B, int C, int M, hk_stream_t stream) {
     if (!x || !cov || !mu || B <= 0 || C <= 0 || M <= 0) return HK_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const long long rows = (long long)B * C;
-    hipLaunchKernelGGL(row_mean_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, mu, rows, M);
-    HK_LAUNCH_CHECK();
-    if (!force_generic()) {
+    if (!force_generic()) {      // the panel kernel computes the channel means itself (and writes mu for the backward)
         const int rc = gram_fast_raw(x, mu, 1.0f / (float)M, cov, B, C, M, st);
         if (rc != HK_ERR_UNSUPPORTED) return rc;
     }
+    const long long rows = (long long)B * C;
+    hipLaunchKernelGGL(row_mean_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, mu, rows, M);
+    HK_LAUNCH_CHECK();
     LdRowSub l;
     l.base = make_plain(x, (long long)C * M, M, C, M);
     l.mu = mu; l.mubs = C;

@@ -437,6 +437,122 @@ def gen_apcnn_train():
           'grads', [rel(grads32[k], grads[k]) for k in keep])
 
 
+# ---------------------------------------------------------------- full BASELINE dispatch shapes
+# The shapes the BASELINE configs actually launch (per-GPU batch 64 / 16): the kernels pick other tilings, grids and
+# queue counts there than at the B = 2 pins above, so the reference is run at the full batch and pinned per sample.
+FULL_PICK = [0, 7, 15, 31, 32, 47, 63]            # first / middle / last sample of each half (two-queue dispatch), and of the first 16
+FULL_PICK16 = [0, 7, 15]                          # AP-CNN (batch 16)
+
+
+def gen_full():
+    out = {'pick': np.array(FULL_PICK), 'pick16': np.array(FULL_PICK16)}
+    per = lambda a: a.double().reshape(a.shape[0], -1)
+
+    # Fast MPN-COV head of configs/MPN.yaml at the benchmark batch: covariance (C = 256), Newton-Schulz (d = 256, 5
+    # iterations), triuvec, and the whole backward  (MPNCOV.py:105-230)
+    x = t(rs_relu_randn(3101, (64, 256, 14, 14))).requires_grad_(True)
+    cov = M_MPN.Covpool.apply(x)
+    cov.retain_grad()
+    sq = M_MPN.Sqrtm.apply(cov, 5)
+    sq.retain_grad()
+    tv = M_MPN.Triuvec.apply(sq)
+    (tv * t(rs_randn(3102, tuple(tv.shape)))).sum().backward()
+    out.update(mpn_cov_sum=per(cov).sum(1), mpn_cov_abs=per(cov).abs().sum(1), mpn_sq_sum=per(sq).sum(1),
+               mpn_sq_abs=per(sq).abs().sum(1), mpn_tv_sum=per(tv).sum(1), mpn_dcov_abs=per(cov.grad).abs().sum(1),
+               mpn_dx_sum=per(x.grad).sum(1), mpn_dx_abs=per(x.grad).abs().sum(1))
+    for s_ in FULL_PICK:
+        out[f'mpn_cov_{s_}'] = sub(cov[s_], 61)
+        out[f'mpn_sq_{s_}'] = sub(sq[s_], 61)
+        out[f'mpn_dcov_{s_}'] = sub(cov.grad[s_], 61)
+        out[f'mpn_dx_{s_}'] = sub(x.grad[s_], 61)
+    print('mpn full done')
+
+    # compact bilinear pooling of configs/CBCNN_S2.yaml, D = 6000, 64 samples (the yaml batch of 16 = the first 16);
+    # the reference's FFT route is per-sample independent: run in slices of 4 to bound its [B*196, 6000] complex buffers
+    cbp = M_CBCNN.CompactBilinearPooling(512, 512, 6000)
+    xn, wn = rs_relu_randn(3201, (64, 512, 14, 14)), rs_randn(3202, (64, 6000))
+    # The gradient passes through dc = du / (2 sqrt(|c| + 1e-10)): round-off of the fp32 FFTs in the small bins is
+    # amplified, and the reference's own float32 gradient is ~1e-4 away from its float64 one.  So the reference is run
+    # twice - float32 (what it executes; pins y) and float64 (same module, sketch matrices cast; pins dX) - and the
+    # float32 run's distance from the float64 one is stored as the yardstick (cbp_e32_*), like gen_apcnn_train.
+    runs = {}
+    for dt in (torch.float32, torch.float64):
+        cbp.sparse_sketch_matrix1 = cbp.sparse_sketch_matrix1.to(dt)
+        cbp.sparse_sketch_matrix2 = cbp.sparse_sketch_matrix2.to(dt)
+        ys, dxs = [], []
+        for i in range(0, 64, 4):
+            xs = t(xn[i:i + 4]).to(dt).requires_grad_(True)
+            y = cbp(xs)
+            (y * t(wn[i:i + 4]).to(dt)).sum().backward()
+            ys.append(y.detach())
+            dxs.append(xs.grad)
+        runs[dt] = (torch.cat(ys), torch.cat(dxs))
+    (y, dx), (y64, dx64) = runs[torch.float32], runs[torch.float64]
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    out.update(cbp_y_sum=per(y).sum(1), cbp_y_abs=per(y).abs().sum(1), cbp_dx64_abs=per(dx64).abs().sum(1),
+               cbp_e32_dx=np.array([rel(dx[i], dx64[i]) for i in range(64)]),
+               cbp_e32_y=np.array([rel(y[i], y64[i]) for i in range(64)]))
+    print('cbp: fp32 reference vs fp64 reference, dx: max', out['cbp_e32_dx'].max(), 'y: max', out['cbp_e32_y'].max())
+    for s_ in FULL_PICK:
+        out[f'cbp_y_{s_}'] = y[s_]
+        out[f'cbp_dx_{s_}'] = sub(dx[s_], 61)
+        out[f'cbp_dx64_{s_}'] = sub(dx64[s_], 61).float()
+    print('cbp full done')
+
+    # AP-CNN at the yaml batch (16) with the iNat2018 class count (8142: border band 0.1 - 0.9, APCNN.py:451-455):
+    # pyramid attention + GAP on 256-channel maps, ROI selection, ROI crop / drop / resize of the 512 x 56 x 56 map
+    torch.manual_seed(11)
+    apn = M_AP.PyramidAttentions(channel_size=256)
+    with torch.no_grad():
+        for i, (k, p_) in enumerate(apn.named_parameters()):
+            if k.endswith('_1.conv.weight'):            # spatial gates (ConvTranspose2d [256,1,3,3]): keep the sigmoid unsaturated
+                p_.copy_(t(rs_randn(3300 + i, tuple(p_.shape))) * np.float32(0.1 / 256 ** 0.5))
+    for k, v in apn.state_dict().items():
+        out['apn_w_' + k.replace('.', '__')] = v.clone()
+    feats = [t(rs_randn(3310 + i, (16, 256, s, s))).requires_grad_(True) for i, s in enumerate((56, 28, 14))]
+    a3, a4, a5, s3, s4, s5 = apn(feats)
+    pooled = [a.mean(dim=(2, 3)) for a in (a3, a4, a5)]
+    sum((p_ * t(rs_randn(3320 + i, tuple(p_.shape)))).sum() for i, p_ in enumerate(pooled)).backward()
+    for lvl, (p_, m_, f_) in enumerate(zip(pooled, (s3, s4, s5), feats)):
+        out[f'apn_pooled{lvl + 3}'] = p_
+        out[f'apn_mask{lvl + 3}_sum'] = per(m_).sum(1)
+        out[f'apn_df{lvl + 3}_abs'] = per(f_.grad).abs().sum(1)
+        for s_ in FULL_PICK16:
+            out[f'apn_df{lvl + 3}_{s_}'] = sub(f_.grad[s_], 211)
+    d = _Dummy()
+    d.num_classes = 8142
+    masks = [t(1.0 / (1.0 + np.exp(-2.0 * rs_randn(3330 + l, (16, 1, hw, hw))))).float() for l, hw in enumerate((56, 28, 14))]
+    rois = [M_AP.ResNet.get_att_roi(d, m_, s_, a_, 448, 448, iou_thred=0.05, topk=k_)
+            for m_, (s_, a_, k_) in zip(masks, ((8, 64, 5), (16, 128, 3), (32, 256, 1)))]
+    out.update(ap_roi3=rois[0], ap_roi4=rois[1], ap_roi5=rois[2])
+    for mode in ('train', 'eval'):
+        d.training = mode == 'train'
+        x2 = t(rs_randn(3340, (16, 512, 56, 56))).requires_grad_(True)
+        random.seed(13)
+        state = random.getstate()
+        yc, _ = M_AP.ResNet.get_roi_crop_feat(d, x2, rois, 8)
+        (yc * t(rs_randn(3341, tuple(yc.shape)))).sum().backward()
+        out[f'ap_y_abs_{mode}'] = per(yc).abs().sum(1)
+        out[f'ap_dx_abs_{mode}'] = per(x2.grad).abs().sum(1)
+        for s_ in FULL_PICK16:
+            out[f'ap_y_{mode}_{s_}'] = sub(yc[s_], 211)
+            out[f'ap_dx_{mode}_{s_}'] = sub(x2.grad[s_], 211)
+        if mode == 'train':                       # the reference's own draw sequence (APCNN.py:494-504), replayed
+            random.setstate(state)
+            picks = []
+            for i in range(16):
+                n3, n4 = int((rois[0][:, 0] == i).sum()), int((rois[1][:, 0] == i).sum())
+                pr = random.random()
+                if pr < 0.3:
+                    picks.append((3, random.randint(0, n3 - 1)))
+                elif pr < 0.6:
+                    picks.append((4, random.randint(0, n4 - 1)))
+                else:
+                    picks.append((0, -1))
+            out['ap_drops'] = np.array(picks)
+    save('full_shapes', **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:                       # regenerate selected fixtures only, e.g. `gen_golden.py mamc`

@@ -89,6 +89,49 @@ def test_backward_128_row_kernel(F, b, c, hw, tune):
     assert rel(res[1][1], xo.grad) < 1e-5
 
 
+@pytest.mark.parametrize('b,c,hw', [(2, 128, 14), (3, 256, 10), (2, 64, 14), (9, 192, 12), (2, 256, 8)])
+def test_backward_bwd3_kernel(F, b, c, hw, tune):
+    """hk_bwd3.h (bwd_v = 11..14: VALU remainder columns and / or the LDS-staged epilogue; 128-row blocks for C % 128 == 0
+    when forced, else 64-row) for the BCNN, signed-sqrt and covariance modes against the 64-row panel kernel (bwd_v = 1)
+    and the oracle.  Columns served by the matrix pipe are the same fma chains as in every other backward kernel; the
+    HW % 16 == 4 remainder columns (14 x 14, 10 x 10 maps) are summed per lq-quarter on the VALU: rounding-level
+    differences there.  The covariance's centring is the mu column: dX = P X - (P mu) 1^T."""
+    gen = torch.Generator().manual_seed(c + hw)
+    x = torch.relu(torch.randn(b, c, hw, hw, generator=gen))
+    res = {}
+    flags = (1, 11, 12, 13, 14) + ((21, 23) if c % 128 == 0 else ())      # 21.. : 128-row blocks forced
+    for flag in flags:
+        tune('bwd_v', flag)
+        out = []
+        for k, fn in enumerate((F.bilinear_pool, F.covpool, lambda t_: F.bilinear_pool(t_, signed_sqrt=True))):
+            xg = x.clone().to(DEV).requires_grad_(True)
+            y = fn(xg)
+            (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(1 + k)).to(DEV)).sum().backward()
+            out.append(xg.grad.clone())
+        res[flag] = out
+    for flag in flags[1:]:
+        for k, tol in enumerate((2e-6, 2e-6, 2e-5)):
+            assert rel(res[flag][k], res[1][k]) < tol, (flag, k)
+    if c % 128 == 0:        # the block height changes which workgroup adds which t-partial, nothing in the covariance's dX
+        assert torch.equal(res[21][1], res[11][1]) and torch.equal(res[23][1], res[13][1])
+    # the epilogue does not change a bit; with the remainder on the VALU only the last HW % 16 columns may differ
+    for k in range(3):
+        assert torch.equal(res[11][k], res[12][k]) and torch.equal(res[13][k], res[14][k]), k
+    nfull = (hw * hw) // 16 * 16
+    if (hw * hw) % 16 == 4:
+        for k in (1,):     # covariance: nothing but the GEMM between dcov and dX (BCNN modes: t = <y, dy> is summed inside)
+            a, r = res[11][k].reshape(b, c, -1), res[13][k].reshape(b, c, -1)
+            assert rel(a[..., nfull:], r[..., nfull:]) < 2e-6 and float(a[..., nfull:].abs().sum()) > 0
+    xo = x.clone().requires_grad_(True)
+    yo = O.bilinear_pool(xo)
+    (yo * torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))).sum().backward()
+    assert rel(res[11][0], xo.grad) < 2e-5
+    xo = x.clone().requires_grad_(True)
+    co = O.covpool(xo)
+    (co * torch.randn(co.shape, generator=torch.Generator().manual_seed(2))).sum().backward()
+    assert rel(res[11][1], xo.grad) < 1e-5 and rel(res[14][1], xo.grad) < 1e-5
+
+
 @pytest.mark.parametrize('mode', ['train', 'eval'])
 def test_roi_crop_backward_lds_variant_bit_identical(F, mode, tune):
     """The uniform-window ROI-refinement backward (apcnn_roi2.hip, the default: one tap-window size per workgroup, four
