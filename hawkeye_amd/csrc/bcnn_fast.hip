@@ -463,14 +463,22 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
     // B * C / 128 >= 192); the covariance at B = 64, C = 256 (128 row blocks) is faster on the 64-row kernel
     // (30 vs 39 us).  tuning().bwd_v: 0 automatic, 1 force the 64-row kernel, 5 force the 128-row one.
     const int v = tuning().bwd_v;
-    // hk_bwd3.h (bwd_v 11..14 = flags 3, 1, 2, 0: VALU remainder columns | LDS-staged epilogue): 128-row blocks where
-    // they fill the chip, else 64-row blocks
+    // hk_bwd3.h - the default for the BCNN, signed-sqrt and covariance modes wherever its blocks fill the chip (128-row
+    // blocks when B C / 128 >= 192, else 64-row blocks when B C / 64 >= 192).  Measured at B = 64, 14 x 14, alternating
+    // rounds (tools/r3_lab.py, profiles/r3_lab_call1.json): BCNN C = 512: 65.2 us against 71.5 (hk_bwd128d.h), 79.1
+    // (64-row panel kernel); VALU remainder alone 68.9, LDS-staged epilogue alone 69.1; covariance C = 256: 20.2 us
+    // against 24.0 (eight-wave register-staged kernel on 64-row blocks), 27.9 (panel kernel), 32.3 with 128-row blocks
+    // (128 workgroups).  bwd_v 11..14 force it with flags 3, 1, 2, 0 (bit 0 VALU remainder columns, bit 1 LDS-staged
+    // epilogue), 21..24 the same with 128-row blocks.
     if constexpr (MODE == 0 || MODE == 1 || MODE == 3) {
-        if ((v >= 11 && v <= 14) || (v >= 21 && v <= 24)) {          // 21..24: the same with 128-row blocks forced
-            const int f = v % 10;
+        const bool forced = (v >= 11 && v <= 14) || (v >= 21 && v <= 24);
+        const bool fill2 = C % 128 == 0 && (long long)B * (C / 128) >= 192;
+        const bool fill1 = (long long)B * nb >= 192;
+        if (forced || (v == 0 && (fill2 || fill1))) {
+            const int f = forced ? v % 10 : 1;
             const int flags = f == 1 ? 3 : (f == 2 ? 1 : (f == 3 ? 2 : 0));
             int rc = HK_ERR_UNSUPPORTED;
-            if (C % 128 == 0 && (v > 20 || (long long)B * (C / 128) >= 192))
+            if (C % 128 == 0 && (v > 20 || fill2))
                 rc = bwd3_launch<HW, MODE, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
             if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, MODE, 1>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
             if (rc != HK_ERR_UNSUPPORTED) return rc;

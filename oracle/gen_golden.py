@@ -23,6 +23,7 @@ REF = os.environ.get('HAWKEYE_REFERENCE', '/root/reference')
 sys.path.insert(0, os.path.join(HERE, '_stubs'))
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+sys.path.insert(0, HERE)
 
 from inputs import rs_randn, rs_relu_randn, rs_signed_channels, sub  # noqa: E402  (tests/golden/inputs.py)
 
@@ -497,6 +498,34 @@ def gen_full():
         out[f'cbp_y_{s_}'] = y[s_]
         out[f'cbp_dx_{s_}'] = sub(dx[s_], 61)
         out[f'cbp_dx64_{s_}'] = sub(dx64[s_], 61).float()
+    # Conditioning of the gradient per sample (a YARDSTICK for the tolerance, not a pin): a bin c_k is a signed sum of
+    # ~44 Gram entries; summed in float32 by ANY route it carries an error ~ eps32 * S_k (S_k = sum of their
+    # magnitudes), and dc_k = du_k / (2 sqrt|c_k|) turns that into a relative change eps32 * S_k / (2 |c_k|) of dc_k -
+    # unbounded as a bin cancels.  dX is linear in dc, so the first-order float32 error of dX is
+    # |L(dc * eps32 S / 2|c| * xi)| / |L(dc)| with random signs xi; evaluated in float64 through the count-sketch identity.
+    # Of the 64 samples here four have a bin that cancels to 1e-2 .. 4e-1 (the reference's own float32 run is 1e-2 .. 6e-1
+    # off on exactly those), the median is 5e-4.
+    import hawkeye_oracle as O_
+    h1, s1, h2, s2 = O_.sketch_hashes(512, 512, 6000)
+    assert (torch.from_numpy(h1) == cbp.sparse_sketch_matrix1.abs().argmax(dim=1)).all()     # the reference's own hashes
+    bins = ((torch.from_numpy(h1)[:, None] + torch.from_numpy(h2)[None, :]) % 6000).reshape(-1)
+    sign = (torch.from_numpy(s1)[:, None] * torch.from_numpy(s2)[None, :]).double().reshape(-1)
+    conds = []
+    for i in range(0, 64, 8):
+        X = t(xn[i:i + 8]).double().reshape(8, 512, 196)
+        Gm = torch.bmm(X, X.transpose(1, 2)).reshape(8, -1)
+        c = torch.zeros(8, 6000, dtype=torch.float64).index_add(1, bins, Gm * sign).requires_grad_(True)
+        S = torch.zeros(8, 6000, dtype=torch.float64).index_add(1, bins, Gm.abs())
+        u = torch.sign(c) * torch.sqrt(c.abs() + 1e-10)
+        (torch.nn.functional.normalize(u) * t(wn[i:i + 8]).double()).sum().backward()
+        dc = c.grad
+        xi = t(np.random.RandomState(3203 + i).choice([-1.0, 1.0], size=(8, 6000)))
+        ddc = dc * (2.0 ** -24 * S / (2 * (c.detach().abs() + 1e-10))) * xi
+        lin = lambda v: torch.bmm((v[:, bins] * sign).reshape(8, 512, 512) + (v[:, bins] * sign).reshape(8, 512, 512).transpose(1, 2), X)
+        conds.append(lin(ddc).reshape(8, -1).norm(dim=1) / lin(dc).reshape(8, -1).norm(dim=1))
+    out['cbp_cond'] = torch.cat(conds)
+    print('cbp: conditioning estimate max', float(out['cbp_cond'].max()), 'median', float(out['cbp_cond'].median()),
+          '; reference fp32 error / (1e-4 + 2 cond): max', float((torch.from_numpy(out['cbp_e32_dx']) / (1e-4 + 2 * out['cbp_cond'])).max()))
     print('cbp full done')
 
     # AP-CNN at the yaml batch (16) with the iNat2018 class count (8142: border band 0.1 - 0.9, APCNN.py:451-455):

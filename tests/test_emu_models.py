@@ -75,7 +75,8 @@ def test_trainers_end_to_end_on_emulated_heads(which, tmp_path, monkeypatch):
     tr = T(cfg)
     tr.train()
     assert len(tr.performance_meters['train']['loss'].values) == 1
-    assert os.path.isfile(os.path.join(tr.log_root, f'{which}_epoch_1.pth'))
+    # (no periodic checkpoint after the first epoch: `epoch != 0 and ...`, reference train.py:296)
+    assert not os.path.isfile(os.path.join(tr.log_root, f'{which}_epoch_1.pth'))
 
 
 def test_candidates_tool_dry_run():
@@ -127,10 +128,11 @@ def test_tester_evaluates_a_trainer_checkpoint(tmp_path, monkeypatch):
     cfg.dataset.transformer.device_finalize = True
     cfg.model.num_classes = 3
     cfg.train.save_frequence = 1
+    cfg.train.epoch = 2
     cfg.freeze()
     tr = BCNNTrainer(cfg)
     tr.train()
-    ckpt = os.path.join(tr.log_root, 'BCNN_epoch_1.pth')
+    ckpt = os.path.join(tr.log_root, 'BCNN_epoch_2.pth')
     assert os.path.isfile(ckpt)
     tcfg = cfg.clone() if hasattr(cfg, 'clone') else CfgNode(cfg.to_dict())
     tcfg.defrost() if hasattr(tcfg, 'defrost') else None

@@ -102,26 +102,27 @@ def test_cbp_at_config_batches_vs_reference(F, g, b):
     torch.cuda.synchronize()
     np.testing.assert_allclose(per(y).abs().sum(1), g['cbp_y_abs'][:b], rtol=1e-5)
     np.testing.assert_allclose(per(y).sum(1), g['cbp_y_sum'][:b], rtol=1e-4, atol=1e-5)
-    # dX: the gradient goes through dc = du / (2 sqrt|c|), which amplifies fp32 round-off in the small bins: the
-    # reference's OWN float32 gradient is e32[s] away from its float64 one (stored per sample: median 1.4e-4, 1e-2 and
-    # worse for the few samples with a bin near zero - conditioning of the function, not of an implementation).  The pin
-    # is the reference run in float64 and the bound per sample is what the reference's float32 run achieves itself.
-    e32 = g['cbp_e32_dx'][:b]
+    # dX: the gradient goes through dc = du / (2 sqrt|c|), which amplifies the float32 error of a bin that cancels: ANY
+    # float32 route is cond[s] (stored per sample: first-order estimate, gen_full) away from the exact gradient - median
+    # 5e-4, 1e-2 .. 4e-1 for the four samples with a cancelling bin, where the reference's own float32 run is 1e-2 .. 6e-1
+    # off too.  The pin is the reference run in float64; the bound per sample is 1e-4 + 2 cond[s].
+    cond = g['cbp_cond'][:b]
     got = per(xg.grad).abs().sum(1).numpy()
-    assert (np.abs(got / g['cbp_dx64_abs'][:b] - 1) < 1e-4 + e32).all()
+    assert (np.abs(got / g['cbp_dx64_abs'][:b] - 1) < 1e-4 + 2 * cond).all()
+    assert np.median(np.abs(got / g['cbp_dx64_abs'][:b] - 1)) < 1e-4
     picks = [s for s in g['pick'].tolist() if s < b]
     assert len(picks) >= 3
     for s in picks:
         assert rel(y[s], g[f'cbp_y_{s}']) < 1e-5, s
-        np.testing.assert_allclose(y[s].detach().cpu().numpy(), g[f"cbp_y_{s}"], rtol=2e-3, atol=2e-6)     # every bin, sign included
-        assert rel(sub(xg.grad[s].cpu(), 61), g[f'cbp_dx64_{s}']) < 1e-4 + e32[s], s
-        assert rel(sub(xg.grad[s].cpu(), 61), g[f'cbp_dx_{s}']) < 1e-4 + 2.0 * e32[s], s
+        np.testing.assert_allclose(y[s].detach().cpu().numpy(), g[f'cbp_y_{s}'], rtol=2e-3, atol=2e-6)     # every bin, sign included
+        assert rel(sub(xg.grad[s].cpu(), 61), g[f'cbp_dx64_{s}']) < 1e-4 + 2 * cond[s], s
+        assert rel(sub(xg.grad[s].cpu(), 61), g[f'cbp_dx_{s}']) < 2e-4 + 4 * cond[s], s       # vs the reference's float32 run
     # two of them against the oracle's restatement of the FFT route
     two = picks[:1] + picks[-1:]
     xo = t(xn[two]).requires_grad_(True)
     yo = O.compact_bilinear_pool(xo, 6000)
     (yo * t(wn[two])).sum().backward()
-    assert rel(y[two], yo) < 1e-5 and rel(xg.grad[two], xo.grad) < 2.0 * float(e32[two].max()) + 1e-4
+    assert rel(y[two], yo) < 1e-5 and rel(xg.grad[two], xo.grad) < 2e-4 + 4 * float(cond[two].max())
     assert torch.allclose(y.norm(dim=1), torch.ones(b, device=DEV), atol=1e-5)
 
 

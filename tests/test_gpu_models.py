@@ -304,10 +304,13 @@ def test_trainer_runs_one_synthetic_epoch(tmp_path):
     cfg.dataset.num_workers = 0
     cfg.dataset.transformer.image_size = 64
     cfg.train.save_frequence = 1
+    cfg.train.epoch = 2
     cfg.freeze()
     tr = BCNNTrainer(cfg)
     tr.train()
-    assert len(tr.performance_meters['train']['loss'].values) == 1
-    assert os.path.isfile(os.path.join(tr.log_root, 'BCNN_epoch_1.pth'))
-    sd = torch.load(os.path.join(tr.log_root, 'BCNN_epoch_1.pth'), map_location='cpu')
+    assert len(tr.performance_meters['train']['loss'].values) == 2
+    # the reference never writes a periodic checkpoint after the FIRST epoch (train.py:296: `epoch != 0 and ...`)
+    assert not os.path.isfile(os.path.join(tr.log_root, 'BCNN_epoch_1.pth'))
+    assert os.path.isfile(os.path.join(tr.log_root, 'BCNN_epoch_2.pth'))
+    sd = torch.load(os.path.join(tr.log_root, 'BCNN_epoch_2.pth'), map_location='cpu')
     assert 'classifier.weight' in sd and not any(k.startswith('module.') for k in sd)
