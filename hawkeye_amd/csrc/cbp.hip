@@ -18,7 +18,11 @@
 #include <cstring>
 #include <algorithm>
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 #include "hk_bgemm.h"
+#define HK_LAB_CBF 1   // TEMPORARY: timing-only variants behind cbp_bin = 5 / 6
+#include "hk_cbp_fused.h"
 #include "../../include/hawkeye_hip.h"
 
 namespace hk {
@@ -42,9 +46,29 @@ struct CbpPlan {  // device-side view of the plan blob
     const unsigned* nzj; // [C]
     int nzn;             // number of non-empty h2 bins (<= C)
     int emax;            // largest number of channels sharing one h2 bin
+    const unsigned* lists;   // fused forward (hk_cbp_fused.h): the (C / 64)^2 sorted tile lists; nullptr when not built
 };
 
 __host__ __device__ inline size_t cbp_align(size_t x) { return (x + 15) & ~(size_t)15; }
+// the blob carries the tile lists of the fused forward for every shape that kernel covers (whether THESE hashes allow
+// it is decided at build time and recorded in header word 4 of the blob: hk_cbp_plan_build)
+static inline bool cbp_has_lists(int C, int D) { return C % 64 == 0 && C <= 1024 && D + 1 <= (1 << 13); }
+
+// Whether the tile lists of a plan blob were built (they are not when some bin holds more entries of one 64x64 tile than
+// a lane's steps - tiny D): decided on the host by hk_cbp_plan_build, needed on the host by hk_cbp_fwd, and the blob is
+// device memory.  A directory device pointer -> flag, written by plan_build and read by fwd under a mutex; a blob that
+// is not in it (copied by the caller) takes the unfused path.
+static std::mutex g_plan_mu;
+static std::unordered_map<const void*, int> g_plan_fused;
+static inline void plan_note(const void* plan, int fused_ok) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plan_fused[plan] = fused_ok;
+}
+static inline int plan_fused_ok(const void* plan) {          // 0 no lists, 1 lists, 2 lists that allow paired steps
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    const auto it = g_plan_fused.find(plan);
+    return it != g_plan_fused.end() ? it->second : 0;
+}
 
 static inline CbpPlan cbp_view(const void* plan, int C, int D) {
     const char* p = (const char*)plan + 16;
@@ -57,7 +81,8 @@ static inline CbpPlan cbp_view(const void* plan, int C, int D) {
     v.ent = (const unsigned*)p;      p += cbp_align((size_t)C * C * 4);
     v.nzb = (const int*)p;           p += cbp_align((size_t)C * 4);
     v.nzo = (const int*)p;           p += cbp_align((size_t)(C + 1) * 4);
-    v.nzj = (const unsigned*)p;
+    v.nzj = (const unsigned*)p;          p += cbp_align((size_t)C * 4);
+    v.lists = cbp_has_lists(C, D) ? (const unsigned*)p : nullptr;
     v.nzn = ((const int*)plan)[2];
     v.emax = ((const int*)plan)[3];
     return v;
@@ -438,6 +463,77 @@ __global__ __launch_bounds__(256) void cbp_norm_kernel(const float* __restrict__
     if (k == 0) inv_norm[b] = 1.0f / n;
 }
 
+// One-launch finishing stage (round 3; the two launches above cost ~5 us each at B = 64 for 6 MB of data - launch
+// latency).  grid (CBP_FQ, B), 1024 threads: every workgroup of a sample adds the sample's `npart` partial bin vectors
+// for ALL D bins (fixed order) - it needs them for the norm - keeps the bins of its own quarter, reduces
+// |u|^2 = sum_k (|c_k| + 1e-10 where c_k != 0) in a fixed order (the same value in all CBP_FQ workgroups of the sample),
+// and writes c_raw / y for its quarter.  The redundant reads are L2 hits (B x npart x 24 KB in total).
+constexpr int CBP_FQ = 4;
+constexpr int CBP_FT = 1024;
+constexpr int CBP_FK = 8;                             // bins per thread: D <= CBP_FK * CBP_FT
+__global__ __launch_bounds__(CBP_FT) void cbp_finish_kernel(const float* __restrict__ part, float* __restrict__ c_raw,
+                                                           float* __restrict__ y, float* __restrict__ inv_norm, int D,
+                                                           int npart) {
+    __shared__ float red[CBP_FT / 64];
+    const int b = blockIdx.y, qd = blockIdx.x, tid = threadIdx.x;
+    const int per = (D + CBP_FQ - 1) / CBP_FQ, k0 = qd * per, k1 = (k0 + per < D) ? k0 + per : D;
+    const float* pb = part + (long long)b * npart * D;
+    // bins tid, tid + 1024, ..: CBP_FK independent loads per partial vector in flight (a loop over the bins with the loop
+    // over the partials inside is one dependent chain of L2 latencies: 15 us for 6 MB)
+    float s[CBP_FK];
+#pragma unroll
+    for (int j = 0; j < CBP_FK; ++j) s[j] = 0.f;
+#pragma unroll 2
+    for (int q = 0; q < npart; ++q) {
+        const float* pq = pb + (long long)q * D;
+#pragma unroll
+        for (int j = 0; j < CBP_FK; ++j) {
+            const int k = tid + CBP_FT * j;
+            s[j] += k < D ? pq[k] : 0.f;              // per bin: partials added in order q = 0, 1, ..
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < CBP_FK; ++j) ss += s[j] != 0.f ? fabsf(s[j]) + 1e-10f : 0.f;   // u^2 = |c| + 1e-10 where c != 0
+    const float tot = block_sum<CBP_FT / 64>(ss, red);
+    const float n = fmaxf(sqrtf(tot), 1e-12f);
+#pragma unroll
+    for (int j = 0; j < CBP_FK; ++j) {
+        const int k = tid + CBP_FT * j;
+        if (k >= k0 && k < k1) {
+            const float v = s[j];
+            const float sg = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);             // sign(0) = 0: u = 0 exactly there
+            c_raw[(long long)b * D + k] = v;
+            y[(long long)b * D + k] = sg * sqrtf(fabsf(v) + 1e-10f) / n;
+        }
+    }
+    if (qd == 0 && tid == 0) inv_norm[b] = 1.0f / n;
+}
+
+// backward, one launch: every workgroup of a sample recomputes t = <y, dy> over all D bins (fixed order), then
+// dc = ((dy - y t) / n) / (2 sqrt(|c| + 1e-10)) for its quarter
+__global__ __launch_bounds__(CBP_FT) void cbp_dc1_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                        const float* __restrict__ c_raw, const float* __restrict__ inv_norm,
+                                                        float* __restrict__ dc, int D) {
+    __shared__ float red[CBP_FT / 64];
+    const int b = blockIdx.y, qd = blockIdx.x, tid = threadIdx.x;
+    const int per = (D + CBP_FQ - 1) / CBP_FQ, k0 = qd * per, k1 = (k0 + per < D) ? k0 + per : D;
+    const long long o = (long long)b * D;
+    float tt = 0.f;
+#pragma unroll
+    for (int j = 0; j < CBP_FK; ++j) {                 // independent loads, fixed order of the adds
+        const int k = tid + CBP_FT * j;
+        tt += k < D ? y[o + k] * dy[o + k] : 0.f;
+    }
+    const float t = block_sum<CBP_FT / 64>(tt, red);
+    const float in = inv_norm[b];
+    for (int k = k0 + tid; k < k1; k += CBP_FT) {
+        const float c = c_raw[o + k];
+        const float du = (dy[o + k] - y[o + k] * t) * in;
+        dc[o + k] = (c != 0.f) ? du / (2.0f * sqrtf(fabsf(c) + 1e-10f)) : 0.f;       // (c == 0: see cbp_dc_kernel)
+    }
+}
+
 // backward of the finishing stage, same two-launch shape:  tp[b][blockIdx.x] = the workgroup's share of <y, dy>
 __global__ __launch_bounds__(256) void cbp_dot_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                       float* __restrict__ tp, int D) {
@@ -500,8 +596,10 @@ struct LdCbpDG {
 using namespace hk;
 
 extern "C" size_t hk_cbp_plan_bytes(int C, int D) {
+    const size_t nb = (size_t)(C / 64);
     return 16 + 4 * cbp_align((size_t)C * 4) + cbp_align((size_t)(D + 1) * 4) + cbp_align((size_t)C * C * 4) +
-           cbp_align((size_t)C * 4) + cbp_align((size_t)(C + 1) * 4) + cbp_align((size_t)C * 4);
+           cbp_align((size_t)C * 4) + cbp_align((size_t)(C + 1) * 4) + cbp_align((size_t)C * 4) +
+           (cbp_has_lists(C, D) ? nb * nb * CBF_LLEN * sizeof(unsigned) + 16 : 0);
 }
 
 extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32_t* h2, const float* s2, int C, int D,
@@ -510,6 +608,7 @@ extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32
     for (int i = 0; i < C; ++i)
         if (h1[i] < 0 || h1[i] >= D || h2[i] < 0 || h2[i] >= D) return HK_ERR_BAD_ARG;   // CBCNN.py:153
     std::vector<char> blob(hk_cbp_plan_bytes(C, D), 0);
+    int fused_ok = 0;
     ((int*)blob.data())[0] = C;
     ((int*)blob.data())[1] = D;
     char* p = blob.data() + 16;
@@ -556,11 +655,23 @@ extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32
         int emax = 0;
         for (int mbin = 0; mbin < D; ++mbin) emax = (int)inv[mbin].size() > emax ? (int)inv[mbin].size() : emax;
         ((int*)blob.data())[3] = emax;
+        // tile lists of the fused forward + one word behind them: 1 = these hashes allow it
+        if (cbp_has_lists(C, D)) {
+            unsigned* lists = (unsigned*)((char*)nzj + cbp_align((size_t)C * 4));
+            std::vector<unsigned> L;
+            const int ok = cbf_build_lists(h1, s1, h2, s2, C, D, L);
+            const size_t nw = (size_t)(C / 64) * (C / 64) * CBF_LLEN;
+            if (ok) memcpy(lists, L.data(), nw * sizeof(unsigned));
+            lists[nw] = (unsigned)ok;
+            fused_ok = ok;
+        }
     }
     hipError_t e = hipMemcpyAsync(plan, blob.data(), blob.size(), hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize((hipStream_t)stream);   // one-time setup: the host blob dies at return
-    return e == hipSuccess ? HK_OK : (int)e;
+    if (e != hipSuccess) return (int)e;
+    plan_note(plan, fused_ok);
+    return HK_OK;
 }
 
 extern "C" size_t hk_cbp_ws_bytes(int B, int C, int HW, int D) {
@@ -590,6 +701,19 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
                            (bin >= 0 ? bin == 0 : B * nchunk >= 256);
     const bool scatter = (bin < 0 || bin == 2) && C <= 512 && C % 4 == 0 && pl.emax <= CBP_EMAX &&
                          rowscatter_lds(C, D) <= 150 * 1024;
+    // Fused Gram + binning (hk_cbp_fused.h): the default wherever the plan carries its tile lists and the shape is one
+    // of the panel kernels'; cbp_bin = 3 forces it, 0 / 1 / 2 force the unfused binning kernels.
+    int npart = nchunk;                                      // partial bin vectors per sample handed to cbp_partsum_kernel
+    bool fused = false;
+    const int fok = plan_fused_ok(plan);
+    if ((bin < 0 || bin >= 3) && !force_generic() && pl.lists && fok) {          // 4: never pair the steps
+        const CbfSchedule sch = cbf_schedule(C / 64, tuning().sched_b > 0 ? tuning().sched_b : B);
+        if ((size_t)B * sch.nitems * D * sizeof(float) + (size_t)B * ((D + 255) / 256) * sizeof(float) <= ws_bytes) {
+            const int rc = cbf_launch(x, pl.lists, (float*)ws, B, C, HW, D, sch, fok == 2 && bin != 4, st);
+            if (rc == HK_OK) { fused = true; npart = sch.nitems; part = (float*)ws; }
+            else if (rc != HK_ERR_UNSUPPORTED) return rc;
+        }
+    }
     // Gram + binning of samples b0 .. b0 + nb - 1 on queue q
     auto gram_and_bin = [&](int b0, int nb, hipStream_t q) -> int {
         const float* xh = x + (long long)b0 * C * HW;
@@ -623,14 +747,20 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
     // (Running the two halves of the batch on two HIP queues, so that one half's binning overlaps the other's Gram - what
     //  pays for the Newton-Schulz chain - was measured here and is NOT done: 121.9 us against 81.5 us on one queue at
     //  B = 64; both kernels want most of a CU's LDS and each half-batch Gram fills only half the CUs.)
-    {
+    if (!fused) {
         const int rc = gram_and_bin(0, B, st);
         if (rc != HK_OK) return rc;
     }
-    float* ssq = part + (long long)B * nchunk * D;
+    if ((fused || rowsketch || scatter) && D <= CBP_FK * CBP_FT) {
+        hipLaunchKernelGGL(cbp_finish_kernel, dim3(CBP_FQ, B), dim3(CBP_FT), 0, st, (const float*)part, c_raw, y, inv_norm, D,
+                           npart);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
+    float* ssq = part + (long long)B * npart * D;
     const dim3 fgrid((D + 255) / 256, B);
-    if (rowsketch || scatter)
-        hipLaunchKernelGGL(cbp_partsum_kernel, fgrid, dim3(256), 0, st, (const float*)part, c_raw, ssq, D, nchunk);
+    if (fused || rowsketch || scatter)
+        hipLaunchKernelGGL(cbp_partsum_kernel, fgrid, dim3(256), 0, st, (const float*)part, c_raw, ssq, D, npart);
     else
         hipLaunchKernelGGL(cbp_partsum_kernel, fgrid, dim3(256), 0, st, (const float*)c_raw, c_raw, ssq, D, 1);
     HK_LAUNCH_CHECK();
@@ -649,10 +779,15 @@ extern "C" int hk_cbp_bwd(const float* x, const void* plan, const float* y, cons
     float* dc = (float*)ws;
     float* tp = dc + (long long)B * D;
     const dim3 fgrid((D + 255) / 256, B);
-    hipLaunchKernelGGL(cbp_dot_kernel, fgrid, dim3(256), 0, st, y, dy, tp, D);
-    HK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(cbp_dc_kernel, fgrid, dim3(256), 0, st, y, dy, c_raw, inv_norm, (const float*)tp, dc, D);
-    HK_LAUNCH_CHECK();
+    if (D <= CBP_FK * CBP_FT) {
+        hipLaunchKernelGGL(cbp_dc1_kernel, dim3(CBP_FQ, B), dim3(CBP_FT), 0, st, y, dy, c_raw, inv_norm, dc, D);
+        HK_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(cbp_dot_kernel, fgrid, dim3(256), 0, st, y, dy, tp, D);
+        HK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(cbp_dc_kernel, fgrid, dim3(256), 0, st, y, dy, c_raw, inv_norm, (const float*)tp, dc, D);
+        HK_LAUNCH_CHECK();
+    }
     if (!force_generic()) {
         const CbpPlan pv = cbp_view(plan, C, D);
         const int rc = cbp_fast_bwd(x, pv.h1, pv.h2, pv.s1, pv.s2, dc, D, dx, B, C, HW, st);

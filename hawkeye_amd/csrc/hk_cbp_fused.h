@@ -1,0 +1,386 @@
+// Compact bilinear pooling, forward: the raw Gram X X^T and the count-sketch binning in ONE kernel - G never reaches HBM.
+//
+// Round 2 ran Gram (writes G: 67 MB at B = 64) -> cbp_rowscatter_kernel (reads it back) -> two finishing launches:
+// 187 MB moved for 27 MB of algorithmic traffic, 76 us at B = 64 and 52 us at the yaml batch of 16, where the Gram
+// launched 128 workgroups on 256 CUs.  Here a workgroup computes 64x64 tiles (I, J), J >= I, of one sample's Gram on
+// the panel-resident MFMA loop of bcnn_fast.hip (A panel = row block I, full K, resident in LDS), parks each finished
+// tile in LDS and bins it from there into a PRIVATE copy of the D output bins, also in LDS; the per-workgroup partial
+// bin vectors (24 KB each) are added in fixed order by cbp_partsum_kernel.
+//
+// Binning a tile deterministically, without atomics, with four waves in parallel: it is a GATHER.  For every ordered
+// pair of 64-row blocks (I, J) the plan holds the 4096 entries (i in I, j in J) -> bin (h1_i + h2_j) mod D, sign
+// s1_i s2_j, sorted by bin and cut into FOUR runs, one per binning wave: wave w owns the bins [w D / 4, (w + 1) D / 4) in
+// every list, so no bin is ever touched by two waves, whatever their relative progress.  Lane t of a wave owns 18
+// consecutive entries of its run (18 x 64 = 1152 >= 1024 + 4.6 sigma of the run length; padded with entries that add 0
+// to a dump bin; the plan build fails over to the unfused path if a run does not fit), and in step e every lane adds
+// one of its entries:
+//     c[bin] += +-T[idx]           T = the tile in LDS
+// The 64 entries of a step are 18 apart in sorted order, so they hit distinct bins unless a bin held more than 18
+// entries of the tile (the plan build checks: at C = 512, D = 6000 the largest count is 7); later steps of a wave may
+// hit the same bin from neighbouring lanes - LDS instructions of one wave execute in order, and a step's (pair of
+// steps') read-modify-write is complete in the instruction stream before the next one's read is issued.  A computed
+// tile (I, J), I < J, feeds two lists: (I, J) and (J, I) (G_ji = G_ij, other bin); a diagonal tile one.  Per bin the
+// additions happen in a fixed order (tile order of the workgroup, position within a list): bit-reproducible.
+//
+// LDS: A panel 50 KB + ONE column panel 50 KB (the next one waits in registers during the tile's MFMA loop and is
+// written behind it - a second panel buffer does not fit next to the bins) + two tile buffers of 17 KB (stored
+// transposed, pitch 68: 16-byte stores without bank conflicts) + D + 1 bins 24 KB = 155.5 KB.
+// Work split: `items` per sample, each one or two runs of tiles (row block, first column block, count) - B = 64: the
+// balanced pairs {p, nb - 1 - p} (nb + 1 tiles, one workgroup per CU); smaller batches: rows cut into runs of <= 3 tiles
+// so that B x items fills the chip (B = 16, C = 512: 16 items per sample = 256 workgroups).
+#pragma once
+#include <vector>
+#include <algorithm>
+#include "hk_gram_tile.h"
+
+namespace hk {
+
+constexpr int CBF_LSTEPS = 18;                     // entries per lane and list (even: the steps go in pairs)
+constexpr int CBF_WLEN = CBF_LSTEPS * 64;          // entries of a wave's run (padded)
+constexpr int CBF_LLEN = 4 * CBF_WLEN;             // words of one list
+constexpr int CBF_TP = 68;                         // pitch of the transposed tile T[j][i]
+constexpr int CBF_TSZ = 64 * CBF_TP + 4;           // + a zero slot (index 64 * 68) for the padding entries
+constexpr int CBF_MAXITEMS = 40;
+
+struct CbfItem {                                   // up to two runs: row block I, column blocks J0 .. J0 + cnt - 1
+    unsigned char I[2], J0[2], cnt[2];
+};
+struct CbfSchedule {
+    int nitems;
+    CbfItem it[CBF_MAXITEMS];
+};
+
+// entry word: bits 0..12 index into T (floats), bits 13..25 bin, bit 26 negative sign
+__host__ __device__ __forceinline__ unsigned cbf_pack(int idx, int bin, int neg) { return (unsigned)idx | ((unsigned)bin << 13) | ((unsigned)neg << 26); }
+
+// Host: the nb x nb lists of (C, D, hashes).  Returns 0 when the fused path cannot be used for these hashes (a bin with
+// more than CBF_LSTEPS entries in one tile, a run that does not fit its padding, D too large for the entry word), 1 when
+// it can, 2 when in addition the two steps of every PAIR (2 p, 2 p + 1) of a wave hit disjoint bins - the kernel then
+// issues the reads of a pair before its writes.  A lane's 18 sorted entries are dealt to its steps with stride 7 (step q
+// takes sorted offset 7 q mod 18), so consecutive steps of a lane - and of its neighbours - are >= 7 apart in sorted
+// order: disjoint unless a bin holds more than 7 entries of the tile (C = 512, D = 6000: at most 7).
+static inline int cbf_build_lists(const int* h1, const float* s1, const int* h2, const float* s2, int C, int D,
+                                  std::vector<unsigned>& out) {
+    if (C % 64 != 0 || D + 1 > (1 << 13)) return 0;
+    const int nb = C / 64;
+    out.assign((size_t)nb * nb * CBF_LLEN, cbf_pack(64 * CBF_TP, D, 0));       // padding: + T[zero slot] to the dump bin
+    struct E { int bin, idx, neg; };
+    std::vector<E> es(4096);
+    bool pairs_ok = true;
+    for (int I = 0; I < nb; ++I)
+        for (int J = 0; J < nb; ++J) {
+            // list (I, J): entries G[i][j], i in block I, j in block J.  The value is read from the tile the workgroup
+            // computed: (I, J) itself when I <= J - stored transposed, T[jl][il] - else tile (J, I), in which G_ij = G_ji
+            // sits at T[il][jl].
+            for (int a = 0; a < 64; ++a)
+                for (int b = 0; b < 64; ++b) {
+                    const int i = I * 64 + a, j = J * 64 + b;
+                    E e;
+                    e.bin = (h1[i] + h2[j]) % D;
+                    e.neg = (s1[i] * s2[j] < 0.f) ? 1 : 0;
+                    e.idx = (I <= J) ? b * CBF_TP + a : a * CBF_TP + b;
+                    es[a * 64 + b] = e;
+                }
+            std::stable_sort(es.begin(), es.end(), [](const E& p, const E& q) { return p.bin < q.bin; });
+            // four runs, one per wave: wave w owns the bins [ceil(w D / 4), ceil((w + 1) D / 4)) in EVERY list - the waves
+            // walk the lists of a workgroup's tiles at their own pace, so a bin must never change hands between lists
+            int cut[5] = {0, 0, 0, 0, 4096};
+            for (int w = 1; w < 4; ++w) {
+                const int b0 = (int)(((long long)w * D + 3) / 4);
+                int c = cut[w - 1];
+                while (c < 4096 && es[c].bin < b0) ++c;
+                cut[w] = c;
+            }
+            unsigned* L = out.data() + ((size_t)I * nb + J) * CBF_LLEN;
+            for (int w = 0; w < 4; ++w) {
+                const int n = cut[w + 1] - cut[w];
+                if (n > CBF_WLEN || n < 0) return 0;
+                // lane t owns sorted positions [18 t, 18 t + 18) of the run, offset o in step (o * 13) mod 18 (the inverse
+                // of q -> 7 q mod 18); word (step q, lane t) at (w * 18 + q) * 64 + t
+                for (int q = 0; q < n; ++q) {
+                    const E& e = es[cut[w] + q];
+                    const int t = q / CBF_LSTEPS, o = q % CBF_LSTEPS, st = (o * 13) % CBF_LSTEPS;
+                    L[(w * CBF_LSTEPS + st) * 64 + t] = cbf_pack(e.idx, e.bin, e.neg);
+                }
+                // the 64 entries of a step must hit distinct bins (the dump bin may repeat); two consecutive steps too
+                // for the pipelined form
+                auto distinct = [&](int st0, int nst) {
+                    int seen[128], ns = 0;
+                    for (int st = st0; st < st0 + nst; ++st)
+                        for (int t = 0; t < 64; ++t) {
+                            const int bin = (int)((L[(w * CBF_LSTEPS + st) * 64 + t] >> 13) & 0x1fff);
+                            if (bin == D) continue;
+                            for (int u = 0; u < ns; ++u)
+                                if (seen[u] == bin) return false;
+                            seen[ns++] = bin;
+                        }
+                    return true;
+                };
+                for (int st = 0; st < CBF_LSTEPS; ++st)
+                    if (!distinct(st, 1)) return 0;
+                for (int st = 0; st + 1 < CBF_LSTEPS; st += 2)
+                    if (!distinct(st, 2)) pairs_ok = false;
+            }
+        }
+    return pairs_ok ? 2 : 1;
+}
+
+// Host: the work items of one sample for a batch of B (target: B x items >= the CU count, runs of <= 3 tiles)
+static inline CbfSchedule cbf_schedule(int nb, int B, int ncu = 256) {
+    CbfSchedule s;
+    s.nitems = 0;
+    auto add = [&](int I0, int J00, int c0, int I1 = 0, int J01 = 0, int c1 = 0) {
+        CbfItem& it = s.it[s.nitems++];
+        it.I[0] = (unsigned char)I0; it.J0[0] = (unsigned char)J00; it.cnt[0] = (unsigned char)c0;
+        it.I[1] = (unsigned char)I1; it.J0[1] = (unsigned char)J01; it.cnt[1] = (unsigned char)c1;
+    };
+    const int pairs = (nb + 1) / 2;
+    if ((long long)B * pairs >= ncu - ncu / 8 || nb * (nb + 1) / 2 <= pairs) {      // balanced pairs {p, nb - 1 - p}
+        for (int p_ = 0; p_ < pairs; ++p_) {
+            const int q = nb - 1 - p_;
+            if (q != p_) add(p_, p_, nb - p_, q, q, nb - q);
+            else add(p_, p_, nb - p_);
+        }
+        return s;
+    }
+    // rows cut into runs of at most `len` tiles: the len with the shortest makespan = rounds of workgroups (one per CU:
+    // the kernel takes nearly all of a CU's LDS) x (tiles per run + 1 for the run's prologue); ties: the longer runs
+    int best = nb;
+    long long best_cost = -1;
+    for (int len = nb; len >= 1; --len) {
+        int n = 0;
+        for (int I = 0; I < nb; ++I) n += (nb - I + len - 1) / len;
+        if (n > CBF_MAXITEMS) break;
+        const long long cost = (((long long)B * n + ncu - 1) / ncu) * (len + 1);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = len; }
+    }
+    for (int I = 0; I < nb; ++I) {
+        const int total = nb - I, runs = (total + best - 1) / best;
+        int J = I;
+        for (int r = 0; r < runs; ++r) {                  // as even as possible: the first (total % runs) runs one longer
+            const int c = total / runs + (r < total % runs ? 1 : 0);
+            add(I, J, c);
+            J += c;
+        }
+    }
+    return s;
+}
+
+// 512 threads: waves 0-3 ("M") run the MFMA loops and stage the panels, waves 4-7 ("N") bin the finished tiles - one M
+// and one N wave per SIMD, so the binning's LDS round trips (34 dependent read-modify-write steps per tile and lane) and
+// its VALU work issue in the shadow of the other wave's MFMAs without any hand interleaving.  Two tile buffers; per
+// tile t every wave passes two barriers:
+//     M: MFMA loop t -> store T[t & 1] -> B1 -> store the next panel (sB, or sA for a new row run) -> B2 -> loop t + 1
+//     N:                                  B1 ->                                                      B2 -> bin tile t
+// T[t & 1] is written before B1(t), read after B2(t) and until the N waves arrive at B1(t + 1), rewritten after
+// B2(t + 1); sB / sA are rewritten between B1 and B2, when no M wave reads them.
+// PIPE: the plan guarantees that two consecutive steps of a wave hit disjoint bins (cbf_build_lists = 2): the reads of
+// steps 2 p, 2 p + 1 are issued before their writes - 9 dependent LDS round trips per list instead of 17.
+template <int HW, bool PIPE, int LABV = 0>
+__global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restrict__ x, const unsigned* __restrict__ lists,
+                                                           float* __restrict__ part, int C, int nb, int B, int D,
+                                                           const CbfSchedule sch) {
+    constexpr int PANEL = 64 * HW;
+    constexpr int N4 = PANEL / 4;
+    constexpr int NST = (N4 + 255) / 256;
+    HK_DYN_LDS16(lds);
+    float* sA = lds;
+    float* sB = lds + PANEL;
+    float* sT = lds + 2 * PANEL;                    // 2 x ([64][68] transposed tile + zero slot)
+    float* sc = sT + 2 * CBF_TSZ;                   // [D + 1] bins (+ dump)
+
+    int b, w;
+    if (!xcd_map(blockIdx.x, B, sch.nitems, b, w)) return;
+    const CbfItem& it = sch.it[w];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_m = wave < 4;                     // wave-uniform role
+    const int mt = tid & 255;                       // thread index within the role
+    const int wq = wave & 3;
+    const int wm = wq >> 1, wn = wq & 1, l31 = lane & 31, lh = lane >> 5;
+    const float* xb = x + (long long)b * C * HW;
+    // the workgroup's tiles in order: tile t = (row block, column block); the first tile of a run starts a new row panel
+    // (the item's six bytes are read ONCE into scalars: `sch` lives in the kernarg segment behind a dynamic index, every
+    //  mention of a field is a global byte load - inside the tile loops that was a memory latency per tile and role)
+    const int iI0 = __builtin_amdgcn_readfirstlane((int)it.I[0]), iI1 = __builtin_amdgcn_readfirstlane((int)it.I[1]);
+    const int iJ0 = __builtin_amdgcn_readfirstlane((int)it.J0[0]), iJ1 = __builtin_amdgcn_readfirstlane((int)it.J0[1]);
+    const int c0 = __builtin_amdgcn_readfirstlane((int)it.cnt[0]);
+    const int ntile = c0 + __builtin_amdgcn_readfirstlane((int)it.cnt[1]);
+    auto tile_I = [&](int t) { return t < c0 ? iI0 : iI1; };
+    auto tile_J = [&](int t) { return t < c0 ? iJ0 + t : iJ1 + (t - c0); };
+
+    for (int k = tid; k <= D; k += 512) sc[k] = 0.f;
+    if (tid < 4) { sT[64 * CBF_TP + tid] = 0.f; sT[CBF_TSZ + 64 * CBF_TP + tid] = 0.f; }
+
+    auto load_panel = [&](f32x4 (&st)[NST], int blk) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)blk * PANEL);
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int f = mt + 256 * u;
+            st[u] = src[f < N4 ? f : N4 - 1];
+        }
+    };
+    auto store_panel = [&](const f32x4 (&st)[NST], float* dstp) {
+        f32x4* dst = reinterpret_cast<f32x4*>(dstp);
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int f = mt + 256 * u;
+            if (f < N4) dst[f] = st[u];
+        }
+    };
+    {   // prologue: the first run's row panel (M waves) and, when it starts off the diagonal, its first column panel (N waves)
+        f32x4 s0[NST];
+        load_panel(s0, is_m ? iI0 : iJ0);
+        if (is_m) store_panel(s0, sA);
+        else if (iJ0 != iI0) store_panel(s0, sB);
+    }
+    __syncthreads();
+
+    if (is_m) {
+        for (int t = 0; t < ntile; ++t) {
+            const int I = tile_I(t), J = tile_J(t);
+            float* T = sT + (t & 1) * CBF_TSZ;
+            // the panel needed next: the column panel of the next tile, or the row panel when the next tile starts a run
+            const bool more = t + 1 < ntile;
+            const bool nxt_is_row = more && t + 1 == c0;
+            const int nxt = more ? (nxt_is_row ? tile_I(t + 1) : tile_J(t + 1)) : J;
+            f32x4 st[NST];
+            load_panel(st, nxt);                     // (unconditional: the staging registers stay registers)
+
+            const float* Ap = sA + (wm * 32 + l31) * HW + 4 * lh;
+            const float* Bp = (J == I ? sA : sB) + (wn * 32 + l31) * HW + 4 * lh;
+            f32x16 acc0, acc1, dummy;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; dummy[i] = 0.f; }
+            GramEpi<1> ep;
+            ep.yb = nullptr; ep.C = 0; ep.i0 = ep.j0 = ep.offdiag = 0; ep.inv = ep.inv_m = 0.f; ep.l31 = l31; ep.lh = lh;
+            gram_tile<HW, false, NST>(Ap, Bp, acc0, acc1, dummy, ep, lh, st, reinterpret_cast<f32x4*>(sB), false, mt);
+            const f32x16 t16 = acc0 + acc1;
+            // the tile, transposed: T[j][i], four consecutive i per 16-byte store (C layout of the 32x32 MFMA:
+            // col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 q4 = (f32x4){t16[4 * g], t16[4 * g + 1], t16[4 * g + 2], t16[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(T + (wn * 32 + l31) * CBF_TP + wm * 32 + 8 * g + 4 * lh) = q4;
+            }
+            HK_LDS_BARRIER();                       // B1
+            // (a row panel that starts off the diagonal cannot follow: only the first run of an item may, and that one is
+            //  loaded by the prologue)
+            if (more) store_panel(st, nxt_is_row ? sA : sB);
+            HK_LDS_BARRIER();                       // B2
+        }
+    } else {
+        // the list words of a tile are requested one tile ahead: they come from L2 / HBM (1.1 MB of lists) and the
+        // gathers cannot start without them
+        auto ldlist = [&](unsigned (&e)[CBF_LSTEPS], int li) {
+            const unsigned* L = lists + (long long)li * CBF_LLEN + (wq * CBF_LSTEPS) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < CBF_LSTEPS; ++q) e[q] = L[q * 64];
+        };
+        auto bin_list = [&](const float* T, const unsigned (&e)[CBF_LSTEPS]) {
+            float v[CBF_LSTEPS];
+#pragma unroll
+            for (int q = 0; q < CBF_LSTEPS; ++q) {                                // the gathers do not depend on the bins
+                const float g_ = T[e[q] & 0x1fffu];
+                v[q] = (e[q] & (1u << 26)) ? -g_ : g_;
+            }
+            // volatile: the read-modify-write steps stay in program order in the instruction stream (lanes of this wave
+            // may hit the same bin in later steps; the LDS executes a wave's instructions in order)
+            auto cb = HK_LDS_VOLATILE(sc);
+            if (LABV == 2) {                        // timing only: the gathers without the ordered part
+                float acc_ = 0.f;
+#pragma unroll
+                for (int q = 0; q < CBF_LSTEPS; ++q) acc_ += v[q];
+                if (acc_ == 1.2345e-30f) cb[0] = acc_;
+                return;
+            }
+#pragma unroll
+            for (int q = 0; q < CBF_LSTEPS; q += 2) {
+                const int b0 = (int)((e[q] >> 13) & 0x1fffu);
+                if (PIPE && q + 1 < CBF_LSTEPS) {
+                    const int b1 = (int)((e[q + 1] >> 13) & 0x1fffu);
+                    const float r0 = cb[b0], r1 = cb[b1];
+                    cb[b0] = r0 + v[q];
+                    cb[b1] = r1 + v[q + 1];
+                } else {
+                    cb[b0] = cb[b0] + v[q];
+                    if (q + 1 < CBF_LSTEPS) {
+                        const int b1 = (int)((e[q + 1] >> 13) & 0x1fffu);
+                        cb[b1] = cb[b1] + v[q + 1];
+                    }
+                }
+            }
+        };
+        // na / nbw: the lists of the NEXT tile, requested right after this tile's second barrier and first touched (the
+        // copy into ea / eb) after the next tile's - a whole tile later, so nothing here waits for a global load
+        // (the younger wave of a SIMD loses the issue arbitration against the MFMA stream of its partner; the binning is a
+        //  few hundred instructions per tile that must not fall behind)
+        __builtin_amdgcn_s_setprio(2);
+        unsigned ea[CBF_LSTEPS], eb[CBF_LSTEPS], na[CBF_LSTEPS], nbw[CBF_LSTEPS];
+        ldlist(na, tile_I(0) * nb + tile_J(0));
+        ldlist(nbw, tile_J(0) * nb + tile_I(0));
+        for (int t = 0; t < ntile; ++t) {
+            const int I = tile_I(t), J = tile_J(t);
+            const float* T = sT + (t & 1) * CBF_TSZ;
+            HK_LDS_BARRIER();                       // B1
+            HK_LDS_BARRIER();                       // B2
+#pragma unroll
+            for (int q = 0; q < CBF_LSTEPS; ++q) { ea[q] = na[q]; eb[q] = nbw[q]; }
+            const int tn = t + 1 < ntile ? t + 1 : t;
+            ldlist(na, tile_I(tn) * nb + tile_J(tn));
+            ldlist(nbw, tile_J(tn) * nb + tile_I(tn));
+            if (LABV != 1) {
+                bin_list(T, ea);
+                if (J != I) bin_list(T, eb);
+            }
+        }
+    }
+    __syncthreads();
+    float* pp = part + ((long long)b * sch.nitems + w) * D;
+    for (int k = tid; k < D; k += 512) pp[k] = sc[k];
+}
+
+static inline size_t cbf_lds_bytes(int HW, int D) {
+    return ((size_t)2 * 64 * HW + 2 * CBF_TSZ + (size_t)((D + 1 + 3) / 4) * 4) * sizeof(float);
+}
+
+// HK_ERR_UNSUPPORTED when the shape is not covered (the caller takes the unfused path)
+static inline int cbf_launch(const float* x, const unsigned* lists, float* part, int B, int C, int HW, int D,
+                             const CbfSchedule& sch, bool pipe, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x)) return HK_ERR_UNSUPPORTED;
+    const size_t lds = cbf_lds_bytes(HW, D);
+    if (lds > 160 * 1024) return HK_ERR_UNSUPPORTED;
+    const int nb = C / 64;
+    const dim3 grid(xcd_grid(B, sch.nitems));
+#define HK_CBF_GO(H)                                                                                              \
+    case H:                                                                                                       \
+        if (pipe) {                                                                                               \
+            HK_ALLOW_BIG_LDS((&cbp_fused_kernel<H, true>), lds);                                                  \
+            hipLaunchKernelGGL((cbp_fused_kernel<H, true>), grid, dim3(512), lds, st, x, lists, part, C, nb, B, D, sch);  \
+        } else {                                                                                                  \
+            HK_ALLOW_BIG_LDS((&cbp_fused_kernel<H, false>), lds);                                                 \
+            hipLaunchKernelGGL((cbp_fused_kernel<H, false>), grid, dim3(512), lds, st, x, lists, part, C, nb, B, D, sch); \
+        }                                                                                                         \
+        break;
+#ifdef HK_LAB_CBF
+    if (HW == 196 && tuning().cbp_bin >= 5) {        // timing-only variants (wrong results): 5 no binning, 6 gathers only
+        HK_ALLOW_BIG_LDS((&cbp_fused_kernel<196, true, 1>), lds);
+        HK_ALLOW_BIG_LDS((&cbp_fused_kernel<196, true, 2>), lds);
+        if (tuning().cbp_bin == 5) hipLaunchKernelGGL((cbp_fused_kernel<196, true, 1>), grid, dim3(512), lds, st, x, lists, part, C, nb, B, D, sch);
+        else hipLaunchKernelGGL((cbp_fused_kernel<196, true, 2>), grid, dim3(512), lds, st, x, lists, part, C, nb, B, D, sch);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
+#endif
+    switch (HW) {
+        HK_CBF_GO(196)
+        HK_CBF_GO(144)
+        HK_CBF_GO(100)
+        HK_CBF_GO(64)
+        default: return HK_ERR_UNSUPPORTED;
+    }
+#undef HK_CBF_GO
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+}  // namespace hk

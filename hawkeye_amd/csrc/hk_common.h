@@ -29,6 +29,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     } while (0)
 #endif
 
+#ifndef HK_LDS_VOLATILE  // a volatile view of an LDS array: accesses stay in program order AND stay ds_read / ds_write.  A plain
+                         // `volatile float*` is a generic pointer: flat_load / flat_store, which also count in vmcnt and
+                         // wait behind every global load in flight (hk_cbp_fused.h: 3 us per tile)
+#define HK_LDS_VOLATILE(p) ((volatile __attribute__((address_space(3))) float*)(p))
+#endif
+
 #ifndef HK_FMAC_PINNED  // acc = fma(a, b, acc) as ONE v_fmac_f32 that stays where it is written: left to the compiler, a chain of
                         // side-product FMAs next to an MFMA stream is packed (v_pk_fma_f32) and sunk to the end of the
                         // loop body, which keeps every operand alive until there (hk_bwd3.h: +75 live registers, spills)
@@ -54,6 +60,8 @@ struct Tuning {
     int ns_tn = 0;          // HK_NS_TN         0: automatic, 64 / 128: forced tile width of the Newton-Schulz products
     int bwd_v = 0;          // HK_BWD_V         Gram backward: 0 / 1 the 64-row kernel (bcnn_fast.hip), 5 the 128-row kernel (hk_bwd128.h)
     int ns_streams = 1;     // HK_NS_STREAMS    1: the two halves of the batch run the Newton-Schulz chain on two HIP queues (default), 0: one queue
+    int sched_b = 0;        // HK_SCHED_B       > 0: work-split heuristics that depend on the batch size behave as if it were this (tests: the
+                            //                  large-batch schedules on small inputs); results do not depend on it
 };
 Tuning& tuning();           // api.hip
 

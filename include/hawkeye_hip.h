@@ -53,7 +53,7 @@ const char* hk_version(void);
  * Names: "bcnn_generic" (1 = generic GEMM path for the Gram / covariance / CBP kernels), "cbp_bin" (-1 = by batch
  * size, 0 row-sketch, 1 CSR gather, 2 row-scatter), "roi_bwd", "linear_slabs" (0 = automatic), "ns_tn" (0 = automatic,
  * 64 / 128), "bwd_v", "ns_streams" (1 = the two halves of the batch run the Newton-Schulz chain on two HIP queues,
- * 0 = one queue).  Values are seeded once from the environment (HK_<NAME>) when the library is first used; the
+ * 0 = one queue), "sched_b" (> 0: batch-size dependent work splits behave as if the batch were this).  Values are seeded once from the environment (HK_<NAME>) when the library is first used; the
  * launch paths never read the environment.  Returns HK_ERR_BAD_ARG for an unknown name.  Process-wide: set them only
  * while no other thread is launching. */
 int hk_tuning_set(const char* name, int value);
@@ -152,9 +152,15 @@ int hk_triu_vec_bwd(const float* dy, float* dx, int B, int d, hk_stream_t stream
  * replaces model/methods/CBCNN.py:96-135 (CompactBilinearPooling.forward) and its
  * autograd backward.
  * hk_cbp_plan_build: host+device one-time setup from the count-sketch hashes
- * (CBCNN.py:76-91): writes a CSR "bin -> (i*C+j, sign)" table into `plan`
+ * (CBCNN.py:76-91): writes the hash tables, a CSR "bin -> (i*C+j, sign)" table and
+ * (C % 64 == 0) the sorted per-tile gather lists of the fused forward into `plan`
  * (device memory, hk_cbp_plan_bytes(C, D) bytes).  h1,h2 int32 [C] in [0,D);
- * s1,s2 fp32 [C] of +-1; all four are HOST pointers.
+ * s1,s2 fp32 [C] of +-1; all four are HOST pointers.  The library remembers, per
+ * plan ADDRESS, whether the fused lists could be built for these hashes (a host-side
+ * directory under a mutex - the blob itself is device memory); hk_cbp_fwd on a blob
+ * the caller has copied elsewhere takes the unfused kernels: same results to rounding.
+ * hk_cbp_fwd: Gram and binning in one kernel (the Gram matrix never reaches HBM),
+ * then two small finishing launches; ws holds the per-workgroup partial bin vectors.
  */
 size_t hk_cbp_plan_bytes(int C, int D);
 int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32_t* h2, const float* s2, int C, int D,

@@ -336,10 +336,11 @@ def test_cbp_dense_small_and_512(F):
         assert yg.argmax(dim=1).cpu().tolist() == y.argmax(dim=1).tolist()
 
 
-@pytest.mark.parametrize('csr', ['0', '1', '2'])
+@pytest.mark.parametrize('csr', ['0', '1', '2', '3', '4'])
 def test_cbp_512_both_binning_kernels(F, csr, tune):
-    """hk_cbp_fwd has three binning kernels (row-scatter: the default; row-sketch; CSR gather); the cbp_bin knob forces
-    one: each must reproduce the reference at the yaml shape."""
+    """hk_cbp_fwd has the fused Gram + binning kernel (3: the default) and three binning kernels behind a separate Gram
+    (row-scatter, row-sketch, CSR gather); the cbp_bin knob forces one: each must reproduce the reference at the yaml
+    shape."""
     tune('cbp_bin', int(csr))
     g = load('cbp_512')
     xn, wn = rs_relu_randn(1234, (2, 512, 14, 14)).astype(np.float32), rs_randn(1236, (2, 6000))
@@ -359,10 +360,35 @@ def test_cbp_rowsketch_equals_csr(F, c, d, b, tune):
     y_csr = F.compact_bilinear_pool(x, plan)
     tune('cbp_bin', 0)
     y_row = F.compact_bilinear_pool(x, plan)
+    tune('cbp_bin', 2)
+    y_sc = F.compact_bilinear_pool(x, plan)                   # row-scatter: the same partial sums as the row-sketch
     tune('cbp_bin', -1)
-    y_def = F.compact_bilinear_pool(x, plan)                  # automatic: row-scatter, same partial sums as the row-sketch
+    y_def = F.compact_bilinear_pool(x, plan)                  # automatic: Gram + binning fused (hk_cbp_fused.h) where the plan has its lists
     assert rel(y_row, y_csr) < 2e-6 and rel(y_def, y_csr) < 2e-6
-    assert torch.equal(y_def, y_row)
+    assert torch.equal(y_sc, y_row)
+    assert torch.equal(y_def, F.compact_bilinear_pool(x, plan))      # and the fused path is bit-reproducible
+
+
+@pytest.mark.parametrize('sched_b,hw', [(64, 14), (16, 14), (16, 10), (5, 8), (1, 12)])
+def test_cbp_fused_schedules(F, tune, sched_b, hw):
+    """The fused Gram + binning kernel splits a sample's 36 upper-triangle tiles into work items by the batch size
+    (balanced row-block pairs at 64; runs of <= 3 tiles at 16; single tiles for a handful of samples).  Every split
+    must give the same bins as the unfused kernels (to rounding: other summation order) and be bit-reproducible; the
+    sched_b knob makes the small test batch take the large-batch schedules."""
+    c, d, b = 512, 6000, 2
+    xn, wn = rs_relu_randn(500 + hw, (b, c, hw, hw)), rs_randn(501, (b, d))
+    plan = _plan(F, c, d)
+    tune('cbp_bin', 2)
+    x0 = t(xn).to(DEV).requires_grad_(True)
+    y0 = F.compact_bilinear_pool(x0, plan)
+    tune('cbp_bin', 3)
+    tune('sched_b', sched_b)
+    x1 = t(xn).to(DEV).requires_grad_(True)
+    y1 = F.compact_bilinear_pool(x1, plan)
+    y2 = F.compact_bilinear_pool(t(xn).to(DEV), plan)
+    assert rel(y1, y0) < 2e-6 and torch.equal(y1.detach(), y2)
+    xo = t(xn).requires_grad_(False)
+    assert rel(y1, O.compact_bilinear_pool(xo, d)) < 1e-5
 
 
 def test_cbp_zero_bins(F):

@@ -130,7 +130,7 @@ def g_cbp():
     return out
 
 
-CBP_FWD = (-1,)
+CBP_FWD = (3, 4, 5, 6)
 CBP_BWD = (0,)
 
 
