@@ -21,7 +21,6 @@
 #include <mutex>
 #include <unordered_map>
 #include "hk_bgemm.h"
-#define HK_LAB_CBF 1   // TEMPORARY: timing-only variants behind cbp_bin = 5 / 6
 #include "hk_cbp_fused.h"
 #include "../../include/hawkeye_hip.h"
 
@@ -52,7 +51,7 @@ struct CbpPlan {  // device-side view of the plan blob
 __host__ __device__ inline size_t cbp_align(size_t x) { return (x + 15) & ~(size_t)15; }
 // the blob carries the tile lists of the fused forward for every shape that kernel covers (whether THESE hashes allow
 // it is decided at build time and recorded in header word 4 of the blob: hk_cbp_plan_build)
-static inline bool cbp_has_lists(int C, int D) { return C % 64 == 0 && C <= 1024 && D + 1 <= (1 << 13); }
+static inline bool cbp_has_lists(int C, int D) { return C % 64 == 0 && C <= 1024 && D + 1 <= CBF_DMAX; }
 
 // Whether the tile lists of a plan blob were built (they are not when some bin holds more entries of one 64x64 tile than
 // a lane's steps - tiny D): decided on the host by hk_cbp_plan_build, needed on the host by hk_cbp_fwd, and the blob is
@@ -706,7 +705,7 @@ extern "C" int hk_cbp_fwd(const float* x, const void* plan, float* y, float* c_r
     int npart = nchunk;                                      // partial bin vectors per sample handed to cbp_partsum_kernel
     bool fused = false;
     const int fok = plan_fused_ok(plan);
-    if ((bin < 0 || bin >= 3) && !force_generic() && pl.lists && fok) {          // 4: never pair the steps
+    if ((bin < 0 || bin == 3 || bin == 4) && !force_generic() && pl.lists && fok) {          // 4: never pair the steps
         const CbfSchedule sch = cbf_schedule(C / 64, tuning().sched_b > 0 ? tuning().sched_b : B);
         if ((size_t)B * sch.nitems * D * sizeof(float) + (size_t)B * ((D + 255) / 256) * sizeof(float) <= ws_bytes) {
             const int rc = cbf_launch(x, pl.lists, (float*)ws, B, C, HW, D, sch, fok == 2 && bin != 4, st);
@@ -802,6 +801,9 @@ extern "C" int hk_cbp_bwd(const float* x, const void* plan, const float* y, cons
 }
 
 #ifdef HK_LAB
+extern "C" int hk_lab_set_cbf_stamps(long long* dev_buffer) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hk::g_cbf_stamps), &dev_buffer, sizeof(dev_buffer));
+}
 extern "C" int hk_lab_set_cbp_stamps(long long* dev_buffer) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(hk::g_cbp_stamps), &dev_buffer, sizeof(dev_buffer));
 }

@@ -41,6 +41,7 @@ constexpr int CBF_LLEN = 4 * CBF_WLEN;             // words of one list
 constexpr int CBF_TP = 68;                         // pitch of the transposed tile T[j][i]
 constexpr int CBF_TSZ = 64 * CBF_TP + 4;           // + a zero slot (index 64 * 68) for the padding entries
 constexpr int CBF_MAXITEMS = 40;
+constexpr int CBF_DMAX = 6144;                     // floats of LDS reserved for the bins: D + 1 <= CBF_DMAX
 
 struct CbfItem {                                   // up to two runs: row block I, column blocks J0 .. J0 + cnt - 1
     unsigned char I[2], J0[2], cnt[2];
@@ -50,8 +51,12 @@ struct CbfSchedule {
     CbfItem it[CBF_MAXITEMS];
 };
 
-// entry word: bits 0..12 index into T (floats), bits 13..25 bin, bit 26 negative sign
-__host__ __device__ __forceinline__ unsigned cbf_pack(int idx, int bin, int neg) { return (unsigned)idx | ((unsigned)bin << 13) | ((unsigned)neg << 26); }
+// entry word: bits 0..14 BYTE offset into T, bits 16..30 BYTE offset of the bin, bit 31 negative sign - every field is
+// usable after one instruction (v_and / v_bfe / v_and): the binning waves share their SIMDs with the MFMA waves, and
+// on gfx950 an fp32 MFMA runs at the vector-FMA rate: every VALU instruction of the binning is time taken from the
+// matrix pipe (tools/cbf_lab.py: 28 cycles per v_mov next to the MFMA stream)
+__host__ __device__ __forceinline__ unsigned cbf_pack(int idx, int bin, int neg) { return (unsigned)(4 * idx) | ((unsigned)(4 * bin) << 16) | ((unsigned)neg << 31); }
+__host__ __device__ __forceinline__ int cbf_bin_of(unsigned w) { return (int)((w >> 16) & 0x7fffu) / 4; }
 
 // Host: the nb x nb lists of (C, D, hashes).  Returns 0 when the fused path cannot be used for these hashes (a bin with
 // more than CBF_LSTEPS entries in one tile, a run that does not fit its padding, D too large for the entry word), 1 when
@@ -61,7 +66,7 @@ __host__ __device__ __forceinline__ unsigned cbf_pack(int idx, int bin, int neg)
 // order: disjoint unless a bin holds more than 7 entries of the tile (C = 512, D = 6000: at most 7).
 static inline int cbf_build_lists(const int* h1, const float* s1, const int* h2, const float* s2, int C, int D,
                                   std::vector<unsigned>& out) {
-    if (C % 64 != 0 || D + 1 > (1 << 13)) return 0;
+    if (C % 64 != 0 || D + 1 > CBF_DMAX) return 0;
     const int nb = C / 64;
     out.assign((size_t)nb * nb * CBF_LLEN, cbf_pack(64 * CBF_TP, D, 0));       // padding: + T[zero slot] to the dump bin
     struct E { int bin, idx, neg; };
@@ -108,7 +113,7 @@ static inline int cbf_build_lists(const int* h1, const float* s1, const int* h2,
                     int seen[128], ns = 0;
                     for (int st = st0; st < st0 + nst; ++st)
                         for (int t = 0; t < 64; ++t) {
-                            const int bin = (int)((L[(w * CBF_LSTEPS + st) * 64 + t] >> 13) & 0x1fff);
+                            const int bin = cbf_bin_of(L[(w * CBF_LSTEPS + st) * 64 + t]);
                             if (bin == D) continue;
                             for (int u = 0; u < ns; ++u)
                                 if (seen[u] == bin) return false;
@@ -176,18 +181,36 @@ static inline CbfSchedule cbf_schedule(int nb, int B, int ncu = 256) {
 // B2(t + 1); sB / sA are rewritten between B1 and B2, when no M wave reads them.
 // PIPE: the plan guarantees that two consecutive steps of a wave hit disjoint bins (cbf_build_lists = 2): the reads of
 // steps 2 p, 2 p + 1 are issued before their writes - 9 dependent LDS round trips per list instead of 17.
-template <int HW, bool PIPE, int LABV = 0>
+// HK_LAB builds only (tools/cbf_lab.py): cycle stamps of lane 0 of wave 0 (M, slots 0-3) and wave 4 (N, slots 4-7) of the
+// first 64 workgroups, per tile
+#ifdef HK_LAB
+static __device__ long long* g_cbf_stamps = nullptr;     // [64 workgroups][32 tiles][16 stamps], set by hk_lab_set_cbf_stamps (cbp.hip)
+#define CBF_STAMP(t_, slot_)                                                                             \
+    do {                                                                                                 \
+        if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 64 && (t_) < 32 && g_cbf_stamps)                 \
+            g_cbf_stamps[((long long)blockIdx.x * 32 + (t_)) * 16 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define CBF_STAMP(t_, slot_) do { } while (0)
+#endif
+
+template <int HW, bool PIPE>
 __global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restrict__ x, const unsigned* __restrict__ lists,
                                                            float* __restrict__ part, int C, int nb, int B, int D,
                                                            const CbfSchedule sch) {
     constexpr int PANEL = 64 * HW;
     constexpr int N4 = PANEL / 4;
     constexpr int NST = (N4 + 255) / 256;
-    HK_DYN_LDS16(lds);
-    float* sA = lds;
-    float* sB = lds + PANEL;
-    float* sT = lds + 2 * PANEL;                    // 2 x ([64][68] transposed tile + zero slot)
+    // LDS: the two tile buffers first, then the bins - everything the binning waves address sits below 64 KB at
+    // compile-time bases, so a tile element is `ds_read vaddr offset:T` and a bin `ds_read / ds_write vaddr offset:bins`
+    // with the entry's fields as the address registers
+    // (STATIC, sized for D < CBF_DMAX: against a dynamic LDS array every address carries the array's link-time base and
+    //  the compiler adds it - zero - with a VALU op per gather)
+    __shared__ __attribute__((aligned(16))) float lds[2 * CBF_TSZ + CBF_DMAX + 2 * PANEL];
+    float* sT = lds;                                // 2 x ([64][68] transposed tile + zero slot)
     float* sc = sT + 2 * CBF_TSZ;                   // [D + 1] bins (+ dump)
+    float* sA = sc + CBF_DMAX;
+    float* sB = sA + PANEL;
 
     int b, w;
     if (!xcd_map(blockIdx.x, B, sch.nitems, b, w)) return;
@@ -244,7 +267,11 @@ __global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restri
             const bool nxt_is_row = more && t + 1 == c0;
             const int nxt = more ? (nxt_is_row ? tile_I(t + 1) : tile_J(t + 1)) : J;
             f32x4 st[NST];
+            CBF_STAMP(t, 0);
             load_panel(st, nxt);                     // (unconditional: the staging registers stay registers)
+            // (pinned: the scheduler otherwise sinks the 13 loads below the MFMA loop - 52 fewer live registers - and the
+            //  panel store behind the first barrier starts by waiting for memory)
+            __builtin_amdgcn_sched_barrier(0);
 
             const float* Ap = sA + (wm * 32 + l31) * HW + 4 * lh;
             const float* Bp = (J == I ? sA : sB) + (wn * 32 + l31) * HW + 4 * lh;
@@ -255,6 +282,7 @@ __global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restri
             ep.yb = nullptr; ep.C = 0; ep.i0 = ep.j0 = ep.offdiag = 0; ep.inv = ep.inv_m = 0.f; ep.l31 = l31; ep.lh = lh;
             gram_tile<HW, false, NST>(Ap, Bp, acc0, acc1, dummy, ep, lh, st, reinterpret_cast<f32x4*>(sB), false, mt);
             const f32x16 t16 = acc0 + acc1;
+            CBF_STAMP(t, 1);
             // the tile, transposed: T[j][i], four consecutive i per 16-byte store (C layout of the 32x32 MFMA:
             // col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
 #pragma unroll
@@ -263,114 +291,102 @@ __global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restri
                 *reinterpret_cast<f32x4*>(T + (wn * 32 + l31) * CBF_TP + wm * 32 + 8 * g + 4 * lh) = q4;
             }
             HK_LDS_BARRIER();                       // B1
+            CBF_STAMP(t, 2);
             // (a row panel that starts off the diagonal cannot follow: only the first run of an item may, and that one is
             //  loaded by the prologue)
             if (more) store_panel(st, nxt_is_row ? sA : sB);
             HK_LDS_BARRIER();                       // B2
+            CBF_STAMP(t, 3);
         }
     } else {
-        // the list words of a tile are requested one tile ahead: they come from L2 / HBM (1.1 MB of lists) and the
-        // gathers cannot start without them
+        // (the younger wave of a SIMD loses the issue arbitration against the MFMA stream of its partner)
+        __builtin_amdgcn_s_setprio(2);
+        // The list words of a tile are requested ONE TILE AHEAD (they come from L2: 1.1 MB of lists, and the gathers cannot
+        // start without them) into the register set the tile after next does not use: tiles alternate between sets A and
+        // B - and between the two tile buffers - so nothing is copied and every LDS base is an immediate.
         auto ldlist = [&](unsigned (&e)[CBF_LSTEPS], int li) {
             const unsigned* L = lists + (long long)li * CBF_LLEN + (wq * CBF_LSTEPS) * 64 + lane;
 #pragma unroll
             for (int q = 0; q < CBF_LSTEPS; ++q) e[q] = L[q * 64];
         };
-        auto bin_list = [&](const float* T, const unsigned (&e)[CBF_LSTEPS]) {
+        const char* scb = reinterpret_cast<const char*>(sc);
+        // one list of the tile in buffer TB into the bins: per entry v_and (T offset), ds_read, v_and + v_xor (sign),
+        // v_bfe (bin offset), ds_read, v_add, ds_write
+        auto bin_list = [&](int TB, const unsigned (&e)[CBF_LSTEPS]) {
+            const char* Tb = reinterpret_cast<const char*>(sT + TB * CBF_TSZ);
             float v[CBF_LSTEPS];
 #pragma unroll
             for (int q = 0; q < CBF_LSTEPS; ++q) {                                // the gathers do not depend on the bins
-                const float g_ = T[e[q] & 0x1fffu];
-                v[q] = (e[q] & (1u << 26)) ? -g_ : g_;
+                const float g_ = *HK_LDS_CONST(Tb + (e[q] & 0x7fffu));
+                v[q] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, g_) ^ (e[q] & 0x80000000u));
             }
             // volatile: the read-modify-write steps stay in program order in the instruction stream (lanes of this wave
             // may hit the same bin in later steps; the LDS executes a wave's instructions in order)
-            auto cb = HK_LDS_VOLATILE(sc);
-            if (LABV == 2) {                        // timing only: the gathers without the ordered part
-                float acc_ = 0.f;
-#pragma unroll
-                for (int q = 0; q < CBF_LSTEPS; ++q) acc_ += v[q];
-                if (acc_ == 1.2345e-30f) cb[0] = acc_;
-                return;
-            }
 #pragma unroll
             for (int q = 0; q < CBF_LSTEPS; q += 2) {
-                const int b0 = (int)((e[q] >> 13) & 0x1fffu);
-                if (PIPE && q + 1 < CBF_LSTEPS) {
-                    const int b1 = (int)((e[q + 1] >> 13) & 0x1fffu);
-                    const float r0 = cb[b0], r1 = cb[b1];
-                    cb[b0] = r0 + v[q];
-                    cb[b1] = r1 + v[q + 1];
+                auto c0p = HK_LDS_VOLATILE(scb + ((e[q] >> 16) & 0x7fffu));
+                auto c1p = HK_LDS_VOLATILE(scb + ((e[q + 1] >> 16) & 0x7fffu));
+                if (PIPE) {
+                    const float r0 = *c0p, r1 = *c1p;
+                    *c0p = r0 + v[q];
+                    *c1p = r1 + v[q + 1];
                 } else {
-                    cb[b0] = cb[b0] + v[q];
-                    if (q + 1 < CBF_LSTEPS) {
-                        const int b1 = (int)((e[q + 1] >> 13) & 0x1fffu);
-                        cb[b1] = cb[b1] + v[q + 1];
-                    }
+                    *c0p = *c0p + v[q];
+                    *c1p = *c1p + v[q + 1];
                 }
             }
         };
-        // na / nbw: the lists of the NEXT tile, requested right after this tile's second barrier and first touched (the
-        // copy into ea / eb) after the next tile's - a whole tile later, so nothing here waits for a global load
-        // (the younger wave of a SIMD loses the issue arbitration against the MFMA stream of its partner; the binning is a
-        //  few hundred instructions per tile that must not fall behind)
-        __builtin_amdgcn_s_setprio(2);
-        unsigned ea[CBF_LSTEPS], eb[CBF_LSTEPS], na[CBF_LSTEPS], nbw[CBF_LSTEPS];
-        ldlist(na, tile_I(0) * nb + tile_J(0));
-        ldlist(nbw, tile_J(0) * nb + tile_I(0));
-        for (int t = 0; t < ntile; ++t) {
-            const int I = tile_I(t), J = tile_J(t);
-            const float* T = sT + (t & 1) * CBF_TSZ;
-            HK_LDS_BARRIER();                       // B1
-            HK_LDS_BARRIER();                       // B2
-#pragma unroll
-            for (int q = 0; q < CBF_LSTEPS; ++q) { ea[q] = na[q]; eb[q] = nbw[q]; }
-            const int tn = t + 1 < ntile ? t + 1 : t;
-            ldlist(na, tile_I(tn) * nb + tile_J(tn));
-            ldlist(nbw, tile_J(tn) * nb + tile_I(tn));
-            if (LABV != 1) {
-                bin_list(T, ea);
-                if (J != I) bin_list(T, eb);
-            }
+        unsigned a0[CBF_LSTEPS], a1[CBF_LSTEPS], b0[CBF_LSTEPS], b1[CBF_LSTEPS];
+        ldlist(a0, tile_I(0) * nb + tile_J(0));
+        ldlist(a1, tile_J(0) * nb + tile_I(0));
+        // one tile: both barriers, then the requests for tile t + 1 into the other register set (pinned: left alone, the
+        // scheduler sinks the 36 loads below the binning and the next tile starts by waiting for them), then the binning
+#define HK_CBF_NTILE(t_, TB_, CUR0, CUR1, NXT0, NXT1)                                                  \
+        do {                                                                                          \
+            const int I_ = tile_I(t_), J_ = tile_J(t_);                                               \
+            CBF_STAMP(t_, 4);                                                                         \
+            HK_LDS_BARRIER();                       /* B1 */                                          \
+            HK_LDS_BARRIER();                       /* B2 */                                          \
+            CBF_STAMP(t_, 5);                                                                         \
+            const int tn_ = (t_) + 1 < ntile ? (t_) + 1 : (t_);                                       \
+            ldlist(NXT0, tile_I(tn_) * nb + tile_J(tn_));                                             \
+            ldlist(NXT1, tile_J(tn_) * nb + tile_I(tn_));                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            CBF_STAMP(t_, 9);                                                                         \
+            bin_list(TB_, CUR0);                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            CBF_STAMP(t_, 6);                                                                         \
+            if (J_ != I_) bin_list(TB_, CUR1);                                                        \
+            CBF_STAMP(t_, 7);                                                                         \
+        } while (0)
+        for (int t = 0; t < ntile; t += 2) {
+            HK_CBF_NTILE(t, 0, a0, a1, b0, b1);
+            if (t + 1 < ntile) HK_CBF_NTILE(t + 1, 1, b0, b1, a0, a1);
         }
+#undef HK_CBF_NTILE
     }
     __syncthreads();
     float* pp = part + ((long long)b * sch.nitems + w) * D;
     for (int k = tid; k < D; k += 512) pp[k] = sc[k];
 }
 
-static inline size_t cbf_lds_bytes(int HW, int D) {
-    return ((size_t)2 * 64 * HW + 2 * CBF_TSZ + (size_t)((D + 1 + 3) / 4) * 4) * sizeof(float);
-}
+static inline size_t cbf_lds_bytes(int HW) { return ((size_t)2 * 64 * HW + 2 * CBF_TSZ + CBF_DMAX) * sizeof(float); }
 
 // HK_ERR_UNSUPPORTED when the shape is not covered (the caller takes the unfused path)
 static inline int cbf_launch(const float* x, const unsigned* lists, float* part, int B, int C, int HW, int D,
                              const CbfSchedule& sch, bool pipe, hipStream_t st) {
     if (C % 64 != 0 || !aligned16(x)) return HK_ERR_UNSUPPORTED;
-    const size_t lds = cbf_lds_bytes(HW, D);
-    if (lds > 160 * 1024) return HK_ERR_UNSUPPORTED;
+    if (cbf_lds_bytes(HW) > 160 * 1024 || D + 1 > CBF_DMAX) return HK_ERR_UNSUPPORTED;
     const int nb = C / 64;
     const dim3 grid(xcd_grid(B, sch.nitems));
 #define HK_CBF_GO(H)                                                                                              \
     case H:                                                                                                       \
         if (pipe) {                                                                                               \
-            HK_ALLOW_BIG_LDS((&cbp_fused_kernel<H, true>), lds);                                                  \
-            hipLaunchKernelGGL((cbp_fused_kernel<H, true>), grid, dim3(512), lds, st, x, lists, part, C, nb, B, D, sch);  \
+                        hipLaunchKernelGGL((cbp_fused_kernel<H, true>), grid, dim3(512), 0, st, x, lists, part, C, nb, B, D, sch);  \
         } else {                                                                                                  \
-            HK_ALLOW_BIG_LDS((&cbp_fused_kernel<H, false>), lds);                                                 \
-            hipLaunchKernelGGL((cbp_fused_kernel<H, false>), grid, dim3(512), lds, st, x, lists, part, C, nb, B, D, sch); \
+                        hipLaunchKernelGGL((cbp_fused_kernel<H, false>), grid, dim3(512), 0, st, x, lists, part, C, nb, B, D, sch); \
         }                                                                                                         \
         break;
-#ifdef HK_LAB_CBF
-    if (HW == 196 && tuning().cbp_bin >= 5) {        // timing-only variants (wrong results): 5 no binning, 6 gathers only
-        HK_ALLOW_BIG_LDS((&cbp_fused_kernel<196, true, 1>), lds);
-        HK_ALLOW_BIG_LDS((&cbp_fused_kernel<196, true, 2>), lds);
-        if (tuning().cbp_bin == 5) hipLaunchKernelGGL((cbp_fused_kernel<196, true, 1>), grid, dim3(512), lds, st, x, lists, part, C, nb, B, D, sch);
-        else hipLaunchKernelGGL((cbp_fused_kernel<196, true, 2>), grid, dim3(512), lds, st, x, lists, part, C, nb, B, D, sch);
-        HK_LAUNCH_CHECK();
-        return HK_OK;
-    }
-#endif
     switch (HW) {
         HK_CBF_GO(196)
         HK_CBF_GO(144)

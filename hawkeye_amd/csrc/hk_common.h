@@ -35,6 +35,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HK_LDS_VOLATILE(p) ((volatile __attribute__((address_space(3))) float*)(p))
 #endif
 
+#ifndef HK_LDS_CONST  // a read-only view of an LDS location through an explicit LDS pointer (constant offsets fold into the
+                      // instruction's offset field; through a generic pointer the compiler adds the - zero - LDS base
+                      // with a VALU op per access)
+#define HK_LDS_CONST(p) ((const __attribute__((address_space(3))) float*)(p))
+#endif
+
 #ifndef HK_FMAC_PINNED  // acc = fma(a, b, acc) as ONE v_fmac_f32 that stays where it is written: left to the compiler, a chain of
                         // side-product FMAs next to an MFMA stream is packed (v_pk_fma_f32) and sunk to the end of the
                         // loop body, which keeps every operand alive until there (hk_bwd3.h: +75 live registers, spills)

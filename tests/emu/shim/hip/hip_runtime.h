@@ -407,6 +407,7 @@ inline T __shfl(T v, int srclane, int = 64) {
 #define HK_DYN_LDS16(name) HK_DYN_LDS(name)
 #define HK_FMAC_PINNED(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
 #define HK_LDS_VOLATILE(p) ((volatile float*)(p))
+#define HK_LDS_CONST(p) ((const float*)(p))
 #define HK_LDS_BARRIER() hipemu::block_barrier()
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                                         \

@@ -130,8 +130,8 @@ def g_cbp():
     return out
 
 
-CBP_FWD = (3, 4, 5, 6)
-CBP_BWD = (0,)
+CBP_FWD = (3, 2)
+CBP_BWD = (0, 1, 4, 5)
 
 
 def g_ns():
