@@ -25,6 +25,7 @@
 #include "hk_common.h"
 #include "hk_bwd128d.h"
 #include "hk_bwd3.h"
+#include "hk_bwd3c.h"
 #include "hk_gram_tile.h"
 
 namespace hk {
@@ -373,6 +374,26 @@ static int gram_launch(const float* x, const float* inv_norm, float* y, int B, i
     return HK_OK;
 }
 
+// hk_bwd3c.h: block height (rb = 2: 128 rows, 1: 64, 0: do not use the kernel), channel split, column split.  128-row
+// blocks where they fill the chip, else 64-row blocks, else 64-row blocks with the column tiles divided between two
+// workgroups (B = 16, C = 512: 256 workgroups; nothing to add up, no memset).  bwd_v 31..35 force (rows, ksplit, nsplit)
+// = (128, 1, 1), (64, 1, 1), (64, 2, 1), (128, 2, 1), (64, 1, 2); measured at B = 16 (tools/r3_lab.py): 64-row 38.5 us,
+// channel split 35.8 (of which the memset of dX 4-5), 128-row 64, round-2 kernels 48 - 65.
+static inline void cbp_bwd3_shape(int v, int B, int C, int& rb, int& ksp, int& nsp) {
+    rb = 0; ksp = 1; nsp = 1;
+    const int nb = C / 64;
+    const long long n128 = C % 128 == 0 ? (long long)B * (C / 128) : 0, n64 = (long long)B * nb;
+    if (v >= 31 && v <= 35) {
+        rb = (v == 31 || v == 34) ? 2 : 1;
+        ksp = (v == 33 || v == 34) ? 2 : 1;
+        nsp = v == 35 ? 2 : 1;
+    } else if (v == 0) {
+        if (n128 >= 192) rb = 2;
+        else if (n64 >= 192) rb = 1;
+        else if (2 * n64 >= 128) { rb = 1; nsp = 2; }
+    }
+}
+
 template <int HW, int MODE>
 static int bwd_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
                       int B, int C, const BwdExtra& ex, hipStream_t st) {
@@ -405,6 +426,18 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
             if (C % 128 == 0 && (v > 20 || fill2))
                 rc = bwd3_launch<HW, MODE, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
             if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, MODE, 1>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
+            if (rc != HK_ERR_UNSUPPORTED) return rc;
+        }
+    }
+    // compact bilinear: hk_bwd3c.h (P generated from dc in LDS, X by LDS-DMA); shape by cbp_bwd3_shape
+    if constexpr (MODE == 2) {
+        int rb, ksp, nsp;
+        cbp_bwd3_shape(v, B, C, rb, ksp, nsp);
+        if (rb) {
+            int rc = HK_ERR_UNSUPPORTED;
+            if (rb == 2) rc = cbp_bwd3_launch<HW, 2>(x, dx, B, C, ex, ksp, nsp, st);
+            if (rc == HK_ERR_UNSUPPORTED) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, ksp, nsp, st);
+            if (rc == HK_ERR_UNSUPPORTED && nsp == 2) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, 1, 1, st);
             if (rc != HK_ERR_UNSUPPORTED) return rc;
         }
     }
@@ -488,6 +521,34 @@ int cov_fast_bwd(const float* x, const float* mu, const float* g, float* dx, int
     BwdExtra ex = {};
     ex.mu = mu;
 #define CALL(H) bwd_launch<H, 1>(x, nullptr, g, nullptr, dx, nullptr, B, C, ex, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
+template <int HW>
+static int cbp_bwd3_try(const float* x, float* dx, int B, int C, const BwdExtra& ex, int rb, int ksp, int nsp, hipStream_t st) {
+    int rc = HK_ERR_UNSUPPORTED;
+    if (rb == 2) rc = cbp_bwd3_launch<HW, 2>(x, dx, B, C, ex, ksp, nsp, st);
+    if (rc == HK_ERR_UNSUPPORTED) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, ksp, nsp, st);
+    if (rc == HK_ERR_UNSUPPORTED && nsp == 2) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, 1, 1, st);   // odd tile count
+    return rc;
+}
+
+// The same with dc computed inside the GEMM kernel from the forward's saved state (hk_bwd3c.h).  HK_ERR_UNSUPPORTED -
+// nothing launched - when the shape / batch would not take that kernel: the caller then forms dc itself.
+int cbp_fast_bwd_fused(const float* x, const int* h1, const int* h2, const float* s1, const float* s2, const float* y,
+                       const float* dy, const float* c_raw, const float* inv_norm, int D, float* dx, int B, int C, int HW,
+                       hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+    const int v = tuning().bwd_v;
+    if (!(v == 0 || (v >= 31 && v <= 35))) return HK_ERR_UNSUPPORTED;
+    BwdExtra ex = {};
+    ex.h1 = h1; ex.h2 = h2; ex.s1 = s1; ex.s2 = s2; ex.dc = nullptr; ex.D = D;
+    ex.cy = y; ex.cdy = dy; ex.ccraw = c_raw; ex.cinv = inv_norm;
+    int rb, ksp, nsp;
+    cbp_bwd3_shape(v, B, C, rb, ksp, nsp);
+    if (!rb) return HK_ERR_UNSUPPORTED;
+#define CALL(H) cbp_bwd3_try<H>(x, dx, B, C, ex, rb, ksp, nsp, st)
     HK_HW_SWITCH(CALL)
 #undef CALL
 }

@@ -29,6 +29,9 @@ namespace hk {
 int gram_fast_raw(const float* x, float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
 int cbp_fast_bwd(const float* x, const int* h1, const int* h2, const float* s1, const float* s2, const float* dc, int D,
                  float* dx, int B, int C, int HW, hipStream_t st);
+int cbp_fast_bwd_fused(const float* x, const int* h1, const int* h2, const float* s1, const float* s2, const float* y,
+                       const float* dy, const float* c_raw, const float* inv_norm, int D, float* dx, int B, int C, int HW,
+                       hipStream_t st);
 static inline bool force_generic() { return tuning().bcnn_generic == 1; }   // A/B lever (hk_tuning_set)
 
 struct CbpPlan {  // device-side view of the plan blob
@@ -775,6 +778,11 @@ extern "C" int hk_cbp_bwd(const float* x, const void* plan, const float* y, cons
         return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_cbp_ws_bytes(B, C, HW, D)) return HK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (!force_generic()) {          // one launch: dc is formed inside the GEMM kernel (hk_bwd3c.h)
+        const CbpPlan pv = cbp_view(plan, C, D);
+        const int rc = cbp_fast_bwd_fused(x, pv.h1, pv.h2, pv.s1, pv.s2, y, dy, c_raw, inv_norm, D, dx, B, C, HW, st);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
     float* dc = (float*)ws;
     float* tp = dc + (long long)B * D;
     const dim3 fgrid((D + 255) / 256, B);

@@ -52,6 +52,11 @@ struct BwdExtra {
     const float* tb;     // [B][nt]     (signed sqrt: partial sums of t = <y, dy>, added in order)
     int nt;
     int dc_lds;          // CBP, 128-row kernel: the sample's dc vector and the hash / sign tables are copied to LDS once
+    // CBP, hk_bwd3c.h with dc == nullptr: dc is computed by the kernel itself from the saved forward state
+    const float* cy;     // [B][D]  y
+    const float* cdy;    // [B][D]  dL/dy
+    const float* ccraw;  // [B][D]  bins before the signed square root
+    const float* cinv;   // [B]     1 / max(|u|, 1e-12)
 };
 
 // t = <y, dy> of sample b from its partial sums (every workgroup adds them itself, fixed order)

@@ -41,6 +41,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HK_LDS_CONST(p) ((const __attribute__((address_space(3))) float*)(p))
 #endif
 
+#ifndef HK_ATOMIC_ADD_F32  // *p += v as one global_atomic_add_f32 (no return value, device scope)
+#define HK_ATOMIC_ADD_F32(p, v) ((void)unsafeAtomicAdd((p), (v)))
+#endif
+
 #ifndef HK_FMAC_PINNED  // acc = fma(a, b, acc) as ONE v_fmac_f32 that stays where it is written: left to the compiler, a chain of
                         // side-product FMAs next to an MFMA stream is packed (v_pk_fma_f32) and sunk to the end of the
                         // loop body, which keeps every operand alive until there (hk_bwd3.h: +75 live registers, spills)

@@ -408,6 +408,7 @@ inline T __shfl(T v, int srclane, int = 64) {
 #define HK_FMAC_PINNED(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
 #define HK_LDS_VOLATILE(p) ((volatile float*)(p))
 #define HK_LDS_CONST(p) ((const float*)(p))
+#define HK_ATOMIC_ADD_F32(p, v) (*(p) += (v))   /* one workgroup at a time: no concurrency to model */
 #define HK_LDS_BARRIER() hipemu::block_barrier()
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                                         \

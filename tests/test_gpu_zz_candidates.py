@@ -132,6 +132,39 @@ def test_backward_bwd3_kernel(F, b, c, hw, tune):
     assert rel(res[11][1], xo.grad) < 1e-5 and rel(res[14][1], xo.grad) < 1e-5
 
 
+@pytest.mark.parametrize('b,c,hw,d', [(2, 128, 14, 2048), (3, 256, 10, 1000), (2, 64, 14, 96), (2, 256, 8, 6000), (3, 128, 12, 500)])
+def test_cbp_backward_bwd3c_kernel(F, b, c, hw, d, tune):
+    """hk_bwd3c.h - the compact-bilinear backward GEMM with P generated from dc in LDS - in its four shapes (bwd_v
+    31..34: 128- / 64-row blocks, channels in one workgroup or split over two with float atomics onto a zeroed dX) against
+    the 64-row panel kernel behind cbp_dc1_kernel (bwd_v = 1).  dc is computed by the kernel itself from the forward's
+    saved state; P is the same two products and one add per element; the split form adds two partial sums - in either
+    order the same bits."""
+    gen = torch.Generator().manual_seed(c + hw + d)
+    x = torch.relu(torch.randn(b, c, hw, hw, generator=gen))
+    wt = torch.randn(b, d, generator=gen)
+    plan = F.CbpPlan(*F.sketch_hashes(c, c, d), d, torch.device(DEV) if DEV != 'cuda'
+                     else torch.device('cuda', torch.cuda.current_device()))
+    res = {}
+    flags = (1, 32, 33, 35) + ((31, 34) if c % 128 == 0 else ())          # 35: column tiles split over two workgroups
+    for flag in flags:
+        tune('bwd_v', flag)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        (F.compact_bilinear_pool(xg, plan) * wt.to(DEV)).sum().backward()
+        res[flag] = xg.grad.clone()
+        xg2 = x.clone().to(DEV).requires_grad_(True)
+        (F.compact_bilinear_pool(xg2, plan) * wt.to(DEV)).sum().backward()
+        assert torch.equal(xg2.grad, res[flag]), flag              # reproducible, the atomically accumulated form too
+    for flag in flags[1:]:       # (dc is formed inside the kernel: t = <y, dy> is summed in another order than by cbp_dc1_kernel)
+        assert rel(res[flag], res[1]) < 2e-6, flag
+    if c % 128 == 0:             # the block height does not change a bit of the unsplit form
+        assert torch.equal(res[31], res[32])
+    assert torch.equal(res[35], res[32])          # nor does dividing the column tiles between two workgroups
+    if d >= 1000:       # (tiny sketches: every bin cancels somewhere - the gradient is ill-conditioned in float32)
+        xo = x.clone().double().requires_grad_(True)
+        (O.compact_bilinear_pool_gram(xo, d) * wt.double()).sum().backward()
+        assert rel(res[33], xo.grad) < 1e-4 + 50 * rel(res[1], xo.grad)
+
+
 @pytest.mark.parametrize('mode', ['train', 'eval'])
 def test_roi_crop_backward_lds_variant_bit_identical(F, mode, tune):
     """The uniform-window ROI-refinement backward (apcnn_roi2.hip, the default: one tap-window size per workgroup, four

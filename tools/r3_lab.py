@@ -131,7 +131,7 @@ def g_cbp():
 
 
 CBP_FWD = (3, 2)
-CBP_BWD = (0, 1, 4, 5)
+CBP_BWD = (0, 32, 33, 35)
 
 
 def g_ns():
