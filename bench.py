@@ -152,17 +152,32 @@ def kernel_rooflines(B, C, HW, dev):
     lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream())
     lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream())
     flops = 2.0 * B * C * C * HW
+    # the classifier on the pooled vector (BCNN.py:42,54): forward on the wide-classifier kernel, backward on the
+    # streaming dy / dW kernels - part of the shipped step, and the forward is its longest hand-written kernel
+    K, J = 200, C * C
+    wl, bl = torch.randn(K, J, device=dev) * 0.01, torch.zeros(K, device=dev)
+    ol, gl = torch.empty(B, K, device=dev), torch.randn(B, K, device=dev)
+    dyl, dwl, dbl = torch.empty(B, J, device=dev), torch.empty(K, J, device=dev), torch.empty(K, device=dev)
+    nwl = lib.hk_linear_ws_bytes(B, J, K)
+    wsl = torch.empty(nwl, dtype=torch.uint8, device=dev)
+    lflops, lbytes = 2.0 * B * J * K, 4.0 * (K * J + B * J + B * K)
+    big = C % 128 == 0 and B * (C // 128) >= 192
     stages = [
         ('bcnn_colsum_partial+finalize', lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream()),
          0.0, 4.0 * B * C * HW),
         ('bcnn_gram_panel_kernel<196>', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
          flops, 4.0 * B * C * HW + 4.0 * B * C * C),
-        ('bcnn_bwd128d_kernel<196>' if (C % 128 == 0 and B * (C // 128) >= 192) else 'bcnn_bwd_panel_kernel<196>',
+        ('gram_bwd3_kernel<196,0,2>' if big else ('gram_bwd3_kernel<196,0,1>' if B * (C // 64) >= 192 else 'bcnn_bwd_panel_kernel<196>'),
          lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp),
                                                                    B, C, HW, stream()),
          flops, 8.0 * B * C * C + 8.0 * B * C * HW),
         ('bcnn_rank1_fix_kernel', lambda: lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream()),
          0.0, 8.0 * B * C * HW),
+        ('linear_skinny_kernel<13> + linear_reduce (classifier fwd 262144->200)',
+         lambda: lib.hk_linear_fwd(ptr(y), ptr(wl), ptr(bl), ptr(ol), B, J, K, ptr(wsl), nwl, stream()), lflops, lbytes),
+        ('linear_dy + linear_dw + bias_grad (classifier bwd, C-ABI kernels; the plugin keeps rocBLAS here)',
+         lambda: lib.hk_linear_bwd(ptr(y), ptr(wl), ptr(gl), ptr(dyl), ptr(dwl), ptr(dbl), B, J, K, stream()), 2 * lflops,
+         2 * lbytes),
     ]
     out = []
     for name, fn, fl, by in stages:
@@ -184,7 +199,7 @@ def pmc_traffic(kernel_prefix):
     16-B-per-lane streaming reads, MI355X_MICROARCH.md section HBM).  PMC cannot be sampled from inside this
     process, so this is the last profiled value, or None when the file is absent."""
     import csv
-    for name in ('r2_pool_kernels_pmc.csv', 'r1b_pool_kernels_pmc.csv'):
+    for name in ('r3_pool_kernels_pmc.csv', 'r2_pool_kernels_pmc.csv', 'r1b_pool_kernels_pmc.csv'):
         try:
             vals = {r['Counter']: float(r['MeanValue']) for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', name)))
                     if r['Kernel'].replace('void ', '').startswith(kernel_prefix) and r['Counter'] in ('FETCH_SIZE', 'WRITE_SIZE')}
@@ -305,7 +320,9 @@ def main():
                 else CINLoss(CfgNode(dict(alpha=2.0, beta=0.5))).to(dev))
         params += list(crit.parameters())
     opt = torch.optim.SGD(params, lr=0.005, momentum=0.9, weight_decay=1e-5)   # configs/BCNN_S2
-    reducer = ddp.GradientAllReducer(model, trace=a.force_pg or a.ddp_trace) if use_pg else None
+    # (the bucket timeline is always recorded with more than one rank: the first multi-GPU run then shows where in the
+    #  backward each all-reduce was issued without a code change)
+    reducer = ddp.GradientAllReducer(model, trace=a.force_pg or a.ddp_trace or world > 1) if use_pg else None
 
     g = torch.Generator(device=dev).manual_seed(rank)
     images = torch.randn(a.batch, 3, a.image, a.image, device=dev, generator=g)
@@ -368,19 +385,24 @@ def main():
         }
         if world == 1 and not a.no_kernels:
             ks = kernel_rooflines(a.batch, 512, (a.image // 32) ** 2, dev)
-            dom = max(ks, key=lambda k: k['us'])
+            shipped = [k for k in ks if 'C-ABI kernels' not in k['kernel']]      # (the classifier backward of the plugin is rocBLAS)
+            dom = max(shipped, key=lambda k: k['us'])
             res['roofline'] = {k: dom[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
             res['roofline']['kernel'] = dom['kernel']
             res['roofline']['us'] = dom['us']
-            tr_bytes, tr_src = pmc_traffic('hk::' + dom['kernel'].split('<')[0])
+            tr_bytes, tr_src = pmc_traffic('hk::' + dom['kernel'].split('<')[0].split(' ')[0])
             res['roofline']['traffic'] = tr_bytes
             res['roofline']['traffic_source'] = (tr_src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, '
                                                  'FETCH doubled per MI355X_MICROARCH.md)') if tr_src else None
 
-            res['roofline']['algorithmic'] = {'flops_per_launch': 2.0 * a.batch * 512 * 512 * (a.image // 32) ** 2,
-                                              'bytes_per_launch': (8.0 * a.batch * (512 * 512 + 512 * (a.image // 32) ** 2)
-                                                                   if 'bwd' in dom['kernel'] else
-                                                                   4.0 * a.batch * (512 * 512 + 512 * (a.image // 32) ** 2))}
+            hw_ = (a.image // 32) ** 2
+            if 'linear' in dom['kernel']:
+                alg = {'flops_per_launch': 2.0 * a.batch * 512 * 512 * 200,
+                       'bytes_per_launch': 4.0 * (200 * 512 * 512 + a.batch * 512 * 512 + a.batch * 200)}
+            else:
+                alg = {'flops_per_launch': 2.0 * a.batch * 512 * 512 * hw_,
+                       'bytes_per_launch': (8.0 if 'bwd' in dom['kernel'] else 4.0) * a.batch * (512 * 512 + 512 * hw_)}
+            res['roofline']['algorithmic'] = alg
             res['kernels'] = ks
             if kernels_before is not None:
                 res['kernels_before'] = kernels_before

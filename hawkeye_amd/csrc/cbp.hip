@@ -485,14 +485,22 @@ __global__ __launch_bounds__(CBP_FT) void cbp_finish_kernel(const float* __restr
     float s[CBP_FK];
 #pragma unroll
     for (int j = 0; j < CBP_FK; ++j) s[j] = 0.f;
-#pragma unroll 2
-    for (int q = 0; q < npart; ++q) {
-        const float* pq = pb + (long long)q * D;
+    for (int q0 = 0; q0 < npart; q0 += 8) {           // eight partial vectors x CBP_FK bins = 64 loads in flight per thread
+        float v[8][CBP_FK];
 #pragma unroll
-        for (int j = 0; j < CBP_FK; ++j) {
-            const int k = tid + CBP_FT * j;
-            s[j] += k < D ? pq[k] : 0.f;              // per bin: partials added in order q = 0, 1, ..
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u < npart ? q0 + u : npart - 1;
+            const float* pq = pb + (long long)q * D;
+#pragma unroll
+            for (int j = 0; j < CBP_FK; ++j) {
+                const int k = tid + CBP_FT * j;
+                v[u][j] = (k < D && q0 + u < npart) ? pq[k] : 0.f;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < CBP_FK; ++j) s[j] += v[u][j];          // per bin: partials added in order q = 0, 1, ..
     }
     float ss = 0.f;
 #pragma unroll

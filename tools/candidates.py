@@ -46,9 +46,15 @@ def sz(full, tiny):
     return tiny if TINY else full
 
 
-def timeit(fn, iters=20, warm=3):
+_first_round_us = [None]
+
+
+def timeit(fn, iters=20, warm=3, rounds=3):
+    """HIP-event time per call (us) of the LAST of `rounds` back-to-back rounds of `iters` calls - the chip's clock settles
+    only after ~10 ms of load, so the first round of a variant reads up to 15 % slower than the same code a moment later
+    (BENCH_r02: 313 vs 268 us for two rows that were the same dispatch).  The first round's value is kept for the row."""
     if TINY:
-        iters, warm = 1, 1
+        iters, warm, rounds = 1, 1, 1
     for _ in range(warm):
         rc = fn()
         if isinstance(rc, int) and rc != 0:
@@ -57,20 +63,27 @@ def timeit(fn, iters=20, warm=3):
         t0 = time.perf_counter()
         for _ in range(iters):
             fn()
+        _first_round_us[0] = None
         return (time.perf_counter() - t0) / iters * 1e6
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(rounds + 1)]
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
+    ev[0].record()
+    for r in range(rounds):
+        for _ in range(iters):
+            fn()
+        ev[r + 1].record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    _first_round_us[0] = ev[0].elapsed_time(ev[1]) / iters * 1e3
+    return ev[rounds - 1].elapsed_time(ev[rounds]) / iters * 1e3
 
 
 def row(op, variant, us, flops=0.0, bytes_=0.0, note=''):
-    rows.append({'op': op, 'variant': variant, 'us': round(us, 1), 'tflops': round(flops / us / 1e6, 1),
-                 'gbs': round(bytes_ / us / 1e3), 'note': note})
+    r = {'op': op, 'variant': variant, 'us': round(us, 1), 'tflops': round(flops / us / 1e6, 1),
+         'gbs': round(bytes_ / us / 1e3), 'note': note}
+    if _first_round_us[0] is not None:
+        r['us_first_round'] = round(_first_round_us[0], 1)
+        _first_round_us[0] = None
+    rows.append(r)
 
 
 def guarded(fn):
@@ -185,8 +198,9 @@ def cbp():
         nws = lib.hk_cbp_ws_bytes(B, C, HW, D)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         ref = None
-        for flag, tag in (('0', 'row-sketch binning (round-1 default at B=64)'), ('1', 'CSR gather binning (round-1 default at B=16)'),
-                          ('2', 'row-scatter binning (bins in LDS, one barrier per row; round-2 default)')):
+        for flag, tag in (('0', 'Gram + row-sketch binning (round-1 default at B=64)'), ('1', 'Gram + CSR gather binning (round-1 default at B=16)'),
+                          ('2', 'Gram + row-scatter binning (round-2 default)'),
+                          ('3', 'Gram and binning fused, G never written (hk_cbp_fused.h; round-3 default)')):
             knob('cbp_bin', flag)
             row(f'cbp fwd B={B}', tag,
                 timeit(lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws,
@@ -194,12 +208,24 @@ def cbp():
             if flag == '0':
                 ref = y.clone()
             elif flag == '2':
-                rows[-1]['bit_identical_to_default'] = bool(torch.equal(y, ref))
+                rows[-1]['bit_identical_to_row_sketch'] = bool(torch.equal(y, ref))
+            elif flag == '3':
+                rows[-1]['rel_vs_row_sketch'] = float((y - ref).norm() / ref.norm())
         knob('cbp_bin', -1)
         dy, dx = torch.randn(B, D, device=dev), torch.empty_like(x)
-        row(f'cbp bwd B={B}', 'dot + dc kernels, Gram backward MODE 2',
-            timeit(lambda: lib.hk_cbp_bwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), ptr(dy), ptr(dx), B, C, HW, D,
-                                          ptr(ws), nws, stream())), 2.0 * B * C * C * HW)
+        ref = None
+        for flag, tag in ((1, 'bwd_v=1: dc kernel + 64-row panel kernel (round 1)'), (4, 'bwd_v=4: dc kernel + eight-wave 64-row kernel'),
+                          (5, 'bwd_v=5: dc kernel + register-staged 128-row kernel (round-2 default at B=64)'),
+                          (0, 'hk_bwd3c.h: dc formed in the kernel, P generated in LDS, X by LDS-DMA (round-3 default)')):
+            knob('bwd_v', flag)
+            row(f'cbp bwd B={B}', tag,
+                timeit(lambda: lib.hk_cbp_bwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), ptr(dy), ptr(dx), B, C, HW, D,
+                                              ptr(ws), nws, stream())), 2.0 * B * C * C * HW)
+            if ref is None:
+                ref = dx.clone()
+            else:
+                rows[-1]['rel_vs_64row'] = float((dx - ref).norm() / ref.norm())
+        knob('bwd_v', 0)
     knob('cbp_bin', -1)
 
 
@@ -216,12 +242,16 @@ def bwd_variants():
     xm = torch.relu(torch.randn(B, dc, HW, device=dev))
     mu, g, dxm = torch.zeros(B, dc, device=dev), torch.randn(B, dc, dc, device=dev), torch.empty_like(xm)
     ref = None
-    for flag in (1, 4, 5, 9):
+    for flag in (1, 4, 5, 9, 14, 12, 13, 0):
         knob('bwd_v', flag)
         tag = {1: 'bwd_v=1: 64-row blocks, P tile built in LDS, 2 WGs/CU (round-1 kernel)',
-               4: 'bwd_v=4: 64-row blocks on the eight-wave raw-tile kernel (default for the covariance at C=256, B=64)',
+               4: 'bwd_v=4: 64-row blocks on the eight-wave raw-tile kernel (round-2 default for the covariance at C=256, B=64)',
                5: 'bwd_v=5: 128-row blocks, raw tiles, one barrier per K-block, 1 WG/CU (hk_bwd128.h)',
-               9: 'bwd_v=9: 128-row blocks staged by LDS-DMA, swizzled tiles (hk_bwd128d.h; BCNN mode only, default)'}[flag]
+               9: 'bwd_v=9: 128-row blocks staged by LDS-DMA, swizzled tiles (hk_bwd128d.h; round-2 default, BCNN mode only)',
+               14: 'bwd_v=14: hk_bwd3.h without its two changes (= bwd_v 9 for BCNN; LDS-DMA + mu column for the covariance)',
+               12: 'bwd_v=12: hk_bwd3.h, remainder columns on the VALU only',
+               13: 'bwd_v=13: hk_bwd3.h, LDS-staged epilogue only',
+               0: 'hk_bwd3.h: VALU remainder columns + LDS-staged epilogue (round-3 default)'}[flag]
         row('bcnn bwd_gemm B=64 C=512', tag,
             timeit(lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream()), iters=40),
             2.0 * B * C * C * HW, 8.0 * B * (C * C + C * HW))

@@ -80,7 +80,7 @@ def train_row(model_name, batch, classes, image=448, steps=6, warmup=3):
 
 def mpn_kernels(B=64, d=256, HW=196):
     x = torch.relu(R(B, d, HW)); cov = E(B, d, d); mu = E(B, d); g = R(B, d, d).triu(); dx = E(B, d, HW)
-    kernel_row('MPN', 'cov_pool fwd (row means + centred Gram)', lambda: lib.hk_cov_pool_fwd(ptr(x), ptr(cov), ptr(mu), B, d, HW, stream()),
+    kernel_row('MPN', 'cov_pool fwd (one kernel: means in LDS + centred Gram)', lambda: lib.hk_cov_pool_fwd(ptr(x), ptr(cov), ptr(mu), B, d, HW, stream()),
                2.0 * B * d * d * HW, 4.0 * B * (d * HW + d * d))
     kernel_row('MPN', 'cov_pool bwd', lambda: lib.hk_cov_pool_bwd(ptr(x), ptr(mu), ptr(g), ptr(dx), B, d, HW, stream()),
                2.0 * B * d * d * HW, 4.0 * B * (2 * d * HW + d * d))
@@ -104,10 +104,10 @@ def cbp_kernels(C=512, HW=196, D=6000):
         x = torch.relu(R(B, C, HW)); y = E(B, D); craw = E(B, D); inv = E(B); dy = R(B, D); dx = E(B, C, HW)
         nws = lib.hk_cbp_ws_bytes(B, C, HW, D); ws = E(nws, dtype=torch.uint8)
         fl = 2.0 * B * C * C * HW
-        kernel_row('CBCNN', f'cbp fwd B={B} (raw Gram + binning + norm)',
+        kernel_row('CBCNN', f'cbp fwd B={B} (fused Gram + binning, finish)',
                    lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws, stream()),
                    fl, 4.0 * B * (C * HW + D))
-        kernel_row('CBCNN', f'cbp bwd B={B}',
+        kernel_row('CBCNN', f'cbp bwd B={B} (dc + P generation + GEMM in one kernel)',
                    lambda: lib.hk_cbp_bwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), ptr(dy), ptr(dx), B, C, HW, D,
                                           ptr(ws), nws, stream()), fl, 4.0 * B * (2 * C * HW + 2 * D))
 

@@ -130,8 +130,8 @@ def g_cbp():
     return out
 
 
-CBP_FWD = (3, 2)
-CBP_BWD = (0, 32, 33, 35)
+CBP_FWD = (3,)
+CBP_BWD = (0,)
 
 
 def g_ns():
