@@ -58,11 +58,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_allreduce(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_gloo_allreduce(tmp_path, world):
+    """2 ranks, and 8 (the node size of BASELINE.json's scaling points: one process per GPU) - every rank trains its own
+    shard, the hook-driven bucketed all-reduce must reproduce the single-process mean gradient on all of them."""
     out = str(tmp_path / 'r0.pt')
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got = torch.load(out)
-    # single-process reference: same init as rank 0, mean of the two shard losses
+    # single-process reference: same init as rank 0, mean of the shard losses
     model = _net(100)
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     torch.manual_seed(7)
@@ -70,8 +73,7 @@ def test_two_rank_gloo_allreduce(tmp_path):
     y = torch.randint(0, 5, (8,))
     for step in range(2):
         opt.zero_grad()
-        loss = 0.5 * (nn.functional.cross_entropy(model(x[0::2]), y[0::2]) +
-                      nn.functional.cross_entropy(model(x[1::2]), y[1::2]))
+        loss = sum(nn.functional.cross_entropy(model(x[r::world]), y[r::world]) for r in range(world)) / world
         loss.backward()
         if step == 0:
             for g, p in zip(got['grads'], model.parameters()):

@@ -183,8 +183,9 @@ def _two_rank_trainer_worker(rank, world, port, log_dir, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_trainer_metrics_are_global(tmp_path):
-    """Two Trainer processes over gloo (heads on the emulated kernels), `debug: False`: rank 0 alone creates the
+@pytest.mark.parametrize('world', [2, 8])
+def test_multi_rank_trainer_metrics_are_global(tmp_path, world):
+    """Two - and eight - Trainer processes over gloo (heads on the emulated kernels), `debug: False`: rank 0 alone creates the
     experiment folder (the other rank waits), validation accuracy / train loss are the averages over BOTH shards on
     every rank (what the reference's single-process DataParallel run reports, and what ReduceLROnPlateau and the
     best-model rule consume), and the replicas end the epoch with identical weights."""
@@ -201,11 +202,15 @@ def test_two_rank_trainer_metrics_are_global(tmp_path):
     s.close()
     out = tmp_path / 'out'
     out.mkdir()
-    mp.spawn(_two_rank_trainer_worker, args=(2, port, str(tmp_path / 'logs'), str(out)), nprocs=2, join=True)
-    r0, r1 = torch.load(out / 'r0.pt'), torch.load(out / 'r1.pt')
-    assert r0['val_acc'] == r1['val_acc'] and r0['train_loss'] == r1['train_loss'] and r0['lr'] == r1['lr']
-    assert r0['val_count'] == r1['val_count'] == 12                        # the whole validation set, not one shard
-    both = r0['local'] + r1['local']
+    mp.spawn(_two_rank_trainer_worker, args=(world, port, str(tmp_path / 'logs'), str(out)), nprocs=world, join=True)
+    rs = [torch.load(out / f'r{r}.pt') for r in range(world)]
+    r0 = rs[0]
+    for r in rs[1:]:
+        assert r0['val_acc'] == r['val_acc'] and r0['train_loss'] == r['train_loss'] and r0['lr'] == r['lr']
+        assert r0['val_count'] == r['val_count'] == 12                     # the whole validation set, not one shard
+        assert torch.equal(r0['w'], r['w'])
+    # 12 validation samples over 8 ranks do not divide: shards of 2 and 1, every sample counted ONCE (a padding sampler
+    # would count 16 and move the accuracy that drives ReduceLROnPlateau / best_model.pth)
+    both = sum(r['local'] for r in rs)
     assert both[1] == 12 and abs(r0['val_acc'] - 100.0 * float(both[0] / both[1])) < 1e-9
-    assert torch.equal(r0['w'], r1['w'])
     assert os.path.isfile(tmp_path / 'logs' / 'bcnn_s2_synthetic' / 'train_config.yaml')

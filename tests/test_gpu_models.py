@@ -273,23 +273,27 @@ def test_rccl_path_executes_on_one_gpu(tmp_path):
     assert issued[0] <= tl['backward_end_ms'] <= tl['joined_ms']
 
 
-def test_bench_spawns_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` (the driver's invocation shape, no torchrun around it) re-executes itself with one
-    process per rank; here both ranks share the box's single GPU over gloo.  Rank 0 prints the one JSON line."""
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_spawns_its_own_ranks(tmp_path, world):
+    """`python bench.py --gpus N` (the driver's invocation shape, no torchrun around it) re-executes itself with one
+    process per rank - 2, and 8 as on the scaling node; here all ranks share the box's single GPU over gloo.  Rank 0 prints
+    the one JSON line, which carries the bucket timeline without being asked (N > 1)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
-    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--share-gpu', '--backend', 'gloo',
-                        '--steps', '2', '--warmup', '1', '--batch', '2', '--image', '64', '--ddp-trace'],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--share-gpu', '--backend', 'gloo',
+                        '--steps', '2', '--warmup', '1', '--batch', '2', '--image', '64'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['n_gpus'] == world and out['config']['global_batch'] == 2 * world and out['scaling'] == 'weak' and out['value'] > 0
     assert out['ddp_buckets_mib'][0] > out['ddp_buckets_mib'][-1] or len(out['ddp_buckets_mib']) == 1
+    tl = out['ddp_timeline']                   # bucket 0 (the classifier: last layer, first gradient) goes out before backward ends
+    assert tl['buckets'][0][2] is not None and tl['buckets'][0][2] <= tl['backward_end_ms'] <= tl['joined_ms']
 
 
 def test_trainer_runs_one_synthetic_epoch(tmp_path):

@@ -115,3 +115,92 @@ def test_presets_shapes_determinism_and_erasing():
     assert (t == 0).any()
     with pytest.raises(ValueError):
         T.ClassificationPresetTrain(64, auto_augment_policy='ra')
+
+
+class _ScriptedRng:
+    """random.Random stand-in that returns scripted values: uniform(a, b) -> a + u (b - a) for the next scripted u in
+    [0, 1]; randint(a, b) / randrange(n) -> the next scripted integer (checked against the range)."""
+
+    def __init__(self, uniforms=(), ints=()):
+        self.u, self.i = list(uniforms), list(ints)
+
+    def uniform(self, a, b):
+        return a + self.u.pop(0) * (b - a)
+
+    def randint(self, a, b):
+        v = self.i.pop(0)
+        assert a <= v <= b, (a, v, b)
+        return v
+
+    def randrange(self, n):
+        v = self.i.pop(0)
+        assert 0 <= v < n, (v, n)
+        return v
+
+
+def test_random_resized_crop_known_answers():
+    """Hand-computed answers of torchvision's RandomResizedCrop.get_params arithmetic (the preset of
+    dataset/transforms.py:26): target area = A u1 with u1 uniform in scale, aspect = exp(uniform(log 3/4, log 4/3)),
+    w = round(sqrt(area * aspect)), h = round(sqrt(area / aspect)), accepted when it fits, offsets uniform integers."""
+    # 400 x 300 image, area fraction 0.08 + 0.5 * 0.92 = 0.54 -> 64 800 px; log-aspect at the middle of its range = 0 -> 1:1
+    # -> w = h = round(254.558) = 255, fits (255 <= 300)
+    box = T.random_resized_crop_box(400, 300, rng=_ScriptedRng(uniforms=[0.5, 0.5], ints=[100, 7]))
+    assert box == (100, 7, 255, 255)
+    # aspect at the upper end (4/3), area fraction 1.0: w = round(sqrt(120000 * 4/3)) = 400, h = round(sqrt(90000)) = 300
+    box = T.random_resized_crop_box(400, 300, rng=_ScriptedRng(uniforms=[1.0, 1.0], ints=[0, 0]))
+    assert box == (0, 0, 400, 300)
+    # first draw does not fit (fraction 1.0, aspect 3/4: w = 300, h = 400 > 300), second does (fraction 0.08, aspect 3/4:
+    # area 9600 -> w = round(sqrt(7200)) = 85, h = round(sqrt(12800)) = 113)
+    box = T.random_resized_crop_box(400, 300, rng=_ScriptedRng(uniforms=[1.0, 0.0, 0.0, 0.0], ints=[315, 187]))
+    assert box == (315, 187, 85, 113)
+    # ten misses -> centre crop at the clamped aspect: 1000 x 100 image (ratio 10 > 4/3) -> w = round(100 * 4/3) = 133
+    box = T.random_resized_crop_box(1000, 100, scale=(1.0, 1.0), rng=_ScriptedRng(uniforms=[0.0, 0.0] * 10))
+    assert box == ((1000 - 133) // 2, 0, 133, 100)
+    # erasing (dataset/transforms.py:32: RandomErasing defaults): 224 x 224, fraction 0.02 + 0.5 * 0.31 = 0.175 -> 8780.8 px,
+    # log-aspect mid-range: ratio (0.3, 3.3) -> exp((ln 0.3 + ln 3.3) / 2) = sqrt(0.99) -> h = round(sqrt(8780.8 * 0.994987))
+    # = round(93.47) = 93, w = round(sqrt(8780.8 / 0.994987)) = round(93.94) = 94
+    assert T.random_erasing_box(224, 224, rng=_ScriptedRng(uniforms=[0.5, 0.5], ints=[10, 20])) == (10, 20, 93, 94)
+
+
+def test_trivial_augment_wide_op_table_known_answers():
+    """TrivialAugmentWide's augmentation space with 31 bins (torchvision autoaugment: _augmentation_space of
+    TrivialAugmentWide), written out: the op list in its order, the magnitude of selected bins, the whole Posterize
+    table (8 - round(k / 5)), which ops are signed - and that a scripted draw (op, bin, sign) applies exactly that."""
+    assert T.TA_OPS == ('Identity', 'ShearX', 'ShearY', 'TranslateX', 'TranslateY', 'Rotate', 'Brightness', 'Color',
+                        'Contrast', 'Sharpness', 'Posterize', 'Solarize', 'AutoContrast', 'Equalize')
+    signed = {op for op in T.TA_OPS if T.TA_SPACE[op][1]}
+    assert signed == {'ShearX', 'ShearY', 'TranslateX', 'TranslateY', 'Rotate', 'Brightness', 'Color', 'Contrast', 'Sharpness'}
+    assert T.TA_SPACE['Posterize'][0].tolist() == [8] * 3 + [7] * 5 + [6] * 5 + [5] * 5 + [4] * 5 + [3] * 5 + [2] * 3
+    for op, top in (('ShearX', 0.99), ('TranslateY', 32.0), ('Rotate', 135.0), ('Contrast', 0.99)):
+        m = T.TA_SPACE[op][0]
+        assert len(m) == 31 and m[0] == 0.0 and math.isclose(m[15], top / 2) and math.isclose(m[30], top)
+        assert math.isclose(m[7], top * 7 / 30)
+    sol = T.TA_SPACE['Solarize'][0]
+    assert sol[0] == 255.0 and math.isclose(sol[10], 255.0 * 20 / 30) and sol[30] == 0.0
+    for op in ('Identity', 'AutoContrast', 'Equalize'):
+        assert T.TA_SPACE[op][0] is None
+    img = _img(48, 48, seed=9)
+    # op 3 = TranslateX, bin 15 -> 16 px, sign draw 1 -> negative: content moves 16 px to the left
+    out = T.trivial_augment_wide(img, rng=_ScriptedRng(ints=[3, 15, 1]))
+    assert (_arr(out)[:, :-16] == _arr(img)[:, 16:]).all() and (_arr(out)[:, -16:] == 0).all()
+    # op 10 = Posterize, bin 30 -> 2 bits kept (unsigned op: no sign draw)
+    out = T.trivial_augment_wide(img, rng=_ScriptedRng(ints=[10, 30]))
+    assert (_arr(out) == (_arr(img) & 0xC0)).all()
+    # op 11 = Solarize, bin 15 -> threshold 127.5
+    out = T.trivial_augment_wide(img, rng=_ScriptedRng(ints=[11, 15]))
+    assert (_arr(out) == np.where(_arr(img) < 127.5, _arr(img), 255 - _arr(img))).all()
+
+
+def test_presets_against_torchvision_fixtures_when_present():
+    """tests/golden/transforms_tv.npz is written by oracle/gen_transform_fixtures.py wherever torchvision is installed (it
+    is not in this image nor on the GPU box: DESIGN.md section 4, 'parity unpinned'); when the file exists the eval preset
+    must reproduce torchvision's output on the same images."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'transforms_tv.npz')
+    if not os.path.exists(path):
+        pytest.skip('no torchvision fixtures (oracle/gen_transform_fixtures.py needs torchvision)')
+    g = np.load(path)
+    for k in range(int(g['n'])):
+        img = Image.fromarray(g[f'img{k}'])
+        out = T.ClassificationPresetEval(int(g['crop']), int(g['resize']))(img)
+        assert float((out - torch.from_numpy(g[f'eval{k}'])).abs().max()) < 2.5 / 255 / 0.224      # resampling: <= 2 grey levels
