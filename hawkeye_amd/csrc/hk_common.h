@@ -69,7 +69,7 @@ struct Tuning {
     int linear_slabs = 0;   // HK_LINEAR_SLABS  0: automatic split-K slab count of hk_linear_fwd
     int ns_tn = 0;          // HK_NS_TN         0: automatic, 64 / 128: forced tile width of the Newton-Schulz products
     int bwd_v = 0;          // HK_BWD_V         Gram backward: 0 / 1 the 64-row kernel (bcnn_fast.hip), 5 the 128-row kernel (hk_bwd128.h)
-    int ns_streams = 1;     // HK_NS_STREAMS    1: the two halves of the batch run the Newton-Schulz chain on two HIP queues (default), 0: one queue
+    int ns_streams = 1;     // HK_NS_STREAMS    n: the batch runs the Newton-Schulz chain in n + 1 parts on n + 1 HIP queues (default 1: two halves), 0: one queue
     int sched_b = 0;        // HK_SCHED_B       > 0: work-split heuristics that depend on the batch size behave as if it were this (tests: the
                             //                  large-batch schedules on small inputs); results do not depend on it
 };
@@ -79,10 +79,12 @@ Tuning& tuning();           // api.hip
 // two independent halves of a batch side by side: fork = everything enqueued on `st` so far happens before the helper
 // queue's work; join = the helper queue's work happens before whatever is enqueued on `st` next.  Event record / wait
 // pairs only - no host synchronisation, capturable in a hipGraph like any fork / join.
+constexpr int HK_MAX_AUX = 3;
 struct AuxQueue {
-    hipStream_t aux = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    std::mutex busy;            // held from fork to join: two host threads driving one device take turns on the helper queue
+    hipStream_t aux[HK_MAX_AUX] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[HK_MAX_AUX] = {nullptr, nullptr, nullptr};
+    bool ok = false;
+    std::mutex busy;            // held from fork to join: two host threads driving one device take turns on the helper queues
 };
 inline AuxQueue* aux_queue() {
     // one slot per device, each created exactly once whatever thread gets there first (std::call_once); after that the
@@ -93,32 +95,39 @@ inline AuxQueue* aux_queue() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     AuxQueue& a = tab[dev];
     std::call_once(once[dev], [&a]() {
-        hipStream_t s = nullptr;
-        hipEvent_t f = nullptr, j = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
-        if (hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) {
-            if (f) (void)hipEventDestroy(f);
-            (void)hipStreamDestroy(s);
-            return;
+        bool good = hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < HK_MAX_AUX && good; ++i)
+            good = hipStreamCreateWithFlags(&a.aux[i], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&a.join[i], hipEventDisableTiming) == hipSuccess;
+        if (!good) {                                   // leave nothing half-made behind
+            for (int i = 0; i < HK_MAX_AUX; ++i) {
+                if (a.join[i]) (void)hipEventDestroy(a.join[i]);
+                if (a.aux[i]) (void)hipStreamDestroy(a.aux[i]);
+                a.join[i] = nullptr; a.aux[i] = nullptr;
+            }
+            if (a.fork) (void)hipEventDestroy(a.fork);
+            a.fork = nullptr;
         }
-        a.fork = f; a.join = j; a.aux = s;
+        a.ok = good;
     });
-    return a.aux ? &a : nullptr;
+    return a.ok ? &a : nullptr;
 }
-// Scope of one fork / join on the helper queue.  Construction (when `enable`): everything enqueued on `st` so far
-// happens before the helper queue's work; join() - or the destructor, on an early error return - makes the helper
-// queue's work happen before whatever is enqueued on `st` next, so a caller that frees or reuses its buffers on `st`
-// after a failed call is still ordered behind the half of the batch that is in flight on the helper queue.
+// Scope of one fork / join onto `n` (<= HK_MAX_AUX) helper queues.  Construction (when n > 0): everything enqueued on
+// `st` so far happens before the helper queues' work; join() - or the destructor, on an early error return - makes their
+// work happen before whatever is enqueued on `st` next, so a caller that frees or reuses its buffers on `st` after a
+// failed call is still ordered behind the parts of the batch that are in flight on the helper queues.
 class AuxScope {
   public:
-    AuxScope(hipStream_t st, bool enable) : st_(st) {
-        if (!enable) return;
+    AuxScope(hipStream_t st, int n) : st_(st) {
+        if (n <= 0) return;
+        if (n > HK_MAX_AUX) n = HK_MAX_AUX;
         q_ = aux_queue();
         if (!q_) return;
         q_->busy.lock();
-        if (hipEventRecord(q_->fork, st_) == hipSuccess && hipStreamWaitEvent(q_->aux, q_->fork, 0) == hipSuccess) {
-            aux_ = q_->aux;
+        bool good = hipEventRecord(q_->fork, st_) == hipSuccess;
+        for (int i = 0; i < n && good; ++i) good = hipStreamWaitEvent(q_->aux[i], q_->fork, 0) == hipSuccess;
+        if (good) {
+            n_ = n;
         } else {
             q_->busy.unlock();
             q_ = nullptr;
@@ -127,19 +136,25 @@ class AuxScope {
     AuxScope(const AuxScope&) = delete;
     AuxScope& operator=(const AuxScope&) = delete;
     ~AuxScope() { (void)join(); }
-    hipStream_t aux() const { return aux_; }        // nullptr: stay on the caller's stream
+    int count() const { return n_; }                          // helper queues in use (0: stay on the caller's stream)
+    hipStream_t aux(int i) const { return q_->aux[i]; }
     int join() {
-        if (!aux_) return HK_OK;
-        hipError_t e = hipEventRecord(q_->join, aux_);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st_, q_->join, 0);
-        aux_ = nullptr;
+        if (!n_) return HK_OK;
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < n_; ++i) {
+            hipError_t r = hipEventRecord(q_->join[i], q_->aux[i]);
+            if (r == hipSuccess) r = hipStreamWaitEvent(st_, q_->join[i], 0);
+            if (e == hipSuccess) e = r;
+        }
+        n_ = 0;
         q_->busy.unlock();
         q_ = nullptr;
         return e == hipSuccess ? HK_OK : (int)e;
     }
 
   private:
-    hipStream_t st_, aux_ = nullptr;
+    hipStream_t st_;
+    int n_ = 0;
     AuxQueue* q_ = nullptr;
 };
 

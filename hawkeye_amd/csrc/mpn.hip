@@ -192,20 +192,23 @@ static inline NsProb ns_yz_pair(const float* Y, const float* Z, long long sbs, f
 // store burst) at the same time - 8-12 us per launch of a 30-120 us launch (profiles/r2_ns_*).  Two independent chains
 // on two queues drift apart, and one's fill / drain is covered by the other's main loop.
 struct NsDispatch {
-    int d, B, h;
+    int d, B;
     hipStream_t st;
     AuxScope aux;
     NsDispatch(int d_, int B_, hipStream_t st_)
-        : d(d_), B(B_), h(B_ / 2), st(st_), aux(st_, tuning().ns_streams == 1 && B_ >= 16) {}
+        : d(d_), B(B_), st(st_), aux(st_, B_ >= 16 ? (tuning().ns_streams < B_ / 8 ? tuning().ns_streams : B_ / 8 - 1) : 0) {}
     int operator()(const NsGroup& g) const {
-        const hipStream_t q = aux.aux();
-        if (!q) return nsmm_launch(g, d, B, st);
-        const int rc = nsmm_launch(g, d, h, st, 0, 0);
-        if (rc != HK_OK) return rc;
-        return nsmm_launch(g, d, B - h, q, 0, h);
+        const int parts = aux.count() + 1;
+        if (parts == 1) return nsmm_launch(g, d, B, st);
+        for (int i = 0; i < parts; ++i) {                    // samples [b0, b1) on queue i (0: the caller's stream)
+            const int b0 = (int)((long long)B * i / parts), b1 = (int)((long long)B * (i + 1) / parts);
+            const int rc = nsmm_launch(g, d, b1 - b0, i == 0 ? st : aux.aux(i - 1), 0, b0);
+            if (rc != HK_OK) return rc;
+        }
+        return HK_OK;
     }
-    // the helper queue's work happens before whatever is enqueued on `st` next (also done by the destructor: an error
-    // return between fork and join leaves nothing running unordered on the helper queue)
+    // the helper queues' work happens before whatever is enqueued on `st` next (also done by the destructor: an error
+    // return between fork and join leaves nothing running unordered on a helper queue)
     int join() { return aux.join(); }
 };
 

@@ -466,12 +466,19 @@ def osme_scale(x, m):
 
 # --------------------------------------------------------------------- generic
 # --------------------------------------------------------------------- CIN channel interaction
-# hk_cin_sci_fwd (Gram + row softmax + W X on the generic 64x64 tile) measured 704-714 us against 611-616 us for rocBLAS
-# bmm + softmax + bmm at the plugin's shape (B = 20, C = 2048, HW = 49; BENCH_r01, profiles/r2_candidates.json): with
-# K = 49 the Gram is two chunks per tile and the chain is bound by writing / re-reading the 335 MB of W.  Until there is
-# a fused kernel that beats the library, the forward takes the library GEMMs (W is still produced and saved: the
-# contrastive branch and the backward kernels consume it); tests set this to True to keep the kernel covered.
-_CIN_SCI_FWD_HIP = False
+# hk_cin_sci_fwd: for C % 64 == 0 and 7x7 / 8x8 / 6x6 maps ONE kernel (cin.hip: two passes over the column blocks, softmax
+# statistics first, then W written once and consumed from registers by the second product) - 415 us at the plugin's shape
+# (B = 20, C = 2048, HW = 49) against 486 us for rocBLAS bmm + softmax + bmm (profiles/r3_lab_*.json).  Other shapes run
+# a three-kernel chain on the generic tile that is slower than the library (706 us at that shape): the forward then
+# takes the library GEMMs; W is produced and saved either way (the contrastive branch and the backward kernels consume
+# it).  Tests set _CIN_SCI_FWD_HIP to True to keep the chain covered.
+_CIN_SCI_FWD_HIP = None          # None: by shape (above); True / False: always / never
+
+
+def _cin_sci_on_hip(c, hw):
+    if _CIN_SCI_FWD_HIP is not None:
+        return bool(_CIN_SCI_FWD_HIP)
+    return c % 64 == 0 and hw in (36, 49, 64)
 
 
 class _CinSci(torch.autograd.Function):
@@ -483,7 +490,7 @@ class _CinSci(torch.autograd.Function):
         lib = _lib.load()
         x = _f32c(x)
         b, c, hw = x.shape
-        if _CIN_SCI_FWD_HIP or not x.is_cuda:
+        if _cin_sci_on_hip(c, hw):
             w = torch.empty(b, c, c, dtype=torch.float32, device=x.device)
             y = torch.empty_like(x)
             check(lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), b, c, hw, stream()), 'hk_cin_sci_fwd')

@@ -80,6 +80,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_readfirstlane(v) (v)      /* only ever applied to wave-uniform values */
 
 extern "C" void hipemu_switch(void** save_sp, void* load_sp);   // tests/emu/shim/hipemu_switch.S

@@ -402,7 +402,7 @@ def test_mamc_npairs_loss_larger_batch(F):
     assert abs(float(lg) - float(lo)) <= 5e-6 * abs(float(lo)) and rel(xg.grad, xo.grad) < 2e-5
 
 
-@pytest.mark.parametrize('b,c,hw', [(4, 24, 12), (2, 70, 5), (6, 130, 49)])
+@pytest.mark.parametrize('b,c,hw', [(4, 24, 12), (2, 70, 5), (6, 130, 49), (4, 128, 49), (2, 192, 64), (10, 64, 36)])
 def test_cin_channel_interaction_ops(F, b, c, hw, monkeypatch):
     """hk_cin_sci_* / hk_cin_cci_*  vs torch autograd of the reference's formulas (CIN.py:31-34, 51-54) in
     fp64: forward values, and the gradients through both branches including the one that reaches W_SCI from the

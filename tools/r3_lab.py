@@ -158,7 +158,7 @@ def g_ns():
     return res
 
 
-NS_STREAMS = (1, 0)
+NS_STREAMS = (1, 2, 3, 0)
 
 
 def g_linear():
@@ -186,7 +186,26 @@ def g_linear():
     return res
 
 
-GROUPS = {'bcnn': g_bcnn, 'ssqrt': g_ssqrt, 'cov': g_cov, 'cbp': g_cbp, 'ns': g_ns, 'linear': g_linear}
+def g_cin():
+    B, C, HW = 20, 2048, 49
+    x = torch.relu(torch.randn(B, C, HW, device=dev))
+    w, y = torch.empty(B, C, C, device=dev), torch.empty(B, C, HW, device=dev)
+    fw = lambda: lib.hk_cin_sci_fwd(p(x), p(w), p(y), B, C, HW, st())
+    assert fw() == 0
+    wr = torch.softmax(torch.bmm(x, x.transpose(1, 2)).mul_(-1.0 / HW), dim=2)
+    yr = torch.bmm(wr, x)
+    err = (float((w - wr).norm() / wr.norm()), float((y - yr).norm() / yr.norm()))
+
+    def tfw():
+        w_ = torch.softmax(torch.bmm(x, x.transpose(1, 2)).mul_(-1.0 / HW), dim=2)
+        torch.bmm(w_, x)
+    r = run_group('CIN SCI forward B=20 C=2048 7x7', [('hk_cin_sci_fwd (one kernel)', {}, fw), ('hk_cin_sci_fwd three-kernel chain', dict(bcnn_generic=1), fw),
+                                                    ('torch bmm + softmax + bmm', {}, tfw)], flops=2 * 2.0 * B * C * C * HW, bytes_=4.0 * B * C * C)
+    r['rel_err_w_y_vs_torch'] = err
+    return [r]
+
+
+GROUPS = {'cin': g_cin, 'bcnn': g_bcnn, 'ssqrt': g_ssqrt, 'cov': g_cov, 'cbp': g_cbp, 'ns': g_ns, 'linear': g_linear}
 
 if __name__ == '__main__':
     which = [a for a in sys.argv[1:] if a in GROUPS] or list(GROUPS)
