@@ -414,16 +414,19 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
     // (64-row panel kernel); VALU remainder alone 68.9, LDS-staged epilogue alone 69.1; covariance C = 256: 20.2 us
     // against 24.0 (eight-wave register-staged kernel on 64-row blocks), 27.9 (panel kernel), 32.3 with 128-row blocks
     // (128 workgroups).  bwd_v 11..14 force it with flags 3, 1, 2, 0 (bit 0 VALU remainder columns, bit 1 LDS-staged
-    // epilogue), 21..24 the same with 128-row blocks.
+    // epilogue), 21..24 the same with 128-row blocks; 15 / 16 add bit 2 (a wave owns 16 rows and all column tiles: the
+    // two waves of a SIMD no longer form the same A fragments) and bit 3 (coef applied to the accumulators, not to every
+    // fragment element): 66.9 -> 65.3 -> 64.1 us in one alternating run (profiles/r3_lab_call21.json); 16 is the default.
     if constexpr (MODE == 0 || MODE == 1 || MODE == 3) {
-        const bool forced = (v >= 11 && v <= 14) || (v >= 21 && v <= 24);
+        const bool forced = (v >= 11 && v <= 16) || (v >= 21 && v <= 24);      // 15 / 16: rows-per-wave split (+ late coef)
         const bool fill2 = C % 128 == 0 && (long long)B * (C / 128) >= 192;
         const bool fill1 = (long long)B * nb >= 192;
         if (forced || (v == 0 && (fill2 || fill1))) {
-            const int f = forced ? v % 10 : 1;
-            const int flags = f == 1 ? 3 : (f == 2 ? 1 : (f == 3 ? 2 : 0));
+            // default: everything on (15); 128-row blocks only - the 64-row form keeps the rows x column-halves split
+            const int f = forced ? v % 10 : 6;
+            const int flags = f == 1 ? 3 : (f == 2 ? 1 : (f == 3 ? 2 : (f == 5 ? 7 : (f == 6 ? 15 : 0))));
             int rc = HK_ERR_UNSUPPORTED;
-            if (C % 128 == 0 && (v > 20 || fill2))
+            if (C % 128 == 0 && (v > 20 || v == 15 || v == 16 || fill2))
                 rc = bwd3_launch<HW, MODE, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
             if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, MODE, 1>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
             if (rc != HK_ERR_UNSUPPORTED) return rc;

@@ -28,7 +28,13 @@ namespace hk {
 
 // RB: 16-row blocks per wave (2: 128-row workgroup blocks, 1: 64-row).  REMV: the HW % 16 == 4 remainder columns on
 // the VALU (false: a last, partly idle MFMA tile like the other kernels).  EPI: LDS-staged 16-byte stores.
-template <int HW, int MODE, int RB, bool REMV, bool EPI>
+// ROWW (128-row blocks): wave w owns rows 16 w .. 16 w + 15 and ALL column tiles, instead of 32 rows x half of the tiles.
+// The two waves of a SIMD then form DIFFERENT A fragments (the other split has both of them do the same rcp / mul / add
+// on the same rows): on gfx950 an fp32 MFMA runs at the vector-FMA rate and VALU work next to it is time taken from the
+// matrix pipe, so the duplicated fragment arithmetic cost ~4 % of a K-block; the price is one ds_read per MFMA instead
+// of one per two.  COEFL: the factor inv^2 / 2M multiplies the accumulators once instead of every fragment element
+// (rounding-level difference from the other backward kernels).
+template <int HW, int MODE, int RB, bool REMV, bool EPI, bool ROWW = false, bool COEFL = false>
 __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy,
                                                            const float* __restrict__ inv_norm, float* __restrict__ dx,
@@ -38,8 +44,12 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     static_assert(RB == 1 || RB == 2, "64- or 128-row blocks");
     constexpr bool HAS_Y = MODE == 0 || MODE == 3;
     constexpr bool MUCOL = MODE == 1;
+    static_assert(!ROWW || RB == 2, "row-per-wave split: 128-row blocks");
     constexpr int NT = REMV ? HW / 16 : (HW + 15) / 16;   // 16-column MFMA tiles
-    constexpr int NH = (NT + 1) / 2;                      // tiles of the first column half
+    constexpr int NH = ROWW ? NT : (NT + 1) / 2;          // tiles of a wave (of the first column half)
+    constexpr int RW = ROWW ? 1 : RB;                     // 16-row blocks of a wave
+    constexpr int NR = ROWW ? 4 : 2;                      // remainder columns of a wave
+    typedef float remv_t __attribute__((ext_vector_type(NR)));
     constexpr int KB = 32;
     constexpr int IB = 64 * RB;                           // rows of a workgroup block
     constexpr int T_SZ = IB * KB;                         // floats of one dy / y tile
@@ -58,10 +68,11 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
-    const int wrow = (wave & 3) * (16 * RB);
-    const int half = wave >> 2;                                 // wave-uniform
+    const int wrow = ROWW ? wave * 16 : (wave & 3) * (16 * RB);
+    const int half = ROWW ? 0 : wave >> 2;                      // wave-uniform
     // this wave's MFMA column tiles nt0 .. nt0 + nloc - 1 (an even tile count: the same number in both halves, compile-time)
-    const int nt0 = half * NH, nloc = (NT % 2 == 0) ? NH : (half ? NT - NH : NH);
+    const int nt0 = half * NH, nloc = (ROWW || NT % 2 == 0) ? NH : (half ? NT - NH : NH);
+    const bool do_t = ROWW || half == 0;                        // the waves that add up t = <y, dy> (each row once)
     const long long cc = (long long)b * C * C;
     const float* xb = x + (long long)b * C * HW;
     const int nkb = C / KB;                                     // even (C % 64 == 0)
@@ -70,15 +81,18 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
         const float in = inv_norm[b];
         coef = in * in / (2.0f * (float)HW);
     }
+    const float cfrag = COEFL ? 1.0f : coef;                    // factor applied per fragment element
     const float t2 = MODE == 3 ? 2.0f * bwd_t_of(ex, b) : 0.f;
 
-    f32x4 acc[RB][NH];
-    float rem[RB][2], mcol[RB];
+    f32x4 acc[RW][NH];
+    float rem[RW][NR], mcol[RW];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
+    for (int i = 0; i < RW; ++i) {
 #pragma unroll
         for (int n = 0; n < NH; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        rem[i][0] = rem[i][1] = mcol[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NR; ++c) rem[i][c] = 0.f;
+        mcol[i] = 0.f;
     }
     float tacc = 0.f;
 
@@ -137,26 +151,26 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     // A fragments of the wave's 16-row blocks for k = 16 s + 4 lq + t, formed from the raw tiles; the mu column rides along
 #define HK_B3_AFRAG(A_, s_, kb_)                                                                               \
     do {                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                       \
+        _Pragma("unroll") for (int i = 0; i < RW; ++i) {                                                       \
             const int row_ = wrow + i * 16 + l15;                                                              \
             const int sl_ = row_ * 32 + (((4 * (s_) + lq) ^ (row_ & 7)) << 2);                                 \
             f32x4 d1_ = *reinterpret_cast<const f32x4*>(S1 + sl_);                                             \
             f32x4 yv_ = (f32x4){1.f, 1.f, 1.f, 1.f};                                                           \
             if (HAS_Y) yv_ = *reinterpret_cast<const f32x4*>(Yt + sl_);                                        \
-            if (MODE == 0 && half == 0)                                                                        \
+            if (MODE == 0 && do_t)                                                                             \
                 tacc += (yv_[0] * d1_[0] + yv_[1] * d1_[1]) + (yv_[2] * d1_[2] + yv_[3] * d1_[3]);             \
             if (MODE == 3) d1_ -= t2 * yv_;                                                                    \
             const float* s2p_ = S2 + (16 * (s_) + 4 * lq) * IB + ((((row_ >> 2) ^ ((lq & 1) << 2))) << 2) + (row_ & 3); \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
-                float w_ = coef;                                                                               \
-                if (MODE == 3) w_ = yv_[t] == 0.f ? 0.f : __builtin_amdgcn_rcpf(fabsf(yv_[t])) * coef;         \
-                if (MODE == 0) w_ = __builtin_amdgcn_rcpf(yv_[t]) * coef;                                      \
+                float w_ = cfrag;                                                                              \
+                if (MODE == 3) w_ = yv_[t] == 0.f ? 0.f : (COEFL ? __builtin_amdgcn_rcpf(fabsf(yv_[t])) : __builtin_amdgcn_rcpf(fabsf(yv_[t])) * coef); \
+                if (MODE == 0) w_ = COEFL ? __builtin_amdgcn_rcpf(yv_[t]) : __builtin_amdgcn_rcpf(yv_[t]) * coef; \
                 A_[i][t] = (d1_[t] + s2p_[t * IB]) * w_;                                                       \
             }                                                                                                  \
         }                                                                                                      \
-        if (MUCOL && half == 0) {                                                                              \
+        if (MUCOL && do_t) {                                                                                   \
             const f32x4 mu_ = *reinterpret_cast<const f32x4*>(mus + (kb_) * KB + 16 * (s_) + 4 * lq);          \
-            _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                     \
+            _Pragma("unroll") for (int i = 0; i < RW; ++i)                                                     \
                 _Pragma("unroll") for (int t = 0; t < 4; ++t) HK_FMAC_PINNED(mcol[i], A_[i][t], mu_[t]);       \
         }                                                                                                      \
     } while (0)
@@ -165,21 +179,19 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     do {                                                                                                       \
         const float* xr_ = X + (16 * (s_) + 4 * lq + (t_)) * HW;                                               \
         _Pragma("unroll") for (int n = 0; n < NH; ++n) B_[n] = (n < nloc) ? xr_[16 * (nt0 + n) + l15] : 0.f;   \
-        if (REMV) R_ = *reinterpret_cast<const f32x2*>(xr_ + 16 * NT + 2 * half);                              \
+        if (REMV) R_ = *reinterpret_cast<const remv_t*>(xr_ + 16 * NT + 2 * half);                             \
     } while (0)
 #define HK_B3_MFMA(A_, B_, R_, t_)                                                                             \
     do {                                                                                                       \
         _Pragma("unroll") for (int n = 0; n < NH; ++n) {                                                       \
             if (n < NH - 1 || n < nloc) {                                                                      \
-                _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                 \
+                _Pragma("unroll") for (int i = 0; i < RW; ++i)                                                 \
                     acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[i][t_], B_[n], acc[i][n], 0, 0, 0);    \
             }                                                                                                  \
         }                                                                                                      \
         if (REMV) {                                                                                            \
-            _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                   \
-                HK_FMAC_PINNED(rem[i][0], A_[i][t_], R_[0]);                                                   \
-                HK_FMAC_PINNED(rem[i][1], A_[i][t_], R_[1]);                                                   \
-            }                                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < RW; ++i)                                                     \
+                _Pragma("unroll") for (int c = 0; c < NR; ++c) HK_FMAC_PINNED(rem[i][c], A_[i][t_], R_[c]);    \
         }                                                                                                      \
     } while (0)
     // One K-block out of stage CUR_ (0 / STAGE): eight MFMA groups (s = 0, 1; t = 0..3), the fragments of a group read
@@ -191,8 +203,8 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
         const float* S2 = S1 + OS2;                                                                            \
         const float* X = S1 + OX;                                                                              \
         constexpr int NXT_ = STAGE - (CUR_);                                                                   \
-        float a0[RB][4], a1[RB][4], bA[NH], bB[NH];                                                            \
-        f32x2 rA = (f32x2){0.f, 0.f}, rB = (f32x2){0.f, 0.f};                                                  \
+        float a0[RW][4], a1[RW][4], bA[NH], bB[NH];                                                            \
+        remv_t rA = (remv_t)(0.f), rB = (remv_t)(0.f);                                                         \
         HK_B3_AFRAG(a0, 0, kb_);                                                                               \
         HK_B3_BFRAG(bA, rA, 0, 0);                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -237,22 +249,28 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     // the four lq-partials of a row's side columns: p0 + p1, then + (p2 + p3), the same value in every lane of the row
     if (REMV) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
+        for (int i = 0; i < RW; ++i)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NR; ++c) {
                 float v = rem[i][c];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                rem[i][c] = v;
+                rem[i][c] = COEFL ? v * coef : v;
             }
+    }
+    if (COEFL) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int n = 0; n < NH; ++n) acc[i][n] *= coef;
     }
     if (MUCOL) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
+        for (int i = 0; i < RW; ++i) {
             float v = mcol[i];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            mcol[i] = v;
+            mcol[i] = COEFL ? v * coef : v;
         }
     }
 
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
         float* CM = lds + IB * HW;                                          // [IB] (P mu) of the block's rows
         // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
+        for (int i = 0; i < RW; ++i) {
             float* orow = O + (wrow + i * 16 + lq * 4) * HW + 16 * nt0 + l15;
 #pragma unroll
             for (int n = 0; n < NH; ++n) {
@@ -272,9 +290,13 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
                     for (int r = 0; r < 4; ++r) orow[r * HW + 16 * n] = acc[i][n][r];
                 }
             }
-            if (REMV && lq == 0)
-                *reinterpret_cast<f32x2*>(O + (wrow + i * 16 + l15) * HW + 16 * NT + 2 * half) = (f32x2){rem[i][0], rem[i][1]};
-            if (MUCOL && half == 0 && lq == 0) CM[wrow + i * 16 + l15] = mcol[i];
+            if (REMV && lq == 0) {
+                remv_t rv_;
+#pragma unroll
+                for (int c = 0; c < NR; ++c) rv_[c] = rem[i][c];
+                *reinterpret_cast<remv_t*>(O + (wrow + i * 16 + l15) * HW + 16 * NT + 2 * half) = rv_;
+            }
+            if (MUCOL && do_t && lq == 0) CM[wrow + i * 16 + l15] = mcol[i];
         }
         __syncthreads();
         const f32x4* o4 = reinterpret_cast<const f32x4*>(O);
@@ -293,12 +315,12 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             float* CM = lds;
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
-                if (half == 0 && lq == 0) CM[wrow + i * 16 + l15] = mcol[i];
+            for (int i = 0; i < RW; ++i)
+                if (do_t && lq == 0) CM[wrow + i * 16 + l15] = mcol[i];
             __syncthreads();
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
+        for (int i = 0; i < RW; ++i) {
             float* drow = dxb + (long long)(wrow + i * 16 + lq * 4) * HW;
 #pragma unroll
             for (int n = 0; n < NH; ++n) {
@@ -311,8 +333,10 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             }
             if (REMV && lq == 0) {
                 const float m_ = MUCOL ? lds[wrow + i * 16 + l15] : 0.f;
-                *reinterpret_cast<f32x2*>(dxb + (long long)(wrow + i * 16 + l15) * HW + 16 * NT + 2 * half) =
-                    (f32x2){rem[i][0] - m_, rem[i][1] - m_};
+                remv_t rv_;
+#pragma unroll
+                for (int c = 0; c < NR; ++c) rv_[c] = rem[i][c] - m_;
+                *reinterpret_cast<remv_t*>(dxb + (long long)(wrow + i * 16 + l15) * HW + 16 * NT + 2 * half) = rv_;
             }
         }
     }
@@ -338,7 +362,8 @@ static inline size_t bwd3_lds_bytes(int C) {
 }
 
 // HK_ERR_UNSUPPORTED unless C % (64 RB) == 0 and the operands are 16-byte aligned (the caller then takes another kernel).
-// flags: bit 0 = VALU remainder (where HW % 16 == 4), bit 1 = LDS-staged epilogue
+// flags: bit 0 = VALU remainder (where HW % 16 == 4), bit 1 = LDS-staged epilogue, bit 2 = a wave owns 16 rows and all
+// column tiles (128-row blocks with both of the above), bit 3 = coef applied to the accumulators
 template <int HW, int MODE, int RB>
 static int bwd3_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
                        int B, int C, const BwdExtra& ex, int flags, hipStream_t st) {
@@ -357,6 +382,21 @@ static int bwd3_launch(const float* x, const float* y, const float* dy, const fl
         hipLaunchKernelGGL((gram_bwd3_kernel<HW, MODE, RB, REMV_, EPI_>), grid, dim3(512), lds, st, x, y, dy, inv_norm, \
                            dx, tpart, C, nI, B, ex);                                                                   \
     } while (0)
+    if constexpr (CANREM && RB == 2) {
+        if (remv && epi && (flags & 4)) {
+            if (flags & 8) {
+                HK_ALLOW_BIG_LDS((&gram_bwd3_kernel<HW, MODE, RB, true, true, true, true>), lds);
+                hipLaunchKernelGGL((gram_bwd3_kernel<HW, MODE, RB, true, true, true, true>), grid, dim3(512), lds, st, x, y, dy,
+                                   inv_norm, dx, tpart, C, nI, B, ex);
+            } else {
+                HK_ALLOW_BIG_LDS((&gram_bwd3_kernel<HW, MODE, RB, true, true, true, false>), lds);
+                hipLaunchKernelGGL((gram_bwd3_kernel<HW, MODE, RB, true, true, true, false>), grid, dim3(512), lds, st, x, y, dy,
+                                   inv_norm, dx, tpart, C, nI, B, ex);
+            }
+            HK_LAUNCH_CHECK();
+            return HK_OK;
+        }
+    }
     if constexpr (CANREM) {
         if (remv && epi) HK_B3_GO(true, true);
         else if (remv) HK_B3_GO(true, false);

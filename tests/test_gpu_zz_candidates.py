@@ -99,7 +99,7 @@ def test_backward_bwd3_kernel(F, b, c, hw, tune):
     gen = torch.Generator().manual_seed(c + hw)
     x = torch.relu(torch.randn(b, c, hw, hw, generator=gen))
     res = {}
-    flags = (1, 11, 12, 13, 14) + ((21, 23) if c % 128 == 0 else ())      # 21.. : 128-row blocks forced
+    flags = (1, 11, 12, 13, 14) + ((21, 23, 15, 16) if c % 128 == 0 else ())      # 21.. : 128-row blocks forced; 15 / 16: a wave per 16 rows (+ late coef)
     for flag in flags:
         tune('bwd_v', flag)
         out = []
@@ -114,6 +114,8 @@ def test_backward_bwd3_kernel(F, b, c, hw, tune):
             assert rel(res[flag][k], res[1][k]) < tol, (flag, k)
     if c % 128 == 0:        # the block height changes which workgroup adds which t-partial, nothing in the covariance's dX
         assert torch.equal(res[21][1], res[11][1]) and torch.equal(res[23][1], res[13][1])
+        # which wave owns which rows does not change the MFMA columns either (the remainder columns are summed alike)
+        assert torch.equal(res[15][1], res[21][1])
     # the epilogue does not change a bit; with the remainder on the VALU only the last HW % 16 columns may differ
     for k in range(3):
         assert torch.equal(res[11][k], res[12][k]) and torch.equal(res[13][k], res[14][k]), k
