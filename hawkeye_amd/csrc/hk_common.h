@@ -45,6 +45,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HK_ATOMIC_ADD_F32(p, v) ((void)unsafeAtomicAdd((p), (v)))
 #endif
 
+#ifndef HK_WAVE_SYNC
+// Orders a wave's LDS writes before its own later LDS reads of other lanes' data (LDS operations of one wave execute in
+// order: no instruction is needed, only the compiler must not move the accesses)
+#define HK_WAVE_SYNC()                        \
+    do {                                      \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_wave_barrier();      \
+        asm volatile("" ::: "memory");        \
+    } while (0)
+#endif
+
 #ifndef HK_FMAC_PINNED  // acc = fma(a, b, acc) as ONE v_fmac_f32 that stays where it is written: left to the compiler, a chain of
                         // side-product FMAs next to an MFMA stream is packed (v_pk_fma_f32) and sunk to the end of the
                         // loop body, which keeps every operand alive until there (hk_bwd3.h: +75 live registers, spills)
@@ -70,6 +81,7 @@ struct Tuning {
     int ns_tn = 0;          // HK_NS_TN         0: automatic, 64 / 128: forced tile width of the Newton-Schulz products
     int bwd_v = 0;          // HK_BWD_V         Gram backward: 0 / 1 the 64-row kernel (bcnn_fast.hip), 5 the 128-row kernel (hk_bwd128.h)
     int ns_streams = 1;     // HK_NS_STREAMS    n: the batch runs the Newton-Schulz chain in n + 1 parts on n + 1 HIP queues (default 1: two halves), 0: one queue
+    int ns_sym = 1;         // HK_NS_SYM        1: hk_ns_sqrtm_fwd_sym skips the tiles below the diagonal blocks, 0: it computes every tile
     int sched_b = 0;        // HK_SCHED_B       > 0: work-split heuristics that depend on the batch size behave as if it were this (tests: the
                             //                  large-batch schedules on small inputs); results do not depend on it
 };

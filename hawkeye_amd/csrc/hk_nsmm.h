@@ -58,8 +58,13 @@ struct NsGroup {
 
 // TN = columns of the workgroup tile (128 or 64; rows are always 128).  EDGE = true: any d / alignment (guarded scalar
 // loads and stores); false: d % 128 == 0, 16-byte aligned operands.
-template <int TN, bool EDGE>
+// SYM = true (needs EDGE = false, no E1 / E2 / C2): every result of the launch is a SYMMETRIC matrix (all forward products
+// of the chain are: the iterates are polynomials in the symmetric input) - only the workgroup tiles that touch the
+// 128 x 128 blocks on or above the diagonal are launched (3 of 4 at d = 256) and a tile right of its diagonal block
+// also writes its transpose (through the LDS the main loop has finished with: 16-byte stores along the rows).
+template <int TN, bool EDGE, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, int nb, int b0, int tilesM, int tilesN) {
+    static_assert(!(SYM && EDGE), "the symmetric schedule is for d % 128 == 0");
     constexpr int TM = 128, BK = 32;
     constexpr int NJ = TN / 64;                 // 32-column MFMA tiles per wave (wave tile = 64 x TN/2)
     constexpr int PA = BK + 4;                  // A chunk [128][32] k-contiguous: pitch 36 (pitch/4 odd: ds_read_b128 conflict-free)
@@ -69,13 +74,24 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
     constexpr int B4 = TN / 4;                  // float4 per staged B row
     __shared__ __attribute__((aligned(16))) float lds[2 * (SA + SB)];
 
-    const int tiles = tilesM * tilesN;
+    constexpr int RT = TM / TN;                 // column tiles per 128-column block
+    const int tiles = SYM ? tilesM * tilesN - RT * (tilesM * (tilesM - 1) / 2) : tilesM * tilesN;
     int b, t_;
     if (!xcd_map(blockIdx.x, nb, g.np * tiles, b, t_)) return;
     b += b0;                                    // this launch covers samples b0 .. b0 + nb - 1
     const int pi = t_ / tiles, tile = t_ % tiles;
     const NsProb& P = g.p[pi];
-    const int m0 = (tile / tilesN) * TM, n0 = (tile % tilesN) * TN;
+    int m0, n0;
+    if (SYM) {                                  // block row I owns the column tiles RT * I .. tilesN - 1
+        int I = 0, rem = tile;
+        while (rem >= tilesN - RT * I) { rem -= tilesN - RT * I; ++I; }
+        m0 = I * TM;
+        n0 = (RT * I + rem) * TN;
+    } else {
+        m0 = (tile / tilesN) * TM;
+        n0 = (tile % tilesN) * TN;
+    }
+    const bool mirror = SYM && n0 >= m0 + TM;   // (uniform) the tile lies right of its diagonal block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -311,6 +327,11 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
                     o1[t] = fmaf(e2, xs2[t], fmaf(e1, xs1[t], fmaf(al, v, dg ? diag : 0.f)));
                     o2[t] = fmaf(alpha2, v, dg ? diag2 : 0.f);
                 }
+                if (SYM && mirror) {            // this wave's image [column][row], pitch 68: lanes along the rows
+                    float* Tw = lds + wave * ((TN / 2) * 68);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) Tw[(j * 32 + 4 * lh + 8 * gq + t) * 68 + i * 32 + l31] = o1[t];
+                }
                 if (!EDGE) {
                     *reinterpret_cast<float4*>(Cb + orow + col) = make_float4(o1[0], o1[1], o1[2], o1[3]);
                     if (has_c2) *reinterpret_cast<float4*>(C2b + orow + col) = make_float4(o2[0], o2[1], o2[2], o2[3]);
@@ -324,6 +345,18 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
                 }
             }
         }
+    if (SYM && mirror) {
+        // C[n][m] = C[m][n]: the wave reads its image back four columns (= rows of the mirrored tile) at a time
+        static_assert(4 * (TN / 2) * 68 <= 2 * (SA + SB), "the four wave images fit the LDS of the main loop");
+        HK_WAVE_SYNC();
+        const float* Tw = lds + wave * ((TN / 2) * 68);
+        const int q = lane & 15, c4 = lane >> 4;
+        float* Mb = Cb + (long long)(n0 + wn * (TN / 2)) * d + m0 + wm * 64;
+#pragma unroll
+        for (int c0 = 0; c0 < TN / 2; c0 += 4)
+            *reinterpret_cast<float4*>(Mb + (long long)(c0 + c4) * d + 4 * q) =
+                *reinterpret_cast<const float4*>(&Tw[(c0 + c4) * 68 + 4 * q]);
+    }
 }
 
 // host side ------------------------------------------------------------------------------------------------------
@@ -357,7 +390,9 @@ static inline bool ns_prob_aligned(const NsProb& p) {
 }
 
 // tn: 0 = choose (128-wide tiles when that still gives two workgroups per CU, else 64-wide), 64 / 128 = forced
-static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, int tn = 0, int b0 = 0) {
+// sym: every result is a symmetric matrix (see the kernel); taken when the fast path applies and no problem has a second
+// result or epilogue operands, otherwise the launch computes all tiles as usual
+static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, int tn = 0, int b0 = 0, bool sym = false) {
     if (g.np < 1 || g.np > 4 || d <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
     bool fast = d % 128 == 0;
     for (int i = 0; i < g.np; ++i) {
@@ -370,6 +405,15 @@ static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, i
     // forced 64 -> 291 / 750 us (fwd / bwd), forced 128 -> 297 / 770, mixed (128 for the multi-problem launches) 291 / 768
     if (tn != 64 && tn != 128) tn = ((long long)g.np * tm * tm * 2 * nb > 2048) ? 128 : 64;
     const int tnn = (d + tn - 1) / tn;
+    for (int i = 0; i < g.np; ++i) sym = sym && !g.p[i].C2 && !g.p[i].E1 && !g.p[i].E2;
+    if (sym && fast) {
+        const int tiles = tm * tnn - (128 / tn) * (tm * (tm - 1) / 2);
+        const dim3 gs(xcd_grid(nb, g.np * tiles));
+        if (tn == 128) hipLaunchKernelGGL((nsmm_kernel<128, false, true>), gs, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+        else hipLaunchKernelGGL((nsmm_kernel<64, false, true>), gs, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     const dim3 grid(xcd_grid(nb, g.np * tm * tnn));
     if (tn == 128) {
         if (fast) hipLaunchKernelGGL((nsmm_kernel<128, false>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);

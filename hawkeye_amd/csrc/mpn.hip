@@ -195,14 +195,16 @@ struct NsDispatch {
     int d, B;
     hipStream_t st;
     AuxScope aux;
-    NsDispatch(int d_, int B_, hipStream_t st_)
-        : d(d_), B(B_), st(st_), aux(st_, B_ >= 16 ? (tuning().ns_streams < B_ / 8 ? tuning().ns_streams : B_ / 8 - 1) : 0) {}
+    bool sym;                // every product of the chain has a symmetric result (hk_ns_sqrtm_fwd_sym)
+    NsDispatch(int d_, int B_, hipStream_t st_, bool sym_ = false)
+        : d(d_), B(B_), st(st_), aux(st_, B_ >= 16 ? (tuning().ns_streams < B_ / 8 ? tuning().ns_streams : B_ / 8 - 1) : 0),
+          sym(sym_) {}
     int operator()(const NsGroup& g) const {
         const int parts = aux.count() + 1;
-        if (parts == 1) return nsmm_launch(g, d, B, st);
+        if (parts == 1) return nsmm_launch(g, d, B, st, 0, 0, sym);
         for (int i = 0; i < parts; ++i) {                    // samples [b0, b1) on queue i (0: the caller's stream)
             const int b0 = (int)((long long)B * i / parts), b1 = (int)((long long)B * (i + 1) / parts);
-            const int rc = nsmm_launch(g, d, b1 - b0, i == 0 ? st : aux.aux(i - 1), 0, b0);
+            const int rc = nsmm_launch(g, d, b1 - b0, i == 0 ? st : aux.aux(i - 1), 0, b0, sym);
             if (rc != HK_OK) return rc;
         }
         return HK_OK;
@@ -278,8 +280,11 @@ extern "C" size_t hk_ns_sqrtm_ws_bytes(int B, int d, int iter_n, int backward) {
 
 // Forward schedule at iterN = 5 (MPNCOV.py:137-164): 12 products in 9 launches -
 //   Y0 = A ZY0 | for i = 1..3: ZY = .5 (3I - Z Y) | {Y' = Y ZY, Z' = ZY Z} in one launch | 3I - Z Y | .5 sqrt(tr) Y (.)
-extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
-                               int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream) {
+// sym = true: `a` is symmetric, so is every product of the chain - the launches skip the tiles below the diagonal blocks
+// (3 of 4 tiles at d = 256) and mirror the rest; the results differ from the full products by the rounding asymmetry
+// of a product of commuting symmetric matrices (~1e-7 relative: tests/test_gpu_full_shapes.py).
+static int ns_sqrtm_fwd_impl(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
+                             int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream, bool sym) {
     if (!a || !out || !norm_a || B <= 0 || d <= 0 || iter_n < 1) return HK_ERR_BAD_ARG;
     if (iter_n >= 2 && (!ysave || !zsave)) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_ns_sqrtm_ws_bytes(B, d, iter_n, 0)) return HK_ERR_WORKSPACE;
@@ -294,11 +299,11 @@ extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float*
     if (iter_n < 2) {
         hipLaunchKernelGGL(ns_scale_kernel<true>, ns_scale_grid(n, B), dim3(256), 0, st, a, norm_a, sq, A, T, n, d);
         HK_LAUNCH_CHECK();
-        return nsmm_launch(ns_group(ns_single(A, n, T, n, out, n, 1.0f, 0.f, sq)), d, B, st);   // :151,:161
+        return nsmm_launch(ns_group(ns_single(A, n, T, n, out, n, 1.0f, 0.f, sq)), d, B, st, 0, 0, sym);   // :151,:161
     }
     hipLaunchKernelGGL(ns_scale_kernel<true>, ns_scale_grid(n, B), dim3(256), 0, st, a, norm_a, sq, A, zsave, sbs, d);
     HK_LAUNCH_CHECK();
-    NsDispatch L(d, B, st);
+    NsDispatch L(d, B, st, sym);
     HK_TRY(L(ns_group(ns_single(A, n, zsave, sbs, ysave, sbs, 1.f, 0.f))));                        // Y0 = A ZY   :154
     for (int i = 1; i < iter_n - 1; ++i) {                                                          // :156-159
         const float* Yp = ysave + (long long)(i - 1) * n;
@@ -313,6 +318,16 @@ extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float*
     HK_TRY(L(ns_group(ns_single(Zl, sbs, Yl, sbs, T, n, -1.f, 3.f))));                             // 3I - Z Y      :160
     HK_TRY(L(ns_group(ns_single(Yl, sbs, T, n, out, n, 0.5f, 0.f, sq))));                          // .5 Y (.) sqrt(normA)
     return L.join();
+}
+
+extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
+                               int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    return ns_sqrtm_fwd_impl(a, out, norm_a, ysave, zsave, B, d, iter_n, ws, ws_bytes, stream, false);
+}
+
+extern "C" int hk_ns_sqrtm_fwd_sym(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
+                                   int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    return ns_sqrtm_fwd_impl(a, out, norm_a, ysave, zsave, B, d, iter_n, ws, ws_bytes, stream, tuning().ns_sym != 0);
 }
 
 // Backward schedule at iterN = 5 (MPNCOV.py:166-202): the reference's 38 products as 34 in 9 launches -

@@ -134,7 +134,7 @@ class _Sqrtm(torch.autograd.Function):
     """replaces Sqrtm, model/methods/MPNCOV.py:137-202."""
 
     @staticmethod
-    def forward(ctx, a, iter_n, assume_symmetric=True):
+    def forward(ctx, a, iter_n, symmetric=False, literal_backward=False):
         lib = _lib.load()
         a = _f32c(a)
         b, d, _ = a.shape
@@ -145,10 +145,11 @@ class _Sqrtm(torch.autograd.Function):
         zsave = torch.empty(b, slots, d, d, dtype=torch.float32, device=a.device)
         nws = lib.hk_ns_sqrtm_ws_bytes(b, d, iter_n, 0)
         ws = _ws(nws, a.device)
-        check(lib.hk_ns_sqrtm_fwd(ptr(a), ptr(out), ptr(norm_a), ptr(ysave), ptr(zsave), b, d, iter_n,
-                                  ptr(ws), nws, stream()), 'hk_ns_sqrtm_fwd')
+        fwd = lib.hk_ns_sqrtm_fwd_sym if symmetric else lib.hk_ns_sqrtm_fwd
+        check(fwd(ptr(a), ptr(out), ptr(norm_a), ptr(ysave), ptr(zsave), b, d, iter_n, ptr(ws), nws, stream()),
+              'hk_ns_sqrtm_fwd')
         ctx.iter_n = iter_n
-        ctx.assume_symmetric = bool(assume_symmetric)
+        ctx.literal_backward = bool(literal_backward)
         ctx.save_for_backward(a, out, norm_a, ysave, zsave)
         return out
 
@@ -162,10 +163,10 @@ class _Sqrtm(torch.autograd.Function):
         nws = lib.hk_ns_sqrtm_ws_bytes(b, d, ctx.iter_n, 1)
         ws = _ws(nws, a.device)
         # 34 products (exact for any input) or, on request, the reference's 38 literally (include/hawkeye_hip.h)
-        fn = lib.hk_ns_sqrtm_bwd if ctx.assume_symmetric else lib.hk_ns_sqrtm_bwd_general
+        fn = lib.hk_ns_sqrtm_bwd_general if ctx.literal_backward else lib.hk_ns_sqrtm_bwd
         check(fn(ptr(a), ptr(out), ptr(norm_a), ptr(ysave), ptr(zsave), ptr(g), ptr(da),
                  b, d, ctx.iter_n, ptr(ws), nws, stream()), 'hk_ns_sqrtm_bwd')
-        return da, None, None
+        return da, None, None, None
 
 
 class _Triuvec(torch.autograd.Function):
@@ -195,11 +196,13 @@ def covpool(x):
     return _Covpool.apply(x)
 
 
-def sqrtm(x, iter_n, assume_symmetric=True):
-    """Newton-Schulz square root of x [B,d,d] (any square matrices, symmetric or not).  The default backward shares one
-    product between Y_i Z_i and Z_i Y_i (the iterates are polynomials in one matrix: they commute for every input);
-    assume_symmetric=False runs the reference's 38 products literally (A/B checks)."""
-    return _Sqrtm.apply(x, int(iter_n), bool(assume_symmetric))
+def sqrtm(x, iter_n, symmetric=False, literal_backward=False):
+    """Newton-Schulz square root of x [B,d,d] (MPNCOV.py:137-202; any square matrices).
+    symmetric=True: the caller guarantees x == x^T (a covariance: what MPNCOV feeds it) - the forward then computes only
+    the tiles on or above the diagonal blocks of every product (hk_ns_sqrtm_fwd_sym; wrong for other inputs).
+    The backward shares one product between Y_i Z_i and Z_i Y_i (the iterates are polynomials in one matrix: they commute
+    for every input); literal_backward=True runs the reference's 38 products literally (A/B checks)."""
+    return _Sqrtm.apply(x, int(iter_n), bool(symmetric), bool(literal_backward))
 
 
 def triuvec(x):

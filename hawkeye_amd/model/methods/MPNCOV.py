@@ -32,7 +32,7 @@ class MPNCOV(nn.Module):
             x = self.conv_dr_block(x)
         x = HF.covpool(x)
         if self.is_sqrt:
-            x = HF.sqrtm(x, self.iterNum)
+            x = HF.sqrtm(x, self.iterNum, symmetric=True)      # a covariance: symmetric by construction
         if self.is_vec:
             x = HF.triuvec(x)
         return x

@@ -122,6 +122,15 @@ int hk_cov_pool_bwd(const float* x, const float* mu, const float* dcov, float* d
 size_t hk_ns_sqrtm_ws_bytes(int B, int d, int iter_n, int backward);
 int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
                     int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream);
+/* hk_ns_sqrtm_fwd_sym: the same, for a SYMMETRIC input `a` (what Covpool produces and all MPNCOV.forward ever feeds
+ * Sqrtm, MPNCOV.py:73-76).  Every product of the chain is then a symmetric matrix (a polynomial in `a`): the launches
+ * compute only the tiles that touch the 128 x 128 blocks on or above the diagonal (3 of 4 at d = 256) and write the
+ * blocks right of the diagonal twice, transposed.  Results differ from hk_ns_sqrtm_fwd by the rounding asymmetry of a
+ * product of commuting symmetric matrices (~1e-7 relative); with an input that is not symmetric the result is WRONG -
+ * use hk_ns_sqrtm_fwd.  d % 128 != 0 falls back to the full schedule.  Saved iterates are interchangeable with
+ * hk_ns_sqrtm_fwd's for either backward. */
+int hk_ns_sqrtm_fwd_sym(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
+                        int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream);
 /* hk_ns_sqrtm_bwd executes 34 products instead of the reference's 38: Z_i Y_i is taken from the accumulator of Y_i Z_i.
  * That is exact for ANY input `a`, symmetric or not: every iterate is a polynomial in the one matrix A = a / tr(a)
  * (Y_0 = A (3I - A)/2, Z_0 = (3I - A)/2, and each step multiplies polynomials in A), and polynomials in one matrix

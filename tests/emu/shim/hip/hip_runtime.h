@@ -407,6 +407,7 @@ inline T __shfl(T v, int srclane, int = 64) {
 #define HK_DYN_LDS(name) float* name = reinterpret_cast<float*>(hipemu::B->dyn_lds)
 #define HK_DYN_LDS16(name) HK_DYN_LDS(name)
 #define HK_FMAC_PINNED(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
+#define HK_WAVE_SYNC() hipemu::wave_barrier()   /* the fibers of a wave are not in lockstep between collectives */
 #define HK_LDS_VOLATILE(p) ((volatile float*)(p))
 #define HK_LDS_CONST(p) ((const float*)(p))
 #define HK_ATOMIC_ADD_F32(p, v) (*(p) += (v))   /* one workgroup at a time: no concurrency to model */

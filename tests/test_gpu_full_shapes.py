@@ -50,8 +50,11 @@ def per(a):
     return a.detach().double().reshape(a.shape[0], -1).cpu()
 
 
-def test_mpn_head_at_batch_64_vs_reference(F, g):
-    """Covariance (C = 256: the eight-wave 64-row backward, the cyclic forward walk), Newton-Schulz at d = 256 with 5
+@pytest.mark.parametrize('symmetric', [True, False])
+def test_mpn_head_at_batch_64_vs_reference(F, g, symmetric):
+    """symmetric = True is what the MPN head runs (hk_ns_sqrtm_fwd_sym: tiles below the diagonal blocks mirrored instead
+    of computed), False the full products of hk_ns_sqrtm_fwd - both against the same reference goldens.
+    Covariance (C = 256: the eight-wave 64-row backward, the cyclic forward walk), Newton-Schulz at d = 256 with 5
     iterations on TWO HIP queues of 32 samples each, triuvec, and the whole backward - MPNCOV.py:105-230 at the batch
     configs[2] is benchmarked at.  Every sample is pinned through its sums, the first / middle / last sample of each
     queue's half through a strided subsample of every tensor, and the same samples against the oracle in full."""
@@ -59,7 +62,7 @@ def test_mpn_head_at_batch_64_vs_reference(F, g):
     xg = t(xn).to(DEV).requires_grad_(True)
     cov = F.covpool(xg)
     cov.retain_grad()
-    sq = F.sqrtm(cov, 5)
+    sq = F.sqrtm(cov, 5, symmetric=symmetric)
     sq.retain_grad()
     tv = F.triuvec(sq)
     (tv * t(wn).to(DEV)).sum().backward()
@@ -86,6 +89,8 @@ def test_mpn_head_at_batch_64_vs_reference(F, g):
     assert rel(cov[picks], co) < 2e-6 and rel(sq[picks], so) < 1e-5
     assert rel(cov.grad[picks], co.grad) < 1e-4 and rel(xg.grad[picks], xo.grad) < 1e-4
     assert torch.equal(cov.detach(), cov.detach().transpose(1, 2))
+    if symmetric:      # the 128 x 128 block right of the diagonal is written twice
+        assert torch.equal(sq.detach()[:, :128, 128:], sq.detach()[:, 128:, :128].transpose(1, 2))
 
 
 @pytest.mark.parametrize('b', [64, 16])

@@ -502,6 +502,41 @@ def test_ns_grouped_products(F, b, d, itn):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize('b,d,itn', [(2, 128, 3), (17, 256, 5), (1, 384, 2), (2, 200, 3), (2, 256, 1)])
+def test_ns_symmetric_forward(F, b, d, itn, tune):
+    """hk_ns_sqrtm_fwd_sym (what the MPN head calls: its input is a covariance): only the tiles on or above the
+    128 x 128 diagonal blocks of each product are computed, blocks right of the diagonal are written twice (transposed).
+    Against the oracle at the tolerance of the full products, against hk_ns_sqrtm_fwd at rounding level, for both tile
+    widths, one / two / three block rows, the two-queue dispatch (b = 17) and a d the schedule does not apply to (200:
+    falls back to the full products, bit-identical)."""
+    x = torch.relu(torch.randn(b, d, 6, 7, generator=torch.Generator().manual_seed(d + itn))) + 0.01
+    xo = x.clone().requires_grad_(True)
+    yo = O.sqrtm(O.covpool(xo), itn)
+    wt = torch.randn(yo.shape, generator=torch.Generator().manual_seed(2))
+    (yo * wt).sum().backward()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    yfull = F.sqrtm(F.covpool(xg), itn)
+    res = []
+    for tn in (64, 128):
+        tune('ns_tn', tn)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        ys = F.sqrtm(F.covpool(xg), itn, symmetric=True)
+        (ys * wt.to(DEV)).sum().backward()
+        assert rel(ys, yo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4, tn
+        assert rel(ys, yfull) < 2e-6, tn
+        res.append(ys.detach())
+        for i in range(d // 128 if d % 128 == 0 else 0):      # mirrored blocks: exact transposes
+            lo = 128 * (i + 1)
+            assert torch.equal(ys.detach()[:, 128 * i:lo, lo:], ys.detach()[:, lo:, 128 * i:lo].transpose(1, 2))
+    tune('ns_tn', 0)
+    assert torch.equal(res[0], res[1])
+    if d % 128:
+        assert torch.equal(res[0], yfull.detach())
+    tune('ns_sym', 0)                                             # the knob: the _sym entry runs the full products
+    assert torch.equal(F.sqrtm(F.covpool(x.to(DEV)), itn, symmetric=True), yfull.detach())
+    tune('ns_sym', 1)
+
+
 @pytest.mark.parametrize('b,d', [(16, 64), (17, 40)])
 def test_ns_two_queue_dispatch_bit_identical(F, b, d, tune):
     """ns_streams=1: the two halves of the batch run the chain on two HIP queues (fork / join through events inside the
@@ -546,12 +581,12 @@ def test_ns_general_input_backward(F, itn):
     wt = torch.randn(b, d, d, generator=gen)
     ao = a.clone().requires_grad_(True)
     (O.sqrtm(ao, itn) * wt).sum().backward()
-    for sym in (False, True):
+    for literal in (True, False):
         ag = a.clone().to(DEV).requires_grad_(True)
-        out = F.sqrtm(ag, itn, assume_symmetric=sym)
+        out = F.sqrtm(ag, itn, literal_backward=literal)
         (out * wt.to(DEV)).sum().backward()
         assert rel(out, O.sqrtm(a, itn)) < 1e-5
-        assert rel(ag.grad, ao.grad) < 1e-5, sym
+        assert rel(ag.grad, ao.grad) < 1e-5, literal
 
 
 _MODEL_CFG = {

@@ -156,6 +156,11 @@ def ns_chain():
             rows[-2]['rel_vs_default'] = float((out - ref[0]).norm() / ref[0].norm())
             rows[-1]['rel_vs_default'] = float((da - ref[1]).norm() / ref[1].norm())
     knob('ns_tn', 0)
+    # what the MPN head calls (its input is a covariance): tiles below the diagonal blocks mirrored, not computed
+    f = timeit(lambda: lib.hk_ns_sqrtm_fwd_sym(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), B, d, 5, ptr(wf), nwf, stream()))
+    row('ns_sqrtm fwd B=64 d=256 it=5', 'hk_ns_sqrtm_fwd_sym (symmetric input: 3 of 4 tiles per product; the MPN head)', f,
+        12 * 2.0 * B * d ** 3)
+    rows[-1]['rel_vs_default'] = float((out - ref[0]).norm() / ref[0].norm())
 
 
 def npairs():

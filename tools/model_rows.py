@@ -87,8 +87,11 @@ def mpn_kernels(B=64, d=256, HW=196):
     out = E(B, d, d); na = E(B); ys = E(B, 4, d, d); zs = E(B, 4, d, d); da = E(B, d, d)
     nwf = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 0); nwb = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 1)
     wsf = E(nwf, dtype=torch.uint8); wsb = E(nwb, dtype=torch.uint8)
-    kernel_row('MPN', 'ns_sqrtm fwd chain (12 products of 256^3 per sample, 11 launches)',
+    kernel_row('MPN', 'ns_sqrtm fwd chain, general input (12 products of 256^3 per sample, 9 launches x 2 queues)',
                lambda: lib.hk_ns_sqrtm_fwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), B, d, 5, ptr(wsf), nwf, stream()),
+               12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10)
+    kernel_row('MPN', 'ns_sqrtm fwd chain, symmetric input = the MPN head (same 12 products, 3 of 4 tiles computed)',
+               lambda: lib.hk_ns_sqrtm_fwd_sym(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), B, d, 5, ptr(wsf), nwf, stream()),
                12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10)
     kernel_row('MPN', 'ns_sqrtm bwd chain (38 products of 256^3 per sample, 13 launches)',
                lambda: lib.hk_ns_sqrtm_bwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), ptr(g), ptr(da), B, d, 5, ptr(wsb),

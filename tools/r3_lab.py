@@ -147,8 +147,10 @@ def g_ns():
     assert fw() == 0
     bw = lambda: lib.hk_ns_sqrtm_bwd(p(a), p(out_), p(na), p(ys), p(zs), p(g), p(da), B, d, it, p(wb), nb, st())
     res = []
-    res.append(run_group('Newton-Schulz fwd B=64 d=256 it=5', [(f'fwd ns_streams={v}', dict(ns_streams=v), fw) for v in NS_STREAMS],
-                         flops=12 * 2.0 * d ** 3 * B))
+    fs = lambda: lib.hk_ns_sqrtm_fwd_sym(p(a), p(out_), p(na), p(ys), p(zs), B, d, it, p(wf), nf, st())
+    items = [(f'fwd ns_streams={v}', dict(ns_streams=v), fw) for v in NS_STREAMS]
+    items += [(f'fwd_sym ns_streams={v} ns_tn={tn}', dict(ns_streams=v, ns_tn=tn), fs) for v in (0, 1, 2, 3) for tn in (64, 128)]
+    res.append(run_group('Newton-Schulz fwd B=64 d=256 it=5', items, flops=12 * 2.0 * d ** 3 * B))
     res.append(run_group('Newton-Schulz bwd B=64 d=256 it=5', [(f'bwd ns_streams={v}', dict(ns_streams=v), bw) for v in NS_STREAMS],
                          flops=38 * 2.0 * d ** 3 * B))
     tv, dtv = torch.empty(B, d * (d + 1) // 2, device=dev), torch.randn(B, d * (d + 1) // 2, device=dev)
@@ -158,7 +160,7 @@ def g_ns():
     return res
 
 
-NS_STREAMS = (1, 2, 3, 0)
+NS_STREAMS = (1, 0)
 
 
 def g_linear():
