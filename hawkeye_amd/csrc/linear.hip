@@ -11,6 +11,7 @@
 //   dW = g^T y        M = classes, N = J, K = B : y read once per class tile row (L2), dW written once
 //   db = sum_b g
 #include <cstdlib>
+#include <type_traits>
 
 #include "hk_bgemm.h"
 #include "hk_bwd128d.h"      // glds16 (LDS-DMA)
@@ -106,6 +107,9 @@ __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __re
         asm volatile("" ::: "memory");                                                                         \
     } while (0)
 
+#ifdef HK_LAB   // tools/linear_lab.py, timing only (results are wrong): 1 = no MFMAs (the stream alone), 2 = no LDS-DMA inside the loop
+__device__ int g_lin_lab = 0;
+#endif
 // MT: 16-sample row tiles per workgroup.  4: up to 64 samples, wave w owns row tile w & 3 and one half of the NT class tiles.
 // 1: up to 16 samples (OSME: N = 10) - every wave owns the same 16 rows and NT / 8 of the class tiles; the product is then
 // a pure stream of W (2 KB of LDS-DMA pieces per MFMA-cycle-pair), the matrix pipe idles.
@@ -184,42 +188,61 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
     const int arow = 16 * rb + l15;
     const int aoff = arow * CH, asw = arow & 7;
     const int boff = A_SZ + (16 * nt0 + l15) * CH, bsw = l15 & 7;      // (16 (nt0 + n) is a multiple of 8)
-    auto frag = [&](int st, int s, f32x4& a, f32x4 (&b)[NH]) {
-        const float* base = lds + st;
-        a = *reinterpret_cast<const f32x4*>(base + aoff + (((4 * s + lq) ^ asw) << 2));
-#pragma unroll
-        for (int n = 0; n < NH; ++n)
-            b[n] = (n < nloc) ? *reinterpret_cast<const f32x4*>(base + boff + n * 16 * CH + (((4 * s + lq) ^ bsw) << 2))
-                              : (f32x4){0.f, 0.f, 0.f, 0.f};
-    };
-    auto mma = [&](const f32x4& a, const f32x4 (&b)[NH]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int n = 0; n < NH; ++n)
-                if (n < NH - 1 || n < nloc) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n][t], acc[n], 0, 0, 0);
-    };
-
+#ifdef HK_LAB
+    const int labv = __builtin_amdgcn_readfirstlane(g_lin_lab);
+#else
+    constexpr int labv = 0;
+#endif
     // prologue: chunks 0 .. NS - 2 into stages 0 .. NS - 2
     for (int c = 0; c < NS - 1 && c < nch; ++c) { dma(c, c * STAGE, 0); dma(c, c * STAGE, 1); }
     vm_barrier(true);
-    f32x4 a0, a1, b0[NH], b1[NH];
-    frag(0, 0, a0, b0);
-    int cur = 0;                                                 // stage of chunk c (float offset), nxt = chunk c + 1
-    for (int c = 0; c < nch; ++c) {
-        const int nxt = cur + STAGE < NS * STAGE ? cur + STAGE : 0;
-        const int dst = cur >= STAGE ? cur - STAGE : (NS - 1) * STAGE;      // stage of chunk c - 1 = chunk c + NS - 1
-        const bool load = c + NS - 1 < nch;                      // uniform
-        frag(cur, 1, a1, b1);
-        mma(a0, b0);
-        if (load) dma(c + NS - 1, dst, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nch) frag(nxt, 0, a0, b0);                   // complete and published by the previous barrier
-        mma(a1, b1);
-        if (load) dma(c + NS - 1, dst, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        vm_barrier(!load);
-        cur = nxt;
+    // The chunk loop, instantiated per number of class tiles of the wave (NL = 7 / 6 of 13, 8 / 7 of 15): with the tile
+    // count a run-time value the eighth fragment read and every seventh MFMA sat behind a (uniform) branch in the middle
+    // of the MFMA stream (82.4 -> 77.3 us at the BCNN shape in one alternating run, profiles/r3_lab_call25.json).
+    // Within a half chunk the compiler places the seven reads of the NEXT fragments behind the last MFMAs of the
+    // current ones and waits for them at once: the wave parks for one LDS latency per half chunk while the other wave
+    // of its SIMD has the matrix pipe.  Pinning the reads ahead of the MFMAs (no wait left) measured SLOWER - 80.6 us
+    // with the reads before the group, 88.1 us with the reads behind its first seven MFMAs.
+    auto run = [&](auto nl_tag) {
+        constexpr int NL = decltype(nl_tag)::value;
+        auto frag = [&](int st, int s, f32x4& a, f32x4 (&b)[NL]) {
+            const float* base = lds + st;
+            a = *reinterpret_cast<const f32x4*>(base + aoff + (((4 * s + lq) ^ asw) << 2));
+#pragma unroll
+            for (int n = 0; n < NL; ++n)
+                b[n] = *reinterpret_cast<const f32x4*>(base + boff + n * 16 * CH + (((4 * s + lq) ^ bsw) << 2));
+        };
+        auto mma = [&](const f32x4& a, const f32x4 (&b)[NL]) {
+            if (labv & 1) return;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int n = 0; n < NL; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n][t], acc[n], 0, 0, 0);
+        };
+        f32x4 a0, a1, b0[NL], b1[NL];
+        frag(0, 0, a0, b0);
+        int cur = 0;                                             // stage of chunk c (float offset), nxt = chunk c + 1
+        for (int c = 0; c < nch; ++c) {
+            const int nxt = cur + STAGE < NS * STAGE ? cur + STAGE : 0;
+            const int dst = cur >= STAGE ? cur - STAGE : (NS - 1) * STAGE;  // stage of chunk c - 1 = chunk c + NS - 1
+            const bool load = c + NS - 1 < nch && !(labv & 2);   // uniform
+            frag(cur, 1, a1, b1);
+            mma(a0, b0);
+            if (load) dma(c + NS - 1, dst, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(c + 1 < nch ? nxt : cur, 0, a0, b0);            // complete and published by the previous barrier
+            mma(a1, b1);
+            if (load) dma(c + NS - 1, dst, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            vm_barrier(!load);
+            cur = nxt;
+        }
+    };
+    if constexpr (MT == 4 && NT % 2 == 1) {
+        if (nloc == NH) run(std::integral_constant<int, NH>{});
+        else run(std::integral_constant<int, NH - 1>{});
+    } else {
+        run(std::integral_constant<int, NH>{});
     }
 
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -541,6 +564,12 @@ extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, 
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
+
+#ifdef HK_LAB
+extern "C" int hk_lab_set_linear_mode(int v) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lin_lab), &v, sizeof(int)) == hipSuccess ? HK_OK : HK_ERR_UNSUPPORTED;
+}
+#endif
 
 extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, float* dy, float* dw, float* db, int B, int J,
                              int K, hk_stream_t stream) {

@@ -29,7 +29,7 @@ def knobs(**kw):
         assert lib.hk_tuning_set(k.encode(), int(v)) == 0, k
 
 
-DEFAULTS = dict(bwd_v=0, cbp_bin=-1, ns_streams=1, ns_tn=0, linear_slabs=0, bcnn_generic=0)
+DEFAULTS = dict(bwd_v=0, cbp_bin=-1, ns_streams=1, ns_tn=0, linear_slabs=0, bcnn_generic=0, ns_sym=1, sched_b=0)
 
 
 def run_group(title, items, flops=None, bytes_=None):
@@ -182,7 +182,8 @@ def g_linear():
             g.t() @ y
             g.sum(0)
         by = 4.0 * (K * J + B * J)
-        res.append(run_group(f'linear fwd {tag}', [('hk_linear_fwd', {}, fw), ('torch (rocBLAS)', {}, tfw)], flops=2.0 * B * J * K, bytes_=by))
+        items = [('hk_linear_fwd', {}, fw)]
+        res.append(run_group(f'linear fwd {tag}', items + [('torch (rocBLAS)', {}, tfw)], flops=2.0 * B * J * K, bytes_=by))
         res.append(run_group(f'linear bwd {tag}', [('hk_linear_bwd', {}, bw), ('torch (rocBLAS x3)', {}, tbw)], flops=4.0 * B * J * K, bytes_=2 * by))
         del y, w, dyy, dw
     return res
