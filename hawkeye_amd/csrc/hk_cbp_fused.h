@@ -5,7 +5,7 @@
 // launched 128 workgroups on 256 CUs.  Here a workgroup computes 64x64 tiles (I, J), J >= I, of one sample's Gram on
 // the panel-resident MFMA loop of bcnn_fast.hip (A panel = row block I, full K, resident in LDS), parks each finished
 // tile in LDS and bins it from there into a PRIVATE copy of the D output bins, also in LDS; the per-workgroup partial
-// bin vectors (24 KB each) are added in fixed order by cbp_partsum_kernel.
+// bin vectors (24 KB each) are added in fixed order by cbp_finish_kernel (cbp.hip), which also normalises.
 //
 // Binning a tile deterministically, without atomics, with four waves in parallel: it is a GATHER.  For every ordered
 // pair of 64-row blocks (I, J) the plan holds the 4096 entries (i in I, j in J) -> bin (h1_i + h2_j) mod D, sign
@@ -24,7 +24,7 @@
 //
 // LDS: A panel 50 KB + ONE column panel 50 KB (the next one waits in registers during the tile's MFMA loop and is
 // written behind it - a second panel buffer does not fit next to the bins) + two tile buffers of 17 KB (stored
-// transposed, pitch 68: 16-byte stores without bank conflicts) + D + 1 bins 24 KB = 155.5 KB.
+// transposed, pitch 68: 16-byte stores without bank conflicts) + CBF_DMAX bins 24 KB = 160 KB, one static array.
 // Work split: `items` per sample, each one or two runs of tiles (row block, first column block, count) - B = 64: the
 // balanced pairs {p, nb - 1 - p} (nb + 1 tiles, one workgroup per CU); smaller batches: rows cut into runs of <= 3 tiles
 // so that B x items fills the chip (B = 16, C = 512: 16 items per sample = 256 workgroups).

@@ -247,7 +247,7 @@ def bwd_variants():
     xm = torch.relu(torch.randn(B, dc, HW, device=dev))
     mu, g, dxm = torch.zeros(B, dc, device=dev), torch.randn(B, dc, dc, device=dev), torch.empty_like(xm)
     ref = None
-    for flag in (1, 4, 5, 9, 14, 12, 13, 0):
+    for flag in (1, 4, 5, 9, 14, 12, 13, 11, 15, 0):
         knob('bwd_v', flag)
         tag = {1: 'bwd_v=1: 64-row blocks, P tile built in LDS, 2 WGs/CU (round-1 kernel)',
                4: 'bwd_v=4: 64-row blocks on the eight-wave raw-tile kernel (round-2 default for the covariance at C=256, B=64)',
@@ -256,7 +256,9 @@ def bwd_variants():
                14: 'bwd_v=14: hk_bwd3.h without its two changes (= bwd_v 9 for BCNN; LDS-DMA + mu column for the covariance)',
                12: 'bwd_v=12: hk_bwd3.h, remainder columns on the VALU only',
                13: 'bwd_v=13: hk_bwd3.h, LDS-staged epilogue only',
-               0: 'hk_bwd3.h: VALU remainder columns + LDS-staged epilogue (round-3 default)'}[flag]
+               11: 'bwd_v=11: hk_bwd3.h, VALU remainder columns + LDS-staged epilogue',
+               15: 'bwd_v=15: as 11 + a wave per 16 rows and all column tiles (128-row blocks only: same as 11 for the covariance)',
+               0: 'hk_bwd3.h, automatic (round-3 default): as 15 + late coefficient at 128-row blocks (BCNN); bwd_v 11 form at 64-row blocks (covariance)'}[flag]
         row('bcnn bwd_gemm B=64 C=512', tag,
             timeit(lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream()), iters=40),
             2.0 * B * C * C * HW, 8.0 * B * (C * C + C * HW))
@@ -312,15 +314,20 @@ def cin():
     nws = lib.hk_cin_cci_ws_bytes(B, C)
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
     fl = 2.0 * B * C * C * HW
-    row('cin sci fwd B=20 C=2048 HW=49', 'hk_cin_sci_fwd (gemm + softmax + gemm)',
+    row('cin sci fwd B=20 C=2048 HW=49', 'hk_cin_sci_fwd (one flash-style kernel: statistics pass + normalised second product, W written once; round-3 default)',
         timeit(lambda: lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), B, C, HW, stream())), 2 * fl, 4.0 * B * (2 * C * C))
 
     def torch_sci():
         ws_ = torch.softmax(-torch.bmm(x, x.transpose(1, 2)) / HW, dim=2)
         return torch.bmm(ws_, x)
+    knob('bcnn_generic', 1)
+    row('cin sci fwd B=20 C=2048 HW=49', 'bcnn_generic=1: Gram kernel + row softmax + second product (round-2 chain)',
+        timeit(lambda: lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), B, C, HW, stream())), 2 * fl, 4.0 * B * (4 * C * C))
+    knob('bcnn_generic', 0)
+    lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), B, C, HW, stream())
     row('cin sci fwd B=20 C=2048 HW=49', 'torch bmm + softmax + bmm (reference)', timeit(torch_sci), 2 * fl,
         4.0 * B * (4 * C * C))
-    rows[-2]['rel_err_vs_torch'] = float((y - torch_sci()).norm() / torch_sci().norm())
+    rows[-3]['rel_err_vs_torch'] = float((y - torch_sci()).norm() / torch_sci().norm())
     row('cin cci fwd', 'hk_cin_cci_fwd (|W - w W\'| in the operand loader)',
         timeit(lambda: lib.hk_cin_cci_fwd(ptr(x), ptr(w), ptr(wt), ptr(yc), B, C, HW, stream())), fl)
     row('cin cci bwd', 'hk_cin_cci_bwd',

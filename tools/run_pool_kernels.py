@@ -36,7 +36,11 @@ if mode in ('ns', 'all'):          # the Newton-Schulz chain (grouped nsmm_kerne
     wt = torch.randn(64, 256, 256, device=dev)
     for _ in range(2):
         xc.grad = None
-        (F.sqrtm(F.covpool(xc), 5) * wt).sum().backward()      # covariance fwd / bwd kernels as well
+        # the MPN head as the model runs it: covariance, symmetric-input chain, triuvec - forward and backward
+        wv = torch.randn(64, 32896, 1, device=dev)
+        (F.triuvec(F.sqrtm(F.covpool(xc), 5, symmetric=True)) * wv).sum().backward()
+        xc.grad = None
+        (F.sqrtm(F.covpool(xc), 5) * wt).sum().backward()      # the general-input forward (all tiles of every product)
     torch.cuda.synchronize()
     print('ns ok', flush=True)
 
@@ -60,9 +64,17 @@ if mode == 'all':                  # the other heads at the BASELINE config shap
     wl, bl = torch.randn(200, 262144, device=dev) * 0.01, torch.zeros(200, device=dev)
     parts = torch.randn(32, 2, 1024, device=dev, requires_grad=True)
     tg = torch.arange(16, device=dev).repeat_interleave(2)
+    xb16 = xb.detach()[:16].clone().requires_grad_(True)                          # configs/CBCNN_S2.yaml's batch
+    xci = torch.relu(torch.randn(20, 2048, 49, device=dev))                        # CIN SCI (CIN.py:31-34) at its config
+    gl = torch.randn(64, 200, device=dev)
+    dyl, dwl, dbl = torch.empty_like(yl), torch.empty_like(wl), torch.empty_like(bl)
     for _ in range(reps):
         xb.grad = None
         (F.compact_bilinear_pool(xb, plan) * wc).sum().backward()
+        xb16.grad = None
+        (F.compact_bilinear_pool(xb16, plan) * wc[:16]).sum().backward()
+        F.cin_sci(xci)
+        lib.hk_linear_bwd(ptr(yl), ptr(wl), ptr(gl), ptr(dyl), ptr(dwl), ptr(dbl), 64, 262144, 200, stream())
         xb.grad = None
         (F.bilinear_pool(xb, signed_sqrt=True) * ws).sum().backward()
         fa.grad = None
