@@ -49,6 +49,8 @@ struct NsProb {
     float* C2;             // nullable second result of the same accumulator
     long long sc2;
     float alpha2, diag2;
+    int bscale_sqrt;       // s_b = sqrt(bscale[b])   (the chain's last product scales by sqrt(trace): MPNCOV.py:161)
+    float* norm_out;       // FIRST launches only: trace(a[b]) is written here
 };
 
 struct NsGroup {
@@ -62,7 +64,12 @@ struct NsGroup {
 // of the chain are: the iterates are polynomials in the symmetric input) - only the workgroup tiles that touch the
 // 128 x 128 blocks on or above the diagonal are launched (3 of 4 at d = 256) and a tile right of its diagonal block
 // also writes its transpose (through the LDS the main loop has finished with: 16-byte stores along the rows).
-template <int TN, bool EDGE, bool SYM = false>
+// FIRST = true: the chain's first launch, straight from the un-normalised input a (term 0 = a a, E1 = a):
+//     tr = trace(a[b])  (every workgroup recomputes it: d diagonal elements, fixed-order block sum; written to norm_out)
+//     C  = Y_0 = A (3I - A) / 2 = (1.5 / tr) a - (0.5 / tr^2) a a          C2 = Z_0 = (3I - A) / 2 = 1.5 I - (0.5 / tr) a
+// (MPNCOV.py:144-154) - the separate pass that normalised a and formed Z_0 (50 MB through HBM and a fork of the helper
+// queue behind it: 12.6 + 6.7 us of a 240 us chain, profiles/r3_ns_launch_timeline.csv) is gone.
+template <int TN, bool EDGE, bool SYM = false, bool FIRST = false>
 __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, int nb, int b0, int tilesM, int tilesN) {
     static_assert(!(SYM && EDGE), "the symmetric schedule is for d % 128 == 0");
     constexpr int TM = 128, BK = 32;
@@ -244,6 +251,16 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
 
     HK_NS_GLOAD(R0);                                          // chunk 0
     HK_NS_GLOAD(R1);                                          // chunk 1 (nk >= 2): both in flight before any wait
+    float tr_inv = 1.f;
+    if (FIRST) {                                              // behind the operand requests: its latency is theirs
+        __shared__ float red[4];
+        const float* ab = P.t[0].A + (long long)b * P.t[0].sa;
+        float sd = 0.f;
+        for (int i = tid; i < d; i += 256) sd += ab[(long long)i * d + i];
+        const float na = block_sum<4>(sd, red);               // the summation order of ns_scale_kernel: the same bits
+        if (tile == 0 && tid == 0 && P.norm_out) P.norm_out[b] = na;
+        tr_inv = 1.0f / na;
+    }
     HK_NS_SSTORE(R0, 0);
     __syncthreads();
     int c = 0;
@@ -267,14 +284,15 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
     // between instantiations).
     // every field of the problem descriptor is read ONCE into a scalar here (P lives in the kernarg segment behind a
     // dynamic index: each mention is a scalar load, and a mention inside a per-element condition becomes a branch)
-    const float sb_ = P.bscale ? P.bscale[b] : 1.0f;
-    const float al = P.alpha * sb_, diag = P.diag, alpha2 = P.alpha2, diag2 = P.diag2;
+    const float sb_ = P.bscale ? (P.bscale_sqrt ? sqrtf(P.bscale[b]) : P.bscale[b]) : 1.0f;
+    const float al = FIRST ? -0.5f * tr_inv * tr_inv : P.alpha * sb_, diag = FIRST ? 0.f : P.diag;
+    const float alpha2 = FIRST ? -0.5f * tr_inv : P.alpha2, diag2 = FIRST ? 1.5f : P.diag2;
     float* Cb = P.C + (long long)b * P.sc;
     const float* E1b = P.E1 ? P.E1 + (long long)b * P.se1 : nullptr;
     const float* E2b = P.E2 ? P.E2 + (long long)b * P.se2 : nullptr;
     float* C2b = P.C2 ? P.C2 + (long long)b * P.sc2 : nullptr;
     const bool has1 = E1b != nullptr, has2 = E2b != nullptr, has_c2 = C2b != nullptr;
-    const float e1 = has1 ? (P.e1_scaled ? P.e1 * sb_ : P.e1) : 0.f;      // (a missing term: 0 * 0 added, exact)
+    const float e1 = FIRST ? 1.5f * tr_inv : (has1 ? (P.e1_scaled ? P.e1 * sb_ : P.e1) : 0.f);   // (a missing term: 0 * 0 added, exact)
     const float e2 = has2 ? P.e2 : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
                     const float v = acc[i][j][4 * gq + t];
                     const bool dg = row == col + t;
                     o1[t] = fmaf(e2, xs2[t], fmaf(e1, xs1[t], fmaf(al, v, dg ? diag : 0.f)));
-                    o2[t] = fmaf(alpha2, v, dg ? diag2 : 0.f);
+                    o2[t] = fmaf(alpha2, FIRST ? xs1[t] : v, dg ? diag2 : 0.f);
                 }
                 if (SYM && mirror) {            // this wave's image [column][row], pitch 68: lanes along the rows
                     float* Tw = lds + wave * ((TN / 2) * 68);
@@ -348,14 +366,36 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
     if (SYM && mirror) {
         // C[n][m] = C[m][n]: the wave reads its image back four columns (= rows of the mirrored tile) at a time
         static_assert(4 * (TN / 2) * 68 <= 2 * (SA + SB), "the four wave images fit the LDS of the main loop");
-        HK_WAVE_SYNC();
-        const float* Tw = lds + wave * ((TN / 2) * 68);
+        float* Tw = lds + wave * ((TN / 2) * 68);
         const int q = lane & 15, c4 = lane >> 4;
-        float* Mb = Cb + (long long)(n0 + wn * (TN / 2)) * d + m0 + wm * 64;
+        const long long moff = (long long)(n0 + wn * (TN / 2)) * d + m0 + wm * 64;
+        auto flush = [&](float* dst) {
+            HK_WAVE_SYNC();
 #pragma unroll
-        for (int c0 = 0; c0 < TN / 2; c0 += 4)
-            *reinterpret_cast<float4*>(Mb + (long long)(c0 + c4) * d + 4 * q) =
-                *reinterpret_cast<const float4*>(&Tw[(c0 + c4) * 68 + 4 * q]);
+            for (int c0 = 0; c0 < TN / 2; c0 += 4)
+                *reinterpret_cast<float4*>(dst + moff + (long long)(c0 + c4) * d + 4 * q) =
+                    *reinterpret_cast<const float4*>(&Tw[(c0 + c4) * 68 + 4 * q]);
+            HK_WAVE_SYNC();
+        };
+        flush(Cb);
+        if (FIRST) {                                        // Z_0's mirror: its tile again, from a (L2-hot), through the image
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int row = m0 + wm * 64 + i * 32 + l31;
+                    const int cbase = n0 + wn * (TN / 2) + j * 32 + 4 * lh;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 xv = *reinterpret_cast<const float4*>(E1b + (long long)row * d + cbase + 8 * gq);
+                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)       // (right of the diagonal block: no diagonal element here)
+                            Tw[(j * 32 + 4 * lh + 8 * gq + t) * 68 + i * 32 + l31] = fmaf(alpha2, xs[t], 0.f);
+                    }
+                }
+            flush(C2b);
+        }
     }
 }
 
@@ -375,6 +415,7 @@ static inline NsProb ns_prob(float* C, long long sc, float alpha, float diag, co
     p.E1 = nullptr; p.se1 = 0; p.e1 = 0.f; p.e1_scaled = 0;
     p.E2 = nullptr; p.se2 = 0; p.e2 = 0.f;
     p.C2 = nullptr; p.sc2 = 0; p.alpha2 = 0.f; p.diag2 = 0.f;
+    p.bscale_sqrt = 0; p.norm_out = nullptr;
     return p;
 }
 static inline NsProb& operator+=(NsProb& p, const NsTerm& t) {
@@ -383,7 +424,8 @@ static inline NsProb& operator+=(NsProb& p, const NsTerm& t) {
 }
 
 static inline bool ns_prob_aligned(const NsProb& p) {
-    bool ok = aligned16(p.C) && p.sc % 4 == 0;
+    bool ok = aligned16(p.C) && p.sc % 4 == 0 && (!p.C2 || (aligned16(p.C2) && p.sc2 % 4 == 0)) &&
+              (!p.E1 || (aligned16(p.E1) && p.se1 % 4 == 0)) && (!p.E2 || (aligned16(p.E2) && p.se2 % 4 == 0));
     for (int i = 0; i < p.nt; ++i)
         ok = ok && aligned16(p.t[i].A) && aligned16(p.t[i].B) && p.t[i].sa % 4 == 0 && p.t[i].sb % 4 == 0;
     return ok;
@@ -392,7 +434,9 @@ static inline bool ns_prob_aligned(const NsProb& p) {
 // tn: 0 = choose (128-wide tiles when that still gives two workgroups per CU, else 64-wide), 64 / 128 = forced
 // sym: every result is a symmetric matrix (see the kernel); taken when the fast path applies and no problem has a second
 // result or epilogue operands, otherwise the launch computes all tiles as usual
-static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, int tn = 0, int b0 = 0, bool sym = false) {
+// first: the chain's first launch (FIRST instantiation: one problem with term 0 = (a, a), E1 = a, C = Y_0, C2 = Z_0)
+static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, int tn = 0, int b0 = 0, bool sym = false,
+                              bool first = false) {
     if (g.np < 1 || g.np > 4 || d <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
     bool fast = d % 128 == 0;
     for (int i = 0; i < g.np; ++i) {
@@ -405,16 +449,33 @@ static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, i
     // forced 64 -> 291 / 750 us (fwd / bwd), forced 128 -> 297 / 770, mixed (128 for the multi-problem launches) 291 / 768
     if (tn != 64 && tn != 128) tn = ((long long)g.np * tm * tm * 2 * nb > 2048) ? 128 : 64;
     const int tnn = (d + tn - 1) / tn;
-    for (int i = 0; i < g.np; ++i) sym = sym && !g.p[i].C2 && !g.p[i].E1 && !g.p[i].E2;
+    if (first && (g.np != 1 || g.p[0].nt != 1 || !g.p[0].E1 || !g.p[0].C2)) return HK_ERR_BAD_ARG;
+    for (int i = 0; i < g.np; ++i) sym = sym && (first || (!g.p[i].C2 && !g.p[i].E1)) && !g.p[i].E2;
     if (sym && fast) {
         const int tiles = tm * tnn - (128 / tn) * (tm * (tm - 1) / 2);
         const dim3 gs(xcd_grid(nb, g.np * tiles));
-        if (tn == 128) hipLaunchKernelGGL((nsmm_kernel<128, false, true>), gs, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
-        else hipLaunchKernelGGL((nsmm_kernel<64, false, true>), gs, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+        if (first) {
+            if (tn == 128) hipLaunchKernelGGL((nsmm_kernel<128, false, true, true>), gs, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+            else hipLaunchKernelGGL((nsmm_kernel<64, false, true, true>), gs, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+        } else {
+            if (tn == 128) hipLaunchKernelGGL((nsmm_kernel<128, false, true>), gs, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+            else hipLaunchKernelGGL((nsmm_kernel<64, false, true>), gs, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+        }
         HK_LAUNCH_CHECK();
         return HK_OK;
     }
     const dim3 grid(xcd_grid(nb, g.np * tm * tnn));
+    if (first) {
+        if (tn == 128) {
+            if (fast) hipLaunchKernelGGL((nsmm_kernel<128, false, false, true>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+            else hipLaunchKernelGGL((nsmm_kernel<128, true, false, true>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+        } else {
+            if (fast) hipLaunchKernelGGL((nsmm_kernel<64, false, false, true>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+            else hipLaunchKernelGGL((nsmm_kernel<64, true, false, true>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
+        }
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     if (tn == 128) {
         if (fast) hipLaunchKernelGGL((nsmm_kernel<128, false>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);
         else hipLaunchKernelGGL((nsmm_kernel<128, true>), grid, dim3(256), 0, st, g, d, nb, b0, tm, tnn);

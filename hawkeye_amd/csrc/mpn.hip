@@ -199,12 +199,12 @@ struct NsDispatch {
     NsDispatch(int d_, int B_, hipStream_t st_, bool sym_ = false)
         : d(d_), B(B_), st(st_), aux(st_, B_ >= 16 ? (tuning().ns_streams < B_ / 8 ? tuning().ns_streams : B_ / 8 - 1) : 0),
           sym(sym_) {}
-    int operator()(const NsGroup& g) const {
+    int operator()(const NsGroup& g, bool first = false) const {
         const int parts = aux.count() + 1;
-        if (parts == 1) return nsmm_launch(g, d, B, st, 0, 0, sym);
+        if (parts == 1) return nsmm_launch(g, d, B, st, 0, 0, sym, first);
         for (int i = 0; i < parts; ++i) {                    // samples [b0, b1) on queue i (0: the caller's stream)
             const int b0 = (int)((long long)B * i / parts), b1 = (int)((long long)B * (i + 1) / parts);
-            const int rc = nsmm_launch(g, d, b1 - b0, i == 0 ? st : aux.aux(i - 1), 0, b0, sym);
+            const int rc = nsmm_launch(g, d, b1 - b0, i == 0 ? st : aux.aux(i - 1), 0, b0, sym, first);
             if (rc != HK_OK) return rc;
         }
         return HK_OK;
@@ -301,10 +301,15 @@ static int ns_sqrtm_fwd_impl(const float* a, float* out, float* norm_a, float* y
         HK_LAUNCH_CHECK();
         return nsmm_launch(ns_group(ns_single(A, n, T, n, out, n, 1.0f, 0.f, sq)), d, B, st, 0, 0, sym);   // :151,:161
     }
-    hipLaunchKernelGGL(ns_scale_kernel<true>, ns_scale_grid(n, B), dim3(256), 0, st, a, norm_a, sq, A, zsave, sbs, d);
-    HK_LAUNCH_CHECK();
+    // the first launch works on a itself: trace, normalisation, Z0 = ZY and Y0 = A ZY in one kernel         :144-154
     NsDispatch L(d, B, st, sym);
-    HK_TRY(L(ns_group(ns_single(A, n, zsave, sbs, ysave, sbs, 1.f, 0.f))));                        // Y0 = A ZY   :154
+    {
+        NsProb p0 = ns_single(a, n, a, n, ysave, sbs, 1.f, 0.f);
+        p0.E1 = a; p0.se1 = n;
+        p0.C2 = zsave; p0.sc2 = sbs;
+        p0.norm_out = norm_a;
+        HK_TRY(L(ns_group(p0), true));
+    }
     for (int i = 1; i < iter_n - 1; ++i) {                                                          // :156-159
         const float* Yp = ysave + (long long)(i - 1) * n;
         const float* Zp = zsave + (long long)(i - 1) * n;
@@ -316,7 +321,11 @@ static int ns_sqrtm_fwd_impl(const float* a, float* out, float* norm_a, float* y
     const float* Yl = ysave + (long long)(iter_n - 2) * n;
     const float* Zl = zsave + (long long)(iter_n - 2) * n;
     HK_TRY(L(ns_group(ns_single(Zl, sbs, Yl, sbs, T, n, -1.f, 3.f))));                             // 3I - Z Y      :160
-    HK_TRY(L(ns_group(ns_single(Yl, sbs, T, n, out, n, 0.5f, 0.f, sq))));                          // .5 Y (.) sqrt(normA)
+    {
+        NsProb pl = ns_single(Yl, sbs, T, n, out, n, 0.5f, 0.f, norm_a);                           // .5 Y (.) sqrt(normA)
+        pl.bscale_sqrt = 1;
+        HK_TRY(L(ns_group(pl)));
+    }
     return L.join();
 }
 
