@@ -49,8 +49,14 @@ struct NsProb {
     float* C2;             // nullable second result of the same accumulator
     long long sc2;
     float alpha2, diag2;
-    int bscale_sqrt;       // s_b = sqrt(bscale[b])   (the chain's last product scales by sqrt(trace): MPNCOV.py:161)
+    int bscale_fn;         // s_b = bscale[b] (0), sqrt(bscale[b]) (1: MPNCOV.py:161,181), 1 / bscale[b] (2: A = a / trace)
     float* norm_out;       // FIRST launches only: trace(a[b]) is written here
+    // LAST launches only (the backward's final product, MPNCOV.py:194-197): next to C = D the workgroup adds up its
+    // tile's share of  sum(g o out)  and  sum(D^T o a)  -> rpart[b][tile][0 / 1]
+    const float* rg;
+    const float* rout;
+    const float* ra;
+    float* rpart;
 };
 
 struct NsGroup {
@@ -69,9 +75,15 @@ struct NsGroup {
 //     C  = Y_0 = A (3I - A) / 2 = (1.5 / tr) a - (0.5 / tr^2) a a          C2 = Z_0 = (3I - A) / 2 = 1.5 I - (0.5 / tr) a
 // (MPNCOV.py:144-154) - the separate pass that normalised a and formed Z_0 (50 MB through HBM and a fork of the helper
 // queue behind it: 12.6 + 6.7 us of a 240 us chain, profiles/r3_ns_launch_timeline.csv) is gone.
-template <int TN, bool EDGE, bool SYM = false, bool FIRST = false>
+// LAST = true: the backward's final product; its epilogue also reduces the two trace terms of MPNCOV.py:175,197 over the
+// tile (fixed order: per thread in register order, then the block tree) - the separate reduction pass over D, g, out
+// and a (16.5 us, profiles/r3_ns_launch_timeline.csv) is gone - and, on the aligned path, writes the tile TRANSPOSED
+// and scaled: C = D^T / trace, which is the gradient up to its diagonal term (MPNCOV.py:195-201; the transposing pass
+// of ns_bwd_final_kernel shrinks to a diagonal update).
+template <int TN, bool EDGE, bool SYM = false, bool FIRST = false, bool LAST = false>
 __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, int nb, int b0, int tilesM, int tilesN) {
     static_assert(!(SYM && EDGE), "the symmetric schedule is for d % 128 == 0");
+    static_assert(!(LAST && (SYM || FIRST)), "the final product of the backward is a general matrix");
     constexpr int TM = 128, BK = 32;
     constexpr int NJ = TN / 64;                 // 32-column MFMA tiles per wave (wave tile = 64 x TN/2)
     constexpr int PA = BK + 4;                  // A chunk [128][32] k-contiguous: pitch 36 (pitch/4 odd: ds_read_b128 conflict-free)
@@ -284,7 +296,15 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
     // between instantiations).
     // every field of the problem descriptor is read ONCE into a scalar here (P lives in the kernarg segment behind a
     // dynamic index: each mention is a scalar load, and a mention inside a per-element condition becomes a branch)
-    const float sb_ = P.bscale ? (P.bscale_sqrt ? sqrtf(P.bscale[b]) : P.bscale[b]) : 1.0f;
+    float sb_ = 1.0f;
+    if (P.bscale) {
+        const float v_ = P.bscale[b];
+        sb_ = P.bscale_fn == 1 ? sqrtf(v_) : (P.bscale_fn == 2 ? 1.0f / v_ : v_);
+    }
+    float rs0 = 0.f, rs1 = 0.f;                               // LAST: this thread's share of the two sums
+    const float* rgb = LAST ? P.rg + (long long)b * d * d : nullptr;
+    const float* rob = LAST ? P.rout + (long long)b * d * d : nullptr;
+    const float* rab = LAST ? P.ra + (long long)b * d * d : nullptr;
     const float al = FIRST ? -0.5f * tr_inv * tr_inv : P.alpha * sb_, diag = FIRST ? 0.f : P.diag;
     const float alpha2 = FIRST ? -0.5f * tr_inv : P.alpha2, diag2 = FIRST ? 1.5f : P.diag2;
     float* Cb = P.C + (long long)b * P.sc;
@@ -345,12 +365,34 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
                     o1[t] = fmaf(e2, xs2[t], fmaf(e1, xs1[t], fmaf(al, v, dg ? diag : 0.f)));
                     o2[t] = fmaf(alpha2, FIRST ? xs1[t] : v, dg ? diag2 : 0.f);
                 }
+                if (LAST) {                     // sum(g o out) and sum(D^T o a) = sum_ij D_ij a_ji: a read transposed -
+                                                // lanes run along `row`, so a[(col + t) d + row] is a coalesced line
+                    if (!EDGE) {
+                        const float4 gv = *reinterpret_cast<const float4*>(rgb + orow + col);
+                        const float4 ov = *reinterpret_cast<const float4*>(rob + orow + col);
+                        rs0 = fmaf(gv.x, ov.x, rs0); rs0 = fmaf(gv.y, ov.y, rs0);
+                        rs0 = fmaf(gv.z, ov.z, rs0); rs0 = fmaf(gv.w, ov.w, rs0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) rs1 = fmaf(o1[t], rab[(long long)(col + t) * d + row], rs1);
+                    } else if (row < d) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (col + t < d) {
+                                rs0 = fmaf(rgb[orow + col + t], rob[orow + col + t], rs0);
+                                rs1 = fmaf(o1[t], rab[(long long)(col + t) * d + row], rs1);
+                            }
+                    }
+                }
                 if (SYM && mirror) {            // this wave's image [column][row], pitch 68: lanes along the rows
                     float* Tw = lds + wave * ((TN / 2) * 68);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) Tw[(j * 32 + 4 * lh + 8 * gq + t) * 68 + i * 32 + l31] = o1[t];
                 }
-                if (!EDGE) {
+                if (!EDGE && LAST) {            // transposed result through the wave's image (as the mirror below)
+                    float* Tw = lds + wave * ((TN / 2) * 68);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) Tw[(j * 32 + 4 * lh + 8 * gq + t) * 68 + i * 32 + l31] = o1[t] * sb_;
+                } else if (!EDGE) {
                     *reinterpret_cast<float4*>(Cb + orow + col) = make_float4(o1[0], o1[1], o1[2], o1[3]);
                     if (has_c2) *reinterpret_cast<float4*>(C2b + orow + col) = make_float4(o2[0], o2[1], o2[2], o2[3]);
                 } else if (row < d) {
@@ -363,20 +405,31 @@ __global__ __launch_bounds__(256, 2) void nsmm_kernel(const NsGroup g, int d, in
                 }
             }
         }
-    if (SYM && mirror) {
-        // C[n][m] = C[m][n]: the wave reads its image back four columns (= rows of the mirrored tile) at a time
-        static_assert(4 * (TN / 2) * 68 <= 2 * (SA + SB), "the four wave images fit the LDS of the main loop");
-        float* Tw = lds + wave * ((TN / 2) * 68);
+    if (LAST) {
+        __shared__ float red[4];
+        rs0 = block_sum<4>(rs0, red);
+        rs1 = block_sum<4>(rs1, red);
+        if (tid == 0) {
+            float* pp = P.rpart + ((long long)b * tiles + tile) * 2;
+            pp[0] = rs0;
+            pp[1] = rs1;
+        }
+    }
+    // C[n][m] = image[n][m]: the wave reads its image back four columns (= rows of the transposed tile) at a time
+    static_assert(4 * (TN / 2) * 68 <= 2 * (SA + SB), "the four wave images fit the LDS of the main loop");
+    float* Tw = lds + wave * ((TN / 2) * 68);
+    const long long moff = (long long)(n0 + wn * (TN / 2)) * d + m0 + wm * 64;
+    auto flush = [&](float* dst) {
         const int q = lane & 15, c4 = lane >> 4;
-        const long long moff = (long long)(n0 + wn * (TN / 2)) * d + m0 + wm * 64;
-        auto flush = [&](float* dst) {
-            HK_WAVE_SYNC();
+        HK_WAVE_SYNC();
 #pragma unroll
-            for (int c0 = 0; c0 < TN / 2; c0 += 4)
-                *reinterpret_cast<float4*>(dst + moff + (long long)(c0 + c4) * d + 4 * q) =
-                    *reinterpret_cast<const float4*>(&Tw[(c0 + c4) * 68 + 4 * q]);
-            HK_WAVE_SYNC();
-        };
+        for (int c0 = 0; c0 < TN / 2; c0 += 4)
+            *reinterpret_cast<float4*>(dst + moff + (long long)(c0 + c4) * d + 4 * q) =
+                *reinterpret_cast<const float4*>(&Tw[(c0 + c4) * 68 + 4 * q]);
+        HK_WAVE_SYNC();
+    };
+    if (LAST && !EDGE) flush(Cb);
+    if (SYM && mirror) {
         flush(Cb);
         if (FIRST) {                                        // Z_0's mirror: its tile again, from a (L2-hot), through the image
 #pragma unroll
@@ -415,7 +468,8 @@ static inline NsProb ns_prob(float* C, long long sc, float alpha, float diag, co
     p.E1 = nullptr; p.se1 = 0; p.e1 = 0.f; p.e1_scaled = 0;
     p.E2 = nullptr; p.se2 = 0; p.e2 = 0.f;
     p.C2 = nullptr; p.sc2 = 0; p.alpha2 = 0.f; p.diag2 = 0.f;
-    p.bscale_sqrt = 0; p.norm_out = nullptr;
+    p.bscale_fn = 0; p.norm_out = nullptr;
+    p.rg = p.rout = p.ra = nullptr; p.rpart = nullptr;
     return p;
 }
 static inline NsProb& operator+=(NsProb& p, const NsTerm& t) {
@@ -435,8 +489,16 @@ static inline bool ns_prob_aligned(const NsProb& p) {
 // sym: every result is a symmetric matrix (see the kernel); taken when the fast path applies and no problem has a second
 // result or epilogue operands, otherwise the launch computes all tiles as usual
 // first: the chain's first launch (FIRST instantiation: one problem with term 0 = (a, a), E1 = a, C = Y_0, C2 = Z_0)
+// last: the backward's final product (LAST instantiation, 64-wide tiles: rpart holds ceil(d / 128) * ceil(d / 64) pairs
+// per sample, whatever the batch size)
+static inline int nsmm_last_tiles(int d) { return ((d + 127) / 128) * ((d + 63) / 64); }
+static inline bool ns_prob_aligned(const NsProb& p);
+// the aligned form of the LAST launch writes C = D^T / trace (else C = D): the caller picks C accordingly
+static inline bool nsmm_last_transposes(const NsProb& p, int d) {
+    return d % 128 == 0 && ns_prob_aligned(p) && aligned16(p.rg) && aligned16(p.rout);
+}
 static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, int tn = 0, int b0 = 0, bool sym = false,
-                              bool first = false) {
+                              bool first = false, bool last = false) {
     if (g.np < 1 || g.np > 4 || d <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
     bool fast = d % 128 == 0;
     for (int i = 0; i < g.np; ++i) {
@@ -444,6 +506,16 @@ static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, i
         fast = fast && ns_prob_aligned(g.p[i]);
     }
     const int tm = (d + 127) / 128;
+    if (last) {
+        if (g.np != 1 || !g.p[0].rg || !g.p[0].rout || !g.p[0].ra || !g.p[0].rpart) return HK_ERR_BAD_ARG;
+        fast = nsmm_last_transposes(g.p[0], d);
+        const int tnn64 = (d + 63) / 64;
+        const dim3 gl(xcd_grid(nb, tm * tnn64));
+        if (fast) hipLaunchKernelGGL((nsmm_kernel<64, false, false, false, true>), gl, dim3(256), 0, st, g, d, nb, b0, tm, tnn64);
+        else hipLaunchKernelGGL((nsmm_kernel<64, true, false, false, true>), gl, dim3(256), 0, st, g, d, nb, b0, tm, tnn64);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     if (tn == 0) tn = tuning().ns_tn;
     // 64-wide tiles unless that would put more than 8 workgroups on every CU: measured at B = 64, d = 256 (ns_bench):
     // forced 64 -> 291 / 750 us (fwd / bwd), forced 128 -> 297 / 770, mixed (128 for the multi-problem launches) 291 / 768

@@ -102,9 +102,10 @@ __global__ __launch_bounds__(256) void ns_bwd_reduce_kernel(const float* __restr
 }
 
 // da = D^T / norm_a + (red0/(2 norm_a) - red1/norm_a^2) I      (MPNCOV.py:195-201); red0 / red1 = the tile partials
-// above added in tile order (every workgroup does it for itself: nt^2 <= 64 values at d = 256)
+// above - or, for iterN >= 2, the np tile partials written by the chain's last product (hk_nsmm.h, LAST) - added in
+// tile order (every workgroup does it for itself: np <= 64 values at d = 256)
 __global__ __launch_bounds__(256) void ns_bwd_final_kernel(const float* __restrict__ D, const float* __restrict__ norm_a,
-                                                           const float* __restrict__ part, int nt,
+                                                           const float* __restrict__ part, int np,
                                                            float* __restrict__ da, int d) {
     __shared__ float tile[32][33];
     __shared__ float red[4];
@@ -114,9 +115,9 @@ __global__ __launch_bounds__(256) void ns_bwd_final_kernel(const float* __restri
     // the tile partials, one per thread, then the fixed-order block sum (a serial loop over them in every one of the
     // 4096 workgroups doubled this kernel's time)
     float r0 = 0.f, r1 = 0.f;
-    for (int t = threadIdx.x; t < nt * nt; t += 256) {
-        r0 += part[((long long)b * nt * nt + t) * 2];
-        r1 += part[((long long)b * nt * nt + t) * 2 + 1];
+    for (int t = threadIdx.x; t < np; t += 256) {
+        r0 += part[((long long)b * np + t) * 2];
+        r1 += part[((long long)b * np + t) * 2 + 1];
     }
     r0 = block_sum<4>(r0, red);
     r1 = block_sum<4>(r1, red);
@@ -133,6 +134,25 @@ __global__ __launch_bounds__(256) void ns_bwd_final_kernel(const float* __restri
         const int ii = i0 + r, jj = j0 + tx;
         if (ii < d && jj < d) da[b * n + (long long)ii * d + jj] = tile[tx][r] / na + (ii == jj ? coef : 0.f);
     }
+}
+
+// The same when the chain's last product has already written D^T / norm_a into da (hk_nsmm.h, LAST on the aligned path):
+// only the diagonal term is left - one workgroup per sample.
+__global__ __launch_bounds__(256) void ns_bwd_diag_kernel(const float* __restrict__ norm_a, const float* __restrict__ part,
+                                                          int np, float* __restrict__ da, int d) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float na = norm_a[b];
+    float r0 = 0.f, r1 = 0.f;
+    for (int t = threadIdx.x; t < np; t += 256) {
+        r0 += part[((long long)b * np + t) * 2];
+        r1 += part[((long long)b * np + t) * 2 + 1];
+    }
+    r0 = block_sum<4>(r0, red);
+    r1 = block_sum<4>(r1, red);
+    const float coef = r0 / (2.0f * na) - r1 / (na * na);
+    float* p = da + (long long)b * d * d;
+    for (int i = threadIdx.x; i < d; i += 256) p[(long long)i * d + i] += coef;
 }
 
 // ----------------------------------------------------------------- triu vec
@@ -199,12 +219,12 @@ struct NsDispatch {
     NsDispatch(int d_, int B_, hipStream_t st_, bool sym_ = false)
         : d(d_), B(B_), st(st_), aux(st_, B_ >= 16 ? (tuning().ns_streams < B_ / 8 ? tuning().ns_streams : B_ / 8 - 1) : 0),
           sym(sym_) {}
-    int operator()(const NsGroup& g, bool first = false) const {
+    int operator()(const NsGroup& g, bool first = false, bool last = false) const {
         const int parts = aux.count() + 1;
-        if (parts == 1) return nsmm_launch(g, d, B, st, 0, 0, sym, first);
+        if (parts == 1) return nsmm_launch(g, d, B, st, 0, 0, sym, first, last);
         for (int i = 0; i < parts; ++i) {                    // samples [b0, b1) on queue i (0: the caller's stream)
             const int b0 = (int)((long long)B * i / parts), b1 = (int)((long long)B * (i + 1) / parts);
-            const int rc = nsmm_launch(g, d, b1 - b0, i == 0 ? st : aux.aux(i - 1), 0, b0, sym, first);
+            const int rc = nsmm_launch(g, d, b1 - b0, i == 0 ? st : aux.aux(i - 1), 0, b0, sym, first, last);
             if (rc != HK_OK) return rc;
         }
         return HK_OK;
@@ -323,7 +343,7 @@ static int ns_sqrtm_fwd_impl(const float* a, float* out, float* norm_a, float* y
     HK_TRY(L(ns_group(ns_single(Zl, sbs, Yl, sbs, T, n, -1.f, 3.f))));                             // 3I - Z Y      :160
     {
         NsProb pl = ns_single(Yl, sbs, T, n, out, n, 0.5f, 0.f, norm_a);                           // .5 Y (.) sqrt(normA)
-        pl.bscale_sqrt = 1;
+        pl.bscale_fn = 1;
         HK_TRY(L(ns_group(pl)));
     }
     return L.join();
@@ -362,9 +382,13 @@ static int ns_sqrtm_bwd_impl(const float* a, const float* out, const float* norm
     const long long sbs = (long long)S * n;
     const float* g = dout;
 
-    hipLaunchKernelGGL(ns_scale_kernel<false>, ns_scale_grid(n, B), dim3(256), 0, st, a, const_cast<float*>(norm_a), sq, A,
-                       (float*)nullptr, n, d);        // sq = sqrt(norm_a): the trace the forward saved
-    HK_LAUNCH_CHECK();
+    if (iter_n < 2) {      // one iteration: the plain schedule (scale pass, product, reduction pass)
+        hipLaunchKernelGGL(ns_scale_kernel<false>, ns_scale_grid(n, B), dim3(256), 0, st, a, const_cast<float*>(norm_a), sq, A,
+                           (float*)nullptr, n, d);    // sq = sqrt(norm_a): the trace the forward saved
+        HK_LAUNCH_CHECK();
+    }
+    int npart = nt * nt;                             // partial sums per sample handed to ns_bwd_final_kernel
+    bool transposed = false;                         // the chain's last launch wrote D^T / norm_a into da
 
     NsDispatch L(d, B, st);
     if (iter_n < 2) {
@@ -384,11 +408,14 @@ static int ns_sqrtm_bwd_impl(const float* a, const float* out, const float* norm
             HK_TRY(L(gr));
         }
         {   // dldY = .5 sq (g (3I - Yl Zl) - Zl Yl g)   :180-181 ;  dldZ = -.5 sq (Yl g) Yl   :182
-            NsProb py = ns_prob(dY, n, 0.5f, 0.f, sq);
+            NsProb py = ns_prob(dY, n, 0.5f, 0.f, norm_a);
+            py.bscale_fn = 1;                                                                       // sq = sqrt(norm_a)
             py += ns_term(g, n, W1, n);
             py += ns_term(W2, n, g, n, -1.f);
             NsGroup gr = ns_group(py);
-            gr += ns_single(W3, n, Yl, sbs, dZ, n, -0.5f, 0.f, sq);
+            NsProb pz = ns_single(W3, n, Yl, sbs, dZ, n, -0.5f, 0.f, norm_a);
+            pz.bscale_fn = 1;
+            gr += pz;
             HK_TRY(L(gr));
         }
         for (int i = iter_n - 3; i >= 0; --i) {                                                      // :183-193
@@ -418,18 +445,33 @@ static int ns_sqrtm_bwd_impl(const float* a, const float* out, const float* norm
             t = dZ; dZ = dZn; dZn = t;
         }
         // der = .5 (dldY (3I - A) - dldZ - A dldY) = 1.5 dldY - .5 dldZ - .5 (dldY A + A dldY)   :194
-        NsProb p = ns_prob(D, n, -0.5f, 0.f);
-        p += ns_term(dY, n, A, n);
-        p += ns_term(A, n, dY, n);
+        // with A = a / norm_a taken from a itself (the product's scale is per sample) and the two trace terms of
+        // :175,197 reduced in this launch's epilogue: no scale pass in front of the chain, no reduction pass behind it
+        NsProb p = ns_prob(D, n, -0.5f, 0.f, norm_a);
+        p.bscale_fn = 2;
+        p += ns_term(dY, n, a, n);
+        p += ns_term(a, n, dY, n);
         p.E1 = dY; p.se1 = n; p.e1 = 1.5f;
         p.E2 = dZ; p.se2 = n; p.e2 = -0.5f;
-        HK_TRY(L(ns_group(p)));
+        p.rg = g; p.rout = out; p.ra = a; p.rpart = part;
+        p.C = da;                                    // aligned path: the launch writes D^T / norm_a into da itself
+        transposed = nsmm_last_transposes(p, d);
+        if (!transposed) p.C = D;
+        HK_TRY(L(ns_group(p), false, true));
+        npart = nsmm_last_tiles(d);
     }
     HK_TRY(L.join());
-    hipLaunchKernelGGL(ns_bwd_reduce_kernel, dim3(nt * nt, B), dim3(256), 0, st, g, out, (const float*)D, a, part, d, nt);
-    HK_LAUNCH_CHECK();
+    if (transposed) {                                // da += (red0 / (2 norm_a) - red1 / norm_a^2) I
+        hipLaunchKernelGGL(ns_bwd_diag_kernel, dim3(B), dim3(256), 0, st, norm_a, (const float*)part, npart, da, d);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
+    if (iter_n < 2) {
+        hipLaunchKernelGGL(ns_bwd_reduce_kernel, dim3(nt * nt, B), dim3(256), 0, st, g, out, (const float*)D, a, part, d, nt);
+        HK_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(ns_bwd_final_kernel, dim3(nt, nt, B), dim3(256), 0, st, (const float*)D, norm_a,
-                       (const float*)part, nt, da, d);
+                       (const float*)part, npart, da, d);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
