@@ -45,6 +45,45 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HK_ATOMIC_ADD_F32(p, v) ((void)unsafeAtomicAdd((p), (v)))
 #endif
 
+// Device-coherent (agent scope, `sc1`) 16-byte accesses through a buffer descriptor: a store is written through to memory
+// and leaves the XCD's L2, a load bypasses the CU's L1 - data handed from one workgroup to another INSIDE a launch needs
+// no fences when both sides use these (MI355X_MICROARCH.md, inter-workgroup visibility) and no address is written twice.
+#ifndef HK_COH_RSRC
+namespace hk {
+typedef __amdgpu_buffer_rsrc_t coh_rsrc_t;
+// a pointer the program knows to be wave-uniform, made provably so for the compiler (a descriptor built from anything
+// it cannot prove uniform is applied through a waterfall loop per access)
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ coh_rsrc_t coh_rsrc(const float* base, long long floats) {      // base, floats: wave-uniform
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(floats * 4), 0x00020000);
+}
+// (the builtin's own vector type is kept behind `auto` / decltype: converting its result to a user vector typedef makes
+//  the compiler load ONE dword and splat it)
+__device__ __forceinline__ float4 coh_load16(coh_rsrc_t rs, int byte_off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
+    static_assert(sizeof(v) == 16, "b128");
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+__device__ __forceinline__ void coh_store16(coh_rsrc_t rs, int byte_off, float4 f) {
+    decltype(__builtin_amdgcn_raw_buffer_load_b128(rs, 0, 0, 16)) v;
+    __builtin_memcpy(&v, &f, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16);
+}
+__device__ __forceinline__ int coh_ticket(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int coh_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coh_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // this wave's stores have left
+__device__ __forceinline__ void coh_nap() { __builtin_amdgcn_s_sleep(8); }
+}  // namespace hk
+#define HK_COH_RSRC 1
+#endif
+
 #ifndef HK_WAVE_SYNC
 // Orders a wave's LDS writes before its own later LDS reads of other lanes' data (LDS operations of one wave execute in
 // order: no instruction is needed, only the compiler must not move the accesses)
@@ -81,6 +120,7 @@ struct Tuning {
     int ns_tn = 0;          // HK_NS_TN         0: automatic, 64 / 128: forced tile width of the Newton-Schulz products
     int bwd_v = 0;          // HK_BWD_V         Gram backward: 0 / 1 the 64-row kernel (bcnn_fast.hip), 5 the 128-row kernel (hk_bwd128.h)
     int ns_streams = 1;     // HK_NS_STREAMS    n: the batch runs the Newton-Schulz chain in n + 1 parts on n + 1 HIP queues (default 1: two halves), 0: one queue
+    int ns_flow = 0;        // HK_NS_FLOW       1 / 2: the Newton-Schulz forward as one dataflow launch (hk_nsmm.h, ns_flow_kernel; 2: skewed ticket order), 0: a launch per step
     int ns_sym = 1;         // HK_NS_SYM        1: hk_ns_sqrtm_fwd_sym skips the tiles below the diagonal blocks, 0: it computes every tile
     int sched_b = 0;        // HK_SCHED_B       > 0: work-split heuristics that depend on the batch size behave as if it were this (tests: the
                             //                  large-batch schedules on small inputs); results do not depend on it

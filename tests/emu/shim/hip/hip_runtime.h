@@ -80,6 +80,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_readfirstlane(v) (v)      /* only ever applied to wave-uniform values */
 
@@ -407,6 +408,18 @@ inline T __shfl(T v, int srclane, int = 64) {
 #define HK_DYN_LDS(name) float* name = reinterpret_cast<float*>(hipemu::B->dyn_lds)
 #define HK_DYN_LDS16(name) HK_DYN_LDS(name)
 #define HK_FMAC_PINNED(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
+#define HK_COH_RSRC 1      /* coherent accesses: plain ones (one workgroup at a time; a ticket order in which a task only waits for earlier tickets never waits here) */
+namespace hk {
+struct coh_rsrc_t { char* p; };
+template <typename T> inline T* uniform_ptr(T* p) { return p; }
+inline coh_rsrc_t coh_rsrc(const float* base, long long) { return coh_rsrc_t{(char*)base}; }
+inline float4 coh_load16(coh_rsrc_t rs, int off) { return *reinterpret_cast<const float4*>(rs.p + off); }
+inline void coh_store16(coh_rsrc_t rs, int off, float4 f) { *reinterpret_cast<float4*>(rs.p + off) = f; }
+inline int coh_ticket(int* p) { return (*p)++; }
+inline int coh_peek(const int* p) { return *p; }
+inline void coh_drain() {}
+inline void coh_nap() {}
+}
 #define HK_WAVE_SYNC() hipemu::wave_barrier()   /* the fibers of a wave are not in lockstep between collectives */
 #define HK_LDS_VOLATILE(p) ((volatile float*)(p))
 #define HK_LDS_CONST(p) ((const float*)(p))

@@ -537,6 +537,34 @@ def test_ns_symmetric_forward(F, b, d, itn, tune):
     tune('ns_sym', 1)
 
 
+@pytest.mark.parametrize('b,d,itn', [(16, 128, 3), (19, 256, 5), (16, 128, 2), (33, 384, 4)])
+def test_ns_dataflow_forward(F, b, d, itn, tune):
+    """ns_flow = 1: the forward chain as ONE launch (hk_nsmm.h, ns_flow_kernel: tickets over (step, sample, tile), a
+    counter per sample and step, write-through stores + device-coherent loads).  The same tile arithmetic as the
+    launch-per-step schedule at the same tile width: bit-identical results, saved iterates and traces - for both forward
+    entry points, an odd batch (XCDs with different sample counts), two / three / five iterations, repeatedly (a missed
+    dependency or a stale line would change bits), and the backward runs on the iterates it saved."""
+    from hawkeye_amd import _lib
+    x = torch.relu(torch.randn(b, d, 5, 6, generator=torch.Generator().manual_seed(b + d))) + 0.01
+    wt = torch.randn(b, d, d, generator=torch.Generator().manual_seed(3))
+    tune('ns_tn', 64)
+    for symmetric in (True, False):
+        res = []
+        for flow in (0, 1, 2, 1):                 # 2: the skewed ticket order
+            tune('ns_flow', flow)
+            xg = x.clone().to(DEV).requires_grad_(True)
+            y = F.sqrtm(F.covpool(xg), itn, symmetric=symmetric)
+            (y * wt.to(DEV)).sum().backward()
+            res.append((y.detach().clone(), xg.grad.clone()))
+        for y, g in res[1:]:
+            assert torch.equal(y, res[0][0]) and torch.equal(g, res[0][1]), symmetric
+    tune('ns_flow', 0)
+    xo = x.clone().requires_grad_(True)
+    yo = O.sqrtm(O.covpool(xo), itn)
+    (yo * wt).sum().backward()
+    assert rel(res[0][0], yo) < 1e-5 and rel(res[0][1], xo.grad) < 1e-4
+
+
 @pytest.mark.parametrize('b,d', [(16, 64), (17, 40)])
 def test_ns_two_queue_dispatch_bit_identical(F, b, d, tune):
     """ns_streams=1: the two halves of the batch run the chain on two HIP queues (fork / join through events inside the

@@ -29,7 +29,7 @@ def knobs(**kw):
         assert lib.hk_tuning_set(k.encode(), int(v)) == 0, k
 
 
-DEFAULTS = dict(bwd_v=0, cbp_bin=-1, ns_streams=1, ns_tn=0, linear_slabs=0, bcnn_generic=0, ns_sym=1, sched_b=0)
+DEFAULTS = dict(bwd_v=0, cbp_bin=-1, ns_streams=1, ns_tn=0, linear_slabs=0, bcnn_generic=0, ns_sym=1, sched_b=0, ns_flow=0)
 
 
 def run_group(title, items, flops=None, bytes_=None):
@@ -149,7 +149,8 @@ def g_ns():
     res = []
     fs = lambda: lib.hk_ns_sqrtm_fwd_sym(p(a), p(out_), p(na), p(ys), p(zs), B, d, it, p(wf), nf, st())
     items = [(f'fwd ns_streams={v}', dict(ns_streams=v), fw) for v in NS_STREAMS]
-    items += [(f'fwd_sym ns_streams={v} ns_tn={tn}', dict(ns_streams=v, ns_tn=tn), fs) for v in (0, 1, 2, 3) for tn in (64, 128)]
+    items += [(f'fwd_sym ns_streams={v} ns_tn={tn}', dict(ns_streams=v, ns_tn=tn), fs) for v in (0, 1) for tn in (64,)]
+    items += [(f'fwd_sym ns_flow={v} (one dataflow launch)', dict(ns_flow=v), fs) for v in (1, 2)]
     res.append(run_group('Newton-Schulz fwd B=64 d=256 it=5', items, flops=12 * 2.0 * d ** 3 * B))
     res.append(run_group('Newton-Schulz bwd B=64 d=256 it=5', [(f'bwd ns_streams={v}', dict(ns_streams=v), bw) for v in NS_STREAMS],
                          flops=38 * 2.0 * d ** 3 * B))
