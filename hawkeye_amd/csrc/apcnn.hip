@@ -111,12 +111,11 @@ __device__ __forceinline__ Cand better(Cand a, Cand b) {  // higher score; ties:
     return (b.s > a.s || (b.s == a.s && b.i > a.i)) ? b : a;
 }
 
-// one 256-thread workgroup per image; scores + alive flags in LDS
-__global__ __launch_bounds__(256) void att_roi_select_kernel(const float* __restrict__ att, float* __restrict__ rois,
-                                                             int* __restrict__ count, int h, int w, int stride,
-                                                             float anchor, int img_h, int img_w, int r0, int r1, int c0,
-                                                             int c1, float thr, int topk) {
-    HK_DYN_LDS(sm);  // score[h*w] ; alive flags packed as floats (>0 alive)
+// one 256-thread workgroup per image; scores + alive flags in LDS (sm: 2 h w floats)
+__device__ __forceinline__ void att_roi_select_body(const float* __restrict__ att, float* __restrict__ rois,
+                                                    int* __restrict__ count, int h, int w, int stride, float anchor,
+                                                    int img_h, int img_w, int r0, int r1, int c0, int c1, float thr,
+                                                    int topk, float* sm) {
     __shared__ float red[4];
     __shared__ Cand wbest[4];
     __shared__ Cand winner;
@@ -190,6 +189,35 @@ __global__ __launch_bounds__(256) void att_roi_select_kernel(const float* __rest
     }
     for (int e = found * 5 + tid; e < topk * 5; e += 256) out[e] = 0.f;
     if (tid == 0) count[b] = found;
+}
+
+__global__ __launch_bounds__(256) void att_roi_select_kernel(const float* __restrict__ att, float* __restrict__ rois,
+                                                             int* __restrict__ count, int h, int w, int stride,
+                                                             float anchor, int img_h, int img_w, int r0, int r1, int c0,
+                                                             int c1, float thr, int topk) {
+    HK_DYN_LDS(sm);  // score[h*w] ; alive flags packed as floats (>0 alive)
+    att_roi_select_body(att, rois, count, h, w, stride, anchor, img_h, img_w, r0, r1, c0, c1, thr, topk, sm);
+}
+
+// The pyramid levels of one forward (APCNN.py:256-266 calls get_att_roi once per level, each a chain of k dependent
+// arg-max rounds on one workgroup per image): blockIdx.y = level, so the three chains run side by side - 41 us for three
+// launches -> the longest level.
+struct RoiLevel {
+    const float* att;
+    float* rois;
+    int* count;
+    int h, w, stride, r0, r1, c0, c1, topk;
+    float anchor;
+};
+struct RoiLevels {
+    RoiLevel l[3];
+};
+__global__ __launch_bounds__(256) void att_roi_select3_kernel(const RoiLevels L, int img_h, int img_w, float thr) {
+    HK_DYN_LDS(sm);
+    const int lv = blockIdx.y;
+    const RoiLevel& q = lv == 0 ? L.l[0] : (lv == 1 ? L.l[1] : L.l[2]);
+    att_roi_select_body(q.att, q.rois, q.count, q.h, q.w, q.stride, q.anchor, img_h, img_w, q.r0, q.r1, q.c0, q.c1, thr,
+                        q.topk, sm);
 }
 
 // ---------------------------------------------------------------------- K10 boxes
@@ -453,6 +481,28 @@ extern "C" int hk_att_roi_select(const float* att, float* rois, int32_t* count, 
     if (sm > 150 * 1024) return HK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(att_roi_select_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, att, rois, (int*)count, h, w,
                        feature_stride, anchor_size, img_h, img_w, keep_r0, keep_r1, keep_c0, keep_c1, iou_thr, topk);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_att_roi_select3(const float* const* att, float* const* rois, int32_t* const* count, int B, const int* h,
+                                  const int* w, const int* feature_stride, const float* anchor_size, int img_h, int img_w,
+                                  const int* keep, float iou_thr, const int* topk, hk_stream_t stream) {
+    if (!att || !rois || !count || !h || !w || !feature_stride || !anchor_size || !keep || !topk || B <= 0)
+        return HK_ERR_BAD_ARG;
+    RoiLevels L;
+    size_t sm = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (!att[i] || !rois[i] || !count[i] || h[i] <= 0 || w[i] <= 0 || topk[i] <= 0) return HK_ERR_BAD_ARG;
+        L.l[i].att = att[i]; L.l[i].rois = rois[i]; L.l[i].count = (int*)count[i];
+        L.l[i].h = h[i]; L.l[i].w = w[i]; L.l[i].stride = feature_stride[i]; L.l[i].anchor = anchor_size[i];
+        L.l[i].r0 = keep[4 * i]; L.l[i].r1 = keep[4 * i + 1]; L.l[i].c0 = keep[4 * i + 2]; L.l[i].c1 = keep[4 * i + 3];
+        L.l[i].topk = topk[i];
+        const size_t need = (size_t)2 * h[i] * w[i] * sizeof(float);
+        sm = need > sm ? need : sm;
+    }
+    if (sm > 150 * 1024) return HK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(att_roi_select3_kernel, dim3(B, 3), dim3(256), sm, (hipStream_t)stream, L, img_h, img_w, iou_thr);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

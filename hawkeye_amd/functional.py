@@ -361,6 +361,33 @@ def att_roi_select(att_mask, feature_stride, anchor_size, img_h, img_w, num_clas
     return rois, cnt
 
 
+def att_roi_select_levels(att_masks, levels, img_h, img_w, num_classes, iou_thred):
+    """The three pyramid levels of one forward in one launch (hk_att_roi_select3): att_masks = (a3, a4, a5),
+    levels = ((feature_stride, anchor_size, topk), ...).  -> [(rois, count)] * 3, the results of three att_roi_select
+    calls bit for bit."""
+    import ctypes
+    lib = _lib.load()
+    assert len(att_masks) == 3 and len(levels) == 3
+    with torch.no_grad():
+        a = [_f32c(m.detach()) for m in att_masks]
+        n = a[0].shape[0]
+        lo, hi = (0.2, 0.8) if num_classes == 200 else (0.1, 0.9)     # APCNN.py:451-455
+        hs, ws = [m.shape[2] for m in a], [m.shape[3] for m in a]
+        keep = []
+        for h, w in zip(hs, ws):
+            keep += [int(lo * h), int(hi * h), int(lo * w), int(hi * w)]
+        rois = [torch.empty(n, int(k), 5, dtype=torch.float32, device=a[0].device) for _, _, k in levels]
+        cnt = [torch.empty(n, dtype=torch.int32, device=a[0].device) for _ in levels]
+        P3, I3, F3, I12 = ctypes.c_void_p * 3, ctypes.c_int * 3, ctypes.c_float * 3, ctypes.c_int * 12
+        arrs = (P3(*[ptr(m) for m in a]), P3(*[ptr(r) for r in rois]), P3(*[ptr(c) for c in cnt]), I3(*hs), I3(*ws),
+                I3(*[int(s) for s, _, _ in levels]), F3(*[float(z) for _, z, _ in levels]), I12(*keep),
+                I3(*[int(k) for _, _, k in levels]))               # host arrays, read by the entry point before it returns
+        ad = [ctypes.addressof(x) for x in arrs]
+        check(lib.hk_att_roi_select3(ad[0], ad[1], ad[2], n, ad[3], ad[4], ad[5], ad[6], int(img_h), int(img_w), ad[7],
+                                     float(iou_thred), ad[8], stream()), 'hk_att_roi_select3')
+    return list(zip(rois, cnt))
+
+
 def roi_boxes(tables, u01, scale):
     """Union / drop boxes on device from three (rois, count) tables.  -> box [B,4], drop [B,4]"""
     lib = _lib.load()

@@ -280,8 +280,7 @@ class ResNet(nn.Module):
         out3, out4, out5, out_concate, (a3, a4, a5) = self._heads(self.fpn([x2, x3, x4]))
 
         # ROI pyramid (no gradient, no host sync)
-        tables = [HF.att_roi_select(a, s, size, img_h, img_w, self.num_classes, 0.05, k)
-                  for a, (s, size, k) in zip((a3, a4, a5), self.LEVELS)]
+        tables = HF.att_roi_select_levels((a3, a4, a5), self.LEVELS, img_h, img_w, self.num_classes, 0.05)   # one launch
 
         # stage II on the refined layer-2 map
         x2r, _ = self.get_roi_crop_feat(x2, tables, 2 ** 3)

@@ -227,6 +227,15 @@ int hk_att_roi_select(const float* att, float* rois, int32_t* count, int B, int 
                       int feature_stride, float anchor_size, int img_h, int img_w, int keep_r0, int keep_r1,
                       int keep_c0, int keep_c1, float iou_thr, int topk, hk_stream_t stream);
 
+/* The three pyramid levels of one forward in ONE launch (grid B x 3): the reference calls get_att_roi once per level
+ * (APCNN.py:256-266), each call a chain of top-k dependent rounds on one workgroup per image - side by side they take
+ * as long as the longest.  Arrays of three (HOST arrays; the pointers in them are device pointers): att[i], rois[i],
+ * count[i], h[i], w[i], feature_stride[i], anchor_size[i], topk[i]; keep[4 i .. 4 i + 3] = keep_r0, keep_r1, keep_c0,
+ * keep_c1 of level i.  Results are those of three hk_att_roi_select calls, bit for bit. */
+int hk_att_roi_select3(const float* const* att, float* const* rois, int32_t* const* count, int B, const int* h,
+                       const int* w, const int* feature_stride, const float* anchor_size, int img_h, int img_w,
+                       const int* keep, float iou_thr, const int* topk, hk_stream_t stream);
+
 /* ROI-guided zoom-in (+ drop block): crop the union box of an image's ROIs,
  * zero one dropped ROI (training), rescale by c*h*w/sum(mask), bilinear resize
  * (align_corners=False) back to H x W.

@@ -454,6 +454,19 @@ def test_att_roi_select_bit_exact(F, ncls):
         np.testing.assert_array_equal(got.numpy(), O.att_roi(m, s, a, 448, 448, ncls, 0.05, k).numpy())
 
 
+@pytest.mark.parametrize('ncls', [200, 8142])
+def test_att_roi_select_three_levels_in_one_launch(F, ncls):
+    """hk_att_roi_select3 (what the AP-CNN forward calls: grid B x 3, one pyramid level per blockIdx.y) returns what
+    three hk_att_roi_select calls return, bit for bit - and with them the reference's boxes and scores (APCNN.py:444-476)."""
+    g = load('apcnn_roi')
+    masks = [m.to(DEV) for m in _masks()]
+    tabs = F.att_roi_select_levels(masks, LEVELS, 448, 448, ncls, 0.05)
+    for lvl, (m, (s, a, k), (rois, cnt)) in enumerate(zip(masks, LEVELS, tabs)):
+        r1, c1 = F.att_roi_select(m, s, a, 448, 448, ncls, 0.05, k)
+        assert torch.equal(rois, r1) and torch.equal(cnt, c1)
+        np.testing.assert_array_equal(_compact(rois, cnt).numpy(), g[f'roi_c{ncls}_l{lvl + 3}'])
+
+
 def test_att_roi_select_exhausts_candidates(F):
     m = torch.zeros(2, 1, 14, 14)
     m[0, 0, 6, 6] = 0.9                    # single candidate above the mean -> 1 ROI although topk = 3

@@ -133,7 +133,11 @@ def apcnn_kernels(B=16, classes=8142):
         tabs.clear()
         for m, (s, a, k) in zip(masks, lv):
             tabs.append(F.att_roi_select(m, s, a, 448, 448, classes, 0.05, k))
-    kernel_row('APCNN', f'att_roi_select x3 levels ({classes}-class border)', roi_all)
+    kernel_row('APCNN', f'att_roi_select, three launches ({classes}-class border; round 2)', roi_all)
+
+    def roi_one():                                     # what the AP-CNN forward calls: one launch, grid B x 3
+        tabs[:] = F.att_roi_select_levels(masks, lv, 448, 448, classes, 0.05)
+    kernel_row('APCNN', f'att_roi_select3: the three levels in one launch ({classes}-class border)', roi_one)
     u = torch.rand(B, 2, device=dev)
     box, drop = F.roi_boxes(tabs, u, 8.0)
     x2 = R(B, 512, 56, 56); y2 = E(B, 512, 56, 56)
