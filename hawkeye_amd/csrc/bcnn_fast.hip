@@ -69,12 +69,22 @@ __device__ __forceinline__ void center_panel(float* p, float* __restrict__ mu_ou
 // the column panels stay RAW: sum_k (x_ik - mu_i)(x_jk - mu_j) = sum_k (x_ik - mu_i) x_jk because a centred row sums
 // to zero, which is exactly the reference's (X Ibar) X^T.  No separate row-mean kernel, no mean look-ups while
 // staging.  (Diagonal tiles read the centred panel on both sides: the same number to rounding.)
+// NormSrc (MODE 0, hk_bcnn_pool_fwd): instead of reading inv_norm[b] the workgroup forms it from the 64-channel-group
+// partial column sums of bcnn_colsum_partial4_kernel - the arithmetic of bcnn_norm_finalize_kernel (bcnn_pool.hip), bit
+// for bit, behind its first panel loads - and the workgroup of row block 0 writes colsum / inv_norm for the backward:
+// the finalize launch (4.5 us between two 6 us / 42 us kernels) is gone.
+struct GramNormSrc {
+    const float* part;      // [B][G][HW], nullable: then inv_norm is read
+    float* colsum;          // [B][HW]
+    float* inv_out;         // [B]
+    int G;
+};
 template <int HW, int MODE, bool CENTER>
 __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ inv_norm,
                                                                  float* __restrict__ y, int C, int nb, int B,
                                                                  int pair_mode, float* __restrict__ mu,
-                                                                 float alpha) {
+                                                                 float alpha, const GramNormSrc ns) {
     constexpr int PANEL = 64 * HW;
     constexpr int N4 = PANEL / 4;
     constexpr int NST = (N4 + 255) / 256;
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     GramEpi<MODE> ep;
     ep.yb = y + (long long)b * C * C;
     ep.C = C;
-    ep.inv = MODE == 0 ? inv_norm[b] : alpha;
+    ep.inv = MODE == 0 ? (ns.part ? 0.f : inv_norm[b]) : alpha;
     float* mub = CENTER ? mu + (long long)b * C : nullptr;
     ep.inv_m = 1.0f / (float)HW;
     ep.l31 = l31;
@@ -109,6 +119,21 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
         for (int u = 0; u < NST; ++u) {
             const int f = tid + 256 * u, fc = f < N4 ? f : N4 - 1;
             st0[u] = src[fc];
+        }
+        if (MODE == 0 && ns.part) {                       // (uniform) the sample's norm, while the panel loads are in flight
+            __shared__ float redn[4];
+            const float* pp = ns.part + (long long)b * ns.G * HW;
+            float ssq = 0.f;
+            for (int hw = tid; hw < HW; hw += 256) {
+                float cs = 0.f;
+                for (int gq = 0; gq < ns.G; ++gq) cs += pp[(long long)gq * HW + hw];
+                if (w == 0) ns.colsum[(long long)b * HW + hw] = cs;
+                ssq += cs * cs;
+            }
+            const float tot = block_sum<4>(ssq, redn);
+            const float n2 = tot / (float)HW + (float)C * (float)C * 1e-5f;
+            ep.inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+            if (w == 0 && tid == 0) ns.inv_out[b] = ep.inv;
         }
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
 #pragma unroll
@@ -364,12 +389,12 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
 
 template <int HW, int MODE, bool CENTER>
 static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, float* mu, float alpha,
-                       hipStream_t st) {
+                       hipStream_t st, GramNormSrc ns = GramNormSrc{nullptr, nullptr, nullptr, 0}) {
     const int nb = C / 64;
     const int pair_mode = ((long long)B * nb > 256) ? 1 : 0;
     const int per = pair_mode ? (nb + 1) / 2 : nb;
     hipLaunchKernelGGL((bcnn_gram_panel_kernel<HW, MODE, CENTER>), dim3(xcd_grid(B, per)), dim3(256), 0, st, x, inv_norm,
-                       y, C, nb, B, pair_mode, mu, alpha);
+                       y, C, nb, B, pair_mode, mu, alpha, ns);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
@@ -480,6 +505,17 @@ static int bwd_launch(const float* x, const float* y, const float* dy, const flo
 int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C, int HW, hipStream_t st) {
     if (C % 64 != 0 || !aligned16(x) || !aligned16(y)) return HK_ERR_UNSUPPORTED;
 #define CALL(H) gram_launch<H, 0, false>(x, inv_norm, y, B, C, nullptr, 1.f, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
+// the same with the norm formed in the kernel from the column-sum partials part [B][G][HW] (G = C / 64 groups);
+// colsum [B][HW] and inv_norm [B] are WRITTEN
+int bcnn_fast_gram_norm(const float* x, const float* part, int G, float* colsum, float* inv_norm, float* y, int B, int C,
+                        int HW, hipStream_t st) {
+    if (C % 64 != 0 || G != C / 64 || !aligned16(x) || !aligned16(y)) return HK_ERR_UNSUPPORTED;
+    const GramNormSrc ns{part, colsum, inv_norm, G};
+#define CALL(H) gram_launch<H, 0, false>(x, nullptr, y, B, C, nullptr, 1.f, st, ns)
     HK_HW_SWITCH(CALL)
 #undef CALL
 }

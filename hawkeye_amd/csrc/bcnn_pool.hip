@@ -22,6 +22,8 @@ namespace hk {
 
 // bcnn_fast.hip: panel-resident kernels for C % 64 == 0 and HW in {196,144,100,64}; HK_ERR_UNSUPPORTED otherwise
 int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C, int HW, hipStream_t st);
+int bcnn_fast_gram_norm(const float* x, const float* part, int G, float* colsum, float* inv_norm, float* y, int B, int C,
+                        int HW, hipStream_t st);
 int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart, int B,
                   int C, int HW, hipStream_t st);
 int gram_fast_raw(const float* x, float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
@@ -337,6 +339,16 @@ extern "C" int hk_bcnn_gram_norm(const float* x, const float* inv_norm, float* y
 extern "C" int hk_bcnn_pool_fwd(const float* x, float* y, float* inv_norm, float* colsum, int B, int C, int HW,
                                 void* ws, size_t ws_bytes, hk_stream_t stream) {
     if (!x || !y || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    // panel-resident Gram: two launches - the 64-channel-group column sums, then the Gram kernel, which forms the norm
+    // from them in its prologue and writes colsum / inv_norm (bcnn_fast.hip, GramNormSrc)
+    const int G = (C + 63) / 64;
+    if (!force_generic() && C % 64 == 0 && G > 1 && ws && ws_bytes >= (size_t)B * G * HW * sizeof(float) && HW % 4 == 0 &&
+        HW / 4 <= 64 && aligned16(x) && aligned16(ws)) {
+        hipLaunchKernelGGL(bcnn_colsum_partial4_kernel, dim3(G, B), dim3(256), 0, (hipStream_t)stream, x, (float*)ws, C, HW, G);
+        HK_LAUNCH_CHECK();
+        const int rc = bcnn_fast_gram_norm(x, (const float*)ws, G, colsum, inv_norm, y, B, C, HW, (hipStream_t)stream);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
     int rc = hk_bcnn_colsum_norm(x, colsum, inv_norm, B, C, HW, ws, ws_bytes, stream);
     if (rc != HK_OK) return rc;
     return hk_bcnn_gram_norm(x, inv_norm, y, B, C, HW, stream);

@@ -74,13 +74,22 @@ def g_bcnn():
     assert lib.hk_bcnn_colsum_norm(p(x), p(cs), p(inv), B, C, HW, p(ws), nws, st()) == 0
     assert lib.hk_bcnn_gram_norm(p(x), p(inv), p(y), B, C, HW, st()) == 0
     bw = lambda: lib.hk_bcnn_bwd_gemm(p(x), p(y), p(dy), p(inv), p(dx), p(tp), B, C, HW, st())
-    items = [(f'bwd_gemm bwd_v={v}', dict(bwd_v=v), bw) for v in (9, 11, 15, 16)]
+    items = [(f'bwd_gemm bwd_v={v}', dict(bwd_v=v), bw) for v in (9, 0)]
     fl = 2.0 * B * C * C * HW
     out = [run_group('BCNN backward GEMM B=64 C=512 14x14', items, flops=fl)]
     items = [('colsum_norm', {}, lambda: lib.hk_bcnn_colsum_norm(p(x), p(cs), p(inv), B, C, HW, p(ws), nws, st()))]
     out.append(run_group('BCNN colsum+norm', items, bytes_=4.0 * B * C * HW))
     items = [('gram_norm', {}, lambda: lib.hk_bcnn_gram_norm(p(x), p(inv), p(y), B, C, HW, st()))]
     out.append(run_group('BCNN Gram fwd', items, flops=fl))
+    y2, inv2, cs2 = torch.empty_like(y), torch.empty_like(inv), torch.empty_like(cs)
+
+    def stages():
+        lib.hk_bcnn_colsum_norm(p(x), p(cs2), p(inv2), B, C, HW, p(ws), nws, st())
+        return lib.hk_bcnn_gram_norm(p(x), p(inv2), p(y2), B, C, HW, st())
+    items = [('hk_bcnn_pool_fwd (column-sum partials + Gram with the norm in its prologue)', {},
+              lambda: lib.hk_bcnn_pool_fwd(p(x), p(y2), p(inv2), p(cs2), B, C, HW, p(ws), nws, st())),
+             ('hk_bcnn_colsum_norm + hk_bcnn_gram_norm (three launches)', {}, stages)]
+    out.append(run_group('BCNN pool forward, whole', items, flops=fl))
     items = [('rank1', {}, lambda: lib.hk_bcnn_bwd_rank1(p(dx), p(tp), p(inv), p(cs), B, C, HW, st()))]
     out.append(run_group('BCNN rank-1 fix', items, bytes_=8.0 * B * C * HW))
     return out
