@@ -14,6 +14,8 @@ t0 = int(rows[lo]['Start_Timestamp'])
 queues = {}
 print('start_us,duration_us,queue,workgroups,lds_bytes,kernel')
 for r in rows[lo:]:
+    if 'hk::' not in r['Kernel_Name']:          # the script's closing prints (torch reductions): not part of the head
+        break
     q = queues.setdefault(r['Queue_Id'], len(queues))
     wg = int(r['Grid_Size_X']) * int(r.get('Grid_Size_Y', 1)) * int(r.get('Grid_Size_Z', 1)) // max(
         1, int(r['Workgroup_Size_X']) * int(r.get('Workgroup_Size_Y', 1)) * int(r.get('Workgroup_Size_Z', 1)))
