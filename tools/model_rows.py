@@ -43,6 +43,9 @@ def kernel_row(model, name, fn, flops=0.0, bytes_=0.0, iters=30):
     rows.append({'model': model, 'kernel': name, 'us': round(us, 1), 'bound': 'mfma' if mfma else 'hbm',
                  'achieved': round(tf if mfma else gbs, 1), 'unit': 'TFLOP/s' if mfma else 'GB/s',
                  'frac': round(tf / bench.PEAK_MFMA_F32_TF if mfma else gbs / bench.PEAK_HBM_GBS, 3)})
+    if us < 12.0:     # back-to-back calls through python + ctypes cost ~8-9 us each: below that the row times the host
+        rows[-1]['note'] = 'host-call-bound row (python + ctypes ~ 9 us per call): rocprofv3 durations in profiles/r3_step_*_kernel_stats.csv'
+
 
 
 def train_row(model_name, batch, classes, image=448, steps=6, warmup=3):
