@@ -73,6 +73,7 @@ __device__ __forceinline__ void center_panel(float* p, float* __restrict__ mu_ou
 // partial column sums of bcnn_colsum_partial4_kernel - the arithmetic of bcnn_norm_finalize_kernel (bcnn_pool.hip), bit
 // for bit, behind its first panel loads - and the workgroup of row block 0 writes colsum / inv_norm for the backward:
 // the finalize launch (4.5 us between two 6 us / 42 us kernels) is gone.
+constexpr int SSQ_STRIDE = 64;         // MODE 2: partial sums per image in the caller's buffer (= SS_CHUNKS of bcnn_pool.hip)
 struct GramNormSrc {
     const float* part;      // [B][G][HW], nullable: then inv_norm is read
     float* colsum;          // [B][HW]
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     ep.l31 = l31;
     ep.lh = lh;
     ep.i0 = ep.j0 = ep.offdiag = 0;
+    ep.ss = 0.f;
 
     {   // first A panel: all loads in flight at once, then the LDS writes
         const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)rb0 * PANEL);
@@ -215,6 +217,11 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     for (int r = 0; r < 16; ++r) prev[r] = ep.direct(prev[r], r);
 #pragma unroll
     for (int g = 0; g < 4; ++g) ep.mirror(prev, g);
+    if (MODE == 2) {        // this workgroup's share of |u|^2 (fixed order) -> mu[b][w]  (row stride SSQ_STRIDE)
+        __shared__ float reds[4];
+        const float tot = block_sum<4>(ep.ss, reds);
+        if (tid == 0) mu[(long long)b * SSQ_STRIDE + w] = tot;
+    }
 }
 
 // ----------------------------------------------------------------------------- backward
@@ -516,6 +523,19 @@ int bcnn_fast_gram_norm(const float* x, const float* part, int G, float* colsum,
     if (C % 64 != 0 || G != C / 64 || !aligned16(x) || !aligned16(y)) return HK_ERR_UNSUPPORTED;
     const GramNormSrc ns{part, colsum, inv_norm, G};
 #define CALL(H) gram_launch<H, 0, false>(x, nullptr, y, B, C, nullptr, 1.f, st, ns)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
+// signed-sqrt Gram (BCNN.py:23-24): y = u = sign(g) sqrt(|g| + 1e-10), g = X X^T / HW, un-normalised; part [B][64]
+// receives *nparts partial sums of u^2 per image
+int gram_fast_ssqrt(const float* x, float* y, float* part, int* nparts, int B, int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(y)) return HK_ERR_UNSUPPORTED;
+    const int nb = C / 64;
+    const int per = ((long long)B * nb > 256) ? (nb + 1) / 2 : nb;
+    if (per > SSQ_STRIDE) return HK_ERR_UNSUPPORTED;
+    *nparts = per;
+#define CALL(H) gram_launch<H, 2, false>(x, nullptr, y, B, C, part, 1.0f / (float)HW, st)
     HK_HW_SWITCH(CALL)
 #undef CALL
 }

@@ -22,6 +22,7 @@ namespace hk {
 
 // bcnn_fast.hip: panel-resident kernels for C % 64 == 0 and HW in {196,144,100,64}; HK_ERR_UNSUPPORTED otherwise
 int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C, int HW, hipStream_t st);
+int gram_fast_ssqrt(const float* x, float* y, float* part, int* nparts, int B, int C, int HW, hipStream_t st);
 int bcnn_fast_gram_norm(const float* x, const float* part, int G, float* colsum, float* inv_norm, float* y, int B, int C,
                         int HW, hipStream_t st);
 int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart, int B,
@@ -262,10 +263,10 @@ __global__ __launch_bounds__(256) void ssqrt_apply_kernel(float* __restrict__ y,
 
 // y *= inv_norm[b],  inv_norm[b] = 1 / max(sqrt(sum of the partials), 1e-12)   (F.normalize defaults)
 __global__ __launch_bounds__(256) void ssqrt_scale_kernel(float* __restrict__ y, const float* __restrict__ part,
-                                                          float* __restrict__ inv_norm, long long n) {
+                                                          float* __restrict__ inv_norm, long long n, int nparts) {
     const int b = blockIdx.y;
     float s = 0.f;
-    for (int c = 0; c < SS_CHUNKS; ++c) s += part[(long long)b * SS_CHUNKS + c];
+    for (int c = 0; c < nparts; ++c) s += part[(long long)b * SS_CHUNKS + c];
     const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
     if (blockIdx.x == 0 && threadIdx.x == 0) inv_norm[b] = inv;
     const long long len = (n + SS_CHUNKS - 1) / SS_CHUNKS, e0 = (long long)blockIdx.x * len;
@@ -407,6 +408,17 @@ extern "C" int hk_bcnn_ssqrt_pool_fwd(const float* x, float* y, float* inv_norm,
     if (!x || !y || !inv_norm || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_bcnn_ssqrt_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)C * C;
+    if (!force_generic()) {        // two passes: the Gram kernel applies the signed sqrt and sums u^2; then the scale
+        int nparts = 0;
+        const int rc2 = gram_fast_ssqrt(x, y, (float*)ws, &nparts, B, C, HW, st);
+        if (rc2 == HK_OK) {
+            hipLaunchKernelGGL(ssqrt_scale_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (const float*)ws, inv_norm, n, nparts);
+            HK_LAUNCH_CHECK();
+            return HK_OK;
+        }
+        if (rc2 != HK_ERR_UNSUPPORTED) return rc2;
+    }
     int rc = force_generic() ? HK_ERR_UNSUPPORTED : gram_fast_raw(x, nullptr, 1.0f / (float)HW, y, B, C, HW, st);
     if (rc == HK_ERR_UNSUPPORTED) {
         const LdPlain xa = make_plain(x, (long long)C * HW, HW, C, HW);
@@ -414,10 +426,9 @@ extern "C" int hk_bcnn_ssqrt_pool_fwd(const float* x, float* y, float* inv_norm,
                                       HW, B, st);
     }
     if (rc != HK_OK) return rc;
-    const long long n = (long long)C * C;
     hipLaunchKernelGGL(ssqrt_apply_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (float*)ws, n);
     HK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ssqrt_scale_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (const float*)ws, inv_norm, n);
+    hipLaunchKernelGGL(ssqrt_scale_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (const float*)ws, inv_norm, n, SS_CHUNKS);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

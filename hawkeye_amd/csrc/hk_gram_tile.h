@@ -6,17 +6,25 @@
 namespace hk {
 
 // MODE 0: BCNN  y = sqrt(acc / M + 1e-5) * inv_norm[b]        MODE 1: raw  y = alpha * acc  (CBP Gram, covariance)
+// MODE 2: signed sqrt (BCNN.py:23-24)  u = sign(g) sqrt(|g| + 1e-10), g = alpha * acc, written un-normalised; the thread
+//         adds up u^2 of what it writes (twice for a tile that is also written mirrored) in ss - the norm's partial sums
+//         come out of the Gram kernel and the separate pass over the 67 MB of G is gone
 template <int MODE>
 struct GramEpi {
     float* yb;       // y + b*C*C
     int C;
     int i0, j0;      // top-left of this wave's 32x32 sub-tile
-    float inv, inv_m;   // MODE 1: inv = alpha
+    float inv, inv_m;   // MODE 1, 2: inv = alpha
     int offdiag;
     int l31, lh;
+    float ss;        // MODE 2
     __device__ __forceinline__ float direct(float v, int r) {
         // v_sqrt_f32 (1 ulp, argument >= 1e-5: no denormal/negative handling needed) - parity budget is 1e-4
-        const float z = MODE == 0 ? __builtin_amdgcn_sqrtf(fmaf(v, inv_m, 1e-5f)) * inv : v * inv;
+        float z = MODE == 0 ? __builtin_amdgcn_sqrtf(fmaf(v, inv_m, 1e-5f)) * inv : v * inv;
+        if (MODE == 2) {
+            z = z == 0.f ? 0.f : copysignf(sqrtf(fabsf(z) + 1e-10f), z);      // (sign(0) = 0, like torch)
+            ss = fmaf(offdiag ? 2.f * z : z, z, ss);
+        }
         const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         yb[(long long)i * C + j0 + l31] = z;
         return z;
