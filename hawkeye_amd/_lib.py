@@ -39,6 +39,7 @@ SIGNATURES = {
     'hk_ns_sqrtm_ws_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'hk_ns_sqrtm_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_ns_sqrtm_fwd_sym': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_ns_sqrtm_triu_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_ns_sqrtm_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_ns_sqrtm_bwd_general': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_triu_vec_fwd': (c_i, [c_f, c_f, c_i, c_i, c_f]),

@@ -58,6 +58,8 @@ struct NsProb {
     const float* ra;
     float* rpart;
     const float* tr_src;   // ns_flow_kernel only: s_b = sqrt(trace(tr_src[b])), recomputed by the workgroup
+    float* tv;             // nullable: the result's upper triangle, row-major packed [b][d (d + 1) / 2] (Triuvec,
+                           // MPNCOV.py:205-230), written next to C by the chain's last forward product
 };
 
 struct NsGroup {
@@ -356,6 +358,7 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
     const float* E2b = P.E2 ? P.E2 + (long long)b * P.se2 : nullptr;
     float* C2b = P.C2 ? P.C2 + (long long)b * P.sc2 : nullptr;
     const bool has1 = E1b != nullptr, has2 = E2b != nullptr, has_c2 = C2b != nullptr;
+    float* tvb = P.tv ? P.tv + (long long)b * ((long long)d * (d + 1) / 2) : nullptr;        // (uniform)
     const float e1 = FIRST ? 1.5f * tr_inv : (has1 ? (P.e1_scaled ? P.e1 * sb_ : P.e1) : 0.f);   // (a missing term: 0 * 0 added, exact)
     const float e2 = has2 ? P.e2 : 0.f;
 #pragma unroll
@@ -408,6 +411,12 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
                     const bool dg = row == col + t;
                     o1[t] = fmaf(e2, xs2[t], fmaf(e1, xs1[t], fmaf(al, v, dg ? diag : 0.f)));
                     o2[t] = fmaf(alpha2, FIRST ? xs1[t] : v, dg ? diag2 : 0.f);
+                }
+                if (tvb && row < d) {           // Triuvec: element (row, c >= row) -> row d - row (row - 1) / 2 + c - row
+                    float* tr = tvb + (long long)row * d - (long long)row * (row - 1) / 2 - row;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (col + t >= row && col + t < d) tr[col + t] = o1[t];
                 }
                 if (LAST) {                     // sum(g o out) and sum(D^T o a) = sum_ij D_ij a_ji: a read transposed -
                                                 // lanes run along `row`, so a[(col + t) d + row] is a coalesced line
@@ -531,7 +540,7 @@ __host__ __device__ static inline NsProb ns_prob(float* C, long long sc, float a
     p.E2 = nullptr; p.se2 = 0; p.e2 = 0.f;
     p.C2 = nullptr; p.sc2 = 0; p.alpha2 = 0.f; p.diag2 = 0.f;
     p.bscale_fn = 0; p.norm_out = nullptr;
-    p.rg = p.rout = p.ra = nullptr; p.rpart = nullptr; p.tr_src = nullptr;
+    p.rg = p.rout = p.ra = nullptr; p.rpart = nullptr; p.tr_src = nullptr; p.tv = nullptr;
     return p;
 }
 static inline NsProb& operator+=(NsProb& p, const NsTerm& t) {

@@ -383,7 +383,7 @@ extern "C" size_t hk_ns_sqrtm_ws_bytes(int B, int d, int iter_n, int backward) {
 // (3 of 4 tiles at d = 256) and mirror the rest; the results differ from the full products by the rounding asymmetry
 // of a product of commuting symmetric matrices (~1e-7 relative: tests/test_gpu_full_shapes.py).
 static int ns_sqrtm_fwd_impl(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
-                             int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream, bool sym) {
+                             int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream, bool sym, float* tv = nullptr) {
     if (!a || !out || !norm_a || B <= 0 || d <= 0 || iter_n < 1) return HK_ERR_BAD_ARG;
     if (iter_n >= 2 && (!ysave || !zsave)) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_ns_sqrtm_ws_bytes(B, d, iter_n, 0)) return HK_ERR_WORKSPACE;
@@ -398,9 +398,11 @@ static int ns_sqrtm_fwd_impl(const float* a, float* out, float* norm_a, float* y
     if (iter_n < 2) {
         hipLaunchKernelGGL(ns_scale_kernel<true>, ns_scale_grid(n, B), dim3(256), 0, st, a, norm_a, sq, A, T, n, d);
         HK_LAUNCH_CHECK();
-        return nsmm_launch(ns_group(ns_single(A, n, T, n, out, n, 1.0f, 0.f, sq)), d, B, st, 0, 0, sym);   // :151,:161
+        NsProb p1 = ns_single(A, n, T, n, out, n, 1.0f, 0.f, sq);                                  // :151,:161
+        p1.tv = tv;
+        return nsmm_launch(ns_group(p1), d, B, st, 0, 0, sym);
     }
-    if (tuning().ns_flow != 0) {                     // the whole chain as one ticket-ordered dataflow launch
+    if (tuning().ns_flow != 0 && !tv) {              // the whole chain as one ticket-ordered dataflow launch
         const int rc = ns_flow_forward(a, out, norm_a, ysave, zsave, B, d, iter_n, (float*)ws, sym, st);
         if (rc != HK_ERR_UNSUPPORTED) return rc;
     }
@@ -427,6 +429,7 @@ static int ns_sqrtm_fwd_impl(const float* a, float* out, float* norm_a, float* y
     {
         NsProb pl = ns_single(Yl, sbs, T, n, out, n, 0.5f, 0.f, norm_a);                           // .5 Y (.) sqrt(normA)
         pl.bscale_fn = 1;
+        pl.tv = tv;
         HK_TRY(L(ns_group(pl)));
     }
     return L.join();
@@ -435,6 +438,15 @@ static int ns_sqrtm_fwd_impl(const float* a, float* out, float* norm_a, float* y
 extern "C" int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
                                int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream) {
     return ns_sqrtm_fwd_impl(a, out, norm_a, ysave, zsave, B, d, iter_n, ws, ws_bytes, stream, false);
+}
+
+// Sqrtm + Triuvec (MPNCOV.py:88-92 applies them back to back): the chain's last product also writes the packed upper
+// triangle tv [B, d (d + 1) / 2] - no separate pass over `out`
+extern "C" int hk_ns_sqrtm_triu_fwd(const float* a, float* out, float* tv, float* norm_a, float* ysave, float* zsave, int B,
+                                    int d, int iter_n, int symmetric, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    if (!tv) return HK_ERR_BAD_ARG;
+    return ns_sqrtm_fwd_impl(a, out, norm_a, ysave, zsave, B, d, iter_n, ws, ws_bytes, stream,
+                             symmetric != 0 && tuning().ns_sym != 0, tv);
 }
 
 extern "C" int hk_ns_sqrtm_fwd_sym(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,

@@ -169,6 +169,45 @@ class _Sqrtm(torch.autograd.Function):
         return da, None, None, None
 
 
+class _SqrtmTriuvec(torch.autograd.Function):
+    """Sqrtm followed by Triuvec (MPNCOV.py:88-92) with the packed upper triangle written by the chain's last product
+    (hk_ns_sqrtm_triu_fwd); backward = Triuvec's scatter, then Sqrtm.backward."""
+
+    @staticmethod
+    def forward(ctx, a, iter_n, symmetric=False):
+        lib = _lib.load()
+        a = _f32c(a)
+        b, d, _ = a.shape
+        out = torch.empty_like(a)
+        tv = torch.empty(b, d * (d + 1) // 2, 1, dtype=torch.float32, device=a.device)
+        norm_a = torch.empty(b, dtype=torch.float32, device=a.device)
+        slots = max(iter_n - 1, 1)
+        ysave = torch.empty(b, slots, d, d, dtype=torch.float32, device=a.device)
+        zsave = torch.empty(b, slots, d, d, dtype=torch.float32, device=a.device)
+        nws = lib.hk_ns_sqrtm_ws_bytes(b, d, iter_n, 0)
+        ws = _ws(nws, a.device)
+        check(lib.hk_ns_sqrtm_triu_fwd(ptr(a), ptr(out), ptr(tv), ptr(norm_a), ptr(ysave), ptr(zsave), b, d, iter_n,
+                                       1 if symmetric else 0, ptr(ws), nws, stream()), 'hk_ns_sqrtm_triu_fwd')
+        ctx.iter_n = iter_n
+        ctx.save_for_backward(a, out, norm_a, ysave, zsave)
+        return tv
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, out, norm_a, ysave, zsave = ctx.saved_tensors
+        b, d, _ = a.shape
+        g = _f32c(g)
+        dsq = torch.empty_like(a)
+        check(lib.hk_triu_vec_bwd(ptr(g), ptr(dsq), b, d, stream()), 'hk_triu_vec_bwd')
+        da = torch.empty_like(a)
+        nws = lib.hk_ns_sqrtm_ws_bytes(b, d, ctx.iter_n, 1)
+        ws = _ws(nws, a.device)
+        check(lib.hk_ns_sqrtm_bwd(ptr(a), ptr(out), ptr(norm_a), ptr(ysave), ptr(zsave), ptr(dsq), ptr(da),
+                                  b, d, ctx.iter_n, ptr(ws), nws, stream()), 'hk_ns_sqrtm_bwd')
+        return da, None, None
+
+
 class _Triuvec(torch.autograd.Function):
     """replaces Triuvec, model/methods/MPNCOV.py:205-230 (keeps its [B, L, 1] output shape)."""
 
@@ -207,6 +246,12 @@ def sqrtm(x, iter_n, symmetric=False, literal_backward=False):
 
 def triuvec(x):
     return _Triuvec.apply(x)
+
+
+def sqrtm_triuvec(x, iter_n, symmetric=False):
+    """triuvec(sqrtm(x, iter_n, symmetric)) in one chain of launches: the last Newton-Schulz product writes the packed
+    upper triangle itself (same bits as the two calls)."""
+    return _SqrtmTriuvec.apply(x, int(iter_n), bool(symmetric))
 
 
 # --------------------------------------------------------------------- CBP

@@ -31,6 +31,8 @@ class MPNCOV(nn.Module):
         if self.dr is not None:
             x = self.conv_dr_block(x)
         x = HF.covpool(x)
+        if self.is_sqrt and self.is_vec:                       # MPNCOV.py:88-92 back to back: one chain of launches
+            return HF.sqrtm_triuvec(x, self.iterNum, symmetric=True)
         if self.is_sqrt:
             x = HF.sqrtm(x, self.iterNum, symmetric=True)      # a covariance: symmetric by construction
         if self.is_vec:

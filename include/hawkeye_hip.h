@@ -145,6 +145,13 @@ int hk_ns_sqrtm_fwd(const float* a, float* out, float* norm_a, float* ysave, flo
  * hk_ns_sqrtm_fwd's for either backward. */
 int hk_ns_sqrtm_fwd_sym(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d,
                         int iter_n, void* ws, size_t ws_bytes, hk_stream_t stream);
+/* Sqrtm followed by Triuvec, as MPNCOV.forward applies them (MPNCOV.py:88-92): the chain's last product writes `out`
+ * [B, d, d] (saved for the backward) AND its row-major packed upper triangle tv [B, d (d + 1) / 2] - what
+ * hk_triu_vec_fwd(out) would return, bit for bit, without the extra pass.  symmetric != 0: the schedule of
+ * hk_ns_sqrtm_fwd_sym (input must be symmetric), else that of hk_ns_sqrtm_fwd.  Backward: hk_triu_vec_bwd then
+ * hk_ns_sqrtm_bwd. */
+int hk_ns_sqrtm_triu_fwd(const float* a, float* out, float* tv, float* norm_a, float* ysave, float* zsave, int B, int d,
+                         int iter_n, int symmetric, void* ws, size_t ws_bytes, hk_stream_t stream);
 /* hk_ns_sqrtm_bwd executes 34 products instead of the reference's 38: Z_i Y_i is taken from the accumulator of Y_i Z_i.
  * That is exact for ANY input `a`, symmetric or not: every iterate is a polynomial in the one matrix A = a / tr(a)
  * (Y_0 = A (3I - A)/2, Z_0 = (3I - A)/2, and each step multiplies polynomials in A), and polynomials in one matrix

@@ -16,6 +16,9 @@ use_in_tree_cache()
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    import torch
+    if torch.get_num_threads() > 16:       # a 256-core host: the CPU tier's small oracle ops are slower on all cores
+        torch.set_num_threads(16)
 
 
 def pytest_collection_modifyitems(config, items):

@@ -588,6 +588,28 @@ def test_ns_dataflow_forward(F, b, d, itn, tune):
     assert rel(res[0][0], yo) < 1e-5 and rel(res[0][1], xo.grad) < 1e-4
 
 
+@pytest.mark.parametrize('b,d,itn', [(2, 128, 3), (17, 256, 5), (3, 70, 4), (2, 64, 1), (2, 33, 2)])
+def test_sqrtm_triuvec_in_one_chain(F, b, d, itn):
+    """hk_ns_sqrtm_triu_fwd (what the MPN head calls): the chain's last product writes the packed upper triangle next to
+    `out` - the bits of triuvec(sqrtm(.)), forward and backward, for the symmetric and the general schedule, aligned and
+    ragged d, one to five iterations."""
+    x = torch.relu(torch.randn(b, d, 5, 6, generator=torch.Generator().manual_seed(7 * d + itn))) + 0.01
+    wt = torch.randn(b, d * (d + 1) // 2, 1, generator=torch.Generator().manual_seed(4))
+    for symmetric in (True, False):
+        res = []
+        for fused in (False, True):
+            xg = x.clone().to(DEV).requires_grad_(True)
+            c = F.covpool(xg)
+            tv = F.sqrtm_triuvec(c, itn, symmetric=symmetric) if fused else F.triuvec(F.sqrtm(c, itn, symmetric=symmetric))
+            (tv * wt.to(DEV)).sum().backward()
+            res.append((tv.detach().clone(), xg.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), symmetric
+    xo = x.clone().requires_grad_(True)
+    yo = O.triuvec(O.sqrtm(O.covpool(xo), itn))
+    (yo * wt).sum().backward()
+    assert rel(res[1][0], yo) < 1e-5 and rel(res[1][1], xo.grad) < 1e-4
+
+
 @pytest.mark.parametrize('b,d', [(16, 64), (17, 40)])
 def test_ns_two_queue_dispatch_bit_identical(F, b, d, tune):
     """ns_streams=1: the two halves of the batch run the chain on two HIP queues (fork / join through events inside the
