@@ -100,6 +100,9 @@ def mpn_kernels(B=64, d=256, HW=196):
                lambda: lib.hk_ns_sqrtm_bwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), ptr(g), ptr(da), B, d, 5, ptr(wsb),
                                            nwb, stream()), 38 * 2.0 * B * d ** 3, 4.0 * B * d * d * 12)
     tv = E(B, d * (d + 1) // 2)
+    kernel_row('MPN', 'ns_sqrtm fwd chain + triu_vec in its last product (hk_ns_sqrtm_triu_fwd, symmetric: what the MPN head calls)',
+               lambda: lib.hk_ns_sqrtm_triu_fwd(ptr(cov), ptr(out), ptr(tv), ptr(na), ptr(ys), ptr(zs), B, d, 5, 1, ptr(wsf), nwf, stream()),
+               12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10)
     kernel_row('MPN', 'triu_vec fwd', lambda: lib.hk_triu_vec_fwd(ptr(out), ptr(tv), B, d, stream()), 0, 4.0 * B * 32896 * 2)
     kernel_row('MPN', 'triu_vec bwd', lambda: lib.hk_triu_vec_bwd(ptr(tv), ptr(da), B, d, stream()), 0, 4.0 * B * (32896 + 65536))
 
