@@ -43,6 +43,8 @@ __device__ long long* g_roi_stamps = nullptr;            // [64 workgroups][32][
 // PPT (template): crop pixels per thread, ceil(H * W / 256) rounded up to an instance - 4 (maps up to 32 x 32), 13 (56 x 56:
 // 255 registers, two workgroups per CU), 16 (64 x 64: one workgroup per CU)
 
+constexpr int ROI_TROW_CW = 44;     // widest crop of the table path: a window of more than 4 taps <=> scale > 1.5 <=> cw < W / 1.5 <= 43
+
 struct RoiShared {
     CropGeom g;
     int ylo[64], yhi[64], xlo[64], xhi[64];
@@ -51,10 +53,12 @@ struct RoiShared {
 
 // One workgroup: image b, maps c0 .. c0 + nmaps - 1.  KW = 3 / 4: compile-time KW x KW window with register weights
 // (KY = KX = KW on entry); 0: table loops over the KY x KX window
+// trow (KW = 0 only): [H][cw] floats of LDS for the row sums of the separable table path
 template <int KW, int ROI2_PPT>
 __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float* __restrict__ dx, const RoiShared& sh,
                                              const float* wy, const float* wx, float* smap, float* omap, int b, int C,
-                                             int c0, int nmaps, int H, int W, int KY, int KX, int training) {
+                                             int c0, int nmaps, int H, int W, int KY, int KX, int training,
+                                             float* trow = nullptr) {
     constexpr bool REGW = KW > 0;
     constexpr int KR = REGW ? KW : 1;
     const int tid = threadIdx.x, hw = H * W;
@@ -67,6 +71,7 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
     // the pixel in the output map, and either the weights (REGW) or the offsets of the window origin in the tables
     int smo[ROI2_PPT], omo[ROI2_PPT];
     int wyo[REGW ? 1 : ROI2_PPT], wxo[REGW ? 1 : ROI2_PPT];
+    int toy[REGW ? 1 : ROI2_PPT], trx[REGW ? 1 : ROI2_PPT];  // table path: the window's first output row, the crop column
     float rwy[REGW ? ROI2_PPT : 1][KR], rwx[REGW ? ROI2_PPT : 1][KR];
 #pragma unroll
     for (int k = 0; k < ROI2_PPT; ++k) {
@@ -97,6 +102,8 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
         } else {
             wyo[k] = wyo_k;
             wxo[k] = wxo_k;
+            toy[k] = wyo_k % 65;
+            trx[k] = wxo_k / 65;
         }
     }
     ROI_STAMP(31, 2);
@@ -156,30 +163,40 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
                 }
             }
         } else {
-#pragma unroll
-            for (int k0 = 0; k0 < ROI2_PPT; k0 += 4) {
-                if (k0 < nk) {                               // uniform
-                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (int a = 0; a < KY; ++a) {
-                        float rowacc[4] = {0.f, 0.f, 0.f, 0.f};
-                        for (int bq = 0; bq < KX; ++bq) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int k = k0 + j < ROI2_PPT ? k0 + j : k0;   // (PPT = 13: slots 13..15 do not exist)
-                                const int so = smo[k] < 0 ? 0 : smo[k];
-                                rowacc[j] = fmaf(wx[wxo[k] + bq], smap[so + a * W + bq], rowacc[j]);
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int k = k0 + j < ROI2_PPT ? k0 + j : k0;
-                            acc[j] = fmaf(wy[wyo[k] + a], rowacc[j], acc[j]);
-                        }
+            // Table path (windows wider than 8 taps, or wider than 4 on a large crop), SEPARABLE: a pixel's gradient is
+            //     rate * sum_a wy[ry][oy0 + a] * ( sum_b wx[rx][ox0 + b] * dY[oy0 + a][ox0 + b] )
+            // and the inner row sum depends on (output row, crop column) only - it used to be recomputed by every pixel
+            // of the column (KY x KX dependent LDS round trips per pixel on ch x cw of the 256 threads: 196-424 us for a
+            // 9 x 11 crop).  Pass 1: all threads form the H x cw row sums once; pass 2: KY terms per pixel.  The same
+            // fmaf chains in the same order as before: bit-identical.
+            // (trow holds ROI_TROW_CW columns: a wider crop - possible only with a window that is narrow in x and tall in
+            //  y - goes through it in column chunks)
+            for (int cx0 = 0; cx0 < g.cw; cx0 += ROI_TROW_CW) {
+                const int cwc = g.cw - cx0 < ROI_TROW_CW ? g.cw - cx0 : ROI_TROW_CW;
+                const int invc = ((1 << 20) + cwc - 1) / cwc;
+                const int ntr = H * cwc;
+                if (cx0 > 0) __syncthreads();              // the previous chunk's row sums have been consumed
+                for (int e = tid; e < ntr; e += 256) {
+                    const int oy = (e * invc) >> 20, rx = cx0 + e - oy * cwc;
+                    float rowacc = 0.f;
+                    if (sh.xhi[rx] >= sh.xlo[rx]) {
+                        int ox0 = sh.xlo[rx];
+                        if (ox0 > W - KX) ox0 = W - KX;
+                        const float* wrow = wx + rx * 65 + ox0;
+                        const float* srow = smap + oy * W + ox0;
+                        for (int bq = 0; bq < KX; ++bq) rowacc = fmaf(wrow[bq], srow[bq], rowacc);
                     }
+                    trow[e] = rowacc;
+                }
+                __syncthreads();
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = k0 + j < ROI2_PPT ? k0 + j : k0;
-                        if (k0 + j < ROI2_PPT && smo[k] >= 0) omap[omo[k]] = acc[j] * g.rate;
+                for (int k = 0; k < ROI2_PPT; ++k) {
+                    if (k < nk && smo[k] >= 0 && trx[k] >= cx0 && trx[k] < cx0 + cwc) {
+                        float acc = 0.f;
+                        const float* wcol = wy + wyo[k];
+                        const float* tcol = trow + toy[k] * cwc + (trx[k] - cx0);
+                        for (int a = 0; a < KY; ++a) acc = fmaf(wcol[a], tcol[a * cwc], acc);
+                        omap[omo[k]] = acc * g.rate;
                     }
                 }
             }
@@ -203,12 +220,13 @@ template <int PPT>
 __global__ __launch_bounds__(256) void roi_crop_bwd_tab3_kernel(const float* __restrict__ dy, const float* __restrict__ box,
                                                                 const float* __restrict__ drop, float* __restrict__ dx,
                                                                 int C, int H, int W, int training, int cpb) {
-    HK_DYN_LDS16(lds);                                     // wy, wx [64 * 65 + 64], smap, omap [64 * 64]: 66.3 KB
+    HK_DYN_LDS16(lds);                                     // wy, wx [64 * 65 + 64], smap, omap [64 * 64], trow [64 * 44]: 77.5 KB
     __shared__ RoiShared sh;
     float* wy = lds;
     float* wx = wy + 64 * 65 + 64;
     float* smap = wx + 64 * 65 + 64;
     float* omap = smap + 64 * 64;
+    float* trow = omap + 64 * 64;                          // (table path only: crops up to ROI_TROW_CW columns)
     const int b = blockIdx.y, c0 = blockIdx.x * cpb, tid = threadIdx.x;
     const int hw = H * W;
     ROI_STAMP(31, 0);
@@ -262,8 +280,8 @@ __global__ __launch_bounds__(256) void roi_crop_bwd_tab3_kernel(const float* __r
         else if (KY <= 8 && KX <= 8 && H >= 8 && W >= 8 && g.ch * g.cw <= 512)
             // small crops: windows up to 8 x 8, but at most two pixels per thread
             roi_bwd_maps<8, 2>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, 8, 8, training);
-        else
-            roi_bwd_maps<0, PPT>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, KY, KX, training);
+        else      // (a window wider than 4 taps means a crop narrower than W / 1.5: its columns fit trow)
+            roi_bwd_maps<0, PPT>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, KY, KX, training, trow);
     } else {                                               // empty crop: the whole map is zero
         for (int cc = 0; cc < nmaps; ++cc) {
             float* dp = dx + ((long long)b * C + c0 + cc) * hw;
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(256) void roi_crop_bwd_tab3_kernel(const float* __r
 int roi_crop_bwd_v2(const float* dy, const float* box, const float* drop, float* dx, int B, int C, int H, int W,
                     int training, hipStream_t st) {
     if (H > 64 || W > 64) return HK_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)(2 * (64 * 65 + 64) + 2 * 64 * 64) * sizeof(float);
+    const size_t lds = (size_t)(2 * (64 * 65 + 64) + 2 * 64 * 64 + 64 * ROI_TROW_CW) * sizeof(float);
     HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<4>, lds);
     HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<13>, lds);
     HK_ALLOW_BIG_LDS(&roi_crop_bwd_tab3_kernel<16>, lds);

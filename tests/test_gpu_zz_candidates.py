@@ -189,6 +189,28 @@ def test_roi_crop_backward_lds_variant_bit_identical(F, mode, tune):
     assert torch.equal(res[0][1], res[1][1])               # the forward kernels too (roi_bwd=1 keeps both round-1 kernels)
 
 
+def test_roi_crop_backward_separable_table_path(F, tune):
+    """Crops whose tap windows are wider than the compile-time instances take the table path, which is separable since
+    round 3 (row sums per (output row, crop column) once, then the column sum per pixel): a 9 x 11 crop (13 x 11 taps), a
+    23 x 24 one (more than 512 pixels with 6 taps), a crop of the full width and 4 rows (29 x 2 taps: wider than the
+    row-sum buffer, two column chunks) and its transpose - bit-identical to the round-1 table kernel."""
+    gen = torch.Generator().manual_seed(19)
+    x = torch.randn(4, 9, 56, 56, generator=gen)
+    wt = torch.randn(4, 9, 56, 56, generator=gen)
+    box = torch.tensor([[20.0, 30.0, 31.9, 39.2], [5.0, 6.0, 28.9, 30.5], [0.0, 10.0, 56.0, 14.2], [41.0, 0.0, 45.9, 56.0]])
+    drop = torch.tensor([[22., 31., 25., 33.], [0., 0., -1., -1.], [30., 11., 40., 12.], [0., 0., -1., -1.]])
+    for mode in (True, False):
+        res = []
+        for flag in (1, 0):
+            tune('roi_bwd', flag)
+            xg = x.clone().to(DEV).requires_grad_(True)
+            y = F.roi_crop_resize(xg, box.to(DEV), drop.to(DEV), mode)
+            (y * wt.to(DEV)).sum().backward()
+            res.append(xg.grad.clone())
+        assert torch.equal(res[0], res[1]) and float(res[0].abs().sum()) > 0, mode
+    tune('roi_bwd', 0)
+
+
 def test_wrappers_refuse_mismatched_shapes(F):
     """The C ABI takes raw pointers and sizes: a tensor of the wrong shape would be read out of bounds (a [N, C] gate
     vector handed to osme_scale as if it were [P, N, C] faulted the GPU in a profiling script).  The host wrappers
