@@ -66,6 +66,10 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
     const int ncrop = g.ch * g.cw;                         // (> 0 here)
     const int nk = __builtin_amdgcn_readfirstlane((ncrop + 255) >> 8);   // slots in use (uniform: scalar branches below)
     const int inv = ((1 << 20) + g.cw - 1) / g.cw;         // q / cw = (q * inv) >> 20, exact for q < 4096, cw <= 64
+    // table path: separable (row sums once, then KY terms per pixel) for SMALL crops, whose windows are the widest and
+    // whose pixels leave most threads idle - 9 x 11: 196 -> 57 us; on larger crops with 5 .. 8 taps and on strips the
+    // per-pixel loops below measured faster (the AP-CNN step's own crop: 78 us against 100-122 us separable)
+    const bool sepr = !REGW && ncrop <= 512 && g.cw <= ROI_TROW_CW;
 
     // geometry of slot k: offset of the window origin in the staged map (< 0: the pixel receives no gradient), offset of
     // the pixel in the output map, and either the weights (REGW) or the offsets of the window origin in the tables
@@ -169,34 +173,91 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
             // of the column (KY x KX dependent LDS round trips per pixel on ch x cw of the 256 threads: 196-424 us for a
             // 9 x 11 crop).  Pass 1: all threads form the H x cw row sums once; pass 2: KY terms per pixel.  The same
             // fmaf chains in the same order as before: bit-identical.
-            // (trow holds ROI_TROW_CW columns: a wider crop - possible only with a window that is narrow in x and tall in
-            //  y - goes through it in column chunks)
-            for (int cx0 = 0; cx0 < g.cw; cx0 += ROI_TROW_CW) {
-                const int cwc = g.cw - cx0 < ROI_TROW_CW ? g.cw - cx0 : ROI_TROW_CW;
-                const int invc = ((1 << 20) + cwc - 1) / cwc;
-                const int ntr = H * cwc;
-                if (cx0 > 0) __syncthreads();              // the previous chunk's row sums have been consumed
-                for (int e = tid; e < ntr; e += 256) {
-                    const int oy = (e * invc) >> 20, rx = cx0 + e - oy * cwc;
-                    float rowacc = 0.f;
-                    if (sh.xhi[rx] >= sh.xlo[rx]) {
-                        int ox0 = sh.xlo[rx];
-                        if (ox0 > W - KX) ox0 = W - KX;
-                        const float* wrow = wx + rx * 65 + ox0;
-                        const float* srow = smap + oy * W + ox0;
-                        for (int bq = 0; bq < KX; ++bq) rowacc = fmaf(wrow[bq], srow[bq], rowacc);
-                    }
-                    trow[e] = rowacc;
-                }
-                __syncthreads();
+            if (sepr) {
+                // (trow holds ROI_TROW_CW columns; sepr implies cw <= ROI_TROW_CW, the loop body runs once - it is written
+                //  for column chunks so that the bound can be lifted)
+                for (int cx0 = 0; cx0 < g.cw; cx0 += ROI_TROW_CW) {
+                    const int cwc = g.cw - cx0 < ROI_TROW_CW ? g.cw - cx0 : ROI_TROW_CW;
+                    const int invc = ((1 << 20) + cwc - 1) / cwc;
+                    const int ntr = H * cwc;
+                    if (cx0 > 0) __syncthreads();              // the previous chunk's row sums have been consumed
+                    // four row sums / four pixels at a time: independent fmaf chains, their LDS reads in flight together
+                    for (int e0 = tid; e0 < ntr; e0 += 1024) {
+                        const float* wrow[4];
+                        const float* srow[4];
+                        float rowacc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < ROI2_PPT; ++k) {
-                    if (k < nk && smo[k] >= 0 && trx[k] >= cx0 && trx[k] < cx0 + cwc) {
-                        float acc = 0.f;
-                        const float* wcol = wy + wyo[k];
-                        const float* tcol = trow + toy[k] * cwc + (trx[k] - cx0);
-                        for (int a = 0; a < KY; ++a) acc = fmaf(wcol[a], tcol[a * cwc], acc);
-                        omap[omo[k]] = acc * g.rate;
+                        for (int j = 0; j < 4; ++j) {
+                            int e = e0 + 256 * j;
+                            e = e < ntr ? e : ntr - 1;
+                            const int oy = (e * invc) >> 20, rx = cx0 + e - oy * cwc;
+                            int ox0 = sh.xhi[rx] >= sh.xlo[rx] ? sh.xlo[rx] : 0;        // (no range: all-zero table row)
+                            if (ox0 > W - KX) ox0 = W - KX;
+                            wrow[j] = wx + rx * 65 + ox0;
+                            srow[j] = smap + oy * W + ox0;
+                        }
+                        for (int bq = 0; bq < KX; ++bq) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) rowacc[j] = fmaf(wrow[j][bq], srow[j][bq], rowacc[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (e0 + 256 * j < ntr) trow[e0 + 256 * j] = rowacc[j];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int k0 = 0; k0 < ROI2_PPT; k0 += 4) {
+                        if (k0 < nk) {                           // uniform
+                            const float* wcol[4];
+                            const float* tcol[4];
+                            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                            bool on[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int k = k0 + j < ROI2_PPT ? k0 + j : k0;   // (PPT = 13: slots 13..15 do not exist)
+                                on[j] = k0 + j < ROI2_PPT && smo[k] >= 0 && trx[k] >= cx0 && trx[k] < cx0 + cwc;
+                                wcol[j] = wy + (on[j] ? wyo[k] : 0);
+                                tcol[j] = trow + (on[j] ? toy[k] * cwc + (trx[k] - cx0) : 0);
+                            }
+                            for (int a = 0; a < KY; ++a) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[j] = fmaf(wcol[j][a], tcol[j][a * cwc], acc[j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int k = k0 + j < ROI2_PPT ? k0 + j : k0;
+                                if (on[j]) omap[omo[k]] = acc[j] * g.rate;
+                            }
+                        }
+                    }
+                }
+            } else {
+                // larger crops with 5 .. 8 taps, strips: per pixel KY x KX taps, four pixels in flight
+#pragma unroll
+                for (int k0 = 0; k0 < ROI2_PPT; k0 += 4) {
+                    if (k0 < nk) {                               // uniform
+                        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int a = 0; a < KY; ++a) {
+                            float rowacc[4] = {0.f, 0.f, 0.f, 0.f};
+                            for (int bq = 0; bq < KX; ++bq) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int k = k0 + j < ROI2_PPT ? k0 + j : k0;   // (PPT = 13: slots 13..15 do not exist)
+                                    const int so = smo[k] < 0 ? 0 : smo[k];
+                                    rowacc[j] = fmaf(wx[wxo[k] + bq], smap[so + a * W + bq], rowacc[j]);
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int k = k0 + j < ROI2_PPT ? k0 + j : k0;
+                                acc[j] = fmaf(wy[wyo[k] + a], rowacc[j], acc[j]);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = k0 + j < ROI2_PPT ? k0 + j : k0;
+                            if (k0 + j < ROI2_PPT && smo[k] >= 0) omap[omo[k]] = acc[j] * g.rate;
+                        }
                     }
                 }
             }
