@@ -17,7 +17,8 @@
 //     live in registers for all maps of the workgroup and its KW * KW taps are unconditional LDS reads, all in flight
 //     together.  The window is shifted to stay inside the map, taps outside a pixel's true range carry table weight 0
 //     and read finite map values, so dX is bit-identical to the table kernel (x + 0 * finite = x).  Small crops (up
-//     to 512 pixels) have windows up to 8 x 8 the same way, two pixels per thread; anything else takes the table loops
+//     to 512 pixels) have windows up to 8 x 8 the same way, two pixels per thread, mid-size crops (up to 1536 pixels)
+//     windows up to 6 x 6 with six pixels per thread; anything else takes the table loops - separable for small crops
 //     (a 12 x 12 instance was tried: its 288 reads in flight push the whole kernel to one workgroup per CU);
 //   * the tables' non-zero ranges come from LDS atomics while the tables are filled (no scans), pixel coordinates from
 //     a multiply-shift instead of integer division;
@@ -341,6 +342,9 @@ __global__ __launch_bounds__(256) void roi_crop_bwd_tab3_kernel(const float* __r
         else if (KY <= 8 && KX <= 8 && H >= 8 && W >= 8 && g.ch * g.cw <= 512)
             // small crops: windows up to 8 x 8, but at most two pixels per thread
             roi_bwd_maps<8, 2>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, 8, 8, training);
+        else if (KY <= 6 && KX <= 6 && H >= 6 && W >= 6 && g.ch * g.cw <= 1536)
+            // mid-size crops (5 or 6 taps: 19 .. 37 pixels a side of a 56-pixel map), up to six pixels per thread
+            roi_bwd_maps<6, 6>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, 6, 6, training);
         else      // (a window wider than 4 taps means a crop narrower than W / 1.5: its columns fit trow)
             roi_bwd_maps<0, PPT>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, KY, KX, training, trow);
     } else {                                               // empty crop: the whole map is zero
