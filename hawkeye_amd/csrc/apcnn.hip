@@ -102,6 +102,26 @@ __global__ __launch_bounds__(256) void att_pool_bwd_kernel(const float* __restri
     }
 }
 
+// The plain-GAP backward (a_s == nullptr: ChannelGate, the FPN's global branch - up to 2048 channels on a 14 x 14 map):
+// df[b,c,:] = dgap[b,c] / HW.  One wave per (b, c) row like the forward; the column-walking kernel above has
+// ceil(HW / 256) x B workgroups - 16 of them for a 14 x 14 map - each looping over all C channels (55 us inside the
+// AP-CNN step, profiles/r3_step_APCNN_kernel_stats.csv).
+template <bool VEC>
+__global__ __launch_bounds__(256) void att_pool_bwd_gap_kernel(const float* __restrict__ dgap, float* __restrict__ df,
+                                                               long long rows, int HW) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float v = dgap[row] * (1.0f / (float)HW);           // (the column kernel: (0 * a + dgap) * inv - the same bits)
+    float* dp = df + row * HW;
+    if (VEC) {
+        const float4 q = make_float4(v, v, v, v);
+        for (int i = lane; i < (HW >> 2); i += 64) reinterpret_cast<float4*>(dp)[i] = q;
+    } else {
+        for (int i = lane; i < HW; i += 64) dp[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------- K9
 struct Cand {
     float s;
@@ -466,6 +486,16 @@ extern "C" int hk_att_pool_fwd(const float* f, const float* a_s, float* gap, flo
 extern "C" int hk_att_pool_bwd(const float* f, const float* a_s, const float* dgap, const float* dsgap, float* df,
                                float* da_s, int B, int C, int HW, hk_stream_t stream) {
     if (!f || !df || B <= 0 || C <= 0 || HW <= 0 || (!dgap && !dsgap)) return HK_ERR_BAD_ARG;
+    if (!a_s && dgap) {                          // plain GAP: row-parallel broadcast
+        const long long rows = (long long)B * C;
+        const dim3 grid((unsigned)((rows + 3) / 4));
+        if (HW % 4 == 0 && aligned16(df))
+            hipLaunchKernelGGL(att_pool_bwd_gap_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dgap, df, rows, HW);
+        else
+            hipLaunchKernelGGL(att_pool_bwd_gap_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dgap, df, rows, HW);
+        HK_LAUNCH_CHECK();
+        return HK_OK;
+    }
     if ((size_t)2 * C * sizeof(float) > 64 * 1024) return HK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(att_pool_bwd_kernel, dim3((HW + 255) / 256, B), dim3(256), 2 * C * sizeof(float),
                        (hipStream_t)stream, f, a_s, dgap, dsgap, df, da_s, C, HW);

@@ -428,6 +428,24 @@ def test_att_pool(F):
         assert none is None and rel(gap2, gap_o) < 1e-6
 
 
+@pytest.mark.parametrize('c,hw', [(2048, (14, 14)), (70, (5, 3)), (256, (28, 28))])
+def test_att_pool_plain_gap_backward(F, c, hw):
+    """The GAP-only form (no attention map: ChannelGate, the FPN's global branch - APCNN.py:377-405, 533-538) has its own
+    row-parallel backward, df[b, c, :] = dgap[b, c] / HW: exactly the mean's gradient, also at 2048 channels on a 14 x 14
+    map (where the column-walking kernel had 16 workgroups) and with an odd map size."""
+    fn = rs_randn(45, (2, c) + hw)
+    f = t(fn).requires_grad_(True)
+    w1 = t(rs_randn(46, (2, c)))
+    (f.mean(dim=(2, 3)) * w1).sum().backward()
+    fg = t(fn).to(DEV).requires_grad_(True)
+    gap, none = F.att_pool(fg, None)
+    (gap * w1.to(DEV)).sum().backward()
+    assert none is None and rel(gap, f.mean(dim=(2, 3))) < 1e-6
+    inv = torch.tensor(1.0, dtype=torch.float32) / float(hw[0] * hw[1])                 # the kernels multiply by fl(1 / HW)
+    assert torch.equal(fg.grad.cpu(), (w1 * inv)[:, :, None, None].expand_as(f).contiguous())
+    assert rel(fg.grad, f.grad) < 1e-6
+
+
 def _masks():
     return [t(1.0 / (1.0 + np.exp(-2.0 * rs_randn(50 + l, (3, 1, hw, hw))))).float()
             for l, hw in enumerate((56, 28, 14))]
