@@ -285,7 +285,7 @@ extern "C" int hk_cin_sci_fwd(const float* x, float* w, float* y, int B, int C, 
     hipLaunchKernelGGL(cin_softmax_rows_kernel, dim3((unsigned)B * C), dim3(256), 0, st, w, C);
     HK_LAUNCH_CHECK();
     const LdPlain lw = make_plain(w, (long long)C * C, C, C, C);
-    return bgemm_launch<true, false>(lw, lx, make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B,
+    return bgemm_launch<true, false, true>(lw, lx, make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B,
                                      st);                                                        // Y = W X       :34
 }
 
@@ -303,10 +303,10 @@ extern "C" int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, f
                                      B, st)));                                                   // dW = dY X^T (+ extra)
     hipLaunchKernelGGL(cin_softmax_bwd_rows_kernel, dim3((unsigned)B * C), dim3(256), 0, st, w, dwbuf, C);
     HK_LAUNCH_CHECK();
-    HK_TRY((bgemm_launch<false, false>(lw, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // W^T dY
+    HK_TRY((bgemm_launch<false, false, true>(lw, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // W^T dY
     LdSym ls;
     ls.p = dwbuf; ls.bs = sw; ls.d = C;
-    return bgemm_launch<true, false>(ls, lx, make_affine(dx, sx, HW, 1.0f / (float)HW, nullptr, 1.f, 0.f), C, HW, C, B, st);
+    return bgemm_launch<true, false, true>(ls, lx, make_affine(dx, sx, HW, 1.0f / (float)HW, nullptr, 1.f, 0.f), C, HW, C, B, st);
 }
 
 extern "C" int hk_cin_cci_fwd(const float* x, const float* w, const float* wt, float* y, int B, int C, int HW,
@@ -315,7 +315,7 @@ extern "C" int hk_cin_cci_fwd(const float* x, const float* w, const float* wt, f
     LdAbsDiff la;
     la.p = w; la.wt = wt; la.C = C; la.B = B;
     const LdPlain lx = make_plain(x, (long long)C * HW, HW, C, HW);
-    return bgemm_launch<true, false>(la, lx, make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B,
+    return bgemm_launch<true, false, true>(la, lx, make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B,
                                      (hipStream_t)stream);                                       // :52-54
 }
 
@@ -338,7 +338,7 @@ extern "C" int hk_cin_cci_bwd(const float* x, const float* w, const float* wt, c
     HK_TRY((bgemm_launch<true, true>(ldy, lx, make_affine(dwc, sw, C, 1.f, nullptr, 0.f, 0.f), C, C, HW, B, st)));
     LdAbsDiff la;
     la.p = w; la.wt = wt; la.C = C; la.B = B;
-    HK_TRY((bgemm_launch<false, false>(la, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // Wc^T dY
+    HK_TRY((bgemm_launch<false, false, true>(la, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // Wc^T dY
     hipLaunchKernelGGL(cin_cci_dw_kernel, dim3(CIN_DW_BLOCKS, B), dim3(256), 0, st, w, wt, (const float*)dwc, dw, dwpart, C, B,
                        CIN_DW_BLOCKS);
     HK_LAUNCH_CHECK();

@@ -117,10 +117,16 @@ struct EpAffine {
 // mode and bf16-split products here; all measured slower or equal on the MI355X (BENCH_r01: 417-563 us against
 // 436 us on the Newton-Schulz forward) and were removed.  The Newton-Schulz chain now has its own grouped kernel
 // (hk_nsmm.h); this one serves the ragged / small shapes: classifier slabs, CIN, n-pairs, generic fallbacks.
-template <bool A_KC, bool B_KC, class AL, class BL, class EP>
+// DEEP = true (long-K, memory-streaming shapes: CIN's C x C by C x 49 products, K = 2048): chunk c + 2 is requested
+// while chunk c is computed (two register sets, loop unrolled by two, no branch around a load or an LDS store: the
+// chunk index is clamped instead, a redundant last load / store is harmless) - with one chunk of prefetch a workgroup
+// waited ~3.5 us per 32-deep chunk and 2.5 resident workgroups per CU did not cover it; measured on CIN's four
+// products: 242 -> 200, 440 -> 407, 379 -> 352, 376 -> 355 us - the rest is the access pattern (128-byte runs of 64
+// rows 8 KB apart per chunk: ~1.8 TB/s).
+template <bool A_KC, bool B_KC, class AL, class BL, class EP, bool DEEP = false>
 __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb,
                                                      int tilesM, int tilesN) {
-    constexpr int T = 1, BKT = 32;
+    constexpr int T = 1, BKT = 32;                       // (64-deep chunks with DEEP: 1.3-1.7x SLOWER on the CIN products)
     constexpr bool SYM = false;
     constexpr int BM = 64 * T, BN = 64 * T, BK = BKT;
     constexpr int PA = A_KC ? BK + 4 : BM + 4;
@@ -163,42 +169,58 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 
     float4 ra[NLA], rb[NLB];
+    float4 ra1[DEEP ? NLA : 1], rb1[DEEP ? NLB : 1];     // DEEP: the second register set
 
 // (macro-local names carry a trailing underscore: the argument expressions mention the caller's `c`)
-#define HK_GLOAD(k0)                                                                                   \
+#define HK_GLOAD_TO(RA_, RB_, k0)                                                                      \
     do {                                                                                               \
         _Pragma("unroll") for (int u = 0; u < NLA; ++u) {                                              \
             const int f_ = tid + 256 * u, r_ = f_ / A4, c_ = f_ % A4;                                       \
-            ra[u] = A_KC ? al.ld4(b, m0 + r_, (k0) + 4 * c_) : al.ld4(b, (k0) + r_, m0 + 4 * c_);          \
+            RA_[u] = A_KC ? al.ld4(b, m0 + r_, (k0) + 4 * c_) : al.ld4(b, (k0) + r_, m0 + 4 * c_);         \
         }                                                                                              \
         _Pragma("unroll") for (int u = 0; u < NLB; ++u) {                                              \
             const int f_ = tid + 256 * u, r_ = f_ / B4, c_ = f_ % B4;                                       \
-            rb[u] = B_KC ? bl.ld4(b, n0 + r_, (k0) + 4 * c_) : bl.ld4(b, (k0) + r_, n0 + 4 * c_);          \
+            RB_[u] = B_KC ? bl.ld4(b, n0 + r_, (k0) + 4 * c_) : bl.ld4(b, (k0) + r_, n0 + 4 * c_);         \
         }                                                                                              \
     } while (0)
+#define HK_GLOAD(k0) HK_GLOAD_TO(ra, rb, k0)
 
-#define HK_SSTORE(buf)                                                                                 \
+#define HK_SSTORE_FROM(RA_, RB_, buf)                                                                  \
     do {                                                                                               \
         float* As_ = lds + (buf) * (SA + SB);                                                          \
         float* Bs_ = As_ + SA;                                                                         \
         _Pragma("unroll") for (int u = 0; u < NLA; ++u) {                                              \
             const int f_ = tid + 256 * u, r_ = f_ / A4, c_ = f_ % A4;                                       \
-            *reinterpret_cast<float4*>(&As_[r_ * PA + 4 * c_]) = ra[u];                                  \
+            *reinterpret_cast<float4*>(&As_[r_ * PA + 4 * c_]) = RA_[u];                                 \
         }                                                                                              \
         _Pragma("unroll") for (int u = 0; u < NLB; ++u) {                                              \
             const int f_ = tid + 256 * u, r_ = f_ / B4, c_ = f_ % B4;                                       \
-            *reinterpret_cast<float4*>(&Bs_[r_ * PB + 4 * c_]) = rb[u];                                  \
+            *reinterpret_cast<float4*>(&Bs_[r_ * PB + 4 * c_]) = RB_[u];                                 \
         }                                                                                              \
     } while (0)
+#define HK_SSTORE(buf) HK_SSTORE_FROM(ra, rb, buf)
 
     const int nk = (K + BK - 1) / BK;
     HK_GLOAD(0);
+    if (DEEP) HK_GLOAD_TO(ra1, rb1, (nk > 1 ? 1 : 0) * BK);   // chunks 0 and 1 in flight before the first wait
     HK_SSTORE(0);
     __syncthreads();
 
-    for (int c = 0; c < nk; ++c) {
+    // DEEP: the loop counts chunk pairs; `half` 0 / 1 = even / odd chunk of the pair (compile-time register sets)
+    const int nloop = DEEP ? (nk + 1) / 2 : nk;
+    for (int cc = 0; cc < nloop; ++cc)
+#pragma unroll
+    for (int half = 0; half < (DEEP ? 2 : 1); ++half) {
+        const int c = DEEP ? 2 * cc + half : cc;
+        if (DEEP && c >= nk) break;                      // (odd chunk count: the pair's second half does not exist)
         const int cur = c & 1;
-        if (c + 1 < nk) HK_GLOAD((c + 1) * BK);
+        if (DEEP) {                                      // chunk c + 2 into the set whose content (chunk c) is in LDS
+            const int cn = c + 2 < nk ? c + 2 : nk - 1;
+            if (half == 0) HK_GLOAD_TO(ra, rb, cn * BK);
+            else HK_GLOAD_TO(ra1, rb1, cn * BK);
+        } else {
+            if (c + 1 < nk) HK_GLOAD((c + 1) * BK);
+        }
         const float* As = lds + cur * (SA + SB);
         const float* Bs = As + SA;
         // operand fragments of step s+1 are fetched before the MFMAs of step s are issued (the dependent MFMAs block
@@ -250,11 +272,18 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
             }
         }
 #undef HK_FRAG
-        if (c + 1 < nk) HK_SSTORE(cur ^ 1);
+        if (DEEP) {                                      // chunk c + 1 (requested a chunk ago) to the other stage; behind the
+            if (half == 0) HK_SSTORE_FROM(ra1, rb1, cur ^ 1);    // last chunk this rewrites a stage nobody reads again
+            else HK_SSTORE_FROM(ra, rb, cur ^ 1);
+        } else {
+            if (c + 1 < nk) HK_SSTORE(cur ^ 1);
+        }
         __syncthreads();
     }
 #undef HK_GLOAD
 #undef HK_SSTORE
+#undef HK_GLOAD_TO
+#undef HK_SSTORE_FROM
 
     if (T == 1) acc[0][0] += acc2;
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -275,11 +304,11 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
     al.finish(b, tm, tn, tilesM, lds);
 }
 
-template <bool A_KC, bool B_KC, class AL, class BL, class EP>
+template <bool A_KC, bool B_KC, bool DEEP = false, class AL, class BL, class EP>
 static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-    hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl, ep,
+    hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP, DEEP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl, ep,
                        M, N, K, nb, tm, tn);
     HK_LAUNCH_CHECK();
     return HK_OK;
