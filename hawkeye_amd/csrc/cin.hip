@@ -299,8 +299,10 @@ extern "C" int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, f
     const LdPlain lx = make_plain(x, sx, HW, C, HW);
     const LdPlain ldy = make_plain(dy, sx, HW, C, HW);
     const LdPlain lw = make_plain(w, sw, C, C, C);
-    HK_TRY((bgemm_launch<true, true>(ldy, lx, make_affine(dwbuf, sw, C, 1.f, nullptr, has_extra ? 1.f : 0.f, 0.f), C, C, HW,
-                                     B, st)));                                                   // dW = dY X^T (+ extra)
+    // dW = dY X^T (+ extra): 335 MB of result for 49-deep products - the tile leaves as 16-byte stores where it can
+    const EpAffine epw = make_affine(dwbuf, sw, C, 1.f, nullptr, has_extra ? 1.f : 0.f, 0.f);
+    if (C % 4 == 0 && aligned16(dwbuf)) HK_TRY((bgemm_launch<true, true, false, true>(ldy, lx, epw, C, C, HW, B, st)));
+    else HK_TRY((bgemm_launch<true, true>(ldy, lx, epw, C, C, HW, B, st)));
     hipLaunchKernelGGL(cin_softmax_bwd_rows_kernel, dim3((unsigned)B * C), dim3(256), 0, st, w, dwbuf, C);
     HK_LAUNCH_CHECK();
     HK_TRY((bgemm_launch<false, false, true>(lw, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // W^T dY
@@ -335,7 +337,9 @@ extern "C" int hk_cin_cci_bwd(const float* x, const float* w, const float* wt, c
     float* dwpart = dwc + (size_t)B * sw;
     const LdPlain lx = make_plain(x, sx, HW, C, HW);
     const LdPlain ldy = make_plain(dy, sx, HW, C, HW);
-    HK_TRY((bgemm_launch<true, true>(ldy, lx, make_affine(dwc, sw, C, 1.f, nullptr, 0.f, 0.f), C, C, HW, B, st)));
+    const EpAffine epw = make_affine(dwc, sw, C, 1.f, nullptr, 0.f, 0.f);
+    if (C % 4 == 0 && aligned16(dwc)) HK_TRY((bgemm_launch<true, true, false, true>(ldy, lx, epw, C, C, HW, B, st)));
+    else HK_TRY((bgemm_launch<true, true>(ldy, lx, epw, C, C, HW, B, st)));
     LdAbsDiff la;
     la.p = w; la.wt = wt; la.C = C; la.B = B;
     HK_TRY((bgemm_launch<false, false, true>(la, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // Wc^T dY

@@ -109,6 +109,18 @@ struct EpAffine {
         if (beta != 0.f) r += beta * (*q);
         *q = r;
     }
+    // the same for four consecutive columns j .. j + 3 of row i (not transposed; 16-byte aligned: see bgemm_kernel VEPI)
+    __device__ __forceinline__ void store4(int b, int i, int j, float4 v) const {
+        const float s = bscale ? alpha * bscale[b] : alpha;
+        float* q = c + (long long)b * bs + (long long)i * ld + j;
+        float r[4] = {s * v.x, s * v.y, s * v.z, s * v.w};
+        if (i >= j && i < j + 4) r[i - j] += diag;
+        if (beta != 0.f) {
+            const float4 o = *reinterpret_cast<const float4*>(q);
+            r[0] += beta * o.x; r[1] += beta * o.y; r[2] += beta * o.z; r[3] += beta * o.w;
+        }
+        *reinterpret_cast<float4*>(q) = make_float4(r[0], r[1], r[2], r[3]);
+    }
 };
 
 // ---------------------------------------------------------------- kernel
@@ -123,7 +135,11 @@ struct EpAffine {
 // waited ~3.5 us per 32-deep chunk and 2.5 resident workgroups per CU did not cover it; measured on CIN's four
 // products: 242 -> 200, 440 -> 407, 379 -> 352, 376 -> 355 us - the rest is the access pattern (128-byte runs of 64
 // rows 8 KB apart per chunk: ~1.8 TB/s).
-template <bool A_KC, bool B_KC, class AL, class BL, class EP, bool DEEP = false>
+// VEPI = true (EP = EpAffine, not transposed, ld % 4 == 0, 16-byte aligned result, N % 4 == 0 - large results with a
+// short K: CIN's dW = dY X^T writes 335 MB for 49-deep products): the tile leaves through LDS as 16-byte stores of
+// whole 256-byte rows instead of one 4-byte store per accumulator register (128-byte runs): same values, same order of
+// operations per element.
+template <bool A_KC, bool B_KC, class AL, class BL, class EP, bool DEEP = false, bool VEPI = false>
 __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb,
                                                      int tilesM, int tilesN) {
     constexpr int T = 1, BKT = 32;                       // (64-deep chunks with DEEP: 1.3-1.7x SLOWER on the CIN products)
@@ -286,6 +302,23 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
 #undef HK_SSTORE_FROM
 
     if (T == 1) acc[0][0] += acc2;
+    if constexpr (VEPI) {
+        // (the last chunk's barrier has passed: the stages are free) tile image [64][68], then 16 float4 per row
+        static_assert(T == 1 && 64 * 68 <= 2 * (SA + SB), "the output image fits the stages");
+        float* img = lds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            img[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + wn * 32 + l31] = acc[0][0][r];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + 256 * u, row = f >> 4, c4 = (f & 15) << 2;
+            const int ii = m0 + row, jj = n0 + c4;
+            if (ii < M && jj < N) ep.store4(b, ii, jj, *reinterpret_cast<const float4*>(&img[row * 68 + c4]));
+        }
+        al.finish(b, tm, tn, tilesM, lds);
+        return;
+    }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < T; ++i)
@@ -304,11 +337,11 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
     al.finish(b, tm, tn, tilesM, lds);
 }
 
-template <bool A_KC, bool B_KC, bool DEEP = false, class AL, class BL, class EP>
+template <bool A_KC, bool B_KC, bool DEEP = false, bool VEPI = false, class AL, class BL, class EP>
 static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-    hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP, DEEP>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl, ep,
+    hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP, DEEP, VEPI>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl, ep,
                        M, N, K, nb, tm, tn);
     HK_LAUNCH_CHECK();
     return HK_OK;
