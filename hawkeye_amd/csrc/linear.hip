@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __re
         asm volatile("" ::: "memory");                                                                         \
     } while (0)
 
-#ifdef HK_LAB   // tools/linear_lab.py, timing only (results are wrong): 1 = no MFMAs (the stream alone), 2 = no LDS-DMA inside the loop
+#ifdef HK_LAB   // tools/linear_lab.py, timing only (results are wrong): bits 1 = no MFMAs, 2 = no LDS-DMA inside the loop, 4 = no fragment reads
 __device__ int g_lin_lab = 0;
 #endif
 // MT: 16-sample row tiles per workgroup.  4: up to 64 samples, wave w owns row tile w & 3 and one half of the NT class tiles.
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
     auto run = [&](auto nl_tag) {
         constexpr int NL = decltype(nl_tag)::value;
         auto frag = [&](int st, int s, f32x4& a, f32x4 (&b)[NL]) {
+            if (labv & 4) return;
             const float* base = lds + st;
             a = *reinterpret_cast<const f32x4*>(base + aoff + (((4 * s + lq) ^ asw) << 2));
 #pragma unroll
@@ -220,6 +221,10 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
                 for (int n = 0; n < NL; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n][t], acc[n], 0, 0, 0);
         };
         f32x4 a0, a1, b0[NL], b1[NL];
+#ifdef HK_LAB
+        a0 = a1 = (f32x4){1.f, 1.f, 1.f, 1.f};
+        for (int n = 0; n < NL; ++n) b0[n] = b1[n] = (f32x4){1.f, 1.f, 1.f, 1.f};
+#endif
         frag(0, 0, a0, b0);
         int cur = 0;                                             // stage of chunk c (float offset), nxt = chunk c + 1
         for (int c = 0; c < nch; ++c) {

@@ -1,6 +1,7 @@
 """Which side of the wide-classifier forward (hk_linear_fwd at 64 x 262144 -> 200) the time belongs to: the instrumented
 build (make -C hawkeye_amd/csrc lab) runs linear_skinny_kernel without its MFMAs (the LDS-DMA stream alone) and without
-the LDS-DMA inside the loop (MFMAs + fragment reads alone).      python tools/linear_lab.py"""
+the LDS-DMA inside the loop (MFMAs + fragment reads alone), without the fragment reads (MFMAs + LDS-DMA), and with the
+MFMAs and barriers alone.      python tools/linear_lab.py"""
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,7 +25,8 @@ for tag, B, J, K in (('bcnn 64 x 262144 -> 200', 64, 262144, 200), ('osme 10 x 1
     res = {}
     for rnd in range(3):
         for mode, name in ((0, 'kernel as shipped'), (1, 'no MFMAs (LDS-DMA stream + fragment reads)'), (2, 'no LDS-DMA in the loop (MFMAs + fragment reads)'),
-                           (3, 'neither (fragment reads + barriers)')):
+                           (3, 'neither (fragment reads + barriers)'), (4, 'no fragment reads (MFMAs + LDS-DMA)'),
+                           (6, 'MFMAs + barriers alone')):
             assert lib.hk_lab_set_linear_mode(mode) == 0
             for _ in range(3):
                 assert fw() == 0
