@@ -122,8 +122,13 @@ constexpr int CIN_DW_BLOCKS = 64;
 // W is written once and never read; X (401 KB per sample) streams from L2.  LDS: x_i block + two x_j blocks, rows as
 // they lie in memory (pitch HW: odd for 7 x 7 maps, conflict-free 4-byte fragment reads).
 // exp = v_exp_f32 on (S - m) log2 e (arguments <= 0): ~1e-6 relative, inside the 1e-4 budget.
+// FOUR waves per workgroup: wave = (row half, column half of every block).  B x C / 64 = 640 workgroups on 256 CUs are
+// 2.5 per CU whatever the workgroup size; as two waves of 32 rows x 64 columns a CU with three of them had two waves on
+// two of its SIMDs (makespan 2 wave-times for 1.25 of work), as four waves of 32 x 32 it has three half-size waves on
+// every SIMD (1.5): 415 -> 297 us.  The two column halves of a row meet twice through LDS: (m, l) after pass 1 (combined
+// in a fixed order) and the partial Y tiles at the end.
 template <int HW>
-__global__ __launch_bounds__(128, 2) void cin_sci_flash_kernel(const float* __restrict__ x, float* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void cin_sci_flash_kernel(const float* __restrict__ x, float* __restrict__ w,
                                                                float* __restrict__ y, int C, int B) {
     constexpr int RB = 64;                               // rows per workgroup and per column block
     constexpr int BLK = RB * HW;                         // floats of one 64-row block of X (contiguous in memory)
@@ -131,7 +136,9 @@ __global__ __launch_bounds__(128, 2) void cin_sci_flash_kernel(const float* __re
     constexpr int KS = (HW + 1) / 2;                     // MFMA k-steps of the Gram (two k per step)
     constexpr int NT2 = (HW + 31) / 32;                  // 32-column tiles of Y
     static_assert(BLK % 4 == 0 && NT2 <= 2, "64 x HW block as float4; maps up to 8 x 8");
+    static_assert(2 * NT2 * 16 * 64 <= 3 * BLK, "the partial Y tiles of two waves fit the block stages");
     __shared__ __attribute__((aligned(16))) float lds[3 * BLK + 8];
+    __shared__ float comb[2][2][32][2];                  // [column half][row half][row]: (m, l) of pass 1
     float* sI = lds;
     float* sJ = lds + BLK;                               // two stages
 
@@ -139,6 +146,7 @@ __global__ __launch_bounds__(128, 2) void cin_sci_flash_kernel(const float* __re
     int b, I;
     if (!xcd_map(blockIdx.x, B, nrb, b, I)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rw = wave & 1, cw = wave >> 1;             // this wave: rows 32 rw .. + 31, columns 32 cw .. + 31 of every block
     const int l31 = lane & 31, lh = lane >> 5;
     const float* xb = x + (long long)b * C * HW;
     const float inv_hw = 1.0f / (float)HW;
@@ -146,104 +154,107 @@ __global__ __launch_bounds__(128, 2) void cin_sci_flash_kernel(const float* __re
 
     auto load_blk = [&](int blk, float* dst) {           // 64 rows of X: BLK4 float4, coalesced
         const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)blk * BLK);
-        for (int f = tid; f < BLK4; f += 128) reinterpret_cast<f32x4*>(dst)[f] = src[f];
+        for (int f = tid; f < BLK4; f += 256) reinterpret_cast<f32x4*>(dst)[f] = src[f];
     };
     if (tid < 8) lds[3 * BLK + tid] = 0.f;               // (the last k-step of an odd HW reads one float past a block)
     load_blk(I, sI);
     load_blk(0, sJ);
     __syncthreads();
 
-    // S tile of this wave's 32 rows x 64 columns of column block `cur` (two 32x32 accumulators, transposed: lane = row)
-    const float* ai = sI + (wave * 32 + l31) * HW + lh;                       // x_i[k = 2 s + lh]
-    auto gram = [&](const float* sj, f32x16 (&acc)[2]) {
+    // S tile of this wave's 32 rows x 32 columns of column block `cur` (one 32x32 accumulator, transposed: lane = row)
+    const float* ai = sI + (rw * 32 + l31) * HW + lh;                         // x_i[k = 2 s + lh]
+    auto gram = [&](const float* sj, f32x16& acc) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        const float* bj0 = sj + l31 * HW + lh;                               // x_j[j = l31 (+ 32)][k = 2 s + lh]
-        const float* bj1 = bj0 + 32 * HW;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* bj = sj + (32 * cw + l31) * HW + lh;                    // x_j[j = 32 cw + l31][k = 2 s + lh]
 #pragma unroll
         for (int s_ = 0; s_ < KS; ++s_) {
             const bool tail = (HW & 1) && s_ == KS - 1;                      // k = HW - 1 alone: the upper lane half adds 0
             const float av = (tail && lh) ? 0.f : ai[2 * s_];
-            const float b0 = (tail && lh) ? 0.f : bj0[2 * s_];
-            const float b1 = (tail && lh) ? 0.f : bj1[2 * s_];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, av, acc[1], 0, 0, 0);
+            const float bv = (tail && lh) ? 0.f : bj[2 * s_];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
         }
     };
 
-    // ---- pass 1: row max and row sum
+    // ---- pass 1: row max and row sum over this wave's columns
     float m = -3.402823466e38f, l = 0.f;
     for (int J = 0; J < nrb; ++J) {
         const float* sj = sJ + (J & 1) * BLK;
         if (J + 1 < nrb) load_blk(J + 1, sJ + ((J + 1) & 1) * BLK);          // (the other stage: free since the last barrier)
-        f32x16 acc[2];
+        f32x16 acc;
         gram(sj, acc);
         float tm = m;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[t][r] = -(acc[t][r] * inv_hw); tm = fmaxf(tm, acc[t][r]); }
+        for (int r = 0; r < 16; ++r) { acc[r] = -(acc[r] * inv_hw); tm = fmaxf(tm, acc[r]); }
         tm = fmaxf(tm, __shfl_xor(tm, 32, 64));                              // both halves of a row agree on the running max
         float ps = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f((acc[t][r] - tm) * LOG2E);
+        for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f((acc[r] - tm) * LOG2E);
         l = l * __builtin_amdgcn_exp2f((m - tm) * LOG2E) + ps;
         m = tm;
         __syncthreads();
     }
     l += __shfl_xor(l, 32, 64);                                              // the two lane halves hold disjoint columns
+    if (lh == 0) { comb[cw][rw][l31][0] = m; comb[cw][rw][l31][1] = l; }
+    load_blk(0, sJ);
+    __syncthreads();
+    {   // the two column halves of a row, in a fixed order
+        const float m0 = comb[0][rw][l31][0], l0 = comb[0][rw][l31][1], m1 = comb[1][rw][l31][0], l1 = comb[1][rw][l31][1];
+        m = fmaxf(m0, m1);
+        l = l0 * __builtin_amdgcn_exp2f((m0 - m) * LOG2E) + l1 * __builtin_amdgcn_exp2f((m1 - m) * LOG2E);
+    }
     const float rl = 1.0f / l;
 
-    // ---- pass 2: W = exp(S - m) / l, written once; Y += W X_j
+    // ---- pass 2: W = exp(S - m) / l, written once; Y += W X_j (this wave: its 32 columns of every block)
     f32x16 yacc[NT2];
 #pragma unroll
     for (int n = 0; n < NT2; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) yacc[n][r] = 0.f;
-    load_blk(0, sJ);
-    __syncthreads();
-    float* wrow = w + ((long long)b * C + I * RB + wave * 32 + l31) * C;     // this lane's row of W
+    float* wrow = w + ((long long)b * C + I * RB + rw * 32 + l31) * C + 32 * cw;   // this lane's row of W, this wave's columns
     for (int J = 0; J < nrb; ++J) {
         const float* sj = sJ + (J & 1) * BLK;
         if (J + 1 < nrb) load_blk(J + 1, sJ + ((J + 1) & 1) * BLK);
-        f32x16 acc[2];
+        f32x16 acc;
         gram(sj, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int r = 0; r < 16; ++r) acc[r] = __builtin_amdgcn_exp2f((-(acc[r] * inv_hw) - m) * LOG2E) * rl;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_amdgcn_exp2f((-(acc[t][r] * inv_hw) - m) * LOG2E) * rl;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)                                      // columns 32 t + 8 g + 4 lh .. + 3
-                *reinterpret_cast<f32x4*>(wrow + J * RB + 32 * t + 8 * g + 4 * lh) =
-                    (f32x4){acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-        }
+        for (int g = 0; g < 4; ++g)                                          // columns 32 cw + 8 g + 4 lh .. + 3
+            *reinterpret_cast<f32x4*>(wrow + J * RB + 8 * g + 4 * lh) =
+                (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
         // Y_i += P X_j: A = P registers (i = lane & 31, k = column), B = x_j[column][n = lane & 31 (+ 32)]
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * cw + (r & 3) + 8 * (r >> 2) + 4 * lh;         // this lane half's column of register r
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;      // this lane half's column of register r
-#pragma unroll
-                for (int n = 0; n < NT2; ++n) {
-                    const int col = 32 * n + l31;
-                    const float bv = col < HW ? sj[j * HW + col] : 0.f;
-                    yacc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[t][r], bv, yacc[n], 0, 0, 0);
-                }
+            for (int n = 0; n < NT2; ++n) {
+                const int col = 32 * n + l31;
+                const float bv = col < HW ? sj[j * HW + col] : 0.f;
+                yacc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], bv, yacc[n], 0, 0, 0);
             }
+        }
         __syncthreads();
     }
+    // the partial Y of the upper column half goes through LDS (the stages are free: everybody passed the last barrier)
+    float* ybuf = lds + rw * (NT2 * 16 * 64);
+    if (cw == 1) {
+#pragma unroll
+        for (int n = 0; n < NT2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ybuf[(n * 16 + r) * 64 + lane] = yacc[n][r];
+    }
+    __syncthreads();
+    if (cw == 1) return;
     // yacc[n]: standard layout - lane & 31 = column n, registers = rows (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32
-    float* yb = y + ((long long)b * C + I * RB + wave * 32) * HW;
+    float* yb = y + ((long long)b * C + I * RB + rw * 32) * HW;
 #pragma unroll
     for (int n = 0; n < NT2; ++n) {
         const int col = 32 * n + l31;
         if (col < HW) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) yb[((r & 3) + 8 * (r >> 2) + 4 * lh) * HW + col] = yacc[n][r];
+            for (int r = 0; r < 16; ++r)
+                yb[((r & 3) + 8 * (r >> 2) + 4 * lh) * HW + col] = yacc[n][r] + ybuf[(n * 16 + r) * 64 + lane];
         }
     }
 }
@@ -253,9 +264,9 @@ static int cin_sci_flash(const float* x, float* w, float* y, int B, int C, int H
     if (C % 64 != 0 || !aligned16(x) || !aligned16(w)) return HK_ERR_UNSUPPORTED;
     const dim3 grid(xcd_grid(B, C / 64));
     switch (HW) {
-        case 49: hipLaunchKernelGGL((cin_sci_flash_kernel<49>), grid, dim3(128), 0, st, x, w, y, C, B); break;
-        case 64: hipLaunchKernelGGL((cin_sci_flash_kernel<64>), grid, dim3(128), 0, st, x, w, y, C, B); break;
-        case 36: hipLaunchKernelGGL((cin_sci_flash_kernel<36>), grid, dim3(128), 0, st, x, w, y, C, B); break;
+        case 49: hipLaunchKernelGGL((cin_sci_flash_kernel<49>), grid, dim3(256), 0, st, x, w, y, C, B); break;
+        case 64: hipLaunchKernelGGL((cin_sci_flash_kernel<64>), grid, dim3(256), 0, st, x, w, y, C, B); break;
+        case 36: hipLaunchKernelGGL((cin_sci_flash_kernel<36>), grid, dim3(256), 0, st, x, w, y, C, B); break;
         default: return HK_ERR_UNSUPPORTED;
     }
     HK_LAUNCH_CHECK();

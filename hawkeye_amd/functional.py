@@ -542,7 +542,7 @@ def osme_scale(x, m):
 # --------------------------------------------------------------------- generic
 # --------------------------------------------------------------------- CIN channel interaction
 # hk_cin_sci_fwd: for C % 64 == 0 and 7x7 / 8x8 / 6x6 maps ONE kernel (cin.hip: two passes over the column blocks, softmax
-# statistics first, then W written once and consumed from registers by the second product) - 415 us at the plugin's shape
+# statistics first, then W written once and consumed from registers by the second product) - 297 us at the plugin's shape
 # (B = 20, C = 2048, HW = 49) against 486 us for rocBLAS bmm + softmax + bmm (profiles/r3_lab_*.json).  Other shapes run
 # a three-kernel chain on the generic tile that is slower than the library (706 us at that shape): the forward then
 # takes the library GEMMs; W is produced and saved either way (the contrastive branch and the backward kernels consume
