@@ -69,6 +69,44 @@ struct LdAbsDiff {
     }
 };
 
+// The same operand for C % 64 == 0 and a 16-byte aligned W: two unconditional 16-byte requests (hk_bgemm.h, LdPlainV), the
+// arithmetic applied when the tile goes to LDS.
+struct LdAbsDiffV {
+    struct Raw { float4 a, o; };
+    const float* p;
+    const float* wt;
+    int C, B;
+    float wb;
+    __device__ __forceinline__ void begin(int b, int, int) { wb = wt[b]; }
+    __device__ __forceinline__ void finish(int, int, int, int, float*) {}
+    __device__ __forceinline__ Raw ldraw(int b, int r, int c) const {
+        const int pb = (b + B / 2) % B;
+        Raw x;
+        x.a = *reinterpret_cast<const float4*>(p + ((long long)b * C + r) * C + c);
+        x.o = *reinterpret_cast<const float4*>(p + ((long long)pb * C + r) * C + c);
+        return x;
+    }
+    __device__ __forceinline__ float4 cook(const Raw& x) const {
+        return make_float4(fabsf(x.a.x - wb * x.o.x), fabsf(x.a.y - wb * x.o.y), fabsf(x.a.z - wb * x.o.z),
+                           fabsf(x.a.w - wb * x.o.w));
+    }
+};
+
+// C x C by C x HW products on tiles that need no bounds branch (every CIN backbone: C = 2048)
+static inline bool cin_inside(int C, const void* w) {     // (knob bcnn_generic = 1 keeps the loaders with bounds checks: A/B)
+    return C % 64 == 0 && aligned16(w) && tuning().bcnn_generic != 1;
+}
+static inline LdPlainV cin_mat(const float* w, int C) {
+    LdPlainV l;
+    l.p = w; l.bs = (long long)C * C; l.ld = C;
+    return l;
+}
+static inline LdPlainC cin_map(const float* x, int C, int HW) {
+    LdPlainC l;
+    l.p = x; l.bs = (long long)C * HW; l.ld = HW; l.C = HW;
+    return l;
+}
+
 // dW[b] (+)= sign(D_b) (.) dWc[b] - w_pb sign(D_pb) (.) dWc[pb],  D_b = W[b] - w_b W[pb]   (sign(0) = 0: torch's abs)
 // dwpart[b][blk] = - sum over this block's elements of sign(D_b) dWc[b] W[pb]
 __global__ __launch_bounds__(256) void cin_cci_dw_kernel(const float* __restrict__ W, const float* __restrict__ wt,
@@ -312,10 +350,19 @@ extern "C" int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, f
     const LdPlain lw = make_plain(w, sw, C, C, C);
     // dW = dY X^T (+ extra): 335 MB of result for 49-deep products - the tile leaves as 16-byte stores where it can
     const EpAffine epw = make_affine(dwbuf, sw, C, 1.f, nullptr, has_extra ? 1.f : 0.f, 0.f);
-    if (C % 4 == 0 && aligned16(dwbuf)) HK_TRY((bgemm_launch<true, true, false, true>(ldy, lx, epw, C, C, HW, B, st)));
+    if (cin_inside(C, dwbuf)) HK_TRY((bgemm_launch<true, true, false, true>(cin_map(dy, C, HW), cin_map(x, C, HW), epw, C, C, HW, B, st)));
+    else if (C % 4 == 0 && aligned16(dwbuf)) HK_TRY((bgemm_launch<true, true, false, true>(ldy, lx, epw, C, C, HW, B, st)));
     else HK_TRY((bgemm_launch<true, true>(ldy, lx, epw, C, C, HW, B, st)));
     hipLaunchKernelGGL(cin_softmax_bwd_rows_kernel, dim3((unsigned)B * C), dim3(256), 0, st, w, dwbuf, C);
     HK_LAUNCH_CHECK();
+    if (cin_inside(C, w) && aligned16(dwbuf)) {
+        // (dG + dG^T) X as two products over dG - the transposed half of LdSym is a 4-byte gather with an 8 KB stride
+        const LdPlainC cx = cin_map(x, C, HW), cdy = cin_map(dy, C, HW);
+        HK_TRY((bgemm_launch<false, false, true>(cin_mat(w, C), cdy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));
+        const EpAffine acc = make_affine(dx, sx, HW, 1.0f / (float)HW, nullptr, 1.f, 0.f);
+        HK_TRY((bgemm_launch<true, false, true>(cin_mat(dwbuf, C), cx, acc, C, HW, C, B, st)));
+        return bgemm_launch<false, false, true>(cin_mat(dwbuf, C), cx, acc, C, HW, C, B, st);
+    }
     HK_TRY((bgemm_launch<false, false, true>(lw, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // W^T dY
     LdSym ls;
     ls.p = dwbuf; ls.bs = sw; ls.d = C;
@@ -325,6 +372,12 @@ extern "C" int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, f
 extern "C" int hk_cin_cci_fwd(const float* x, const float* w, const float* wt, float* y, int B, int C, int HW,
                               hk_stream_t stream) {
     if (!x || !w || !wt || !y || B <= 0 || (B & 1) || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    if (cin_inside(C, w)) {
+        LdAbsDiffV lv;
+        lv.p = w; lv.wt = wt; lv.C = C; lv.B = B; lv.wb = 0.f;
+        return bgemm_launch<true, false, true>(lv, cin_map(x, C, HW), make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f),
+                                               C, HW, C, B, (hipStream_t)stream);
+    }
     LdAbsDiff la;
     la.p = w; la.wt = wt; la.C = C; la.B = B;
     const LdPlain lx = make_plain(x, (long long)C * HW, HW, C, HW);
@@ -349,11 +402,18 @@ extern "C" int hk_cin_cci_bwd(const float* x, const float* w, const float* wt, c
     const LdPlain lx = make_plain(x, sx, HW, C, HW);
     const LdPlain ldy = make_plain(dy, sx, HW, C, HW);
     const EpAffine epw = make_affine(dwc, sw, C, 1.f, nullptr, 0.f, 0.f);
-    if (C % 4 == 0 && aligned16(dwc)) HK_TRY((bgemm_launch<true, true, false, true>(ldy, lx, epw, C, C, HW, B, st)));
+    if (cin_inside(C, dwc)) HK_TRY((bgemm_launch<true, true, false, true>(cin_map(dy, C, HW), cin_map(x, C, HW), epw, C, C, HW, B, st)));
+    else if (C % 4 == 0 && aligned16(dwc)) HK_TRY((bgemm_launch<true, true, false, true>(ldy, lx, epw, C, C, HW, B, st)));
     else HK_TRY((bgemm_launch<true, true>(ldy, lx, epw, C, C, HW, B, st)));
     LdAbsDiff la;
     la.p = w; la.wt = wt; la.C = C; la.B = B;
-    HK_TRY((bgemm_launch<false, false, true>(la, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // Wc^T dY
+    if (cin_inside(C, w)) {
+        LdAbsDiffV lv;
+        lv.p = w; lv.wt = wt; lv.C = C; lv.B = B; lv.wb = 0.f;
+        HK_TRY((bgemm_launch<false, false, true>(lv, cin_map(dy, C, HW), make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));
+    } else {
+        HK_TRY((bgemm_launch<false, false, true>(la, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // Wc^T dY
+    }
     hipLaunchKernelGGL(cin_cci_dw_kernel, dim3(CIN_DW_BLOCKS, B), dim3(256), 0, st, w, wt, (const float*)dwc, dw, dwpart, C, B,
                        CIN_DW_BLOCKS);
     HK_LAUNCH_CHECK();

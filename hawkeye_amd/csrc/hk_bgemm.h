@@ -17,6 +17,8 @@
 // (ds_read_b32, 32 consecutive floats per half-wave).  The summation order over
 // k is therefore a fixed permutation of 0..K-1: deterministic, fp32 exact fma.
 #pragma once
+#include <type_traits>
+
 #include "hk_common.h"
 
 namespace hk {
@@ -47,6 +49,58 @@ struct LdPlain {
         }
         return v;
     }
+};
+
+// Branch-free variants for operands whose requested tiles lie INSIDE the matrix (CIN: C % 64 == 0, K = C).  A load
+// behind a bounds branch costs more than the branch: the compiler cannot count how many loads a later, conditional
+// request has put in flight, so every wait on an earlier request becomes s_waitcnt vmcnt(0) - with the loaders above the
+// DEEP kernel waited for chunk c + 2 before it stored chunk c + 1 (one chunk of real prefetch, ~3 us per 32-deep chunk).
+// LdPlainV: every float4 is inside the operand and 16-byte aligned.  LdPlainC: rows inside, columns clamped to C - 1 and
+// zero-filled afterwards - four unconditional 4-byte loads (C x 49 maps: pitch 49).
+struct LdPlainV {
+    const float* p;
+    long long bs;
+    int ld;
+    __device__ __forceinline__ void begin(int, int, int) {}
+    __device__ __forceinline__ void finish(int, int, int, int, float*) {}
+    __device__ __forceinline__ float4 ld4(int b, int r, int c) const {
+        return *reinterpret_cast<const float4*>(p + (long long)b * bs + (long long)r * ld + c);
+    }
+};
+struct LdPlainC {
+    struct Raw { float v[4]; int n; };               // n: how many of the four columns exist
+    const float* p;
+    long long bs;
+    int ld, C;
+    __device__ __forceinline__ void begin(int, int, int) {}
+    __device__ __forceinline__ void finish(int, int, int, int, float*) {}
+    __device__ __forceinline__ Raw ldraw(int b, int r, int c) const {
+        const float* q = p + (long long)b * bs + (long long)r * ld;
+        Raw x;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x.v[t] = q[c + t < C ? c + t : C - 1];
+        x.n = C - c;
+        return x;
+    }
+    __device__ __forceinline__ float4 cook(const Raw& x) const {
+        return make_float4(x.n > 0 ? x.v[0] : 0.f, x.n > 1 ? x.v[1] : 0.f, x.n > 2 ? x.v[2] : 0.f, x.n > 3 ? x.v[3] : 0.f);
+    }
+};
+
+// A loader may split ld4 into the memory request (`Raw ldraw(b, r, c)`, kept in registers while in flight) and the
+// arithmetic on it (`float4 cook(Raw)`, applied when the tile goes to LDS) - otherwise arithmetic inside ld4 waits for
+// the data where it was requested.  Loaders without a `Raw` member are used as they are.
+template <class L, class = void>
+struct LdTraits {
+    using Raw = float4;
+    static __device__ __forceinline__ Raw ld(L& l, int b, int r, int c) { return l.ld4(b, r, c); }
+    static __device__ __forceinline__ float4 cook(const L&, const Raw& x) { return x; }
+};
+template <class L>
+struct LdTraits<L, std::void_t<typename L::Raw>> {
+    using Raw = typename L::Raw;
+    static __device__ __forceinline__ Raw ld(L& l, int b, int r, int c) { return l.ldraw(b, r, c); }
+    static __device__ __forceinline__ float4 cook(const L& l, const Raw& x) { return l.cook(x); }
 };
 
 // Plain operand minus a per-(batch,row) scalar (spatial centring for the
@@ -133,8 +187,10 @@ struct EpAffine {
 // while chunk c is computed (two register sets, loop unrolled by two, no branch around a load or an LDS store: the
 // chunk index is clamped instead, a redundant last load / store is harmless) - with one chunk of prefetch a workgroup
 // waited ~3.5 us per 32-deep chunk and 2.5 resident workgroups per CU did not cover it; measured on CIN's four
-// products: 242 -> 200, 440 -> 407, 379 -> 352, 376 -> 355 us - the rest is the access pattern (128-byte runs of 64
-// rows 8 KB apart per chunk: ~1.8 TB/s).
+// products: 242 -> 200, 440 -> 407, 379 -> 352, 376 -> 355 us.  What was left (~1.8 TB/s) was NOT the access pattern: the
+// loaders' bounds branches made every wait a vmcnt(0) (see LdPlainV above) - with branch-free loaders the same kernel
+// streams |W - w W'| X at 4.1 TB/s (344 -> 163 us).  The loop walks chunk PAIRS without a branch inside (the launcher takes
+// the plain kernel for an odd chunk count).
 // VEPI = true (EP = EpAffine, not transposed, ld % 4 == 0, 16-byte aligned result, N % 4 == 0 - large results with a
 // short K: CIN's dW = dY X^T writes 335 MB for 49-deep products): the tile leaves through LDS as 16-byte stores of
 // whole 256-byte rows instead of one 4-byte store per accumulator register (128-byte runs): same values, same order of
@@ -184,19 +240,21 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 
-    float4 ra[NLA], rb[NLB];
-    float4 ra1[DEEP ? NLA : 1], rb1[DEEP ? NLB : 1];     // DEEP: the second register set
+    using TA = LdTraits<AL>;
+    using TB = LdTraits<BL>;
+    typename TA::Raw ra[NLA], ra1[DEEP ? NLA : 1];       // DEEP: the second register set
+    typename TB::Raw rb[NLB], rb1[DEEP ? NLB : 1];
 
 // (macro-local names carry a trailing underscore: the argument expressions mention the caller's `c`)
 #define HK_GLOAD_TO(RA_, RB_, k0)                                                                      \
     do {                                                                                               \
         _Pragma("unroll") for (int u = 0; u < NLA; ++u) {                                              \
             const int f_ = tid + 256 * u, r_ = f_ / A4, c_ = f_ % A4;                                       \
-            RA_[u] = A_KC ? al.ld4(b, m0 + r_, (k0) + 4 * c_) : al.ld4(b, (k0) + r_, m0 + 4 * c_);         \
+            RA_[u] = A_KC ? TA::ld(al, b, m0 + r_, (k0) + 4 * c_) : TA::ld(al, b, (k0) + r_, m0 + 4 * c_); \
         }                                                                                              \
         _Pragma("unroll") for (int u = 0; u < NLB; ++u) {                                              \
             const int f_ = tid + 256 * u, r_ = f_ / B4, c_ = f_ % B4;                                       \
-            RB_[u] = B_KC ? bl.ld4(b, n0 + r_, (k0) + 4 * c_) : bl.ld4(b, (k0) + r_, n0 + 4 * c_);         \
+            RB_[u] = B_KC ? TB::ld(bl, b, n0 + r_, (k0) + 4 * c_) : TB::ld(bl, b, (k0) + r_, n0 + 4 * c_); \
         }                                                                                              \
     } while (0)
 #define HK_GLOAD(k0) HK_GLOAD_TO(ra, rb, k0)
@@ -207,11 +265,11 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
         float* Bs_ = As_ + SA;                                                                         \
         _Pragma("unroll") for (int u = 0; u < NLA; ++u) {                                              \
             const int f_ = tid + 256 * u, r_ = f_ / A4, c_ = f_ % A4;                                       \
-            *reinterpret_cast<float4*>(&As_[r_ * PA + 4 * c_]) = RA_[u];                                 \
+            *reinterpret_cast<float4*>(&As_[r_ * PA + 4 * c_]) = TA::cook(al, RA_[u]);                   \
         }                                                                                              \
         _Pragma("unroll") for (int u = 0; u < NLB; ++u) {                                              \
             const int f_ = tid + 256 * u, r_ = f_ / B4, c_ = f_ % B4;                                       \
-            *reinterpret_cast<float4*>(&Bs_[r_ * PB + 4 * c_]) = RB_[u];                                 \
+            *reinterpret_cast<float4*>(&Bs_[r_ * PB + 4 * c_]) = TB::cook(bl, RB_[u]);                   \
         }                                                                                              \
     } while (0)
 #define HK_SSTORE(buf) HK_SSTORE_FROM(ra, rb, buf)
@@ -227,13 +285,13 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
     for (int cc = 0; cc < nloop; ++cc)
 #pragma unroll
     for (int half = 0; half < (DEEP ? 2 : 1); ++half) {
-        const int c = DEEP ? 2 * cc + half : cc;
-        if (DEEP && c >= nk) break;                      // (odd chunk count: the pair's second half does not exist)
+        const int c = DEEP ? 2 * cc + half : cc;         // (DEEP: the launcher guarantees an even chunk count)
         const int cur = c & 1;
         if (DEEP) {                                      // chunk c + 2 into the set whose content (chunk c) is in LDS
             const int cn = c + 2 < nk ? c + 2 : nk - 1;
             if (half == 0) HK_GLOAD_TO(ra, rb, cn * BK);
             else HK_GLOAD_TO(ra1, rb1, cn * BK);
+            __builtin_amdgcn_sched_barrier(0);           // the requests stay here, ahead of the chunk's MFMAs
         } else {
             if (c + 1 < nk) HK_GLOAD((c + 1) * BK);
         }
@@ -341,8 +399,12 @@ template <bool A_KC, bool B_KC, bool DEEP = false, bool VEPI = false, class AL, 
 static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-    hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP, DEEP, VEPI>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl, ep,
-                       M, N, K, nb, tm, tn);
+    if (DEEP && ((K + 31) / 32) % 2 != 0)                // the two-chunk pipeline walks chunk PAIRS, no branch inside
+        hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP, false, VEPI>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl,
+                           ep, M, N, K, nb, tm, tn);
+    else
+        hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP, DEEP, VEPI>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl,
+                           ep, M, N, K, nb, tm, tn);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
