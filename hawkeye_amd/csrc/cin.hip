@@ -101,6 +101,11 @@ static inline LdPlainV cin_mat(const float* w, int C) {
     l.p = w; l.bs = (long long)C * C; l.ld = C;
     return l;
 }
+static inline LdPlainN cin_cols(const float* x, int C, int HW) {          // a C x HW map as the K x N operand
+    LdPlainN l;
+    l.p = x; l.bs = (long long)C * HW; l.ld = HW; l.C = HW;
+    return l;
+}
 static inline LdPlainC cin_map(const float* x, int C, int HW) {
     LdPlainC l;
     l.p = x; l.bs = (long long)C * HW; l.ld = HW; l.C = HW;
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(64) void cin_cci_dw_reduce_kernel(const float* __re
 }
 
 constexpr int CIN_DW_BLOCKS = 64;
+constexpr int CIN_SETS = 2;            // chunks of a streamed C x C operand requested ahead per workgroup (hk_bgemm.h, DEEP; 4 measured no faster: 174 / 590 / 1022 us against 168 / 580 / 1003 - the products are then paced by the matrix pipe, 64-column tiles for 49 columns)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // SCI forward in ONE kernel (round 3).  The chain above - Gram -> row softmax -> W X on the generic tile - writes S, reads
@@ -334,7 +340,7 @@ extern "C" int hk_cin_sci_fwd(const float* x, float* w, float* y, int B, int C, 
     hipLaunchKernelGGL(cin_softmax_rows_kernel, dim3((unsigned)B * C), dim3(256), 0, st, w, C);
     HK_LAUNCH_CHECK();
     const LdPlain lw = make_plain(w, (long long)C * C, C, C, C);
-    return bgemm_launch<true, false, true>(lw, lx, make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B,
+    return bgemm_launch<true, false, CIN_SETS>(lw, lx, make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B,
                                      st);                                                        // Y = W X       :34
 }
 
@@ -350,23 +356,23 @@ extern "C" int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, f
     const LdPlain lw = make_plain(w, sw, C, C, C);
     // dW = dY X^T (+ extra): 335 MB of result for 49-deep products - the tile leaves as 16-byte stores where it can
     const EpAffine epw = make_affine(dwbuf, sw, C, 1.f, nullptr, has_extra ? 1.f : 0.f, 0.f);
-    if (cin_inside(C, dwbuf)) HK_TRY((bgemm_launch<true, true, false, true>(cin_map(dy, C, HW), cin_map(x, C, HW), epw, C, C, HW, B, st)));
-    else if (C % 4 == 0 && aligned16(dwbuf)) HK_TRY((bgemm_launch<true, true, false, true>(ldy, lx, epw, C, C, HW, B, st)));
+    if (cin_inside(C, dwbuf)) HK_TRY((bgemm_launch<true, true, 0, true>(cin_map(dy, C, HW), cin_map(x, C, HW), epw, C, C, HW, B, st)));
+    else if (C % 4 == 0 && aligned16(dwbuf)) HK_TRY((bgemm_launch<true, true, 0, true>(ldy, lx, epw, C, C, HW, B, st)));
     else HK_TRY((bgemm_launch<true, true>(ldy, lx, epw, C, C, HW, B, st)));
     hipLaunchKernelGGL(cin_softmax_bwd_rows_kernel, dim3((unsigned)B * C), dim3(256), 0, st, w, dwbuf, C);
     HK_LAUNCH_CHECK();
     if (cin_inside(C, w) && aligned16(dwbuf)) {
         // (dG + dG^T) X as two products over dG - the transposed half of LdSym is a 4-byte gather with an 8 KB stride
-        const LdPlainC cx = cin_map(x, C, HW), cdy = cin_map(dy, C, HW);
-        HK_TRY((bgemm_launch<false, false, true>(cin_mat(w, C), cdy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));
+        const LdPlainN cx = cin_cols(x, C, HW), cdy = cin_cols(dy, C, HW);
+        HK_TRY((bgemm_launch<false, false, CIN_SETS>(cin_mat(w, C), cdy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));
         const EpAffine acc = make_affine(dx, sx, HW, 1.0f / (float)HW, nullptr, 1.f, 0.f);
-        HK_TRY((bgemm_launch<true, false, true>(cin_mat(dwbuf, C), cx, acc, C, HW, C, B, st)));
-        return bgemm_launch<false, false, true>(cin_mat(dwbuf, C), cx, acc, C, HW, C, B, st);
+        HK_TRY((bgemm_launch<true, false, CIN_SETS>(cin_mat(dwbuf, C), cx, acc, C, HW, C, B, st)));
+        return bgemm_launch<false, false, CIN_SETS>(cin_mat(dwbuf, C), cx, acc, C, HW, C, B, st);
     }
-    HK_TRY((bgemm_launch<false, false, true>(lw, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // W^T dY
+    HK_TRY((bgemm_launch<false, false, CIN_SETS>(lw, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // W^T dY
     LdSym ls;
     ls.p = dwbuf; ls.bs = sw; ls.d = C;
-    return bgemm_launch<true, false, true>(ls, lx, make_affine(dx, sx, HW, 1.0f / (float)HW, nullptr, 1.f, 0.f), C, HW, C, B, st);
+    return bgemm_launch<true, false, CIN_SETS>(ls, lx, make_affine(dx, sx, HW, 1.0f / (float)HW, nullptr, 1.f, 0.f), C, HW, C, B, st);
 }
 
 extern "C" int hk_cin_cci_fwd(const float* x, const float* w, const float* wt, float* y, int B, int C, int HW,
@@ -375,13 +381,13 @@ extern "C" int hk_cin_cci_fwd(const float* x, const float* w, const float* wt, f
     if (cin_inside(C, w)) {
         LdAbsDiffV lv;
         lv.p = w; lv.wt = wt; lv.C = C; lv.B = B; lv.wb = 0.f;
-        return bgemm_launch<true, false, true>(lv, cin_map(x, C, HW), make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f),
+        return bgemm_launch<true, false, CIN_SETS>(lv, cin_cols(x, C, HW), make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f),
                                                C, HW, C, B, (hipStream_t)stream);
     }
     LdAbsDiff la;
     la.p = w; la.wt = wt; la.C = C; la.B = B;
     const LdPlain lx = make_plain(x, (long long)C * HW, HW, C, HW);
-    return bgemm_launch<true, false, true>(la, lx, make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B,
+    return bgemm_launch<true, false, CIN_SETS>(la, lx, make_affine(y, (long long)C * HW, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B,
                                      (hipStream_t)stream);                                       // :52-54
 }
 
@@ -402,17 +408,17 @@ extern "C" int hk_cin_cci_bwd(const float* x, const float* w, const float* wt, c
     const LdPlain lx = make_plain(x, sx, HW, C, HW);
     const LdPlain ldy = make_plain(dy, sx, HW, C, HW);
     const EpAffine epw = make_affine(dwc, sw, C, 1.f, nullptr, 0.f, 0.f);
-    if (cin_inside(C, dwc)) HK_TRY((bgemm_launch<true, true, false, true>(cin_map(dy, C, HW), cin_map(x, C, HW), epw, C, C, HW, B, st)));
-    else if (C % 4 == 0 && aligned16(dwc)) HK_TRY((bgemm_launch<true, true, false, true>(ldy, lx, epw, C, C, HW, B, st)));
+    if (cin_inside(C, dwc)) HK_TRY((bgemm_launch<true, true, 0, true>(cin_map(dy, C, HW), cin_map(x, C, HW), epw, C, C, HW, B, st)));
+    else if (C % 4 == 0 && aligned16(dwc)) HK_TRY((bgemm_launch<true, true, 0, true>(ldy, lx, epw, C, C, HW, B, st)));
     else HK_TRY((bgemm_launch<true, true>(ldy, lx, epw, C, C, HW, B, st)));
     LdAbsDiff la;
     la.p = w; la.wt = wt; la.C = C; la.B = B;
     if (cin_inside(C, w)) {
         LdAbsDiffV lv;
         lv.p = w; lv.wt = wt; lv.C = C; lv.B = B; lv.wb = 0.f;
-        HK_TRY((bgemm_launch<false, false, true>(lv, cin_map(dy, C, HW), make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));
+        HK_TRY((bgemm_launch<false, false, CIN_SETS>(lv, cin_cols(dy, C, HW), make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));
     } else {
-        HK_TRY((bgemm_launch<false, false, true>(la, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // Wc^T dY
+        HK_TRY((bgemm_launch<false, false, CIN_SETS>(la, ldy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));  // Wc^T dY
     }
     hipLaunchKernelGGL(cin_cci_dw_kernel, dim3(CIN_DW_BLOCKS, B), dim3(256), 0, st, w, wt, (const float*)dwc, dw, dwpart, C, B,
                        CIN_DW_BLOCKS);

@@ -87,6 +87,22 @@ struct LdPlainC {
     }
 };
 
+// LdPlainN: as LdPlainC without the zero fill - for an operand whose clamped columns are OUTPUT columns beyond N (B given
+// as K x N): what lands there is never stored, and with no arithmetic on the loaded registers nothing waits for them before
+// the tile goes to LDS.
+struct LdPlainN {
+    const float* p;
+    long long bs;
+    int ld, C;
+    __device__ __forceinline__ void begin(int, int, int) {}
+    __device__ __forceinline__ void finish(int, int, int, int, float*) {}
+    __device__ __forceinline__ float4 ld4(int b, int r, int c) const {
+        const float* q = p + (long long)b * bs + (long long)r * ld;
+        const int l = C - 1;
+        return make_float4(q[c < l ? c : l], q[c + 1 < l ? c + 1 : l], q[c + 2 < l ? c + 2 : l], q[c + 3 < l ? c + 3 : l]);
+    }
+};
+
 // A loader may split ld4 into the memory request (`Raw ldraw(b, r, c)`, kept in registers while in flight) and the
 // arithmetic on it (`float4 cook(Raw)`, applied when the tile goes to LDS) - otherwise arithmetic inside ld4 waits for
 // the data where it was requested.  Loaders without a `Raw` member are used as they are.
@@ -195,7 +211,7 @@ struct EpAffine {
 // short K: CIN's dW = dY X^T writes 335 MB for 49-deep products): the tile leaves through LDS as 16-byte stores of
 // whole 256-byte rows instead of one 4-byte store per accumulator register (128-byte runs): same values, same order of
 // operations per element.
-template <bool A_KC, bool B_KC, class AL, class BL, class EP, bool DEEP = false, bool VEPI = false>
+template <bool A_KC, bool B_KC, class AL, class BL, class EP, int DEEP = 0, bool VEPI = false>
 __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int nb,
                                                      int tilesM, int tilesN) {
     constexpr int T = 1, BKT = 32;                       // (64-deep chunks with DEEP: 1.3-1.7x SLOWER on the CIN products)
@@ -242,8 +258,12 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
 
     using TA = LdTraits<AL>;
     using TB = LdTraits<BL>;
-    typename TA::Raw ra[NLA], ra1[DEEP ? NLA : 1];       // DEEP: the second register set
-    typename TB::Raw rb[NLB], rb1[DEEP ? NLB : 1];
+    constexpr int NSET = DEEP ? DEEP : 1;                // register sets of requested chunks (DEEP: 2 or 4)
+    static_assert(DEEP == 0 || DEEP == 2 || DEEP == 4, "an even number of sets: the LDS stage of a chunk is then compile-time");
+    typename TA::Raw ras[NSET][NLA];
+    typename TB::Raw rbs[NSET][NLB];
+    auto& ra = ras[0];
+    auto& rb = rbs[0];
 
 // (macro-local names carry a trailing underscore: the argument expressions mention the caller's `c`)
 #define HK_GLOAD_TO(RA_, RB_, k0)                                                                      \
@@ -276,21 +296,21 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
 
     const int nk = (K + BK - 1) / BK;
     HK_GLOAD(0);
-    if (DEEP) HK_GLOAD_TO(ra1, rb1, (nk > 1 ? 1 : 0) * BK);   // chunks 0 and 1 in flight before the first wait
+#pragma unroll
+    for (int h = 1; h < NSET; ++h) HK_GLOAD_TO(ras[h], rbs[h], (h < nk ? h : nk - 1) * BK);   // chunks 0 .. NSET - 1 in flight
     HK_SSTORE(0);
     __syncthreads();
 
-    // DEEP: the loop counts chunk pairs; `half` 0 / 1 = even / odd chunk of the pair (compile-time register sets)
-    const int nloop = DEEP ? (nk + 1) / 2 : nk;
+    // DEEP: the loop counts groups of NSET chunks; chunk c = NSET cc + half lives in register set `half` (compile-time)
+    const int nloop = DEEP ? nk / NSET : nk;             // (DEEP: the launcher guarantees nk % NSET == 0)
     for (int cc = 0; cc < nloop; ++cc)
 #pragma unroll
-    for (int half = 0; half < (DEEP ? 2 : 1); ++half) {
-        const int c = DEEP ? 2 * cc + half : cc;         // (DEEP: the launcher guarantees an even chunk count)
+    for (int half = 0; half < NSET; ++half) {
+        const int c = DEEP ? NSET * cc + half : cc;
         const int cur = c & 1;
-        if (DEEP) {                                      // chunk c + 2 into the set whose content (chunk c) is in LDS
-            const int cn = c + 2 < nk ? c + 2 : nk - 1;
-            if (half == 0) HK_GLOAD_TO(ra, rb, cn * BK);
-            else HK_GLOAD_TO(ra1, rb1, cn * BK);
+        if (DEEP) {                                      // chunk c + NSET into the set whose content (chunk c) is in LDS
+            const int cn = c + NSET < nk ? c + NSET : nk - 1;
+            HK_GLOAD_TO(ras[half], rbs[half], cn * BK);
             __builtin_amdgcn_sched_barrier(0);           // the requests stay here, ahead of the chunk's MFMAs
         } else {
             if (c + 1 < nk) HK_GLOAD((c + 1) * BK);
@@ -347,8 +367,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
         }
 #undef HK_FRAG
         if (DEEP) {                                      // chunk c + 1 (requested a chunk ago) to the other stage; behind the
-            if (half == 0) HK_SSTORE_FROM(ra1, rb1, cur ^ 1);    // last chunk this rewrites a stage nobody reads again
-            else HK_SSTORE_FROM(ra, rb, cur ^ 1);
+            HK_SSTORE_FROM(ras[(half + 1) % NSET], rbs[(half + 1) % NSET], cur ^ 1);   // last chunk: a stage nobody reads again
         } else {
             if (c + 1 < nk) HK_SSTORE(cur ^ 1);
         }
@@ -395,12 +414,12 @@ __global__ __launch_bounds__(256) void bgemm_kernel(AL al, BL bl, EP ep, int M, 
     al.finish(b, tm, tn, tilesM, lds);
 }
 
-template <bool A_KC, bool B_KC, bool DEEP = false, bool VEPI = false, class AL, class BL, class EP>
+template <bool A_KC, bool B_KC, int DEEP = 0, bool VEPI = false, class AL, class BL, class EP>
 static inline int bgemm_launch(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int nb, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return HK_ERR_BAD_ARG;
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-    if (DEEP && ((K + 31) / 32) % 2 != 0)                // the two-chunk pipeline walks chunk PAIRS, no branch inside
-        hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP, false, VEPI>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl,
+    if (DEEP && ((K + 31) / 32) % (DEEP ? DEEP : 1) != 0)   // the pipeline walks groups of DEEP chunks, no branch inside
+        hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP, 0, VEPI>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl,
                            ep, M, N, K, nb, tm, tn);
     else
         hipLaunchKernelGGL((bgemm_kernel<A_KC, B_KC, AL, BL, EP, DEEP, VEPI>), dim3(xcd_grid(nb, tm * tn)), dim3(256), 0, st, al, bl,
