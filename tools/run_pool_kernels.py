@@ -65,7 +65,9 @@ if mode == 'all':                  # the other heads at the BASELINE config shap
     parts = torch.randn(32, 2, 1024, device=dev, requires_grad=True)
     tg = torch.arange(16, device=dev).repeat_interleave(2)
     xb16 = xb.detach()[:16].clone().requires_grad_(True)                          # configs/CBCNN_S2.yaml's batch
-    xci = torch.relu(torch.randn(20, 2048, 49, device=dev))                        # CIN SCI (CIN.py:31-34) at its config
+    xci = torch.relu(torch.randn(20, 2048, 49, device=dev)).requires_grad_(True)   # CIN channel interaction (CIN.py:24-60) at its config
+    wci = torch.randn(20, device=dev, requires_grad=True)
+    gci = torch.randn(20, 2048, 49, device=dev)
     gl = torch.randn(64, 200, device=dev)
     dyl, dwl, dbl = torch.empty_like(yl), torch.empty_like(wl), torch.empty_like(bl)
     for _ in range(reps):
@@ -73,7 +75,9 @@ if mode == 'all':                  # the other heads at the BASELINE config shap
         (F.compact_bilinear_pool(xb, plan) * wc).sum().backward()
         xb16.grad = None
         (F.compact_bilinear_pool(xb16, plan) * wc[:16]).sum().backward()
-        F.cin_sci(xci)
+        xci.grad = None
+        yci, wsci = F.cin_sci(xci)
+        ((yci * gci).sum() + (F.cin_cci(wsci, xci, wci) * gci).sum()).backward()   # SCI + CCI forward and both backward chains
         lib.hk_linear_bwd(ptr(yl), ptr(wl), ptr(gl), ptr(dyl), ptr(dwl), ptr(dbl), 64, 262144, 200, stream())
         xb.grad = None
         (F.bilinear_pool(xb, signed_sqrt=True) * ws).sum().backward()
