@@ -303,6 +303,169 @@ __global__ __launch_bounds__(256, 3) void cin_sci_flash_kernel(const float* __re
     }
 }
 
+// SCI backward, the row-owned part in ONE kernel (same structure as cin_sci_flash_kernel; rows i of one sample per
+// workgroup, four waves = row half x column half):
+//   dW_ij = dY_i . X_j (+ E_ij, the gradient that reaches W from the contrastive branch)   recomputed per tile, never stored
+//   pass 1   t_i = sum_j W_ij dW_ij
+//   pass 2   dG_ij = -W_ij (dW_ij - t_i)  written once (over E), and dx_i += (dG X)_i / HW from the accumulator registers
+// instead of dW = dY X^T (335 MB written, E read), the row softmax backward (670 MB read, 335 MB written) and the product
+// dG X (335 MB read): the chain had two 335 MB results, each at the ~1.5 TB/s such a write gets here.  W and E are read
+// twice (16-byte requests issued ahead of the tile's MFMAs).  dx must hold W^T dY already; dG^T X is added afterwards by
+// the streamed product.
+template <int HW, bool EXTRA>
+__global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ dy, float* dg,
+                                                                   float* __restrict__ dx, int C, int B) {
+    constexpr int RB = 64;
+    constexpr int BLK = RB * HW;
+    constexpr int BLK4 = BLK / 4;
+    constexpr int KS = (HW + 1) / 2;
+    constexpr int NT2 = (HW + 31) / 32;
+    static_assert(BLK % 4 == 0 && NT2 <= 2, "64 x HW block as float4; maps up to 8 x 8");
+    static_assert(2 * NT2 * 16 * 64 <= 3 * BLK, "the partial dx tiles of two waves fit the block stages");
+    __shared__ __attribute__((aligned(16))) float lds[3 * BLK + 8];
+    __shared__ float comb[2][2][32];
+    float* sI = lds;
+    float* sJ = lds + BLK;
+
+    const int nrb = C / RB;
+    int b, I;
+    if (!xcd_map(blockIdx.x, B, nrb, b, I)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rw = wave & 1, cw = wave >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float* xb = x + (long long)b * C * HW;
+    const float inv_hw = 1.0f / (float)HW;
+    auto load_blk = [&](const float* src_, float* dst) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(src_);
+        for (int f = tid; f < BLK4; f += 256) reinterpret_cast<f32x4*>(dst)[f] = src[f];
+    };
+    if (tid < 8) lds[3 * BLK + tid] = 0.f;
+    load_blk(dy + ((long long)b * C + I * RB) * HW, sI);
+    load_blk(xb, sJ);
+    __syncthreads();
+
+    const float* ai = sI + (rw * 32 + l31) * HW + lh;                         // dY_i[k = 2 s + lh]
+    auto gram = [&](const float* sj, f32x16& acc) {                           // dW tile, transposed: lane = row i, registers = columns
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* bj = sj + (32 * cw + l31) * HW + lh;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            const bool tail = (HW & 1) && s_ == KS - 1;
+            const float av = (tail && lh) ? 0.f : ai[2 * s_];
+            const float bv = (tail && lh) ? 0.f : bj[2 * s_];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
+        }
+    };
+    const long long rowoff = ((long long)b * C + I * RB + rw * 32 + l31) * C + 32 * cw + 4 * lh;
+    const float* wrow = w + rowoff;                                           // this lane's row, this wave's columns
+    float* grow = dg + rowoff;
+    auto ldrow = [&](const float* base, int J, f32x4 (&v)[4]) {               // columns 8 g + 4 lh .. + 3 of block J
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(base + J * RB + 8 * g);
+    };
+
+    // ---- pass 1: t_i = sum_j W_ij dW_ij
+    float t = 0.f;
+    for (int J = 0; J < nrb; ++J) {
+        const float* sj = sJ + (J & 1) * BLK;
+        f32x4 wv[4], ev[4];
+        ldrow(wrow, J, wv);
+        if (EXTRA) ldrow(grow, J, ev);
+        if (J + 1 < nrb) load_blk(xb + (long long)(J + 1) * BLK, sJ + ((J + 1) & 1) * BLK);
+        f32x16 acc;
+        gram(sj, acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t += wv[g][k] * (EXTRA ? acc[4 * g + k] + ev[g][k] : acc[4 * g + k]);
+        __syncthreads();
+    }
+    t += __shfl_xor(t, 32, 64);
+    if (lh == 0) comb[cw][rw][l31] = t;
+    load_blk(xb, sJ);
+    __syncthreads();
+    t = comb[0][rw][l31] + comb[1][rw][l31];
+
+    // ---- pass 2: dG written once, dx_i += dG X / HW
+    f32x16 yacc[NT2];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[n][r] = 0.f;
+    for (int J = 0; J < nrb; ++J) {
+        const float* sj = sJ + (J & 1) * BLK;
+        f32x4 wv[4], ev[4];
+        ldrow(wrow, J, wv);
+        if (EXTRA) ldrow(grow, J, ev);
+        if (J + 1 < nrb) load_blk(xb + (long long)(J + 1) * BLK, sJ + ((J + 1) & 1) * BLK);
+        f32x16 acc;
+        gram(sj, acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = EXTRA ? acc[4 * g + k] + ev[g][k] : acc[4 * g + k];
+                acc[4 * g + k] = -wv[g][k] * (d - t);
+            }
+            *reinterpret_cast<f32x4*>(grow + J * RB + 8 * g) = (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * cw + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int n = 0; n < NT2; ++n) {
+                const int col = 32 * n + l31;
+                const float bv = col < HW ? sj[j * HW + col] : 0.f;
+                yacc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], bv, yacc[n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* ybuf = lds + rw * (NT2 * 16 * 64);
+    if (cw == 1) {
+#pragma unroll
+        for (int n = 0; n < NT2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ybuf[(n * 16 + r) * 64 + lane] = yacc[n][r];
+    }
+    __syncthreads();
+    if (cw == 1) return;
+    float* xo = dx + ((long long)b * C + I * RB + rw * 32) * HW;
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+        const int col = 32 * n + l31;
+        if (col < HW) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* q = xo + ((r & 3) + 8 * (r >> 2) + 4 * lh) * HW + col;
+                *q += (yacc[n][r] + ybuf[(n * 16 + r) * 64 + lane]) * inv_hw;
+            }
+        }
+    }
+}
+
+static int cin_sci_bwd_flash(const float* x, const float* w, const float* dy, float* dg, int has_extra, float* dx, int B,
+                             int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(w) || !aligned16(dy) || !aligned16(dg)) return HK_ERR_UNSUPPORTED;
+    const dim3 grid(xcd_grid(B, C / 64));
+#define HK_CIN_BF(HW_)                                                                                                 \
+    do {                                                                                                                \
+        if (has_extra) hipLaunchKernelGGL((cin_sci_bwd_flash_kernel<HW_, true>), grid, dim3(256), 0, st, x, w, dy, dg, dx, C, B);  \
+        else hipLaunchKernelGGL((cin_sci_bwd_flash_kernel<HW_, false>), grid, dim3(256), 0, st, x, w, dy, dg, dx, C, B);           \
+    } while (0)
+    switch (HW) {
+        case 49: HK_CIN_BF(49); break;
+        case 64: HK_CIN_BF(64); break;
+        case 36: HK_CIN_BF(36); break;
+        default: return HK_ERR_UNSUPPORTED;
+    }
+#undef HK_CIN_BF
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
 // HK_ERR_UNSUPPORTED when the shape is not one the kernel covers (the caller takes the three-kernel chain)
 static int cin_sci_flash(const float* x, float* w, float* y, int B, int C, int HW, hipStream_t st) {
     if (C % 64 != 0 || !aligned16(x) || !aligned16(w)) return HK_ERR_UNSUPPORTED;
@@ -354,6 +517,14 @@ extern "C" int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, f
     const LdPlain lx = make_plain(x, sx, HW, C, HW);
     const LdPlain ldy = make_plain(dy, sx, HW, C, HW);
     const LdPlain lw = make_plain(w, sw, C, C, C);
+    if (cin_inside(C, w) && (HW == 49 || HW == 64 || HW == 36) && aligned16(dwbuf) && aligned16(x) && aligned16(dy)) {
+        // W^T dY, then the row-owned part in one kernel (dW never stored, dG written once, dG X from registers), then dG^T X
+        const LdPlainN cx = cin_cols(x, C, HW), cdy = cin_cols(dy, C, HW);
+        HK_TRY((bgemm_launch<false, false, CIN_SETS>(cin_mat(w, C), cdy, make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C, B, st)));
+        HK_TRY(cin_sci_bwd_flash(x, w, dy, dwbuf, has_extra, dx, B, C, HW, st));
+        return bgemm_launch<false, false, CIN_SETS>(cin_mat(dwbuf, C), cx, make_affine(dx, sx, HW, 1.0f / (float)HW, nullptr, 1.f, 0.f),
+                                                    C, HW, C, B, st);
+    }
     // dW = dY X^T (+ extra): 335 MB of result for 49-deep products - the tile leaves as 16-byte stores where it can
     const EpAffine epw = make_affine(dwbuf, sw, C, 1.f, nullptr, has_extra ? 1.f : 0.f, 0.f);
     if (cin_inside(C, dwbuf)) HK_TRY((bgemm_launch<true, true, 0, true>(cin_map(dy, C, HW), cin_map(x, C, HW), epw, C, C, HW, B, st)));
