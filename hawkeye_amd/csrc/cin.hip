@@ -366,14 +366,25 @@ __global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* 
         for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(base + J * RB + 8 * g);
     };
 
+    // W / E of block J + 1 are requested while block J is computed (two register sets, the loop walks block pairs; the
+    // request of the X block comes first - its wait would otherwise wait for these too - and is never behind a branch)
+    auto next_x = [&](int J) {
+        const int Jn = J + 1 < nrb ? J + 1 : J;                              // (last block: a redundant copy into the idle stage)
+        load_blk(xb + (long long)Jn * BLK, sJ + ((J + 1) & 1) * BLK);
+    };
+    auto next_we = [&](int J, f32x4 (&wn)[4], f32x4 (&en)[4]) {
+        const int Jn = J + 1 < nrb ? J + 1 : J;
+        ldrow(wrow, Jn, wn);
+        if (EXTRA) ldrow(grow, Jn, en);
+    };
+
     // ---- pass 1: t_i = sum_j W_ij dW_ij
     float t = 0.f;
-    for (int J = 0; J < nrb; ++J) {
+    f32x4 wa[4], ea[4], wb[4], eb[4];
+    auto pass1 = [&](int J, f32x4 (&wv)[4], f32x4 (&ev)[4], f32x4 (&wn)[4], f32x4 (&en)[4]) {
         const float* sj = sJ + (J & 1) * BLK;
-        f32x4 wv[4], ev[4];
-        ldrow(wrow, J, wv);
-        if (EXTRA) ldrow(grow, J, ev);
-        if (J + 1 < nrb) load_blk(xb + (long long)(J + 1) * BLK, sJ + ((J + 1) & 1) * BLK);
+        next_x(J);
+        next_we(J, wn, en);
         f32x16 acc;
         gram(sj, acc);
 #pragma unroll
@@ -381,6 +392,13 @@ __global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* 
 #pragma unroll
             for (int k = 0; k < 4; ++k) t += wv[g][k] * (EXTRA ? acc[4 * g + k] + ev[g][k] : acc[4 * g + k]);
         __syncthreads();
+    };
+    ldrow(wrow, 0, wa);
+    if (EXTRA) ldrow(grow, 0, ea);
+    {
+        int J = 0;
+        for (; J + 1 < nrb; J += 2) { pass1(J, wa, ea, wb, eb); pass1(J + 1, wb, eb, wa, ea); }
+        if (J < nrb) pass1(J, wa, ea, wb, eb);
     }
     t += __shfl_xor(t, 32, 64);
     if (lh == 0) comb[cw][rw][l31] = t;
@@ -394,12 +412,10 @@ __global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* 
     for (int n = 0; n < NT2; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) yacc[n][r] = 0.f;
-    for (int J = 0; J < nrb; ++J) {
+    auto pass2 = [&](int J, f32x4 (&wv)[4], f32x4 (&ev)[4], f32x4 (&wn)[4], f32x4 (&en)[4]) {
         const float* sj = sJ + (J & 1) * BLK;
-        f32x4 wv[4], ev[4];
-        ldrow(wrow, J, wv);
-        if (EXTRA) ldrow(grow, J, ev);
-        if (J + 1 < nrb) load_blk(xb + (long long)(J + 1) * BLK, sJ + ((J + 1) & 1) * BLK);
+        next_x(J);
+        next_we(J, wn, en);                                                  // (E of block J + 1: other columns than the dG stored below)
         f32x16 acc;
         gram(sj, acc);
 #pragma unroll
@@ -422,6 +438,13 @@ __global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* 
             }
         }
         __syncthreads();
+    };
+    ldrow(wrow, 0, wa);
+    if (EXTRA) ldrow(grow, 0, ea);
+    {
+        int J = 0;
+        for (; J + 1 < nrb; J += 2) { pass2(J, wa, ea, wb, eb); pass2(J + 1, wb, eb, wa, ea); }
+        if (J < nrb) pass2(J, wa, ea, wb, eb);
     }
     float* ybuf = lds + rw * (NT2 * 16 * 64);
     if (cw == 1) {
