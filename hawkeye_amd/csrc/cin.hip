@@ -489,6 +489,109 @@ static int cin_sci_bwd_flash(const float* x, const float* w, const float* dy, fl
     return HK_OK;
 }
 
+// CCI backward, the gradient that reaches W: dW[b] = sign(D_b) (.) dWc[b] - w_pb sign(D_pb) (.) dWc[pb] with dWc = dY X^T.
+// The chain wrote dWc (335 MB at the ~1.5 TB/s such a result gets) and read it back in cin_cci_dw_kernel; here the two
+// tiles dWc[b]_ij = dY[b]_i . X[b]_j and dWc[pb]_ij are recomputed on the matrix pipe (25 MFMAs each, K = HW) in the
+// transposed accumulator layout of cin_sci_flash_kernel, combined with the W[b] / W[pb] tiles (16-byte requests issued
+// ahead of the block's barriers) and written once.  dwpart[b][I] = - sum over the workgroup's rows of sign(D_b) dWc[b] W[pb].
+template <int HW>
+__global__ __launch_bounds__(256, 2) void cin_cci_dw_flash_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                  const float* __restrict__ wt, const float* __restrict__ dy,
+                                                                  float* __restrict__ dW, float* __restrict__ dwpart, int C,
+                                                                  int B) {
+    constexpr int RB = 64;
+    constexpr int BLK = RB * HW;
+    constexpr int BLK4 = BLK / 4;
+    constexpr int KS = (HW + 1) / 2;
+    static_assert(BLK % 4 == 0, "64 x HW block as float4");
+    __shared__ __attribute__((aligned(16))) float lds[4 * BLK + 8];          // dY[b]_I, dY[pb]_I, X[b]_J, X[pb]_J
+    __shared__ float red[4];
+
+    const int nrb = C / RB;
+    int b, I;
+    if (!xcd_map(blockIdx.x, B, nrb, b, I)) return;
+    const int pb = (b + B / 2) % B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rw = wave & 1, cw = wave >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float wb = wt[b], wp = wt[pb];
+    const long long sx = (long long)C * HW;
+    auto load_blk = [&](const float* src_, float* dst) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(src_);
+        for (int f = tid; f < BLK4; f += 256) reinterpret_cast<f32x4*>(dst)[f] = src[f];
+    };
+    if (tid < 8) lds[4 * BLK + tid] = 0.f;               // (the last k-step of an odd HW reads one float past a block)
+    load_blk(dy + b * sx + (long long)I * BLK, lds);
+    load_blk(dy + pb * sx + (long long)I * BLK, lds + BLK);
+
+    auto gram = [&](const float* si, const float* sj, f32x16& acc) {          // transposed tile: lane = row i, registers = columns
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* ai = si + (rw * 32 + l31) * HW + lh;
+        const float* bj = sj + (32 * cw + l31) * HW + lh;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            const bool tail = (HW & 1) && s_ == KS - 1;
+            const float av = (tail && lh) ? 0.f : ai[2 * s_];
+            const float bv = (tail && lh) ? 0.f : bj[2 * s_];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
+        }
+    };
+    const long long roff = ((long long)(I * RB + rw * 32 + l31)) * C + 32 * cw + 4 * lh;
+    const float* wrow = W + (long long)b * C * C + roff;
+    const float* orow = W + (long long)pb * C * C + roff;
+    float* drow = dW + (long long)b * C * C + roff;
+    float part = 0.f;
+    for (int J = 0; J < nrb; ++J) {
+        f32x4 wv[4], ov[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            wv[g] = *reinterpret_cast<const f32x4*>(wrow + J * RB + 8 * g);
+            ov[g] = *reinterpret_cast<const f32x4*>(orow + J * RB + 8 * g);
+        }
+        __syncthreads();                                                     // the previous block's tiles are done with
+        load_blk(x + b * sx + (long long)J * BLK, lds + 2 * BLK);
+        load_blk(x + pb * sx + (long long)J * BLK, lds + 3 * BLK);
+        __syncthreads();
+        f32x16 ab, ap;
+        gram(lds, lds + 2 * BLK, ab);
+        gram(lds + BLK, lds + 3 * BLK, ap);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = wv[g][k], o = ov[g][k];
+                const float db = a - wb * o, dp = o - wp * a;
+                const float sb = (db > 0.f) ? 1.f : ((db < 0.f) ? -1.f : 0.f);
+                const float sp = (dp > 0.f) ? 1.f : ((dp < 0.f) ? -1.f : 0.f);
+                const float gb = sb * ab[4 * g + k];
+                v[k] = gb - wp * sp * ap[4 * g + k];
+                part += gb * o;
+            }
+            *reinterpret_cast<f32x4*>(drow + J * RB + 8 * g) = v;
+        }
+    }
+    part = block_sum<4>(part, red);
+    if (tid == 0) dwpart[(long long)b * nrb + I] = -part;
+}
+
+static int cin_cci_dw_flash(const float* x, const float* w, const float* wt, const float* dy, float* dw, float* dwpart, int B,
+                            int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || C / 64 > CIN_DW_BLOCKS || !aligned16(x) || !aligned16(w) || !aligned16(dy) || !aligned16(dw) ||
+        tuning().bcnn_generic == 1)
+        return HK_ERR_UNSUPPORTED;
+    const dim3 grid(xcd_grid(B, C / 64));
+    switch (HW) {
+        case 49: hipLaunchKernelGGL((cin_cci_dw_flash_kernel<49>), grid, dim3(256), 0, st, x, w, wt, dy, dw, dwpart, C, B); break;
+        case 64: hipLaunchKernelGGL((cin_cci_dw_flash_kernel<64>), grid, dim3(256), 0, st, x, w, wt, dy, dw, dwpart, C, B); break;
+        case 36: hipLaunchKernelGGL((cin_cci_dw_flash_kernel<36>), grid, dim3(256), 0, st, x, w, wt, dy, dw, dwpart, C, B); break;
+        default: return HK_ERR_UNSUPPORTED;
+    }
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
 // HK_ERR_UNSUPPORTED when the shape is not one the kernel covers (the caller takes the three-kernel chain)
 static int cin_sci_flash(const float* x, float* w, float* y, int B, int C, int HW, hipStream_t st) {
     if (C % 64 != 0 || !aligned16(x) || !aligned16(w)) return HK_ERR_UNSUPPORTED;
@@ -601,6 +704,19 @@ extern "C" int hk_cin_cci_bwd(const float* x, const float* w, const float* wt, c
     float* dwpart = dwc + (size_t)B * sw;
     const LdPlain lx = make_plain(x, sx, HW, C, HW);
     const LdPlain ldy = make_plain(dy, sx, HW, C, HW);
+    if (cin_inside(C, w)) {                        // dWc recomputed inside the kernel that consumes it, never stored
+        LdAbsDiffV lv;
+        lv.p = w; lv.wt = wt; lv.C = C; lv.B = B; lv.wb = 0.f;
+        const int rcf = cin_cci_dw_flash(x, w, wt, dy, dw, dwpart, B, C, HW, st);
+        if (rcf == HK_OK) {
+            HK_TRY((bgemm_launch<false, false, CIN_SETS>(lv, cin_cols(dy, C, HW), make_affine(dx, sx, HW, 1.f, nullptr, 0.f, 0.f), C, HW, C,
+                                                         B, st)));                                 // Wc^T dY
+            hipLaunchKernelGGL(cin_cci_dw_reduce_kernel, dim3(B), dim3(64), 0, st, (const float*)dwpart, dwt, C / 64);
+            HK_LAUNCH_CHECK();
+            return HK_OK;
+        }
+        if (rcf != HK_ERR_UNSUPPORTED) return rcf;
+    }
     const EpAffine epw = make_affine(dwc, sw, C, 1.f, nullptr, 0.f, 0.f);
     if (cin_inside(C, dwc)) HK_TRY((bgemm_launch<true, true, 0, true>(cin_map(dy, C, HW), cin_map(x, C, HW), epw, C, C, HW, B, st)));
     else if (C % 4 == 0 && aligned16(dwc)) HK_TRY((bgemm_launch<true, true, 0, true>(ldy, lx, epw, C, C, HW, B, st)));
