@@ -6,9 +6,14 @@
 //   SCI:  W = softmax_rows(-X X^T / HW) ; Y = W X                          hk_cin_sci_fwd / hk_cin_sci_bwd
 //   CCI:  Wc[b] = | W[b] - w_b W[partner(b)] | ; Yc = Wc X                 hk_cin_cci_fwd / hk_cin_cci_bwd
 //         partner(b) = (b + B/2) mod B  (CIN.py:45-51: the two batch halves are contrast pairs)
-// Both products and all four backward products run on the f32-MFMA GEMM (hk_bgemm.h); |W - w W'| is never stored:
-// it is formed in the operand loader (LdAbsDiff) for Yc and for dX.  Row softmax and its backward are one workgroup
-// per row, fixed reduction order.
+// For C % 64 == 0 and 7x7 / 8x8 / 6x6 maps (every CIN backbone) the row-owned work is three two-pass / one-pass kernels
+// on the same tile scheme (64 rows of one sample per workgroup, four waves = row half x column half, K = HW Gram tiles
+// recomputed on the matrix pipe instead of stored): cin_sci_flash_kernel (forward), cin_sci_bwd_flash_kernel (dW, softmax
+// backward and dG X), cin_cci_dw_flash_kernel (the gradient reaching W from the contrastive branch); the C x C by C x HW
+// products that remain (W^T dY, dG^T X, |W - w W'| X and its transpose) stream their big operand once through the generic
+// tile with branch-free loaders (hk_bgemm.h: DEEP, LdPlainV / LdPlainN; LdAbsDiffV forms |W - w W'| on the way to LDS -
+// it is never stored).  Other shapes take the chains on the generic tile (bounds-checked loaders, row softmax and its
+// backward as one workgroup per row, fixed reduction order); knob bcnn_generic = 1 forces them (A/B, tests).
 #include "hk_bgemm.h"
 #include "../../include/hawkeye_hip.h"
 
