@@ -13,10 +13,11 @@ MIOpen, bilinear pooling on the gfx950 kernels) -> CrossEntropy(label_smoothing
 throughout (the reference's dtype; parity target 1e-4).  Weak scaling: every
 rank trains batch 64; `value` = all images of all ranks / max-over-ranks time.
 
-Rank 0 prints ONE JSON line.  At N=1 it also carries
-  roofline     - the dominant hand-written kernel: algorithmic FLOPs / HIP-event time
-  kernels      - the same for every stage of the pooling head
+Rank 0 prints ONE short JSON line as the LAST line of stdout (< 4 KB: `final_line`).  At N=1 it also carries
+  roofline     - the dominant hand-written kernel of the step: algorithmic FLOPs / HIP-event time
   cpu_baseline - the oracle's BCNN (reference algorithm on the torch CPU path) timed on the host cores
+Everything else (per-kernel rows of the pooling head, the other BASELINE.json configs, the DDP bucket timeline) goes
+to gpurun_out/bench_detail.json and, as a short table, to stderr - never onto the line the driver parses.
 """
 import argparse
 import ctypes
@@ -50,8 +51,6 @@ def parse():
                     help='BCNN is the metric; the others are side measurements (OSMENet / CIN: --image 224, their own criteria)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernels', action='store_true')
-    ap.add_argument('--no-candidates', action='store_true',
-                    help='skip the subprocess that times the opt-in variants (tools/candidates.py)')
     ap.add_argument('--channels-last', type=int, default=1,
                     help='NHWC tensors through the backbone: MIOpen picks NHWC igemm kernels either way; this removes its '
                          'NCHW<->NHWC batched_transpose passes (5.7%% of the step): measured 298.8 vs 273.2 img/s')
@@ -132,11 +131,35 @@ def time_events(fn, iters, warm=3, rounds=1):
     return ev[rounds - 1].elapsed_time(ev[rounds]) / iters, ev[0].elapsed_time(ev[1]) / iters
 
 
+def roof_row(name, us, flops_alg, bytes_alg, flops_exec=None, us_first=None):
+    """One roofline row.  `flops_alg` / `bytes_alg` are the ALGORITHMIC work per launch (SURVEY 8d, DESIGN.md section 3);
+    `flops_exec` what the kernel really issues to the matrix pipe when that differs (the symmetric Gram forward computes
+    36 of 64 tiles, the classifier pads 200 classes to 208).  `frac` is priced on min(algorithmic, executed): a kernel
+    that skips work the algorithm does not need is not credited with it, a kernel that pads is not credited with the
+    padding - so frac <= the busy fraction of the pipe and never exceeds 1."""
+    fe = flops_alg if flops_exec is None else flops_exec
+    fl = min(flops_alg, fe)
+    bound = 'mfma' if fl > 0 and flops_alg / max(bytes_alg, 1.0) > PEAK_MFMA_F32_TF * 1e3 / PEAK_HBM_GBS else 'hbm'
+    tf, gbs = fl / us / 1e6, bytes_alg / us / 1e3
+    row = {'kernel': name, 'us': round(us, 2), 'bound': bound,
+           'achieved': round(tf if bound == 'mfma' else gbs, 2),
+           'peak': PEAK_MFMA_F32_TF if bound == 'mfma' else PEAK_HBM_GBS,
+           'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+           'frac': round(min((tf / PEAK_MFMA_F32_TF) if bound == 'mfma' else (gbs / PEAK_HBM_GBS), 1.0), 4),
+           'traffic': None, 'flops_algorithmic': flops_alg, 'flops_executed': fe, 'bytes_algorithmic': bytes_alg}
+    if bound == 'mfma':
+        row['frac_hbm'] = round(gbs / PEAK_HBM_GBS, 4)
+    if us_first is not None:
+        row['us_first_round'] = round(us_first, 2)
+    return row
+
+
 def kernel_rooflines(B, C, HW, dev):
-    """Per-stage timing of the bilinear-pooling head at the metric's shape.  Algorithmic work:
+    """Per-stage timing of the bilinear-pooling head + classifier at the metric's shape.  Algorithmic work:
     gram_norm  FLOPs 2*B*C*C*HW ; bytes 4*B*C*HW (x) + 4*B*C*C (y)
     bwd_gemm   FLOPs 2*B*C*C*HW ; bytes 2*4*B*C*C (y, dy) + 2*4*B*C*HW (x, dx)
-    colsum     bytes 4*B*C*HW ;  rank1 bytes 2*4*B*C*HW"""
+    colsum     bytes 4*B*C*HW ;  rank1 bytes 2*4*B*C*HW
+    classifier fwd FLOPs 2*B*J*K ; bytes 4*(K*J + B*J + B*K);  bwd twice that (dy = g W and dW = g^T y)"""
     from hawkeye_amd import _lib
     from hawkeye_amd._lib import ptr, stream
     lib = _lib.load()
@@ -152,8 +175,8 @@ def kernel_rooflines(B, C, HW, dev):
     lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream())
     lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream())
     flops = 2.0 * B * C * C * HW
-    # the classifier on the pooled vector (BCNN.py:42,54): forward on the wide-classifier kernel, backward on the
-    # streaming dy / dW kernels - part of the shipped step, and the forward is its longest hand-written kernel
+    nb = C // 64
+    sym = (nb * (nb + 1) // 2) / float(nb * nb) if C % 64 == 0 else 1.0      # tiles J >= I only
     K, J = 200, C * C
     wl, bl = torch.randn(K, J, device=dev) * 0.01, torch.zeros(K, device=dev)
     ol, gl = torch.empty(B, K, device=dev), torch.randn(B, K, device=dev)
@@ -161,54 +184,57 @@ def kernel_rooflines(B, C, HW, dev):
     nwl = lib.hk_linear_ws_bytes(B, J, K)
     wsl = torch.empty(nwl, dtype=torch.uint8, device=dev)
     lflops, lbytes = 2.0 * B * J * K, 4.0 * (K * J + B * J + B * K)
-    big = C % 128 == 0 and B * (C // 128) >= 192
+    kpad = (K + 15) // 16 * 16 / float(K)
     stages = [
-        ('bcnn_colsum_partial+finalize (stage entry point; hk_bcnn_pool_fwd folds the finalize into the Gram prologue)',
+        ('bcnn_colsum_partial4_kernel + finalize (stage entry point)',
          lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream()),
-         0.0, 4.0 * B * C * HW),
-        ('hk_bcnn_pool_fwd, whole: colsum partials + Gram with the norm in its prologue (two launches)',
+         0.0, 4.0 * B * C * HW, None, False),
+        ('hk_bcnn_pool_fwd, whole (two launches: colsum partials + Gram with the norm in its prologue)',
          lambda: lib.hk_bcnn_pool_fwd(ptr(x), ptr(y), ptr(inv), ptr(cs), B, C, HW, ptr(wsc), nwsc, stream()),
-         flops, 8.0 * B * C * HW + 4.0 * B * C * C),
+         flops, 8.0 * B * C * HW + 4.0 * B * C * C, flops * sym, False),
         ('bcnn_gram_panel_kernel<196>', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
-         flops, 4.0 * B * C * HW + 4.0 * B * C * C),
-        ('gram_bwd3_kernel<196,0,2>' if big else ('gram_bwd3_kernel<196,0,1>' if B * (C // 64) >= 192 else 'bcnn_bwd_panel_kernel<196>'),
-         lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp),
-                                                                   B, C, HW, stream()),
-         flops, 8.0 * B * C * C + 8.0 * B * C * HW),
+         flops, 4.0 * B * C * HW + 4.0 * B * C * C, flops * sym, True),
+        ('gram_bwd3_kernel<196,0,2>',
+         lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream()),
+         flops, 8.0 * B * C * C + 8.0 * B * C * HW, None, True),
         ('bcnn_rank1_fix_kernel', lambda: lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream()),
-         0.0, 8.0 * B * C * HW),
-        ('linear_skinny_kernel<13> + linear_reduce (classifier fwd 262144->200)',
-         lambda: lib.hk_linear_fwd(ptr(y), ptr(wl), ptr(bl), ptr(ol), B, J, K, ptr(wsl), nwl, stream()), lflops, lbytes),
-        ('linear_dy + linear_dw + bias_grad (classifier bwd, C-ABI kernels; the plugin keeps rocBLAS here)',
-         lambda: lib.hk_linear_bwd(ptr(y), ptr(wl), ptr(gl), ptr(dyl), ptr(dwl), ptr(dbl), B, J, K, stream()), 2 * lflops,
-         2 * lbytes),
+         0.0, 8.0 * B * C * HW, None, True),
+        ('hk_linear_fwd: linear_skinny_kernel + linear_reduce_kernel (classifier 262144->200)',
+         lambda: lib.hk_linear_fwd(ptr(y), ptr(wl), ptr(bl), ptr(ol), B, J, K, ptr(wsl), nwl, stream()),
+         lflops, lbytes, lflops * kpad, True),
+        ('hk_linear_bwd: dy = g W, dW = g^T y, db (classifier backward 262144->200)',
+         lambda: lib.hk_linear_bwd(ptr(y), ptr(wl), ptr(gl), ptr(dyl), ptr(dwl), ptr(dbl), B, J, K, stream()),
+         2 * lflops, 2 * lbytes, lflops * (1.0 + kpad), True),
     ]
     out = []
-    for name, fn, fl, by in stages:
+    for name, fn, fl, by, fe, single in stages:
         ms, ms_first = time_events(fn, 50, rounds=4)       # steady state: the fourth back-to-back round of 50 launches
-        tf, gbs = fl / ms / 1e9, by / ms / 1e6
-        bound = 'mfma' if fl > 0 and fl / by > PEAK_MFMA_F32_TF * 1e3 / PEAK_HBM_GBS else 'hbm'
-        out.append({'kernel': name, 'us': round(ms * 1e3, 2), 'us_first_round': round(ms_first * 1e3, 2), 'bound': bound,
-                    'achieved': round(tf if bound == 'mfma' else gbs, 2),
-                    'peak': PEAK_MFMA_F32_TF if bound == 'mfma' else PEAK_HBM_GBS,
-                    'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
-                    'frac': round((tf / PEAK_MFMA_F32_TF) if bound == 'mfma' else (gbs / PEAK_HBM_GBS), 4),
-                    'traffic': None})
+        row = roof_row(name, ms * 1e3, fl, by, fe, ms_first * 1e3)
+        row['shipped_kernel'] = single      # False: a stage entry point / a multi-launch sum, not a candidate for `roofline`
+        out.append(row)
     return out
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r1b_pool_kernels_pmc.csv:
-    FETCH_SIZE / WRITE_SIZE in KiB, separate passes; FETCH_SIZE doubled - gfx950 reports half of the bytes of
-    16-B-per-lane streaming reads, MI355X_MICROARCH.md section HBM).  PMC cannot be sampled from inside this
-    process, so this is the last profiled value, or None when the file is absent."""
+def pmc_traffic(row_name):
+    """HBM bytes per launch sequence of a `kernel_rooflines` row from the committed rocprofv3 PMC passes
+    (profiles/rN_pool_kernels_pmc.csv: FETCH_SIZE / WRITE_SIZE in KiB, separate --pmc passes; FETCH_SIZE doubled - gfx950
+    reports half of the bytes of 16-B-per-lane streaming reads, MI355X_MICROARCH.md section HBM), summed over every
+    kernel the row names.  PMC cannot be sampled from inside this process, so this is the last profiled value, or None
+    when no file has all of the row's kernels."""
     import csv
-    for name in ('r3_pool_kernels_pmc.csv', 'r2_pool_kernels_pmc.csv', 'r1b_pool_kernels_pmc.csv'):
+    import re
+    names = re.findall(r'[a-z][a-z0-9_]*_kernel', row_name)
+    for name in ('r4_pool_kernels_pmc.csv', 'r3_pool_kernels_pmc.csv', 'r2_pool_kernels_pmc.csv'):
         try:
-            vals = {r['Counter']: float(r['MeanValue']) for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', name)))
-                    if r['Kernel'].replace('void ', '').startswith(kernel_prefix) and r['Counter'] in ('FETCH_SIZE', 'WRITE_SIZE')}
-            return round((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0), 'profiles/' + name
-        except Exception:
+            rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', name))))
+            total = 0.0
+            for kn in names:
+                vals = {r['Counter']: float(r['MeanValue']) for r in rows
+                        if r['Kernel'].replace('void ', '').startswith('hk::' + kn) and r['Counter'] in ('FETCH_SIZE', 'WRITE_SIZE')}
+                total += (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
+            if names:
+                return round(total), 'profiles/' + name
+        except Exception:  # noqa: BLE001
             continue
     return None, None
 
@@ -247,30 +273,6 @@ def cpu_baseline(image, classes):
                       f'torch CPU fp32, {threads} threads of {os.cpu_count()} host cores'}
 
 
-def candidates(timeout_s=150):
-    """Timings of the opt-in variants / SURVEY-8f rows next to the paths they would replace (tools/candidates.py), in a
-    subprocess AFTER the headline measurement: whatever happens in there (error, timeout) only shows up inside this
-    field.  They are not part of `value`."""
-    import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'candidates.py'), '--step']
-    try:
-        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
-    except Exception as e:  # noqa: BLE001
-        return {'error': repr(e)[:300]}
-    try:
-        out, err = p.communicate(timeout=timeout_s)
-    except subprocess.TimeoutExpired:
-        p.kill()                                          # do not wait for it: the headline must still be printed
-        return {'error': f'timeout after {timeout_s}s'}
-    lines = [ln for ln in out.splitlines() if ln.startswith('[')]
-    if p.returncode != 0 or not lines:
-        return {'error': f'rc={p.returncode}', 'stderr_tail': err[-400:]}
-    try:
-        return json.loads(lines[-1])
-    except ValueError as e:
-        return {'error': repr(e)[:300]}
-
-
 def other_models(timeout_s=240):
     """The other BASELINE.json configs on this GPU (configs[2..4] at their single-GPU shapes): MPN bs64, CBCNN bs64 /
     bs16, AP-CNN with the iNat2018 class count (8142) bs16 - ms/step, images/sec and the per-kernel rooflines of their
@@ -290,6 +292,52 @@ def other_models(timeout_s=240):
         return json.loads(lines[-1])
     except ValueError as e:
         return {'error': repr(e)[:300]}
+
+
+LINE_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+             'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+LINE_MAX = 4096
+
+
+def final_line(res):
+    """The one line the driver parses: the contract's keys + `roofline` + `cpu_baseline`, nothing else, < 4 KB
+    (round 3's 24.5 KB line - 84 A/B rows on it - was past the driver's capture window: BENCH_r03.json parsed: null).
+    tests/test_bench_line_cpu.py holds this to the limit on canned numbers."""
+    line = json.dumps({k: res[k] for k in LINE_KEYS if k in res}, separators=(',', ':'))
+    if len(line) >= LINE_MAX:                             # never lose the headline to an oversized field
+        slim = {k: res[k] for k in LINE_KEYS if k in res}
+        for k in ('cpu_baseline', 'roofline'):
+            if isinstance(slim.get(k), dict):
+                slim[k] = {kk: (vv[:80] if isinstance(vv, str) else vv) for kk, vv in slim[k].items()}
+        line = json.dumps(slim, separators=(',', ':'))
+    assert len(line) < LINE_MAX and '\n' not in line, len(line)
+    return line
+
+
+def emit(res, detail):
+    """Detail -> gpurun_out/bench_detail.json + a short table on stderr; then the final line, last on stdout."""
+    if detail:
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'), 'w') as f:
+                json.dump({'headline': {k: res[k] for k in LINE_KEYS if k in res}, **detail}, f, indent=1)
+        except OSError as e:
+            print(f'[bench] could not write gpurun_out/bench_detail.json: {e}', file=sys.stderr)
+        for k in detail.get('kernels', []):
+            print(f"[bench] {k['us']:9.2f} us  {k['bound']:4s} frac {k['frac']:.3f}  {k['kernel'][:100]}", file=sys.stderr)
+        om = detail.get('other_models')
+        for k in (om if isinstance(om, list) else []):
+            if 'us' in k:
+                print(f"[bench] {k['us']:9.2f} us  {k.get('bound', ''):4s} frac {k.get('frac', 0):.3f}  {k.get('model', '')}: "
+                      f"{k.get('kernel', '')[:90]}", file=sys.stderr)
+            elif 'ms_per_step' in k:
+                print(f"[bench] {k['ms_per_step']:9.2f} ms/step {k.get('images_per_sec')} img/s  {k.get('model')}: "
+                      f"{k.get('train_step')}", file=sys.stderr)
+        if isinstance(om, dict):
+            print(f'[bench] other_models: {om}', file=sys.stderr)
+        sys.stderr.flush()
+    sys.stdout.flush()
+    print(final_line(res), flush=True)
 
 
 def main():
@@ -387,42 +435,28 @@ def main():
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}',
                        'memory_format': 'channels_last' if a.channels_last else 'contiguous'},
         }
+        detail = {}
         if world == 1 and not a.no_kernels:
             ks = kernel_rooflines(a.batch, 512, (a.image // 32) ** 2, dev)
-            # single kernels of the shipped step (the classifier backward of the plugin is rocBLAS; 'whole' rows time two launches)
-            shipped = [k for k in ks if 'C-ABI kernels' not in k['kernel'] and 'whole' not in k['kernel']]
-            dom = max(shipped, key=lambda k: k['us'])
-            res['roofline'] = {k: dom[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
-            res['roofline']['kernel'] = dom['kernel']
-            res['roofline']['us'] = dom['us']
-            tr_bytes, tr_src = pmc_traffic('hk::' + dom['kernel'].split('<')[0].split(' ')[0])
-            res['roofline']['traffic'] = tr_bytes
-            res['roofline']['traffic_source'] = (tr_src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, '
-                                                 'FETCH doubled per MI355X_MICROARCH.md)') if tr_src else None
-
-            hw_ = (a.image // 32) ** 2
-            if 'linear' in dom['kernel']:
-                alg = {'flops_per_launch': 2.0 * a.batch * 512 * 512 * 200,
-                       'bytes_per_launch': 4.0 * (200 * 512 * 512 + a.batch * 512 * 512 + a.batch * 200)}
-            else:
-                alg = {'flops_per_launch': 2.0 * a.batch * 512 * 512 * hw_,
-                       'bytes_per_launch': (8.0 if 'bwd' in dom['kernel'] else 4.0) * a.batch * (512 * 512 + 512 * hw_)}
-            res['roofline']['algorithmic'] = alg
-            res['kernels'] = ks
+            # the step's longest single hand-written launch sequence (stage entry points and multi-launch sums excluded)
+            dom = max((k for k in ks if k['shipped_kernel']), key=lambda k: k['us'])
+            tr_bytes, tr_src = pmc_traffic(dom['kernel'])
+            res['roofline'] = {'bound': dom['bound'], 'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
+                               'frac': dom['frac'], 'traffic': tr_bytes, 'kernel': dom['kernel'][:96], 'us': dom['us'],
+                               'flops_algorithmic': dom['flops_algorithmic'], 'flops_executed': dom['flops_executed'],
+                               'bytes_algorithmic': dom['bytes_algorithmic'], 'traffic_source': tr_src}
+            detail['kernels'] = ks
             if kernels_before is not None:
-                res['kernels_before'] = kernels_before
+                detail['kernels_before'] = kernels_before
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.image, a.classes)
         if reducer is not None and reducer.trace:
-            res['ddp_timeline'] = reducer.timeline()
-            res['ddp_buckets_mib'] = [mb for _, mb in reducer.describe()]
-        if world == 1 and not a.no_candidates and a.model == 'BCNN':
-            torch.cuda.empty_cache()
-            res['candidates'] = candidates()
+            detail['ddp_timeline'] = reducer.timeline()
+            detail['ddp_buckets_mib'] = [mb for _, mb in reducer.describe()]
         if world == 1 and not a.no_other_models and a.model == 'BCNN' and not a.force_pg:
             torch.cuda.empty_cache()
-            res['other_models'] = other_models()
-        print(json.dumps(res), flush=True)
+            detail['other_models'] = other_models()
+        emit(res, detail)
     if world > 1:
         torch.distributed.destroy_process_group()
 

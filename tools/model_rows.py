@@ -36,16 +36,16 @@ def R(*shape):
     return torch.randn(*shape, device=dev)
 
 
-def kernel_row(model, name, fn, flops=0.0, bytes_=0.0, iters=30):
+def kernel_row(model, name, fn, flops=0.0, bytes_=0.0, iters=30, flops_exec=None):
+    """flops / bytes_: algorithmic work per call; flops_exec: what the kernels issue when that is less (symmetric
+    Newton-Schulz forward: 6 of 8 tiles per product; backward: 34 of the reference's 38 products) - bench.roof_row prices
+    `frac` on the smaller of the two."""
     us = bench.time_events(fn, iters, rounds=3)[0] * 1e3           # third back-to-back round: settled clocks (bench.py)
-    tf, gbs = flops / us / 1e6, bytes_ / us / 1e3
-    mfma = flops > 0 and flops / max(bytes_, 1.0) > bench.PEAK_MFMA_F32_TF * 1e3 / bench.PEAK_HBM_GBS
-    rows.append({'model': model, 'kernel': name, 'us': round(us, 1), 'bound': 'mfma' if mfma else 'hbm',
-                 'achieved': round(tf if mfma else gbs, 1), 'unit': 'TFLOP/s' if mfma else 'GB/s',
-                 'frac': round(tf / bench.PEAK_MFMA_F32_TF if mfma else gbs / bench.PEAK_HBM_GBS, 3)})
+    r = bench.roof_row(name, us, flops, bytes_, flops_exec)
+    r['model'] = model
+    rows.append(r)
     if us < 12.0:     # back-to-back calls through python + ctypes cost ~8-9 us each: below that the row times the host
-        rows[-1]['note'] = 'host-call-bound row (python + ctypes ~ 9 us per call): rocprofv3 durations in profiles/r3_step_*_kernel_stats.csv'
-
+        r['note'] = 'host-call-bound row (python + ctypes ~ 9 us per call): rocprofv3 durations in profiles/r4_step_*_kernel_stats.csv'
 
 
 def train_row(model_name, batch, classes, image=448, steps=6, warmup=3):
@@ -84,7 +84,7 @@ def train_row(model_name, batch, classes, image=448, steps=6, warmup=3):
 def mpn_kernels(B=64, d=256, HW=196):
     x = torch.relu(R(B, d, HW)); cov = E(B, d, d); mu = E(B, d); g = R(B, d, d).triu(); dx = E(B, d, HW)
     kernel_row('MPN', 'cov_pool fwd (one kernel: means in LDS + centred Gram)', lambda: lib.hk_cov_pool_fwd(ptr(x), ptr(cov), ptr(mu), B, d, HW, stream()),
-               2.0 * B * d * d * HW, 4.0 * B * (d * HW + d * d))
+               2.0 * B * d * d * HW, 4.0 * B * (d * HW + d * d), flops_exec=2.0 * B * d * d * HW * 10 / 16)
     kernel_row('MPN', 'cov_pool bwd', lambda: lib.hk_cov_pool_bwd(ptr(x), ptr(mu), ptr(g), ptr(dx), B, d, HW, stream()),
                2.0 * B * d * d * HW, 4.0 * B * (2 * d * HW + d * d))
     out = E(B, d, d); na = E(B); ys = E(B, 4, d, d); zs = E(B, 4, d, d); da = E(B, d, d)
@@ -95,14 +95,15 @@ def mpn_kernels(B=64, d=256, HW=196):
                12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10)
     kernel_row('MPN', 'ns_sqrtm fwd chain, symmetric input = the MPN head (same 12 products, 3 of 4 tiles computed)',
                lambda: lib.hk_ns_sqrtm_fwd_sym(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), B, d, 5, ptr(wsf), nwf, stream()),
-               12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10)
+               12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10, flops_exec=0.75 * 12 * 2.0 * B * d ** 3)
     kernel_row('MPN', 'ns_sqrtm bwd chain (38 products of 256^3 per sample, 13 launches)',
                lambda: lib.hk_ns_sqrtm_bwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), ptr(g), ptr(da), B, d, 5, ptr(wsb),
-                                           nwb, stream()), 38 * 2.0 * B * d ** 3, 4.0 * B * d * d * 12)
+                                           nwb, stream()), 38 * 2.0 * B * d ** 3, 4.0 * B * d * d * 12,
+               flops_exec=34 * 2.0 * B * d ** 3)
     tv = E(B, d * (d + 1) // 2)
     kernel_row('MPN', 'ns_sqrtm fwd chain + triu_vec in its last product (hk_ns_sqrtm_triu_fwd, symmetric: what the MPN head calls)',
                lambda: lib.hk_ns_sqrtm_triu_fwd(ptr(cov), ptr(out), ptr(tv), ptr(na), ptr(ys), ptr(zs), B, d, 5, 1, ptr(wsf), nwf, stream()),
-               12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10)
+               12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10, flops_exec=0.75 * 12 * 2.0 * B * d ** 3)
     kernel_row('MPN', 'triu_vec fwd', lambda: lib.hk_triu_vec_fwd(ptr(out), ptr(tv), B, d, stream()), 0, 4.0 * B * 32896 * 2)
     kernel_row('MPN', 'triu_vec bwd', lambda: lib.hk_triu_vec_bwd(ptr(tv), ptr(da), B, d, stream()), 0, 4.0 * B * (32896 + 65536))
 
@@ -115,7 +116,7 @@ def cbp_kernels(C=512, HW=196, D=6000):
         fl = 2.0 * B * C * C * HW
         kernel_row('CBCNN', f'cbp fwd B={B} (fused Gram + binning, finish)',
                    lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws, stream()),
-                   fl, 4.0 * B * (C * HW + D))
+                   fl, 4.0 * B * (C * HW + D), flops_exec=fl * 36 / 64)     # Gram tiles J >= I only
         kernel_row('CBCNN', f'cbp bwd B={B} (dc + P generation + GEMM in one kernel)',
                    lambda: lib.hk_cbp_bwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), ptr(dy), ptr(dx), B, C, HW, D,
                                           ptr(ws), nws, stream()), fl, 4.0 * B * (2 * C * HW + 2 * D))
