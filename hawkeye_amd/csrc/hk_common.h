@@ -101,6 +101,12 @@ __device__ __forceinline__ void coh_nap() { __builtin_amdgcn_s_sleep(8); }
 #define HK_FMAC_PINNED(acc, a, b) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
 #endif
 
+#ifndef HK_PIN_LOADED   // "this value is used here, unconditionally": placed behind a batch of loads whose results only feed selects,
+                        // it keeps the loads ahead of the selects (the compiler otherwise sinks each load into its
+                        // select's branch and waits for it there, one memory round trip per element)
+#define HK_PIN_LOADED(v) asm volatile("" : "+v"(v))
+#endif
+
 #define HK_LAUNCH_CHECK()                                 \
     do {                                                  \
         hipError_t e__ = hipGetLastError();               \

@@ -662,10 +662,6 @@ def npairs_loss(parts, targets):
 
 
 # --------------------------------------------------------------------- classifier
-_LINEAR_BWD_HIP_MAX = 16 * 1024 * 1024      # features x outputs up to which hk_linear_bwd beats rocBLAS (see backward)
-_FORCE_HIP_LINEAR_BWD = False                # tests / benchmarks: always take hk_linear_bwd
-
-
 class _Linear(torch.autograd.Function):
     """replaces nn.Linear on the pooled vector (model/methods/BCNN.py:42,54 and the other heads' classifiers)."""
 
@@ -694,15 +690,6 @@ class _Linear(torch.autograd.Function):
         g = _f32c(g)
         b, j = y.shape
         k = weight.shape[0]
-        if j * k > _LINEAR_BWD_HIP_MAX and not _FORCE_HIP_LINEAR_BWD:
-            # measured on the MI355X (profiles/r2_candidates.json): hk_linear_bwd wins at the MPN shape (32896 -> 200:
-            # 58 vs 74 us), ties with rocBLAS at BCNN's (262144 -> 200: 213 us on the streaming kernels of linear.hip
-            # against 200-205 us; 315 us on the generic tiles) and loses at OSME's (100352 -> 1024: 375 vs 303 us) -
-            # the two widest keep the library GEMMs for dy / dW
-            dy = g @ weight if ctx.needs_input_grad[0] else None
-            dw = g.t() @ y if ctx.needs_input_grad[1] else None
-            db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            return dy, dw, db
         dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
         db = torch.empty(k, dtype=torch.float32, device=y.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None

@@ -5,7 +5,6 @@ the reference (model/utils.py:5-28): convolutions Kaiming-normal on fan-out for 
 (1, 0), Linear layers Kaiming-normal (default fan-in) with zero bias.  `load_state_dict` is the reference's
 "take what matches by name and shape" loader used for ImageNet checkpoints.
 """
-import os
 
 import torch.nn as nn
 from torch.nn import init
@@ -45,12 +44,10 @@ def load_state_dict(model, state_dict):
 
 def wide_linear(layer, x):
     """`layer(x)` for the classifier / part FCs that sit directly on a pooled vector (tens of thousands of features,
-    a few hundred outputs): the split-K f32-MFMA kernel hk_linear_fwd - 134 us against rocBLAS' 385 us at
-    the BCNN shape (it picks a 16x64 macro-tile for a 45 us HBM-bound product), 30 vs 79 us at MPN's, 203 vs 266 us at
-    OSME's; the backward takes hk_linear_bwd where that wins and the library GEMMs elsewhere (functional._Linear).  The
-    `nn.Linear` stays the parameter holder, so `state_dict` keys, initialisers and optimiser groups are untouched.
-    HAWKEYE_HIP_LINEAR=0 switches back to `layer(x)` (A/B lever)."""
-    if os.environ.get('HAWKEYE_HIP_LINEAR', '1') != '0':
-        from .. import functional as F        # hawkeye_amd.functional
-        return F.linear(x, layer.weight, layer.bias)
-    return layer(x)
+    a few hundred outputs) on the hand-written kernels: hk_linear_fwd (linear_skinny_kernel: W and the features streamed
+    once through LDS-DMA) and hk_linear_bwd (linear_bwd64_kernel: dy = g W and dW = g^T y in one launch; OSME's part FCs:
+    linear_bwd16_kernel) - SURVEY 8f-1, replaces `self.classifier(x)` at model/methods/BCNN.py:54, CBCNN.py:34,
+    MPNCOV.py:37 and `self.fcs[p](...)` at OSME.py:43.  The `nn.Linear` stays the parameter holder, so `state_dict` keys,
+    initialisers and optimiser groups are untouched.  There is no switch back to the library GEMMs."""
+    from .. import functional as F        # hawkeye_amd.functional
+    return F.linear(x, layer.weight, layer.bias)

@@ -36,16 +36,44 @@ def _cpu_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _plugin_modules():
+    import importlib
+    return [importlib.import_module('hawkeye_amd.model.methods.' + n) for n in ('BCNN', 'CBCNN', 'MPNCOV', 'OSME')]
+
+
+def _torch_wide_linear(layer, x):
+    return layer(x)
+
+
+def set_wide_linear(kernel):
+    """Test lever: the plugins' classifier on the kernels (True: hawkeye_amd.model.utils.wide_linear, the product's only
+    path) or on torch's nn.Linear (False: the yardstick some tests compare against).  Returns the previous bindings for
+    restore_wide_linear()."""
+    from hawkeye_amd.model.utils import wide_linear
+    plugs = _plugin_modules()
+    saved = [m.wide_linear for m in plugs]
+    for m in plugs:
+        m.wide_linear = wide_linear if kernel else _torch_wide_linear
+    return saved
+
+
+def restore_wide_linear(saved):
+    for m, f in zip(_plugin_modules(), saved):
+        m.wide_linear = f
+
+
 @contextlib.contextmanager
 def emulated():
     lib = load_emu()
     saved = (_lib._lib, F.ptr, F.stream, F._on)
     _lib._lib, F.ptr, F.stream, F._on = lib, _cpu_ptr, (lambda: None), (lambda device: contextlib.nullcontext())
-    # the plugins route their wide classifier through hk_linear_fwd by default; emulating a 262144-feature split-K
-    # GEMM takes minutes, so whole-model cases keep nn.Linear here unless a test asks for the kernel explicitly
-    had = os.environ.get('HAWKEYE_HIP_LINEAR')
-    if had is None:
-        os.environ['HAWKEYE_HIP_LINEAR'] = '0'
+    # the plugins route their wide classifier through hk_linear_fwd / bwd; emulating a 262144-feature GEMM takes
+    # minutes, so whole-model cases run `layer(x)` (torch CPU) here unless a test puts the real wide_linear back
+    # (torch_classifier() below does the same for a GPU test that wants the library as its yardstick)
+    plugs = _plugin_modules()
+    wl_saved = [m.wide_linear for m in plugs]
+    for m in plugs:
+        m.wide_linear = _torch_wide_linear
     # the CIN forward takes the library GEMMs for the shapes its one-kernel form does not cover; on the emulated device
     # every shape goes through the kernels (there is no library to take, and the chain stays covered)
     cin_saved = F._CIN_SCI_FWD_HIP
@@ -55,5 +83,5 @@ def emulated():
     finally:
         _lib._lib, F.ptr, F.stream, F._on = saved
         F._CIN_SCI_FWD_HIP = cin_saved
-        if had is None:
-            os.environ.pop('HAWKEYE_HIP_LINEAR', None)
+        for m, f in zip(plugs, wl_saved):
+            m.wide_linear = f

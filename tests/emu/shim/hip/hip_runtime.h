@@ -408,6 +408,7 @@ inline T __shfl(T v, int srclane, int = 64) {
 #define HK_DYN_LDS(name) float* name = reinterpret_cast<float*>(hipemu::B->dyn_lds)
 #define HK_DYN_LDS16(name) HK_DYN_LDS(name)
 #define HK_FMAC_PINNED(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
+#define HK_PIN_LOADED(v) ((void)0)
 #define HK_COH_RSRC 1      /* coherent accesses: plain ones (one workgroup at a time; a ticket order in which a task only waits for earlier tickets never waits here) */
 namespace hk {
 struct coh_rsrc_t { char* p; };

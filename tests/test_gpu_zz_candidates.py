@@ -692,15 +692,15 @@ _MODEL_CFG = {
 
 
 @pytest.mark.parametrize('b,j,k', [(2, 6000, 200), (2, 32896, 200), (3, 262144, 200), (16, 6000, 8142), (64, 65536, 200),
-                                   (37, 65728, 130)])
-def test_linear_bwd_direct_at_classifier_shapes(F, b, j, k, monkeypatch):
-    """hk_linear_bwd on its own at the three classifier widths of the plugins (CBCNN 6000: not a multiple of 64, so the
-    48-column / 8-deep tails of the tile kernel are exercised; MPN 32896; BCNN 262144: from 65536 features, up to 64
-    samples and 208 classes the streaming kernels linear_dy_kernel / linear_dw_kernel - full and ragged sample / class
-    tiles, a ragged last slab) and the iNat class count:
+                                   (37, 65728, 130), (10, 100352, 1024), (7, 16448, 300), (16, 20032, 1000)])
+def test_linear_bwd_direct_at_classifier_shapes(F, b, j, k):
+    """hk_linear_bwd on its own at the classifier widths of the plugins (CBCNN 6000: not a multiple of 64, so the
+    48-column / 8-deep tails of the tile kernel are exercised; MPN 32896 and BCNN 262144: up to 64 samples and 208 classes
+    both products in one launch of linear_bwd64_kernel - full and ragged sample / class tiles, a ragged last slab, 50
+    and 52 class steps; OSME 100352 -> 1024 at N = 10: linear_bwd16_kernel, ragged class blocks and slabs) and the iNat
+    class count:
     dy = g W, dW = g^T y, db = sum_b g against fp64.  Nothing but the kernel is between the inputs and the check, so a
     failure here is the kernel's."""
-    monkeypatch.setattr(F, '_FORCE_HIP_LINEAR_BWD', True)     # (the widest shapes default to the library GEMMs: faster)
     gen = torch.Generator().manual_seed(j + k)
     y = torch.randn(b, j, generator=gen)
     w = torch.randn(k, j, generator=gen) / j ** 0.5
@@ -717,9 +717,36 @@ def test_linear_bwd_direct_at_classifier_shapes(F, b, j, k, monkeypatch):
     assert float((yg.grad.double().cpu() - g.double() @ w.double()).abs().max()) < 1e-5 * float((g.double() @ w.double()).abs().max())
 
 
+@pytest.mark.parametrize('b,j,k', [(33, 16384, 200), (5, 16448, 208), (9, 16384, 260), (64, 16384, 193)])
+def test_linear_bwd_single_products(F, b, j, k):
+    """Only one of the two gradients wanted (stage-1 training: the classifier alone; or a frozen classifier): the role of
+    linear_bwd64_kernel / the instance of linear_bwd16_kernel whose result is not asked for does not run, the other one
+    and db are unchanged - bit for bit the values of the combined launch."""
+    gen = torch.Generator().manual_seed(b + j + k)
+    y = torch.randn(b, j, generator=gen)
+    w = torch.randn(k, j, generator=gen) / j ** 0.5
+    bias = torch.randn(k, generator=gen)
+    g = torch.randn(b, k, generator=gen).to(DEV)
+
+    def grads(need_y, need_w):
+        yg = y.clone().to(DEV).requires_grad_(need_y)
+        wg, bg = w.clone().to(DEV).requires_grad_(need_w), bias.clone().to(DEV).requires_grad_(True)
+        (F.linear(yg, wg, bg) * g).sum().backward()
+        return yg.grad, wg.grad, bg.grad
+    dy2, dw2, db2 = grads(True, True)
+    dy1, none_w, db1 = grads(True, False)
+    none_y, dw1, db3 = grads(False, True)
+    assert none_w is None and none_y is None
+    assert torch.equal(dy1, dy2) and torch.equal(dw1, dw2) and torch.equal(db3, db2)
+    assert rel(db1, db2) < 1e-6            # (without the dW role db is its own small kernel: another summation order)
+    assert rel(dy2, g.double().cpu() @ w.double()) < 2e-6 and rel(dw2, g.double().cpu().t() @ y.double()) < 2e-6
+    assert rel(db2, g.double().cpu().sum(0)) < 2e-6
+
+
 @pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN'])
 def test_models_with_hip_classifier(F, name, monkeypatch):
-    """HAWKEYE_HIP_LINEAR=1: the classifier on the pooled vector runs on hk_linear_*.  Checked in separate places so that
+    """The classifier on the pooled vector on hk_linear_* (the product's only path) against the same model with torch's
+    nn.Linear in its place (a test lever: tests/emu/harness.py::set_wide_linear).  Checked in separate places so that
     a failure says where it comes from:
       (a) logits vs the REFERENCE model (tests/golden/model_logits.npz) and the classifier's own gradients vs torch's;
       (b) the gradient hk_linear_bwd hands back at the POOLED VECTOR against fp64 (g W with the same weights) - the
@@ -740,7 +767,6 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
     from hawkeye_amd.model.registry import MODEL
     from inputs import rs_randn, seeded_init
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'model_logits.npz'))
-    monkeypatch.setattr(F, '_FORCE_HIP_LINEAR_BWD', True)     # hk_linear_bwd at every width, also where rocBLAS is the default
     m = MODEL.get(name)(CfgNode(dict(name=name, **_MODEL_CFG[name])))
     seeded_init(m, 900)
     m = m.to(DEV).eval()
@@ -760,8 +786,9 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
     hook = pool.register_forward_hook(keep)
     target = torch.tensor([3, 77], device=DEV)
     runs = []
+    from emu.harness import restore_wide_linear, set_wide_linear
     for flag in ('0', '0', '1'):
-        monkeypatch.setenv('HAWKEYE_HIP_LINEAR', flag)
+        saved_wl = set_wide_linear(flag == '1')
         m.zero_grad()
         y = m(x)
         assert rel(y, g[name]) < 1e-4 and y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
@@ -769,6 +796,7 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
         runs.append(dict(cw=m.classifier.weight.grad.clone(), cb=m.classifier.bias.grad.clone(), trunk=w0.grad.clone(),
                          pooled=seen[-1], pgrad=seen[-1].grad.clone(), logits=y.detach(),
                          fgrad=None if feats[-1].grad is None else feats[-1].grad.clone()))
+        restore_wide_linear(saved_wl)
     hook.remove()
     t0, t0b, t1 = runs
     # (a) the classifier's own gradients
