@@ -38,11 +38,6 @@
 
 namespace hk {
 
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-
 // LABV (HK_LAB builds, timing only - results are wrong): 1 = every K-block is staged from the addresses of K-block 0 (the
 // pieces come from L2 with a short latency: separates "waiting for HBM at the barrier" from the cost of the staging itself)
 template <int HW, int MODE, int LABV = 0>

@@ -107,6 +107,17 @@ __device__ __forceinline__ void coh_nap() { __builtin_amdgcn_s_sleep(8); }
 #define HK_PIN_LOADED(v) asm volatile("" : "+v"(v))
 #endif
 
+// s_waitcnt vmcnt(n) + s_barrier: the workgroup barrier that ends a pipeline step of an LDS-DMA stream - waits for all but
+// the n most recent vector-memory operations of this wave (the pieces it has just issued), then publishes the stage
+#define HK_VMCNT_IMM(n) (((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))     /* gfx9 s_waitcnt: vmcnt only */
+#define HK_VM_BARRIER(n)                                                                                       \
+    do {                                                                                                       \
+        asm volatile("" ::: "memory");                 /* no LDS access moves across */                        \
+        __builtin_amdgcn_s_waitcnt(HK_VMCNT_IMM(n));                                                           \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        asm volatile("" ::: "memory");                                                                         \
+    } while (0)
+
 #define HK_LAUNCH_CHECK()                                 \
     do {                                                  \
         hipError_t e__ = hipGetLastError();               \
@@ -128,6 +139,7 @@ struct Tuning {
     int ns_streams = 1;     // HK_NS_STREAMS    n: the batch runs the Newton-Schulz chain in n + 1 parts on n + 1 HIP queues (default 1: two halves), 0: one queue
     int ns_flow = 0;        // HK_NS_FLOW       1 / 2: the Newton-Schulz forward as one dataflow launch (hk_nsmm.h, ns_flow_kernel; 2: skewed ticket order), 0: a launch per step
     int ns_sym = 1;         // HK_NS_SYM        1: hk_ns_sqrtm_fwd_sym skips the tiles below the diagonal blocks, 0: it computes every tile
+    int lin_walk = 1;       // HK_LIN_WALK      classifier backward: 1: workgroup s walks chunks s, s + S, ..; 0: a contiguous slab per workgroup
     int sched_b = 0;        // HK_SCHED_B       > 0: work-split heuristics that depend on the batch size behave as if it were this (tests: the
                             //                  large-batch schedules on small inputs); results do not depend on it
 };
@@ -218,6 +230,13 @@ class AuxScope {
 
 constexpr int WAVE = 64;
 constexpr int NXCD = 8;
+
+// LDS-DMA: one global_load_lds_dwordx4 - lane l of the wave copies the 16 bytes at ITS global address g to the
+// wave-uniform LDS address l + 16 l (1 KB per wave-instruction, no registers, counted in vmcnt)
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

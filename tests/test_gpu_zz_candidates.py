@@ -718,7 +718,7 @@ def test_linear_bwd_direct_at_classifier_shapes(F, b, j, k):
 
 
 @pytest.mark.parametrize('b,j,k', [(33, 16384, 200), (5, 16448, 208), (9, 16384, 260), (64, 16384, 193)])
-def test_linear_bwd_single_products(F, b, j, k):
+def test_linear_bwd_single_products(F, b, j, k, tune):
     """Only one of the two gradients wanted (stage-1 training: the classifier alone; or a frozen classifier): the role of
     linear_bwd64_kernel / the instance of linear_bwd16_kernel whose result is not asked for does not run, the other one
     and db are unchanged - bit for bit the values of the combined launch."""
@@ -741,6 +741,9 @@ def test_linear_bwd_single_products(F, b, j, k):
     assert rel(db1, db2) < 1e-6            # (without the dW role db is its own small kernel: another summation order)
     assert rel(dy2, g.double().cpu() @ w.double()) < 2e-6 and rel(dw2, g.double().cpu().t() @ y.double()) < 2e-6
     assert rel(db2, g.double().cpu().sum(0)) < 2e-6
+    tune('lin_walk', 0)                     # a contiguous slab of chunks per workgroup instead of the interleaved walk: same bits
+    dy0, dw0, db0 = grads(True, True)
+    assert torch.equal(dy0, dy2) and torch.equal(dw0, dw2) and torch.equal(db0, db2)
 
 
 @pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN'])

@@ -1,0 +1,41 @@
+// Timing-only instances of the classifier-backward kernel (hawkeye_amd/csrc/hk_linear_bwd.h, LABV != 0): which side of
+// linear_bwd64_kernel - the MFMA stream, the LDS-DMA reads, the stores, the fragment reads - the time of the whole is
+// made of.  Results of these instances are WRONG by construction; nothing in the product links this file.
+//   make -C tools/probe && python tools/linear_lab.py
+#include "../../hawkeye_amd/csrc/hk_linear_bwd.h"
+
+using namespace hk;
+
+template <int LABV>
+static int launch(const float* g, const float* w, const float* y, float* dy, float* dw, float* db, int B, int J, int K, int walk,
+                  hipStream_t st) {
+    const int nchunk = J / 64;
+    const int CPS = (nchunk + 255) / 256, S = (nchunk + CPS - 1) / CPS;
+    const size_t ldsb = (size_t)2 * (50 + 16) * 1024;
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bwd64_kernel<50, LABV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ldsb) != hipSuccess) return -1;
+        once = true;
+    }
+    hipLaunchKernelGGL((linear_bwd64_kernel<50, LABV>), dim3(S), dim3(512), ldsb, st, g, w, y, dy, dw, db, B, J, K, CPS, S, walk);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// K must be 197..200 (50 class steps), B <= 64, J % 64 == 0
+extern "C" int hk_probe_linear_bwd64(int labv, const float* g, const float* w, const float* y, float* dy, float* dw, float* db, int B,
+                                     int J, int K, int walk, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (labv) {
+        case 0: return launch<0>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 1: return launch<1>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 2: return launch<2>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 4: return launch<4>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 6: return launch<6>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 7: return launch<7>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 9: return launch<9>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 14: return launch<14>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 8: return launch<8>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        default: return -3;
+    }
+}

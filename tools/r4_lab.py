@@ -22,7 +22,7 @@ st = lambda: P(torch.cuda.current_stream().cuda_stream)
 p = lambda t: P(t.data_ptr()) if t is not None else None
 ROUNDS, ITERS = 5, 20
 PEAK_TF, PEAK_GBS = 157.3, 8000.0
-DEFAULTS = dict(bwd_v=0, cbp_bin=-1, ns_streams=1, ns_tn=0, linear_slabs=0, bcnn_generic=0, ns_sym=1, sched_b=0)
+DEFAULTS = dict(bwd_v=0, cbp_bin=-1, ns_streams=1, ns_tn=0, linear_slabs=0, bcnn_generic=0, ns_sym=1, sched_b=0, lin_walk=1)
 
 
 def knobs(**kw):
@@ -69,8 +69,12 @@ def run_group(title, items, flops=None, bytes_=None):
 
 def g_linear():
     out = []
-    for name, B, J, K in (('BCNN 64 x 262144 -> 200', 64, 262144, 200), ('MPN 64 x 32896 -> 200', 64, 32896, 200),
-                          ('OSME 10 x 100352 -> 1024', 10, 100352, 1024), ('CBCNN-Gram 16 x 262144 -> 200', 16, 262144, 200)):
+    shapes = [('BCNN 64 x 262144 -> 200', 64, 262144, 200), ('MPN 64 x 32896 -> 200', 64, 32896, 200),
+              ('OSME 10 x 100352 -> 1024', 10, 100352, 1024), ('CBCNN-Gram 16 x 262144 -> 200', 16, 262144, 200)]
+    if 'pitch' in sys.argv:       # is the 1 MB row pitch of BCNN's W (J = 2^18 floats) what holds the streams at 3.8 TB/s?
+        shapes = [('BCNN 64 x 262144 -> 200', 64, 262144, 200), ('pitch + 4 KB: 64 x 263168 -> 200', 64, 263168, 200),
+                  ('pitch + 16 KB: 64 x 266240 -> 200', 64, 266240, 200)]
+    for name, B, J, K in shapes:
         y = torch.randn(B, J, device=dev)
         w = torch.randn(K, J, device=dev) * 0.01
         bias = torch.zeros(K, device=dev)
@@ -95,6 +99,7 @@ def g_linear():
         items = [('hk_linear_fwd', {}, fwd, fl, by),
                  ('rocBLAS fwd (torch.addmm)', {}, lib_fwd, fl, by),
                  ('hk_linear_bwd (dy + dW + db)', {}, bwd, 2 * fl, 2 * by),
+                 ('hk_linear_bwd, contiguous slabs (lin_walk=0)', dict(lin_walk=0), bwd, 2 * fl, 2 * by),
                  ('hk_linear_bwd generic tiles (linear_slabs=-1)', dict(linear_slabs=-1), bwd, 2 * fl, 2 * by),
                  ('hk_linear_bwd dy only', {}, bwd_dy, fl, by),
                  ('hk_linear_bwd dW + db only', {}, bwd_dw, fl, by),
