@@ -76,6 +76,18 @@ __device__ __forceinline__ void coh_store16(coh_rsrc_t rs, int byte_off, float4 
     __builtin_memcpy(&v, &f, 16);
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16);
 }
+// Plain (cached) stores through a buffer descriptor: the hardware drops the lanes whose byte offset lies beyond the
+// descriptor's size - a ragged edge needs no predicate, so the instruction ALWAYS issues (a store under `if (row < n)` is
+// skipped altogether when no lane passes: its place in a counted s_waitcnt vmcnt(n) would then be taken by an older load)
+__device__ __forceinline__ coh_rsrc_t buf_rsrc(const float* base, long long floats) { return coh_rsrc(base, floats); }
+__device__ __forceinline__ void buf_store16(coh_rsrc_t rs, unsigned byte_off, f32x4 f) {
+    decltype(__builtin_amdgcn_raw_buffer_load_b128(rs, 0, 0, 0)) v;
+    __builtin_memcpy(&v, &f, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store4(coh_rsrc_t rs, unsigned byte_off, float f) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), rs, (int)byte_off, 0, 0);
+}
 __device__ __forceinline__ int coh_ticket(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int coh_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void coh_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // this wave's stores have left

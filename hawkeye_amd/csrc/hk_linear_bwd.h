@@ -16,38 +16,47 @@ namespace hk {
 // launch, one 8-wave workgroup per CU walking 64-feature chunks.
 //     dy [B][J] = g W      (reads W, writes dy)          dW [K][J] = g^T y      (reads y, writes dW)
 // The two products share nothing but g [B][K] (51 KB), so inside a workgroup they are two ROLES of four waves each, one
-// wave of each role per SIMD: the W / dy stream and the y / dW stream run side by side (553 MB of combined traffic
-// against two serial passes at 2.4-3.1 TB/s in round 3) and the matrix pipe of every SIMD always has a wave of the other
-// role to issue from.  What makes the MFMA stream dense - 204 MFMAs per wave and chunk against 13 / 4 LDS-DMA pieces,
-// 50 / 16 fragment reads, 4 / 16 stores and ONE barrier:
-//   * g never moves: role dy keeps A = g[16 st + l15][4 s + lq] of its sample tile st for all NKS class steps in
-//     registers, role dW keeps A = g^T of its three (+ a quarter of the thirteenth) class tiles for all 16 sample steps;
+// wave of each role per SIMD: the W / dy stream and the y / dW stream run side by side (553 MB of combined traffic; the
+// stream alone takes 108 us = 5.2 TB/s for this half-read half-write mix, the 13.4 GFLOP alone 109 us - the two sides
+// are of equal length, so everything here is about keeping BOTH busy all the time):
+//   * g never moves: it is staged once through LDS (coalesced, zero-padded to [64][209]) and role dy keeps
+//     A = g[16 st + l15][4 s + lq] of its sample tile st for all NKS class steps in registers, role dW keeps A = g^T of its
+//     three (+ a quarter of the thirteenth) class tiles for all 16 sample steps;
 //   * the B operand is the streamed tile exactly as it lies in memory.  A tile row is 64 consecutive features; LDS-DMA
 //     piece p holds rows 4 p .. 4 p + 3 (lane l: row 4 p + (l >> 4), features 4 (l & 15) ..+3), so the fragment of class /
 //     sample step s is ONE linear ds_read_b128 at 1 KB s + 16 lane - no swizzle, no conflicts - whose four floats feed the
 //     four MFMAs of the step: MFMA t computes the output columns {4 n + t}.  A lane's four accumulators therefore hold
 //     four CONSECUTIVE features of a row and leave as 16-byte stores (256-byte runs per row) straight from registers;
-//   * two LDS stages (2 x 66 KB).  The pieces of chunk c + 1 are issued behind the first MFMA steps of chunk c and have
-//     the rest of the chunk (~6 us) to land; the barrier that ends chunk c waits for them and publishes the stage;
+//   * the pipeline unit is HALF a chunk - classes 0 .. 2 NKS - 1 of W and samples 0 .. 31 of y, then the other halves,
+//     accumulated in the same registers - on FOUR LDS stages of 33 KB: the pieces of unit u + 3 are issued behind the
+//     first MFMA steps of unit u, so ~100 KB per CU are always on their way (with whole chunks on two stages the next
+//     chunk was requested in a burst and memory idled for the rest of the chunk: 143 us);
 //   * nothing but MFMAs between two barriers that is not spread out: fragments are read two (dy) / one (dW) step ahead
-//     of their use, and the results of chunk c leave DURING chunk c + 1, one store behind each MFMA step (16 stores in a
-//     burst behind the barrier kept the wave off the matrix pipe for ~1.6 us per chunk: store issue, not bandwidth).
-// The last class tile (classes 192 ..) is dealt to the four dW waves by output column quarter (wave i: columns {4 n + i},
-// 4-byte stores: 4 % of dW).  db = sum_b g falls out of the dW role's resident fragments in the workgroup of chunk 0.
-// A role whose result is not wanted (dy == nullptr: stage-1 training of the classifier alone) exits at once; finished
-// waves do not take part in s_barrier.  Deterministic: no atomics, fixed summation order.
-template <int NKS, int LABV = 0>
+//     of their use, and the results of chunk c leave DURING chunk c + 1, a store behind an MFMA step (16 stores in a burst
+//     behind the barrier kept a wave off the matrix pipe for ~1.6 us per chunk: store issue, not bandwidth);
+//   * the barrier that ends unit u waits for the pieces of unit u + 1 only: s_waitcnt vmcnt(n) with n = everything this
+//     wave has issued since (two units of pieces, three units of stores; vmcnt retires in issue order).  The count is
+//     exact because every store ALWAYS issues: ragged sample / class edges are cut by the buffer descriptor's bounds
+//     check (buf_store16), not by a branch around the instruction.
+// The last class tile (classes 192 ..) is dealt to the four DY waves by output column quarter (wave i: columns {4 n + i},
+// one more MFMA in eight of its 25 steps, 4-byte stores: 4 % of dW) - the dW waves hold 48 resident fragments, 48
+// accumulators and the 48 finished values of the previous chunk, the dy waves have room.  db = sum_b g falls out of the
+// resident fragments in the workgroup of chunk 0.  Deterministic: no atomics, fixed summation order.
+// MODE 0: both products; 1: dy only (the dW waves leave, class tile 12 is skipped); 2: dW only (the dy waves compute
+// nothing but their quarter of class tile 12, no W traffic).
+template <int NKS, int MODE = 0, int LABV = 0>
 __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                               const float* __restrict__ y, float* __restrict__ dy,
                                                               float* __restrict__ dw, float* __restrict__ db, int B, int J,
                                                               int K, int CPS, int S, int walk) {
+    static_assert(NKS % 2 == 0 && NKS <= 52, "two halves of class steps; up to 208 classes");
     constexpr int CH = 64;                               // features per chunk
-    constexpr int WP = NKS, YP = 16;                     // 1 KB pieces of the W tile [4 NKS][64] / the y tile [64][64]
-    constexpr int STAGE = (WP + YP) * 256;               // floats
-    constexpr int NPW = (WP + 3) / 4;                    // W pieces per dy wave (at most)
-    // every store instruction of the dW role is issued whatever K is (no tile of this wave is empty): its stores can be
-    // COUNTED in the wait that ends a chunk.  50 class steps <=> 197 <= K <= 200.
-    constexpr bool COUNTED = NKS == 50;
+    constexpr int NKH = NKS / 2;                         // class steps = 1 KB W pieces per half chunk
+    constexpr int YPH = 8;                               // y pieces per half chunk (32 samples)
+    constexpr int STAGE = (NKH + YPH) * 256;             // floats of one LDS stage (half a chunk)
+    constexpr int NPW = (NKH + 3) / 4;                   // W pieces per dy wave and unit (at most)
+    constexpr int GP = 209;                              // row pitch of the g image
+    static_assert(64 * GP <= 2 * STAGE, "the g image fits stages 2 and 3");
     HK_DYN_LDS16(lds);
     const int slab = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -61,232 +70,315 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
     int nch = walk ? (nchunk - slab + S - 1) / S : nchunk - cfirst;
     nch = nch < CPS ? nch : CPS;
     if (slab >= S || nch <= 0) return;
+    const int U = 2 * nch;                                       // pipeline units
     const bool role_dy = wave < 4;                               // wave-uniform
-    if (role_dy ? dy == nullptr : dw == nullptr) return;
+    constexpr bool DO_DY = MODE != 2, DO_DW = MODE != 1;
     const long long f0 = (long long)cfirst * CH;                 // first feature of the workgroup
     const long long fstep = (long long)cstep * CH;               // features from one of its chunks to the next
     const float* Lf = lds + 4 * lane;                            // this lane's 16 bytes of a piece
     const bool st_ok = !(LABV & 4) || B < 0;                     // (timing-only instances: the stores stay in the code, never run)
-    using T_ = std::true_type;
-    using F_ = std::false_type;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    // ---- g -> LDS image [64][GP] in stages 2 and 3 (zero beyond B samples / K classes), coalesced
+    {
+        constexpr int NE = (64 * GP + 511) / 512;
+        float tmp[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 512 * i, b = e / GP, c = e - b * GP;
+            tmp[i] = g[(long long)(b < B ? b : B - 1) * K + (c < K ? c : K - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) HK_PIN_LOADED(tmp[i]);      // (every load before the first select: see HK_PIN_LOADED)
+        float* gi = lds + 2 * STAGE;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 512 * i, b = e / GP, c = e - b * GP;
+            if (e < 64 * GP) gi[e] = (b < B && c < K) ? tmp[i] : 0.f;
+        }
+    }
+    const float* gi = lds + 2 * STAGE;
 
     if (role_dy) {
-        const int st = wave;                                     // sample tile
-        // pieces p = wave + 4 u of the W tile: class row 4 p + lq (clamped to K - 1), features 4 l15 ..+3 (byte offsets
-        // from the chunk's base: K J 4 < 4 GB is checked by the launcher)
-        unsigned wo[NPW];
+        const int st = wave;                                     // sample tile; also the column quarter of class tile 12
+        // pieces p = wave + 4 i of a W half tile: class row 4 (h NKH + p) + lq (clamped to K - 1), features 4 l15 ..+3
+        // (byte offsets from the chunk's base: K J 4 < 4 GB is checked by the launcher)
+        unsigned wo[2][NPW];
 #pragma unroll
-        for (int u = 0; u < NPW; ++u) {
-            int c = 4 * (wave + 4 * u) + lq;
-            c = c < K ? c : K - 1;
-            wo[u] = 4u * ((unsigned)c * (unsigned)J + 4u * l15);
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) {
+                int c = 4 * (h * NKH + wave + 4 * i) + lq;
+                c = c < K ? c : K - 1;
+                wo[h][i] = 4u * ((unsigned)c * (unsigned)J + 4u * l15);
+            }
+        const int npc = (NKH - wave + 3) / 4;                    // pieces of this wave per unit: NPW or NPW - 1
         const char* wbase = reinterpret_cast<const char*>(w + f0);
-        auto dma = [&](int c, int sto, int u) {                  // piece u of chunk c into the stage at float offset sto
-            const int p = wave + 4 * u;                          // (4 u + 3 < WP folds at compile time: only the last u branches)
-            if (4 * u + 3 < WP || p < WP)
-                glds16(reinterpret_cast<const float*>(wbase + (long long)c * (fstep * 4) + wo[u]), lds + sto + 256 * p);
+        auto dma = [&](int v, int h, int i) __attribute__((always_inline)) {   // piece i of unit v (= chunk v >> 1, half h == v & 1)
+            const int p = wave + 4 * i;                          // (4 i + 3 < NKH folds at compile time: only the last i branches)
+            if (DO_DY && (4 * i + 3 < NKH || p < NKH))
+                glds16(reinterpret_cast<const float*>(wbase + (long long)(v >> 1) * (fstep * 4) + wo[h][i]),
+                       lds + (v & 3) * STAGE + 256 * p);
         };
 #pragma unroll
-        for (int u = 0; u < NPW; ++u) dma(0, 0, u);
-        // resident A fragments: ga[s] = g[16 st + l15][4 s + lq]  (zero beyond B samples / K classes)
-        float ga[NKS];
-        {
-            const int b = 16 * st + l15;
-            const float* gb = g + (long long)(b < B ? b : B - 1) * K;
-            // every load issued before the first use (clamped addresses; HK_PIN_LOADED keeps the compiler from sinking a
-            // load into the select that follows it - it did, with an s_waitcnt vmcnt(0) per element: 50 L2 round trips)
+        for (int i = 0; i < NPW; ++i) dma(0, 0, i);
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) ga[s] = gb[4 * s + lq < K ? 4 * s + lq : K - 1];
+        for (int i = 0; i < NPW; ++i) dma(1, 1, i);
+        HK_LDS_BARRIER();                                        // the g image is written
+        // resident A fragments: ga[s] = g[16 st + l15][4 s + lq];  class tile 12: g13[s] = g[4 s + lq][192 + l15]
+        float ga[DO_DY ? NKS : 1], g13[DO_DW ? 16 : 1];
+        if (DO_DY) {
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) HK_PIN_LOADED(ga[s]);
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) ga[s] = (b < B && 4 * s + lq < K) ? ga[s] : 0.f;
+            for (int s = 0; s < NKS; ++s) ga[s] = gi[(16 * st + l15) * GP + 4 * s + lq];
         }
-        // this lane's rows of the output tile: sample 16 st + 4 lq + r, features 4 l15 ..+3 (32-bit element offsets)
-        int orow[4];
+        if (DO_DW) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) orow[r] = (16 * st + 4 * lq + r) * J + 4 * l15;
-        f32x4 out[4];                                            // the finished rows of the previous chunk
-        auto store_row = [&](int c, int r) {                     // row r of chunk c's tile
-            if (16 * st + 4 * lq + r < B && st_ok) *reinterpret_cast<f32x4*>(dy + f0 + (long long)c * fstep + orow[r]) = out[r];
+            for (int s = 0; s < 16; ++s) g13[s] = gi[(4 * s + lq) * GP + 192 + l15];
+            if (db != nullptr && cfirst == 0 && wave == 0) {     // db of the classes 192 ..: see the dW role
+                float sum = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) sum += g13[s];
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                if (lq == 0 && 192 + l15 < K) db[192 + l15] = sum;
+            }
+        }
+        HK_LDS_BARRIER();                                        // ... and read by everybody: stages 2, 3 are free
+        if (U > 2) {
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) dma(2, 0, i);
+        }
+        // this lane's rows of the dy tile: sample 16 st + 4 lq + r, features 4 l15 ..+3; of class tile 12: class 192 + 4 lq + r,
+        // feature 4 l15 + st (byte offsets; rows beyond B / K lie beyond the descriptor's end: dropped by the hardware)
+        const coh_rsrc_t rs = buf_rsrc(dy, DO_DY ? (long long)B * J : 0);
+        const coh_rsrc_t rs12 = buf_rsrc(dw, DO_DW ? (long long)K * J : 0);
+        unsigned orow[4], orow12[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            orow[r] = 4u * ((unsigned)(16 * st + 4 * lq + r) * (unsigned)J + 4u * l15);
+            orow12[r] = 4u * ((unsigned)(192 + 4 * lq + r) * (unsigned)J + 4u * l15 + st);
+        }
+        f32x4 out[4], out13;                                     // the finished rows of the previous chunk
+        auto store_row = [&](int c, int r) __attribute__((always_inline)) {       // row r of chunk c's dy tile
+            if (DO_DY && st_ok) buf_store16(rs, orow[r] + 4u * (unsigned)(f0 + (long long)c * fstep), out[r]);
         };
-        HK_VM_BARRIER(0);
-        auto chunk = [&](int c, int cur, auto load_tag, auto prev_tag) {
-            constexpr bool LOAD = decltype(load_tag)::value, PREV = decltype(prev_tag)::value;
-            const int nxt = cur ? 0 : STAGE;
-            const float* T = Lf + cur;
-            f32x4 acc[4];
+        auto store_12 = [&](int c, int r) __attribute__((always_inline)) {        // row r of chunk c's quarter of class tile 12
+            if (DO_DW && st_ok) buf_store4(rs12, orow12[r] + 4u * (unsigned)(f0 + (long long)c * fstep), out13[r]);
+        };
+        constexpr int PW = DO_DY ? 2 * NPW : 0;                  // pieces issued in two units (by a wave with NPW of them)
+        constexpr int SW = 3 * ((DO_DY ? 2 : 0) + (DO_DW ? 2 : 0));   // stores issued in three units
+        // unit 0 has landed when all but the pieces of units 1 and 2 have
+        if (U > 2 && !LABV) { if (npc == NPW) HK_VM_BARRIER(PW); else HK_VM_BARRIER(PW >= 2 ? PW - 2 : 0); }
+        else HK_VM_BARRIER(0);
+        f32x4 acc[4], acc13;
+        // H: half (u & 1); LOAD: unit u + 3 exists; PREV: chunk (u >> 1) - 1 has rows to store; WK: how the end-of-unit wait counts
+        auto unit = [&](int u, auto h_tag, auto load_tag, auto prev_tag, auto wk_tag) __attribute__((always_inline)) {
+            constexpr int H = decltype(h_tag)::value, WK = decltype(wk_tag)::value;
+            constexpr bool LOAD = decltype(load_tag)::value != 0, PREV = decltype(prev_tag)::value != 0;
+            const float* T = Lf + (u & 3) * STAGE;
+            const float* T1 = T + 256 * NKH + st;                // y[32 H + 4 s + lq][4 l15 + st] at + 256 s
+            if (H == 0) {
+                acc13 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             f32x4 fr[3];                                        // fragment of step s in fr[s % 3], read two steps ahead
+            float f1[2];
             fr[0] = fr[1] = fr[2] = (f32x4){1.f, 1.f, 1.f, 1.f};
+            f1[0] = f1[1] = 1.f;
             if (!(LABV & 8)) {
-                fr[0] = *reinterpret_cast<const f32x4*>(T);
-                fr[1] = *reinterpret_cast<const f32x4*>(T + 256);
+                if (DO_DY) {
+                    fr[0] = *reinterpret_cast<const f32x4*>(T);
+                    fr[1] = *reinterpret_cast<const f32x4*>(T + 256);
+                }
+                if (DO_DW) f1[0] = T1[0];
             }
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                if (s + 2 < NKS && !(LABV & 8)) fr[(s + 2) % 3] = *reinterpret_cast<const f32x4*>(T + 256 * (s + 2));
-                if (LOAD && s < NPW && !(LABV & 2)) dma(c + 1, nxt, s);
-                if (PREV && s >= NPW && s < NPW + 4) store_row(c - 1, s - NPW);
+            for (int s = 0; s < NKH; ++s) {
+                if (!(LABV & 8)) {
+                    if (DO_DY && s + 2 < NKH) fr[(s + 2) % 3] = *reinterpret_cast<const f32x4*>(T + 256 * (s + 2));
+                    if (DO_DW && s + 1 < 8) f1[(s + 1) & 1] = T1[256 * (s + 1)];
+                }
+                if (LOAD && s < NPW && !(LABV & 2)) dma(u + 3, H ^ 1, s);
+                if (PREV && (s == 8 || s == 16)) store_row((u >> 1) - 1, 2 * H + (s == 16));
+                if (PREV && (s == 12 || s == 20)) store_12((u >> 1) - 1, 2 * H + (s == 20));
                 if (!(LABV & 1)) {
+                    if (DO_DY) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], fr[s % 3][t], acc[t], 0, 0, 0);
+                        for (int t = 0; t < 4; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[DO_DY ? H * NKH + s : 0], fr[s % 3][t], acc[t], 0, 0, 0);
+                    }
+                    if (DO_DW && s < 8)
+                        acc13 = __builtin_amdgcn_mfma_f32_16x16x4f32(g13[DO_DW ? 8 * H + s : 0], f1[s & 1], acc13, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);               // a step's requests stay in ITS step
             }
-            // C/D layout: row = 4 lq + r, column l15 of MFMA t = feature 4 l15 + t
+            if (H == 1) {                                        // C/D layout: row = 4 lq + r, column l15 of MFMA t = feature 4 l15 + t
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[r] = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-            HK_VM_BARRIER(0);      // (the previous chunk's stores went out behind steps 13 .. 16 of 50: long complete)
-        };
-        int cur = 0;
-        if (nch == 1) {
-            chunk(0, 0, F_{}, F_{});
-        } else {
-            chunk(0, 0, T_{}, F_{});
-            cur = STAGE;
-            for (int c = 1; c + 1 < nch; ++c) {
-                chunk(c, cur, T_{}, T_{});
-                cur = cur ? 0 : STAGE;
+                for (int r = 0; r < 4; ++r) out[r] = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                out13 = acc13;
             }
-            chunk(nch - 1, cur, F_{}, T_{});
+            // younger than the pieces of unit u + 1: the pieces of units u + 2, u + 3 and (WK 2) the stores of the units
+            // u - 2, u - 1, u (all of them behind their unit's last piece)
+            if (WK == 0 || LABV) HK_VM_BARRIER(0);
+            else if (WK == 1) { if (npc == NPW) HK_VM_BARRIER(PW); else HK_VM_BARRIER(PW >= 2 ? PW - 2 : 0); }
+            else { if (npc == NPW) HK_VM_BARRIER(PW + SW); else HK_VM_BARRIER(PW >= 2 ? PW - 2 + SW : SW); }
+        };
+        auto run = [&](int u) __attribute__((always_inline)) {                                  // any unit, by its place in the pipeline
+            const bool load = u + 3 < U, prev = u >= 2;
+            if (u & 1) {
+                if (load && u >= 4) unit(u, I1{}, I1{}, I1{}, I2{});
+                else if (load && prev) unit(u, I1{}, I1{}, I1{}, I1{});
+                else if (load) unit(u, I1{}, I1{}, I0{}, I1{});
+                else if (prev) unit(u, I1{}, I0{}, I1{}, I0{});
+                else unit(u, I1{}, I0{}, I0{}, I0{});
+            } else {
+                if (load && u >= 4) unit(u, I0{}, I1{}, I1{}, I2{});
+                else if (load && prev) unit(u, I0{}, I1{}, I1{}, I1{});
+                else if (load) unit(u, I0{}, I1{}, I0{}, I1{});
+                else if (prev) unit(u, I0{}, I0{}, I1{}, I0{});
+                else unit(u, I0{}, I0{}, I0{}, I0{});
+            }
+        };
+        int u = 0;
+        for (; u < 4 && u < U; ++u) run(u);
+        for (; u + 4 < U; u += 2) {                              // steady state (u is even)
+            unit(u, I0{}, I1{}, I1{}, I2{});
+            unit(u + 1, I1{}, I1{}, I1{}, I2{});
         }
+        for (; u < U; ++u) run(u);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) store_row(nch - 1, r);
+        for (int r = 0; r < 4; ++r) {
+            store_row(nch - 1, r);
+            store_12(nch - 1, r);
+        }
     } else {
-        const int wv = wave - 4;                                 // class tiles 3 wv .. 3 wv + 2, and column quarter wv of tile 12
-        // pieces q = wv + 4 u of the y tile: sample row 4 q + lq (clamped to B - 1)
-        unsigned yo[4];
+        const int wv = wave - 4;                                 // class tiles 3 wv .. 3 wv + 2
+        // pieces q = wv + 4 i of a y half tile: sample row 32 h + 4 q + lq (clamped to B - 1)
+        unsigned yo[2][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int b = 4 * (wv + 4 * u) + lq;
-            b = b < B ? b : B - 1;
-            yo[u] = 4u * ((unsigned)b * (unsigned)J + 4u * l15);
-        }
-        const char* ybase = reinterpret_cast<const char*>(y + f0);
-        auto dma = [&](int c, int sto, int u) {
-            glds16(reinterpret_cast<const float*>(ybase + (long long)c * (fstep * 4) + yo[u]), lds + sto + 256 * (WP + wv + 4 * u));
-        };
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dma(0, 0, u);
-        // resident A fragments: gt[i][s] = g[4 s + lq][16 (3 wv + i) + l15], g13[s] = g[4 s + lq][192 + l15]
-        float gt[3][16], g13[16];
-        int cls4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cls4[i] = i < 3 ? 16 * (3 * wv + i) + l15 : 192 + l15;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {                           // (all loads, then pins, then selects: see role dy)
-            const float* gb = g + (long long)(4 * s + lq < B ? 4 * s + lq : B - 1) * K;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) (i < 3 ? gt[i][s] : g13[s]) = gb[cls4[i] < K ? cls4[i] : K - 1];
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) HK_PIN_LOADED((i < 3 ? gt[i][s] : g13[s]));
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float& r = i < 3 ? gt[i][s] : g13[s];
-                r = (4 * s + lq < B && cls4[i] < K) ? r : 0.f;
+            for (int i = 0; i < 2; ++i) {
+                int b = 32 * h + 4 * (wv + 4 * i) + lq;
+                b = b < B ? b : B - 1;
+                yo[h][i] = 4u * ((unsigned)b * (unsigned)J + 4u * l15);
             }
-        if (db != nullptr && cfirst == 0) {
+        const char* ybase = reinterpret_cast<const char*>(y + f0);
+        auto dma = [&](int v, int h, int i) __attribute__((always_inline)) {
+            glds16(reinterpret_cast<const float*>(ybase + (long long)(v >> 1) * (fstep * 4) + yo[h][i]),
+                   lds + (v & 3) * STAGE + 256 * (NKH + wv + 4 * i));
+        };
+        if (DO_DW) {
+            dma(0, 0, 0); dma(0, 0, 1);
+            dma(1, 1, 0); dma(1, 1, 1);
+        }
+        HK_LDS_BARRIER();                                        // the g image is written
+        // resident A fragments: gt[i][s] = g[4 s + lq][16 (3 wv + i) + l15]
+        float gt[3][16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gt[i][s] = gi[(4 * s + lq) * GP + 16 * (3 * wv + i) + l15];
+        if (DO_DW && db != nullptr && cfirst == 0) {
             // db[k] = sum_b g[b][k]: the 16 sample steps of this lane in order, then the four lq groups (fixed tree)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 3; ++i) {
                 float sum = 0.f;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) sum += i < 3 ? gt[i][s] : g13[s];
+                for (int s = 0; s < 16; ++s) sum += gt[i][s];
                 sum += __shfl_xor(sum, 16, 64);
                 sum += __shfl_xor(sum, 32, 64);
-                if (lq == 0 && cls4[i] < K && (i < 3 || wv == 0)) db[cls4[i]] = sum;
+                const int cls = 16 * (3 * wv + i) + l15;
+                if (lq == 0 && cls < K) db[cls] = sum;
             }
         }
-        // this lane's rows of a 16-class output tile: class 4 lq + r of the tile, features 4 l15 ..+3
-        int orow[4];
+        HK_LDS_BARRIER();                                        // ... and read by everybody: stages 2, 3 are free
+        if (!DO_DW) return;                                      // (finished waves do not take part in s_barrier)
+        if (U > 2) { dma(2, 0, 0); dma(2, 0, 1); }
+        // this lane's rows of a 16-class output tile: class 4 lq + r of the tile, features 4 l15 ..+3 (byte offsets; classes
+        // beyond K lie beyond the descriptor's end)
+        const coh_rsrc_t rs = buf_rsrc(dw, (long long)K * J);
+        unsigned orow[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) orow[r] = (4 * lq + r) * J + 4 * l15;
-        f32x4 out[3][4], out13;                                  // the finished rows of the previous chunk
-        auto store_row = [&](int c, int e) {                     // store e (0 .. 11: tile e / 4, row e % 4; 12 .. 15: tile 12, row e - 12)
-            float* o = dw + f0 + (long long)c * fstep;
-            if (e < 12) {
-                const int cls0 = 16 * (3 * wv + e / 4);
-                if (cls0 + 4 * lq + e % 4 < K && st_ok) *reinterpret_cast<f32x4*>(o + (long long)cls0 * J + orow[e % 4]) = out[e / 4][e % 4];
-            } else {
-                if (192 + 4 * lq + (e - 12) < K && st_ok) o[(long long)192 * J + orow[e - 12] + wv] = out13[e - 12];
-            }
+        for (int r = 0; r < 4; ++r) orow[r] = 4u * ((unsigned)(4 * lq + r) * (unsigned)J + 4u * l15);
+        f32x4 out[3][4];                                         // the finished rows of the previous chunk
+        auto store_row = [&](int c, int e) __attribute__((always_inline)) {       // store e: tile e / 4, row e % 4
+            if (!st_ok) return;
+            const unsigned fo = 4u * (unsigned)(f0 + (long long)c * fstep);
+            buf_store16(rs, orow[e % 4] + fo + 4u * (unsigned)(16 * (3 * wv + e / 4)) * (unsigned)J, out[e / 4][e % 4]);
         };
-        HK_VM_BARRIER(0);
-        auto chunk = [&](int c, int cur, auto load_tag, auto prev_tag) {
-            constexpr bool LOAD = decltype(load_tag)::value, PREV = decltype(prev_tag)::value;
-            const int nxt = cur ? 0 : STAGE;
-            const float* T = Lf + cur + 256 * WP;
-            f32x4 acc[3][4], acc13 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (U > 2 && !LABV) HK_VM_BARRIER(4); else HK_VM_BARRIER(0);
+        f32x4 acc[3][4];
+        auto unit = [&](int u, auto h_tag, auto load_tag, auto prev_tag, auto wk_tag) __attribute__((always_inline)) {
+            constexpr int H = decltype(h_tag)::value, WK = decltype(wk_tag)::value;
+            constexpr bool LOAD = decltype(load_tag)::value != 0, PREV = decltype(prev_tag)::value != 0;
+            const float* T = Lf + (u & 3) * STAGE + 256 * NKH;
+            if (H == 0) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // tile 12: this wave's output columns {4 n + wv} = y[4 s + lq][4 l15 + wv], its own 4-byte read (a select on the
-            // wave-uniform wv turns into a jump table in the middle of the MFMA stream; the read's 4-way bank conflict
-            // is 16 reads per chunk)
-            const float* T1 = lds + cur + 256 * WP + 4 * lane + wv;
-            f32x4 fr[2];                                        // fragments of step s in fr[s & 1] / f1[s & 1], read one step ahead
-            float f1[2];
-            fr[0] = fr[1] = (f32x4){1.f, 1.f, 1.f, 1.f};
-            f1[0] = f1[1] = 1.f;
-            if (!(LABV & 8)) {
-                fr[0] = *reinterpret_cast<const f32x4*>(T);
-                f1[0] = T1[0];
+                    for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            f32x4 fr[2];                                        // fragment of step s in fr[s & 1], read one step ahead
+            fr[0] = fr[1] = (f32x4){1.f, 1.f, 1.f, 1.f};
+            if (!(LABV & 8)) fr[0] = *reinterpret_cast<const f32x4*>(T);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (s + 1 < 16 && !(LABV & 8)) {
-                    fr[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(T + 256 * (s + 1));
-                    f1[(s + 1) & 1] = T1[256 * (s + 1)];
-                }
-                // the next chunk's pieces first (steps 0 .. 3), then the previous chunk's 16 stores (steps 4 .. 15: 1-2 a step)
-                if (LOAD && s < 4 && !(LABV & 2)) dma(c + 1, nxt, s);
-                if (PREV && s >= 4) {
-                    store_row(c - 1, s - 4);
-                    if (s >= 12) store_row(c - 1, s);
-                }
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8 && !(LABV & 8)) fr[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(T + 256 * (s + 1));
+                // both pieces of unit u + 3 first, then a store of the previous chunk in each of the next six steps (every
+                // store is younger than the unit's last piece: the count in the wait below)
+                if (LOAD && s == 0 && !(LABV & 2)) { dma(u + 3, H ^ 1, 0); dma(u + 3, H ^ 1, 1); }
+                if (PREV && s < 6) store_row((u >> 1) - 1, 6 * H + s);
                 if (!(LABV & 1)) {
                     const f32x4 f = fr[s & 1];
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
-                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[i][s], f[t], acc[i][t], 0, 0, 0);
-                    acc13 = __builtin_amdgcn_mfma_f32_16x16x4f32(g13[s], f1[s & 1], acc13, 0, 0, 0);
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[i][8 * H + s], f[t], acc[i][t], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (H == 1) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[i][r] = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-            out13 = acc13;
-            // the pieces of chunk c + 1 were issued BEFORE this chunk's 16 stores: with every store certain to issue
-            // (COUNTED) the wait leaves exactly those 16 in flight (vmcnt retires in issue order); otherwise it drains
-            if (COUNTED && PREV) HK_VM_BARRIER(16); else HK_VM_BARRIER(0);
-        };
-        int cur = 0;
-        if (nch == 1) {
-            chunk(0, 0, F_{}, F_{});
-        } else {
-            chunk(0, 0, T_{}, F_{});
-            cur = STAGE;
-            for (int c = 1; c + 1 < nch; ++c) {
-                chunk(c, cur, T_{}, T_{});
-                cur = cur ? 0 : STAGE;
+                    for (int r = 0; r < 4; ++r) out[i][r] = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
             }
-            chunk(nch - 1, cur, F_{}, T_{});
+            // younger than the pieces of unit u + 1: two pieces in each of the units u + 2, u + 3 and (WK 2) six stores in
+            // each of the units u - 2, u - 1, u
+            if (WK == 0 || LABV) HK_VM_BARRIER(0);
+            else if (WK == 1) HK_VM_BARRIER(4);
+            else HK_VM_BARRIER(22);
+        };
+        auto run = [&](int u) __attribute__((always_inline)) {
+            const bool load = u + 3 < U, prev = u >= 2;
+            if (u & 1) {
+                if (load && u >= 4) unit(u, I1{}, I1{}, I1{}, I2{});
+                else if (load && prev) unit(u, I1{}, I1{}, I1{}, I1{});
+                else if (load) unit(u, I1{}, I1{}, I0{}, I1{});
+                else if (prev) unit(u, I1{}, I0{}, I1{}, I0{});
+                else unit(u, I1{}, I0{}, I0{}, I0{});
+            } else {
+                if (load && u >= 4) unit(u, I0{}, I1{}, I1{}, I2{});
+                else if (load && prev) unit(u, I0{}, I1{}, I1{}, I1{});
+                else if (load) unit(u, I0{}, I1{}, I0{}, I1{});
+                else if (prev) unit(u, I0{}, I0{}, I1{}, I0{});
+                else unit(u, I0{}, I0{}, I0{}, I0{});
+            }
+        };
+        int u = 0;
+        for (; u < 4 && u < U; ++u) run(u);
+        for (; u + 4 < U; u += 2) {
+            unit(u, I0{}, I1{}, I1{}, I2{});
+            unit(u + 1, I1{}, I1{}, I1{}, I2{});
         }
+        for (; u < U; ++u) run(u);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) store_row(nch - 1, e);
+        for (int e = 0; e < 12; ++e) store_row(nch - 1, e);
     }
 }
 

@@ -363,14 +363,20 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
         const int CPS = (nchunk + 255) / 256, S = (nchunk + CPS - 1) / CPS;      // one workgroup per CU
         const int walk = tuning().lin_walk;
         const int nks = (K + 3) / 4 == 50 ? 50 : 52;
-        const size_t ldsb = (size_t)2 * (nks + 16) * 1024;
+        const size_t ldsb = (size_t)4 * (nks / 2 + 8) * 1024;        // four stages of half a chunk
+#define HK_LAUNCH_BWD64(NKS_, MODE_)                                                                           \
+    do {                                                                                                       \
+        HK_ALLOW_BIG_LDS((&linear_bwd64_kernel<NKS_, MODE_>), ldsb);                                           \
+        hipLaunchKernelGGL((linear_bwd64_kernel<NKS_, MODE_>), dim3(S), dim3(512), ldsb, st, g, w, y, dy, dw, db, B, J, K, CPS, \
+                           S, walk);                                                                           \
+    } while (0)
+        const int mode = dy && dw ? 0 : (dy ? 1 : 2);            // both products / dy only / dW only
         if (nks == 50) {
-            HK_ALLOW_BIG_LDS(&linear_bwd64_kernel<50>, ldsb);
-            hipLaunchKernelGGL(linear_bwd64_kernel<50>, dim3(S), dim3(512), ldsb, st, g, w, y, dy, dw, db, B, J, K, CPS, S, walk);
+            if (mode == 0) HK_LAUNCH_BWD64(50, 0); else if (mode == 1) HK_LAUNCH_BWD64(50, 1); else HK_LAUNCH_BWD64(50, 2);
         } else {
-            HK_ALLOW_BIG_LDS(&linear_bwd64_kernel<52>, ldsb);
-            hipLaunchKernelGGL(linear_bwd64_kernel<52>, dim3(S), dim3(512), ldsb, st, g, w, y, dy, dw, db, B, J, K, CPS, S, walk);
+            if (mode == 0) HK_LAUNCH_BWD64(52, 0); else if (mode == 1) HK_LAUNCH_BWD64(52, 1); else HK_LAUNCH_BWD64(52, 2);
         }
+#undef HK_LAUNCH_BWD64
         HK_LAUNCH_CHECK();
         if (db && !dw) {                                  // (db rides on the dW role)
             hipLaunchKernelGGL(linear_bias_grad_kernel, dim3((K + 3) / 4), dim3(256), 0, st, g, db, B, K);

@@ -411,9 +411,13 @@ inline T __shfl(T v, int srclane, int = 64) {
 #define HK_PIN_LOADED(v) ((void)0)
 #define HK_COH_RSRC 1      /* coherent accesses: plain ones (one workgroup at a time; a ticket order in which a task only waits for earlier tickets never waits here) */
 namespace hk {
-struct coh_rsrc_t { char* p; };
+struct coh_rsrc_t { char* p; long long bytes; };
 template <typename T> inline T* uniform_ptr(T* p) { return p; }
-inline coh_rsrc_t coh_rsrc(const float* base, long long) { return coh_rsrc_t{(char*)base}; }
+inline coh_rsrc_t coh_rsrc(const float* base, long long floats) { return coh_rsrc_t{(char*)base, floats * 4}; }
+inline coh_rsrc_t buf_rsrc(const float* base, long long floats) { return coh_rsrc(base, floats); }
+// bounds-checked like the hardware: lanes beyond the descriptor's size are dropped
+inline void buf_store16(coh_rsrc_t rs, unsigned off, hipemu::v4f f) { if ((long long)off + 16 <= rs.bytes) memcpy(rs.p + off, &f, 16); }
+inline void buf_store4(coh_rsrc_t rs, unsigned off, float f) { if ((long long)off + 4 <= rs.bytes) memcpy(rs.p + off, &f, 4); }
 inline float4 coh_load16(coh_rsrc_t rs, int off) { return *reinterpret_cast<const float4*>(rs.p + off); }
 inline void coh_store16(coh_rsrc_t rs, int off, float4 f) { *reinterpret_cast<float4*>(rs.p + off) = f; }
 inline int coh_ticket(int* p) { return (*p)++; }

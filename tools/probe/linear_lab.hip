@@ -6,20 +6,28 @@
 
 using namespace hk;
 
-template <int LABV>
-static int launch(const float* g, const float* w, const float* y, float* dy, float* dw, float* db, int B, int J, int K, int walk,
+template <int LABV, int MODE>
+static int launch_m(const float* g, const float* w, const float* y, float* dy, float* dw, float* db, int B, int J, int K, int walk,
                   hipStream_t st) {
     const int nchunk = J / 64;
     const int CPS = (nchunk + 255) / 256, S = (nchunk + CPS - 1) / CPS;
-    const size_t ldsb = (size_t)2 * (50 + 16) * 1024;
+    const size_t ldsb = (size_t)4 * (25 + 8) * 1024;
     static bool once = false;
     if (!once) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bwd64_kernel<50, LABV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bwd64_kernel<50, MODE, LABV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ldsb) != hipSuccess) return -1;
         once = true;
     }
-    hipLaunchKernelGGL((linear_bwd64_kernel<50, LABV>), dim3(S), dim3(512), ldsb, st, g, w, y, dy, dw, db, B, J, K, CPS, S, walk);
+    hipLaunchKernelGGL((linear_bwd64_kernel<50, MODE, LABV>), dim3(S), dim3(512), ldsb, st, g, w, y, dy, dw, db, B, J, K, CPS, S, walk);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int LABV>
+static int launch(const float* g, const float* w, const float* y, float* dy, float* dw, float* db, int B, int J, int K, int walk,
+                  hipStream_t st) {
+    if (dy && dw) return launch_m<LABV, 0>(g, w, y, dy, dw, db, B, J, K, walk, st);
+    if (dy) return launch_m<LABV, 1>(g, w, y, dy, dw, db, B, J, K, walk, st);
+    return launch_m<LABV, 2>(g, w, y, dy, dw, db, B, J, K, walk, st);
 }
 
 // K must be 197..200 (50 class steps), B <= 64, J % 64 == 0
