@@ -151,7 +151,8 @@ struct Tuning {
     int ns_streams = 1;     // HK_NS_STREAMS    n: the batch runs the Newton-Schulz chain in n + 1 parts on n + 1 HIP queues (default 1: two halves), 0: one queue
     int ns_flow = 0;        // HK_NS_FLOW       1 / 2: the Newton-Schulz forward as one dataflow launch (hk_nsmm.h, ns_flow_kernel; 2: skewed ticket order), 0: a launch per step
     int ns_sym = 1;         // HK_NS_SYM        1: hk_ns_sqrtm_fwd_sym skips the tiles below the diagonal blocks, 0: it computes every tile
-    int lin_walk = 1;       // HK_LIN_WALK      classifier backward: 1: workgroup s walks chunks s, s + S, ..; 0: a contiguous slab per workgroup
+    int lin_walk = -1;      // HK_LIN_WALK      classifier backward: 1: workgroup s walks chunks s, s + S, ..; 0: a contiguous slab per workgroup;
+                            //                  -1: the measured winner per kernel (linear_bwd64_kernel 1, linear_bwd16_kernel 0)
     int sched_b = 0;        // HK_SCHED_B       > 0: work-split heuristics that depend on the batch size behave as if it were this (tests: the
                             //                  large-batch schedules on small inputs); results do not depend on it
 };

@@ -361,7 +361,7 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
         tuning().linear_slabs >= 0 && aligned16(y) && aligned16(w) && aligned16(dy) && aligned16(dw)) {
         const int nchunk = J / 64;
         const int CPS = (nchunk + 255) / 256, S = (nchunk + CPS - 1) / CPS;      // one workgroup per CU
-        const int walk = tuning().lin_walk;
+        const int walk = tuning().lin_walk < 0 ? 1 : tuning().lin_walk;      // interleaved chunks: 141 vs 153 us at BCNN's shape
         const int nks = (K + 3) / 4 == 50 ? 50 : 52;
         const size_t ldsb = (size_t)4 * (nks / 2 + 8) * 1024;        // four stages of half a chunk
 #define HK_LAUNCH_BWD64(NKS_, MODE_)                                                                           \
@@ -389,7 +389,7 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
         aligned16(y) && aligned16(w) && aligned16(dy) && aligned16(dw)) {
         const int nchunk = J / 64;
         const int CPS = (nchunk + 255) / 256, S = (nchunk + CPS - 1) / CPS;
-        const int walk = tuning().lin_walk;
+        const int walk = tuning().lin_walk < 0 ? 0 : tuning().lin_walk;      // contiguous slabs: 154-174 vs 164-188 us at OSME's shape
         const size_t ldsb = (size_t)2 * 8 * 1024 * sizeof(float);
         if (dy && dw) hipLaunchKernelGGL((linear_bwd16_kernel<true, true>), dim3(S), dim3(512), ldsb, st, g, w, y, dy, dw, db, B, J, K, CPS, S, walk);
         else if (dy) hipLaunchKernelGGL((linear_bwd16_kernel<true, false>), dim3(S), dim3(512), ldsb, st, g, w, y, dy, dw, db, B, J, K, CPS, S, walk);

@@ -66,7 +66,8 @@ const char* hk_version(void);
  *   "ns_streams"    n: the batch runs the Newton-Schulz chain in n + 1 parts on n + 1 HIP queues (default 1, at most 3)
  *   "ns_sym"        1 (default): hk_ns_sqrtm_fwd_sym skips the tiles below the diagonal blocks; 0: it computes all
  *   "ns_flow"       0 (default): a launch per step; 1 / 2: the forward chain as one dataflow launch (same bits)
- *   "lin_walk"      classifier backward: 1 (default) workgroup s walks the 64-feature chunks s, s + S, ..; 0: a contiguous slab
+ *   "lin_walk"      classifier backward: 1 workgroup s walks the 64-feature chunks s, s + S, ..; 0 a contiguous slab per
+ *                   workgroup; -1 (default) the measured winner per kernel
  *   "sched_b"       > 0: batch-size dependent work splits behave as if the batch were this (tests)
  * Values are seeded once from the environment (HK_<NAME>) when the library is first used; the launch paths never read
  * the environment.  Returns HK_ERR_BAD_ARG for an unknown name.  Process-wide: set them only while no other thread is

@@ -741,9 +741,10 @@ def test_linear_bwd_single_products(F, b, j, k, tune):
     assert rel(db1, db2) < 1e-6            # (without the dW role db is its own small kernel: another summation order)
     assert rel(dy2, g.double().cpu() @ w.double()) < 2e-6 and rel(dw2, g.double().cpu().t() @ y.double()) < 2e-6
     assert rel(db2, g.double().cpu().sum(0)) < 2e-6
-    tune('lin_walk', 0)                     # a contiguous slab of chunks per workgroup instead of the interleaved walk: same bits
-    dy0, dw0, db0 = grads(True, True)
-    assert torch.equal(dy0, dy2) and torch.equal(dw0, dw2) and torch.equal(db0, db2)
+    for walk in (0, 1):                     # a contiguous slab of chunks per workgroup / the interleaved walk: same bits
+        tune('lin_walk', walk)
+        dy0, dw0, db0 = grads(True, True)
+        assert torch.equal(dy0, dy2) and torch.equal(dw0, dw2) and torch.equal(db0, db2)
 
 
 @pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN'])

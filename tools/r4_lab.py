@@ -22,7 +22,7 @@ st = lambda: P(torch.cuda.current_stream().cuda_stream)
 p = lambda t: P(t.data_ptr()) if t is not None else None
 ROUNDS, ITERS = 5, 20
 PEAK_TF, PEAK_GBS = 157.3, 8000.0
-DEFAULTS = dict(bwd_v=0, cbp_bin=-1, ns_streams=1, ns_tn=0, linear_slabs=0, bcnn_generic=0, ns_sym=1, sched_b=0, lin_walk=1)
+DEFAULTS = dict(bwd_v=0, cbp_bin=-1, ns_streams=1, ns_tn=0, linear_slabs=0, bcnn_generic=0, ns_sym=1, sched_b=0, lin_walk=-1)
 
 
 def knobs(**kw):
@@ -100,6 +100,7 @@ def g_linear():
                  ('rocBLAS fwd (torch.addmm)', {}, lib_fwd, fl, by),
                  ('hk_linear_bwd (dy + dW + db)', {}, bwd, 2 * fl, 2 * by),
                  ('hk_linear_bwd, contiguous slabs (lin_walk=0)', dict(lin_walk=0), bwd, 2 * fl, 2 * by),
+                 ('hk_linear_bwd, interleaved chunks (lin_walk=1)', dict(lin_walk=1), bwd, 2 * fl, 2 * by),
                  ('hk_linear_bwd generic tiles (linear_slabs=-1)', dict(linear_slabs=-1), bwd, 2 * fl, 2 * by),
                  ('hk_linear_bwd dy only', {}, bwd_dy, fl, by),
                  ('hk_linear_bwd dW + db only', {}, bwd_dw, fl, by),
