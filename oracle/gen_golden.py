@@ -398,6 +398,32 @@ def gen_models(models):
     save('model_osme', logits=logits, parts=parts)
 
 
+def gen_models_448():
+    """The same three reference models at the CONFIGS' input size: two 448 x 448 images -> 14 x 14 feature maps, where the
+    plugins dispatch the panel / fused kernels (bcnn_gram_panel_kernel<196>, cbp_fused_kernel<196>, the covariance panel
+    kernel + nsmm chain at d = 256) and the wide-classifier kernels at their real widths (262144 / 6000 / 32896 -> 200).
+    Pins eval logits, and - through a cross-entropy on targets (3, 77) - the classifier's own gradients."""
+    from inputs import seeded_init
+    models = gen_keys()
+    res = {}
+    for name in ('BCNN', 'CBCNN', 'MPN'):
+        m = models[name]
+        seeded_init(m, 930)
+        m.eval()
+        x = t(rs_randn(931, (2, 3, 448, 448)))
+        for p_ in m.parameters():
+            p_.requires_grad_(True)
+        y = m(x)
+        torch.nn.functional.cross_entropy(y, torch.tensor([3, 77])).backward()
+        res[name] = y.detach()
+        res[name + '_cls_w_grad'] = sub(m.classifier.weight.grad, 1009)
+        res[name + '_cls_w_grad_abs'] = m.classifier.weight.grad.abs().sum().reshape(1)
+        res[name + '_cls_b_grad'] = m.classifier.bias.grad.clone()
+        w0 = next(m.backbone.parameters())
+        res[name + '_conv0_grad'] = w0.grad.clone()
+    save('model_logits_448', **res)
+
+
 APCNN_TRAIN_BATCH = 8
 
 

@@ -55,6 +55,33 @@ def test_logits_match_reference(name):
     assert y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
 
 
+@pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN'])
+def test_models_at_config_input_size_vs_reference(name):
+    """Whole plugins at the CONFIGS' input size (two 448 x 448 images -> 14 x 14 maps): here the heads dispatch what the
+    benchmarked configs dispatch - bcnn_gram_panel_kernel<196> / gram_bwd3_kernel, cbp_fused_kernel<196> / cbp_bwd3_kernel,
+    the covariance panel kernel + Newton-Schulz chain at d = 256 - and the classifier runs on linear_skinny_kernel /
+    linear_bwd64_kernel at its real width (262144 / 6000 / 32896 -> 200).  Against the REFERENCE models on the same seeded
+    weights and images (tests/golden/model_logits_448.npz, oracle/gen_golden.py::gen_models_448): eval logits 1e-4 +
+    argmax; through a cross-entropy, the classifier's gradients (the head's backward at full size) 1e-4; the first
+    convolution's gradient (everything behind the head, incl. MIOpen's backward) as a bound on gross disagreement."""
+    g = load('model_logits_448')
+    m = build(name, **CFG[name])
+    seeded_init(m, 930)
+    m = m.to(DEV).eval()
+    y = m(t(rs_randn(931, (2, 3, 448, 448))).to(DEV))
+    assert rel(y, g[name]) < 1e-4, rel(y, g[name])
+    assert y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
+    torch.nn.functional.cross_entropy(y, torch.tensor([3, 77], device=DEV)).backward()
+    gw = m.classifier.weight.grad
+    assert rel(gw.reshape(-1)[::1009], g[name + '_cls_w_grad']) < 1e-4
+    assert abs(float(gw.abs().sum()) - float(g[name + '_cls_w_grad_abs'][0])) < 1e-4 * float(g[name + '_cls_w_grad_abs'][0])
+    assert rel(m.classifier.bias.grad, g[name + '_cls_b_grad']) < 1e-4
+    w0 = next(m.backbone.parameters())
+    e0 = rel(w0.grad, g[name + '_conv0_grad'])
+    print(f'[448 {name}] first-conv gradient vs reference: {e0:.2e}')
+    assert e0 < 2e-2, e0
+
+
 def test_pyramid_attentions_module_vs_reference_golden():
     """SURVEY row A7 at MODULE level: the plugin's PyramidAttentions (spatial gate on MIOpen, hk_att_pool, channel gates
     averaged bottom-up, pooled = sgap + a_c * gap) with the REFERENCE's weights, against what the reference's
