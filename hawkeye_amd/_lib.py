@@ -51,6 +51,8 @@ SIGNATURES = {
     'hk_cbp_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_att_pool_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     'hk_att_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    'hk_att_pool3_fwd': (c_i, [c_f] * 8 + [c_i] * 5 + [c_f]),
+    'hk_att_pool3_bwd': (c_i, [c_f] * 14 + [c_i] * 5 + [c_f]),
     'hk_att_roi_select3': (c_i, [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_fl, c_f, c_f]),     # host arrays passed as void*
     'hk_att_roi_select': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
     'hk_roi_crop_resize_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),

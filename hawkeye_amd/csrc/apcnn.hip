@@ -122,6 +122,87 @@ __global__ __launch_bounds__(256) void att_pool_bwd_gap_kernel(const float* __re
     }
 }
 
+// The three pyramid levels of AP-CNN (56 x 56, 28 x 28, 14 x 14 at 448 x 448 inputs) in ONE launch per direction.  The
+// per-level launches above are launch-bound at the two small levels (B = 16: 9.7 + 9.8 + 11.8 us forward for 68 MB = 8.5 us
+// of traffic, 17 + 12.5 + 10 us backward); the levels are independent (APCNN.py:256-266: only the channel gates chain),
+// so their rows / column blocks are dealt out of one grid, the largest level first.  Same per-row / per-column
+// arithmetic as the kernels above: bit-identical results.
+struct AttLevels {
+    const float* f[3];
+    const float* a[3];
+    float* gap[3];          // forward: outputs; backward: dgap (read)
+    float* sgap[3];         //                             dsgap (read)
+    float* df[3];
+    float* da[3];
+    int hw[3];
+    int blk0[4];            // backward: first blockIdx.x of each level (blk0[3] = grid.x)
+};
+
+__global__ __launch_bounds__(256) void att_pool3_fwd_kernel(AttLevels L, long long rows, int C) {
+    const long long r3 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r3 >= 3 * rows) return;
+    const int lvl = (int)(r3 / rows);                          // wave-uniform
+    const long long row = r3 - lvl * rows;
+    const int lane = threadIdx.x & 63, HW = L.hw[lvl];
+    const int b = (int)(row / C);
+    const float* fp = L.f[lvl] + row * HW;
+    const float* ap = L.a[lvl] + (long long)b * HW;
+    float s0 = 0.f, s1 = 0.f;
+    const int n4 = HW >> 2;
+    for (int i = lane; i < n4; i += 64) {
+        const float4 v = reinterpret_cast<const float4*>(fp)[i];
+        const float4 a = reinterpret_cast<const float4*>(ap)[i];
+        s0 += (v.x + v.y) + (v.z + v.w);
+        s1 += (v.x * a.x + v.y * a.y) + (v.z * a.z + v.w * a.w);
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+        L.gap[lvl][row] = s0 / (float)HW;
+        L.sgap[lvl][row] = s1 / (float)HW;
+    }
+}
+
+__global__ __launch_bounds__(256) void att_pool3_bwd_kernel(AttLevels L, int C) {
+    HK_DYN_LDS(sm);  // dgap[C], dsgap[C] of this image and level
+    const int lvl = (int)blockIdx.x >= L.blk0[2] ? 2 : ((int)blockIdx.x >= L.blk0[1] ? 1 : 0);   // block-uniform
+    const int b = blockIdx.y, HW = L.hw[lvl];
+    float* sg = sm;
+    float* ss = sm + C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        sg[c] = L.gap[lvl][(long long)b * C + c];
+        ss[c] = L.sgap[lvl][(long long)b * C + c];
+    }
+    __syncthreads();
+    const int hw = ((int)blockIdx.x - L.blk0[lvl]) * 256 + threadIdx.x;
+    if (hw >= HW) return;
+    const float inv = 1.0f / (float)HW;
+    const float a = L.a[lvl][(long long)b * HW + hw];
+    const float* fp = L.f[lvl] + (long long)b * C * HW + hw;
+    float* dp = L.df[lvl] + (long long)b * C * HW + hw;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int c = 0;
+    for (; c + 16 <= C; c += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = fp[(long long)(c + u) * HW];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            acc0 += ss[c + u] * v[u];
+            acc1 += ss[c + u + 1] * v[u + 1];
+            acc2 += ss[c + u + 2] * v[u + 2];
+            acc3 += ss[c + u + 3] * v[u + 3];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) dp[(long long)(c + u) * HW] = (ss[c + u] * a + sg[c + u]) * inv;
+    }
+    for (; c < C; ++c) {
+        acc0 += ss[c] * fp[(long long)c * HW];
+        dp[(long long)c * HW] = (ss[c] * a + sg[c]) * inv;
+    }
+    L.da[lvl][(long long)b * HW + hw] = ((acc0 + acc1) + (acc2 + acc3)) * inv;
+}
+
 // ---------------------------------------------------------------------- K9
 struct Cand {
     float s;
@@ -479,6 +560,63 @@ extern "C" int hk_att_pool_fwd(const float* f, const float* a_s, float* gap, flo
         hipLaunchKernelGGL(att_pool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, f, a_s, gap, sgap, rows, C, HW);
     else
         hipLaunchKernelGGL(att_pool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, f, a_s, gap, sgap, rows, C, HW);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_att_pool3_fwd(const float* f0, const float* f1, const float* f2, const float* a0, const float* a1,
+                                const float* a2, float* gap, float* sgap, int B, int C, int HW0, int HW1, int HW2,
+                                hk_stream_t stream) {
+    if (!f0 || !f1 || !f2 || !a0 || !a1 || !a2 || !gap || !sgap || B <= 0 || C <= 0 || HW0 <= 0 || HW1 <= 0 || HW2 <= 0)
+        return HK_ERR_BAD_ARG;
+    const long long rows = (long long)B * C;
+    const float* fs[3] = {f0, f1, f2};
+    const float* as[3] = {a0, a1, a2};
+    const int hws[3] = {HW0, HW1, HW2};
+    bool vec = true;
+    for (int l = 0; l < 3; ++l) vec = vec && hws[l] % 4 == 0 && aligned16(fs[l]) && aligned16(as[l]);
+    if (!vec) {                                   // ragged maps: the per-level kernels
+        for (int l = 0; l < 3; ++l) {
+            const int rc = hk_att_pool_fwd(fs[l], as[l], gap + l * rows, sgap + l * rows, B, C, hws[l], stream);
+            if (rc != HK_OK) return rc;
+        }
+        return HK_OK;
+    }
+    AttLevels L = {};
+    for (int l = 0; l < 3; ++l) {
+        L.f[l] = fs[l]; L.a[l] = as[l]; L.hw[l] = hws[l];
+        L.gap[l] = gap + l * rows; L.sgap[l] = sgap + l * rows;
+    }
+    hipLaunchKernelGGL(att_pool3_fwd_kernel, dim3((unsigned)((3 * rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, L, rows, C);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_att_pool3_bwd(const float* f0, const float* f1, const float* f2, const float* a0, const float* a1,
+                                const float* a2, const float* dgap, const float* dsgap, float* df0, float* df1, float* df2,
+                                float* da0, float* da1, float* da2, int B, int C, int HW0, int HW1, int HW2,
+                                hk_stream_t stream) {
+    if (!f0 || !f1 || !f2 || !a0 || !a1 || !a2 || !dgap || !dsgap || !df0 || !df1 || !df2 || !da0 || !da1 || !da2 || B <= 0 ||
+        C <= 0 || HW0 <= 0 || HW1 <= 0 || HW2 <= 0)
+        return HK_ERR_BAD_ARG;
+    if ((size_t)2 * C * sizeof(float) > 64 * 1024) return HK_ERR_UNSUPPORTED;
+    const long long rows = (long long)B * C;
+    AttLevels L = {};
+    const float* fs[3] = {f0, f1, f2};
+    const float* as[3] = {a0, a1, a2};
+    float* dfs[3] = {df0, df1, df2};
+    float* das[3] = {da0, da1, da2};
+    const int hws[3] = {HW0, HW1, HW2};
+    int nb = 0;
+    for (int l = 0; l < 3; ++l) {
+        L.f[l] = fs[l]; L.a[l] = as[l]; L.df[l] = dfs[l]; L.da[l] = das[l]; L.hw[l] = hws[l];
+        L.gap[l] = const_cast<float*>(dgap) + l * rows;
+        L.sgap[l] = const_cast<float*>(dsgap) + l * rows;
+        L.blk0[l] = nb;
+        nb += (hws[l] + 255) / 256;
+    }
+    L.blk0[3] = nb;
+    hipLaunchKernelGGL(att_pool3_bwd_kernel, dim3(nb, B), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, L, C);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

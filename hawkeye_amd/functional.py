@@ -389,6 +389,48 @@ def att_pool(f, a_s=None):
     return _AttPool.apply(f, a_s)
 
 
+class _AttPool3(torch.autograd.Function):
+    """The three pyramid levels of PyramidAttentions (APCNN.py:256-266) in one launch per direction:
+    (f3, f4, f5, a3, a4, a5) -> gap [3,B,C], sgap [3,B,C]."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, f2, a0, a1, a2):
+        lib = _lib.load()
+        fs = [_f32c(f) for f in (f0, f1, f2)]
+        as_ = [_f32c(a) for a in (a0, a1, a2)]
+        b, c = fs[0].shape[:2]
+        hws = [f.shape[2] * f.shape[3] for f in fs]
+        for f, a, hw in zip(fs, as_, hws):
+            if f.shape[:2] != (b, c) or a.numel() != b * hw:
+                raise _lib.HawkeyeHipError(f'att_pool_levels: level shapes {tuple(f.shape)} / {tuple(a.shape)} do not match [{b},{c},h,w] / [{b},1,h,w]')
+        gap = torch.empty(3, b, c, dtype=torch.float32, device=fs[0].device)
+        sgap = torch.empty_like(gap)
+        check(lib.hk_att_pool3_fwd(ptr(fs[0]), ptr(fs[1]), ptr(fs[2]), ptr(as_[0]), ptr(as_[1]), ptr(as_[2]), ptr(gap), ptr(sgap),
+                                   b, c, hws[0], hws[1], hws[2], stream()), 'hk_att_pool3_fwd')
+        ctx.save_for_backward(*fs, *as_)
+        return gap, sgap
+
+    @staticmethod
+    def backward(ctx, dgap, dsgap):
+        lib = _lib.load()
+        fs, as_ = ctx.saved_tensors[:3], ctx.saved_tensors[3:]
+        b, c = fs[0].shape[:2]
+        hws = [f.shape[2] * f.shape[3] for f in fs]
+        dgap = _f32c(dgap) if dgap is not None else torch.zeros(3, b, c, dtype=torch.float32, device=fs[0].device)
+        dsgap = _f32c(dsgap) if dsgap is not None else torch.zeros(3, b, c, dtype=torch.float32, device=fs[0].device)
+        dfs = [torch.empty_like(f) for f in fs]
+        das = [torch.empty_like(a) for a in as_]
+        check(lib.hk_att_pool3_bwd(ptr(fs[0]), ptr(fs[1]), ptr(fs[2]), ptr(as_[0]), ptr(as_[1]), ptr(as_[2]), ptr(dgap), ptr(dsgap),
+                                   ptr(dfs[0]), ptr(dfs[1]), ptr(dfs[2]), ptr(das[0]), ptr(das[1]), ptr(das[2]),
+                                   b, c, hws[0], hws[1], hws[2], stream()), 'hk_att_pool3_bwd')
+        return (*dfs, *das)
+
+
+def att_pool_levels(feats, atts):
+    """feats: three [B,C,h,w] pyramid levels, atts: their spatial attentions [B,1,h,w] -> (gap [3,B,C], sgap [3,B,C])."""
+    return _AttPool3.apply(*feats, *atts)
+
+
 def att_roi_select(att_mask, feature_stride, anchor_size, img_h, img_w, num_classes, iou_thred, topk):
     """Device-side get_att_roi (APCNN.py:444-476).  -> (rois [B,topk,5], count [B] int32),
     rows beyond count are zero.  No gradient (reference: torch.no_grad, :447)."""

@@ -123,17 +123,18 @@ class PyramidAttentions(nn.Module):
         self.A5_1, self.A5_2 = SpatialGate(channel_size), ChannelGate(channel_size)
 
     def forward(self, inputs):
-        pooled, gaps, masks, ch_prev = [], [], [], None
-        for f, sg, cg, lvl in zip(inputs, (self.A3_1, self.A4_1, self.A5_1), (self.A3_2, self.A4_2, self.A5_2), (3, 4, 5)):
-            a_s = sg(f)                                       # ConvTranspose + sigmoid (MIOpen)
-            gap, sgap = HF.att_pool(f, a_s)                   # one pass over F
+        pooled, gaps, ch_prev = [], [], None
+        masks = [sg(f) for f, sg in zip(inputs, (self.A3_1, self.A4_1, self.A5_1))]       # ConvTranspose + sigmoid (MIOpen)
+        # one pass over every F, the three levels in one launch (only the channel gates below chain across levels)
+        gap3, sgap3 = HF.att_pool_levels(inputs, masks)
+        for lvl, cg in enumerate((self.A3_2, self.A4_2, self.A5_2)):
+            gap, sgap = gap3[lvl], sgap3[lvl]
             a_c = cg.from_gap(gap)
             if ch_prev is not None:
                 a_c = (a_c + ch_prev) / 2                     # APCNN.py:260,265
             ch_prev = a_c
             pooled.append(sgap + a_c * gap)
             gaps.append(gap)
-            masks.append(a_s)
         return pooled, gaps, masks
 
 

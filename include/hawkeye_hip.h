@@ -220,6 +220,16 @@ int hk_att_pool_fwd(const float* f, const float* a_s, float* gap, float* sgap, i
 int hk_att_pool_bwd(const float* f, const float* a_s, const float* dgap, const float* dsgap, float* df,
                     float* da_s, int B, int C, int HW, hk_stream_t stream);
 
+/* The three pyramid levels of PyramidAttentions.forward (APCNN.py:256-266) in one launch per direction: the levels'
+ * poolings are independent (only the channel gates chain), and at 28 x 28 / 14 x 14 a launch per level is launch-bound.
+ *   f_l [B,C,HW_l] ; a_l [B,HW_l] ; gap, sgap [3][B][C] (level-major) ; dgap, dsgap likewise ; df_l, da_l like f_l, a_l
+ * Same arithmetic per row / column as hk_att_pool_fwd / _bwd: bit-identical results. */
+int hk_att_pool3_fwd(const float* f0, const float* f1, const float* f2, const float* a0, const float* a1, const float* a2,
+                     float* gap, float* sgap, int B, int C, int HW0, int HW1, int HW2, hk_stream_t stream);
+int hk_att_pool3_bwd(const float* f0, const float* f1, const float* f2, const float* a0, const float* a1, const float* a2,
+                     const float* dgap, const float* dsgap, float* df0, float* df1, float* df2, float* da0, float* da1,
+                     float* da2, int B, int C, int HW0, int HW1, int HW2, hk_stream_t stream);
+
 /* Attention -> ROI: border mask, one square anchor per cell, keep score > mean,
  * greedy NMS (IoU < thr keeps, area without +1, highest score first; ties:
  * highest cell index first), top-k, clamp to the image.  One workgroup per image,

@@ -446,6 +446,28 @@ def test_att_pool_plain_gap_backward(F, c, hw):
     assert rel(fg.grad, f.grad) < 1e-6
 
 
+@pytest.mark.parametrize('b,c,sizes', [(3, 32, (28, 14, 7)), (2, 20, (12, 6, 3)), (2, 16, (8, 4, 2))])
+def test_att_pool_three_levels_in_one_launch(F, b, c, sizes):
+    """hk_att_pool3_fwd / _bwd (the three pyramid levels of PyramidAttentions in one launch per direction, APCNN.py:256-266)
+    against three hk_att_pool calls: the same arithmetic per row / column, so forward and both gradients are
+    bit-identical; map sizes that are not multiples of four take the per-level fallback inside the entry point."""
+    fs = [t(rs_randn(60 + i, (b, c, s, s))) for i, s in enumerate(sizes)]
+    as_ = [t((1 / (1 + np.exp(-rs_randn(63 + i, (b, 1, s, s))))).astype(np.float32)) for i, s in enumerate(sizes)]
+    w1, w2 = t(rs_randn(66, (3, b, c))).to(DEV), t(rs_randn(67, (3, b, c))).to(DEV)
+    f1 = [f.clone().to(DEV).requires_grad_(True) for f in fs]
+    a1 = [a.clone().to(DEV).requires_grad_(True) for a in as_]
+    outs = [F.att_pool(f, a) for f, a in zip(f1, a1)]
+    sum((g * w1[i]).sum() + (sg * w2[i]).sum() for i, (g, sg) in enumerate(outs)).backward()
+    f3 = [f.clone().to(DEV).requires_grad_(True) for f in fs]
+    a3 = [a.clone().to(DEV).requires_grad_(True) for a in as_]
+    gap, sgap = F.att_pool_levels(f3, a3)
+    ((gap * w1).sum() + (sgap * w2).sum()).backward()
+    for i in range(3):
+        assert torch.equal(gap[i], outs[i][0]) and torch.equal(sgap[i], outs[i][1]), i
+        assert torch.equal(f3[i].grad, f1[i].grad) and torch.equal(a3[i].grad, a1[i].grad), i
+        assert rel(gap[i], fs[i].mean(dim=(2, 3))) < 1e-6 and rel(sgap[i], (as_[i] * fs[i]).mean(dim=(2, 3))) < 1e-6
+
+
 def _masks():
     return [t(1.0 / (1.0 + np.exp(-2.0 * rs_randn(50 + l, (3, 1, hw, hw))))).float()
             for l, hw in enumerate((56, 28, 14))]

@@ -132,6 +132,18 @@ def apcnn_kernels(B=16, classes=8142):
         kernel_row('APCNN', f'att_pool bwd {hw}x{hw}',
                    lambda: lib.hk_att_pool_bwd(ptr(ff), ptr(aa), ptr(dgp), ptr(dsg), ptr(dff), ptr(daa), B, 256, n, stream()),
                    0, 8.0 * B * 256 * n)
+    ffs = [R(B, 256, s, s) for s in (56, 28, 14)]
+    aas = [torch.rand(B, 1, s, s, device=dev) for s in (56, 28, 14)]
+    gp3, sg3, dgp3, dsg3 = E(3, B, 256), E(3, B, 256), R(3, B, 256), R(3, B, 256)
+    dfs, das = [torch.empty_like(f) for f in ffs], [torch.empty_like(a) for a in aas]
+    tot = sum(4.0 * B * 256 * s * s for s in (56, 28, 14))
+    kernel_row('APCNN', 'att_pool3 fwd: the three levels in one launch (what PyramidAttentions calls)',
+               lambda: lib.hk_att_pool3_fwd(ptr(ffs[0]), ptr(ffs[1]), ptr(ffs[2]), ptr(aas[0]), ptr(aas[1]), ptr(aas[2]), ptr(gp3), ptr(sg3),
+                                            B, 256, 3136, 784, 196, stream()), 0, tot)
+    kernel_row('APCNN', 'att_pool3 bwd: the three levels in one launch',
+               lambda: lib.hk_att_pool3_bwd(ptr(ffs[0]), ptr(ffs[1]), ptr(ffs[2]), ptr(aas[0]), ptr(aas[1]), ptr(aas[2]), ptr(dgp3), ptr(dsg3),
+                                            ptr(dfs[0]), ptr(dfs[1]), ptr(dfs[2]), ptr(das[0]), ptr(das[1]), ptr(das[2]),
+                                            B, 256, 3136, 784, 196, stream()), 0, 2 * tot)
     masks = [torch.rand(B, 1, s, s, device=dev) for s in (56, 28, 14)]
     lv = [(8, 64., 5), (16, 128., 3), (32, 256., 1)]
     tabs = []
