@@ -46,6 +46,7 @@ SIGNATURES = {
     'hk_triu_vec_bwd': (c_i, [c_f, c_f, c_i, c_i, c_f]),
     'hk_cbp_plan_bytes': (c_sz, [c_i, c_i]),
     'hk_cbp_plan_build': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f]),
+    'hk_cbp_plan_destroy': (c_i, [c_f]),
     'hk_cbp_ws_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'hk_cbp_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_cbp_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),

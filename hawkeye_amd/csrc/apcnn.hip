@@ -647,6 +647,7 @@ extern "C" int hk_att_roi_select(const float* att, float* rois, int32_t* count, 
     if (!att || !rois || !count || B <= 0 || h <= 0 || w <= 0 || topk <= 0) return HK_ERR_BAD_ARG;
     const size_t sm = (size_t)2 * h * w * sizeof(float);
     if (sm > 150 * 1024) return HK_ERR_UNSUPPORTED;
+    HK_ALLOW_BIG_LDS(&att_roi_select_kernel, sm);                 // maps above ~90 x 90: more than the default 64 KB
     hipLaunchKernelGGL(att_roi_select_kernel, dim3(B), dim3(256), sm, (hipStream_t)stream, att, rois, (int*)count, h, w,
                        feature_stride, anchor_size, img_h, img_w, keep_r0, keep_r1, keep_c0, keep_c1, iou_thr, topk);
     HK_LAUNCH_CHECK();
@@ -670,6 +671,7 @@ extern "C" int hk_att_roi_select3(const float* const* att, float* const* rois, i
         sm = need > sm ? need : sm;
     }
     if (sm > 150 * 1024) return HK_ERR_UNSUPPORTED;
+    HK_ALLOW_BIG_LDS(&att_roi_select3_kernel, sm);
     hipLaunchKernelGGL(att_roi_select3_kernel, dim3(B, 3), dim3(256), sm, (hipStream_t)stream, L, img_h, img_w, iou_thr);
     HK_LAUNCH_CHECK();
     return HK_OK;

@@ -53,13 +53,16 @@ struct CbpPlan {  // device-side view of the plan blob
 
 __host__ __device__ inline size_t cbp_align(size_t x) { return (x + 15) & ~(size_t)15; }
 // the blob carries the tile lists of the fused forward for every shape that kernel covers (whether THESE hashes allow
-// it is decided at build time and recorded in header word 4 of the blob: hk_cbp_plan_build)
+// it is decided at build time and recorded in the word BEHIND the lists and in the host-side directory below:
+// hk_cbp_plan_build)
 static inline bool cbp_has_lists(int C, int D) { return C % 64 == 0 && C <= 1024 && D + 1 <= CBF_DMAX; }
 
 // Whether the tile lists of a plan blob were built (they are not when some bin holds more entries of one 64x64 tile than
 // a lane's steps - tiny D): decided on the host by hk_cbp_plan_build, needed on the host by hk_cbp_fwd, and the blob is
-// device memory.  A directory device pointer -> flag, written by plan_build and read by fwd under a mutex; a blob that
-// is not in it (copied by the caller) takes the unfused path.
+// device memory.  A directory device pointer -> flag, written by plan_build, erased by hk_cbp_plan_destroy and read by fwd
+// under a mutex; a blob that is not in it (copied by the caller) takes the unfused path.  An address is only trusted
+// between its build and its destroy: a caller that frees a plan's memory calls hk_cbp_plan_destroy first, so a different
+// blob later placed at the same address cannot inherit a stale "fused ok".
 static std::mutex g_plan_mu;
 static std::unordered_map<const void*, int> g_plan_fused;
 static inline void plan_note(const void* plan, int fused_ok) {
@@ -681,6 +684,13 @@ extern "C" int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32
     e = hipStreamSynchronize((hipStream_t)stream);   // one-time setup: the host blob dies at return
     if (e != hipSuccess) return (int)e;
     plan_note(plan, fused_ok);
+    return HK_OK;
+}
+
+extern "C" int hk_cbp_plan_destroy(const void* plan) {
+    if (!plan) return HK_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plan_fused.erase(plan);
     return HK_OK;
 }
 

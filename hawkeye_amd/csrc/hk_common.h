@@ -169,13 +169,17 @@ struct AuxQueue {
     bool ok = false;
     std::mutex busy;            // held from fork to join: two host threads driving one device take turns on the helper queues
 };
-inline AuxQueue* aux_queue() {
+inline AuxQueue* aux_queue(hipStream_t st) {
     // one slot per device, each created exactly once whatever thread gets there first (std::call_once); after that the
     // slot is read-only.  A slot whose creation failed stays empty and callers fall back to the caller's stream.
+    // The device is the one that OWNS the caller's stream (the helper queues fork from / join into that stream); the
+    // entry points require it to be the current device as well - the helper queues are created on it - and fall back to
+    // one queue otherwise.
     static AuxQueue tab[16];
     static std::once_flag once[16];
-    int dev = 0;
+    int dev = 0, sdev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (st != nullptr && (hipStreamGetDevice(st, &sdev) != hipSuccess || sdev != dev)) return nullptr;
     AuxQueue& a = tab[dev];
     std::call_once(once[dev], [&a]() {
         bool good = hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess;
@@ -204,7 +208,7 @@ class AuxScope {
     AuxScope(hipStream_t st, int n) : st_(st) {
         if (n <= 0) return;
         if (n > HK_MAX_AUX) n = HK_MAX_AUX;
-        q_ = aux_queue();
+        q_ = aux_queue(st);
         if (!q_) return;
         q_->busy.lock();
         bool good = hipEventRecord(q_->fork, st_) == hipSuccess;

@@ -293,6 +293,14 @@ class CbpPlan:
             check(lib.hk_cbp_plan_build(h1.ctypes.data, s1.ctypes.data, h2.ctypes.data, s2.ctypes.data,
                                         self.C, self.D, ptr(self.blob), stream()), 'hk_cbp_plan_build')
 
+    def __del__(self):
+        # the library keeps a host-side note per plan ADDRESS: forget it before torch can hand the memory to someone else
+        try:
+            if getattr(self, 'blob', None) is not None:
+                _lib.load().hk_cbp_plan_destroy(ptr(self.blob))
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
 
 class _CompactBilinearPool(torch.autograd.Function):
     """replaces CompactBilinearPooling.forward, model/methods/CBCNN.py:96-135."""

@@ -191,10 +191,13 @@ int hk_triu_vec_bwd(const float* dy, float* dx, int B, int d, hk_stream_t stream
  * plan ADDRESS, whether the fused lists could be built for these hashes (a host-side
  * directory under a mutex - the blob itself is device memory); hk_cbp_fwd on a blob
  * the caller has copied elsewhere takes the unfused kernels: same results to rounding.
+ * hk_cbp_plan_destroy(plan) forgets the address: call it BEFORE freeing or reusing the
+ * plan's memory, so that another blob placed there later cannot inherit the entry.
  * hk_cbp_fwd: Gram and binning in one kernel (the Gram matrix never reaches HBM),
  * then two small finishing launches; ws holds the per-workgroup partial bin vectors.
  */
 size_t hk_cbp_plan_bytes(int C, int D);
+int hk_cbp_plan_destroy(const void* plan);
 int hk_cbp_plan_build(const int32_t* h1, const float* s1, const int32_t* h2, const float* s2, int C, int D,
                       void* plan, hk_stream_t stream);
 size_t hk_cbp_ws_bytes(int B, int C, int HW, int D);

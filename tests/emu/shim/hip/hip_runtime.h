@@ -54,6 +54,7 @@ struct hipemu_event_tag;
 typedef hipemu_event_tag* hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipStreamGetDevice(hipStream_t, int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(sizeof(void*)); return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(sizeof(void*)); return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
