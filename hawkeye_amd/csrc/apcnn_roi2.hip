@@ -29,17 +29,6 @@
 
 namespace hk {
 
-// HK_LAB builds only (tools/roi_lab.py): cycle stamps of thread 0 of the first 64 workgroups of image 0
-#ifdef HK_LAB
-__device__ long long* g_roi_stamps = nullptr;            // [64 workgroups][32][8]
-#define ROI_STAMP(kb_, slot_)                                                                          \
-    do {                                                                                              \
-        if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0 && (kb_) < 32 && g_roi_stamps)     \
-            g_roi_stamps[((long long)blockIdx.x * 32 + (kb_)) * 8 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define ROI_STAMP(kb_, slot_) do { } while (0)
-#endif
 
 // PPT (template): crop pixels per thread, ceil(H * W / 256) rounded up to an instance - 4 (maps up to 32 x 32), 13 (56 x 56:
 // 255 registers, two workgroups per CU), 16 (64 x 64: one workgroup per CU)
@@ -111,7 +100,6 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
             trx[k] = wxo_k / 65;
         }
     }
-    ROI_STAMP(31, 2);
 
     const bool vec = (hw % 4 == 0) && ((((uintptr_t)dy) & 15) == 0) && ((((uintptr_t)dx) & 15) == 0);
     const int n4 = hw / 4;
@@ -129,7 +117,6 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
     for (int cc = 0; cc < nmaps; ++cc) {
         const float* gp = dy + ((long long)b * C + c0 + cc) * hw;
         float* dp = dx + ((long long)b * C + c0 + cc) * hw;
-        ROI_STAMP(cc, 0);
         __syncthreads();                                   // previous map: gathered by everyone, output image written out
         if (vec) {
             float4* s4 = reinterpret_cast<float4*>(smap);
@@ -141,7 +128,6 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
             for (int p = tid; p < hw; p += 256) smap[p] = gp[p];
         }
         __syncthreads();
-        ROI_STAMP(cc, 1);
         if (vec && cc + 1 < nmaps) issue(cc + 1);          // in flight during the gather below
         if (REGW) {
             // two slots per (uniform) block: both slots' KW * KW reads are in flight before the first is used
@@ -263,7 +249,6 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
                 }
             }
         }
-        ROI_STAMP(cc, 2);
         __syncthreads();                                   // output image complete
         if (vec) {
 #pragma unroll
@@ -274,7 +259,6 @@ __device__ __forceinline__ void roi_bwd_maps(const float* __restrict__ dy, float
         } else {
             for (int p = tid; p < hw; p += 256) dp[p] = omap[p];
         }
-        ROI_STAMP(cc, 3);
     }
 }
 
@@ -291,7 +275,6 @@ __global__ __launch_bounds__(256) void roi_crop_bwd_tab3_kernel(const float* __r
     float* trow = omap + 64 * 64;                          // (table path only: crops up to ROI_TROW_CW columns)
     const int b = blockIdx.y, c0 = blockIdx.x * cpb, tid = threadIdx.x;
     const int hw = H * W;
-    ROI_STAMP(31, 0);
     if (tid == 0) {
         sh.g = crop_geom(box + b * 4, drop + b * 4, C, H, W, training);
         sh.kmax[0] = sh.kmax[1] = 1;
@@ -333,7 +316,6 @@ __global__ __launch_bounds__(256) void roi_crop_bwd_tab3_kernel(const float* __r
         int KY = sh.kmax[0], KX = sh.kmax[1];
         KY = KY < H ? KY : H;
         KX = KX < W ? KX : W;
-        ROI_STAMP(31, 1);
         // (a map smaller than the compile-time window cannot take it: the window has to fit inside the map)
         if (KY <= 3 && KX <= 3 && H >= 3 && W >= 3)
             roi_bwd_maps<3, PPT>(dy, dx, sh, wy, wx, smap, omap, b, C, c0, nmaps, H, W, 3, 3, training);
@@ -353,7 +335,6 @@ __global__ __launch_bounds__(256) void roi_crop_bwd_tab3_kernel(const float* __r
             for (int p = tid; p < hw; p += 256) dp[p] = 0.f;
         }
     }
-    ROI_STAMP(31, 3);
 }
 
 int roi_crop_bwd_v2(const float* dy, const float* box, const float* drop, float* dx, int B, int C, int H, int W,
@@ -493,8 +474,3 @@ int roi_crop_fwd_v2(const float* x, const float* box, const float* drop, float* 
 
 }  // namespace hk
 
-#ifdef HK_LAB
-extern "C" int hk_lab_set_roi_stamps(long long* dev_buffer) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hk::g_roi_stamps), &dev_buffer, sizeof(dev_buffer));
-}
-#endif

@@ -18,7 +18,7 @@ const Knob kKnobs[] = {
     {"roi_bwd", "HK_ROI_BWD", &Tuning::roi_bwd},                {"linear_slabs", "HK_LINEAR_SLABS", &Tuning::linear_slabs},
     {"ns_tn", "HK_NS_TN", &Tuning::ns_tn},                      {"bwd_v", "HK_BWD_V", &Tuning::bwd_v},
     {"ns_streams", "HK_NS_STREAMS", &Tuning::ns_streams},        {"sched_b", "HK_SCHED_B", &Tuning::sched_b},
-    {"ns_sym", "HK_NS_SYM", &Tuning::ns_sym},                    {"ns_flow", "HK_NS_FLOW", &Tuning::ns_flow},
+    {"ns_sym", "HK_NS_SYM", &Tuning::ns_sym},
     {"lin_walk", "HK_LIN_WALK", &Tuning::lin_walk},
 };
 Tuning from_env() {

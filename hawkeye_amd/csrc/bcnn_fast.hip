@@ -23,16 +23,12 @@
 //   68 KB of LDS per workgroup -> 2 workgroups per CU overlap each other's phases.
 #include <cstdlib>
 #include "hk_common.h"
-#include "hk_bwd128d.h"
 #include "hk_bwd3.h"
 #include "hk_bwd3c.h"
 #include "hk_gram_tile.h"
 
 namespace hk {
 
-#ifdef HK_LAB
-__device__ long long* g_lab_stamps = nullptr;
-#endif
 
 // ----------------------------------------------------------------------------- forward
 // (GramEpi and gram_tile: hk_gram_tile.h)
@@ -307,7 +303,6 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, 0, tid, ex, b);
     for (int kb = 0; kb < nb; ++kb) {
         __syncthreads();                                   // previous MFMA phase finished with sP / sX
-        HK_STAMP(kb, 0);
         if (MODE != 2) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                  // dy(K,I) transposed into the scratch: T[i][k] = dy[k][i]
@@ -319,7 +314,6 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
             }
             __syncthreads();
         }
-        HK_STAMP(kb, 1);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                      // P tile
             const int f = tid + 256 * u, r = f >> 4, c4 = (f & 15) * 4;
@@ -350,17 +344,14 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
             *reinterpret_cast<f32x4*>(&sP[r * PP + c4]) = p;
         }
         __syncthreads();                                   // scratch reads done: X block may overwrite it
-        HK_STAMP(kb, 2);
 #pragma unroll
         for (int u = 0; u < NSX; ++u) {
             const int f = tid + 256 * u;
             if (f < XN4) reinterpret_cast<f32x4*>(sX)[f] = rx[u];
         }
         __syncthreads();
-        HK_STAMP(kb, 3);
         // next K-block's operands: in flight during the MFMA phase (last iteration: harmless re-read)
         bwd_load<HW, NSX, MODE>(ry, rd, rt, rx, y, dy, xb, cc, C, I, (kb + 1 < nb ? kb + 1 : kb), tid, ex, b);
-        HK_STAMP(kb, 4);
 
         const float* ap = sP + (wave * 16 + l15) * PP + 4 * lq;
 #pragma unroll
@@ -374,7 +365,6 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bp[16 * n], acc[n], 0, 0, 0);
             }
         }
-        HK_STAMP(kb, 5);
     }
 
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -406,93 +396,55 @@ static int gram_launch(const float* x, const float* inv_norm, float* y, int B, i
     return HK_OK;
 }
 
-// hk_bwd3c.h: block height (rb = 2: 128 rows, 1: 64, 0: do not use the kernel), channel split, column split.  128-row
-// blocks where they fill the chip, else 64-row blocks, else 64-row blocks with the column tiles divided between two
-// workgroups (B = 16, C = 512: 256 workgroups; nothing to add up, no memset).  bwd_v 31..35 force (rows, ksplit, nsplit)
-// = (128, 1, 1), (64, 1, 1), (64, 2, 1), (128, 2, 1), (64, 1, 2); measured at B = 16 (tools/r3_lab.py): 64-row 38.5 us,
-// channel split 35.8 (of which the memset of dX 4-5), 128-row 64, round-2 kernels 48 - 65.
-static inline void cbp_bwd3_shape(int v, int B, int C, int& rb, int& ksp, int& nsp) {
-    rb = 0; ksp = 1; nsp = 1;
-    const int nb = C / 64;
+// The batch size the work-split decisions below see: the real one, or tuning().sched_b (tests: the large-batch forms on
+// small inputs; results never depend on it)
+static inline int sched_batch(int B) { return tuning().sched_b > 0 ? tuning().sched_b : B; }
+
+// hk_bwd3c.h: block height (rb = 2: 128 rows, 1: 64, 0: do not use the kernel) and column split.  128-row blocks where
+// they fill the chip, else 64-row blocks, else 64-row blocks with the column tiles divided between two workgroups
+// (B = 16, C = 512: 256 workgroups; nothing to add up).  Measured at B = 16: 64-row blocks 38.5 us, 128-row 64, column
+// split 26.6 (a channel split with float atomics onto a zeroed dX: 35.8, removed).
+static inline void cbp_bwd3_shape(int Breal, int C, int& rb, int& nsp) {
+    rb = 0; nsp = 1;
+    const int nb = C / 64, B = sched_batch(Breal);
     const long long n128 = C % 128 == 0 ? (long long)B * (C / 128) : 0, n64 = (long long)B * nb;
-    if (v >= 31 && v <= 35) {
-        rb = (v == 31 || v == 34) ? 2 : 1;
-        ksp = (v == 33 || v == 34) ? 2 : 1;
-        nsp = v == 35 ? 2 : 1;
-    } else if (v == 0) {
-        if (n128 >= 192) rb = 2;
-        else if (n64 >= 192) rb = 1;
-        else if (2 * n64 >= 128) { rb = 1; nsp = 2; }
-    }
+    if (n128 >= 192) rb = 2;
+    else if (n64 >= 192) rb = 1;
+    else if (2 * n64 >= 128) { rb = 1; nsp = 2; }
 }
 
+// tuning().bwd_v: 0 automatic, 1 force the four-wave 64-row panel kernel (the reference form the tests compare with)
 template <int HW, int MODE>
 static int bwd_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
                       int B, int C, const BwdExtra& ex, hipStream_t st) {
-    const int nb = C / 64;
-    // Structures measured at B=64, C=512, HW=196 (round 1 + profiles/r2_candidates.json):
-    //   bcnn_bwd_panel_kernel   64-row blocks, P built in LDS, four barriers per K-block, 2 WGs/CU    85-88 us
-    //   two-barrier variant     (transposed dy fetched directly: 4x the L1 requests)                  93 us  (removed)
-    //   raw 32-row K-blocks     (3 WGs/CU)                                                            89-92 us  (removed)
-    //   producer / consumer     (512 threads)                                                         94 us  (removed)
-    //   bcnn_bwd128_kernel      hk_bwd128.h: 128-row blocks, raw tiles, one barrier per K-block, 8 waves  77-80 us
-    // The 128-row kernel needs C % 128 == 0 and enough row blocks to fill the chip (one workgroup per CU:
-    // B * C / 128 >= 192); the covariance at B = 64, C = 256 (128 row blocks) is faster on the 64-row kernel
-    // (30 vs 39 us).  tuning().bwd_v: 0 automatic, 1 force the 64-row kernel, 5 force the 128-row one.
+    const int nb = C / 64, Bs = sched_batch(B);
     const int v = tuning().bwd_v;
-    // hk_bwd3.h - the default for the BCNN, signed-sqrt and covariance modes wherever its blocks fill the chip (128-row
-    // blocks when B C / 128 >= 192, else 64-row blocks when B C / 64 >= 192).  Measured at B = 64, 14 x 14, alternating
-    // rounds (tools/r3_lab.py, profiles/r3_lab_call1.json): BCNN C = 512: 65.2 us against 71.5 (hk_bwd128d.h), 79.1
-    // (64-row panel kernel); VALU remainder alone 68.9, LDS-staged epilogue alone 69.1; covariance C = 256: 20.2 us
-    // against 24.0 (eight-wave register-staged kernel on 64-row blocks), 27.9 (panel kernel), 32.3 with 128-row blocks
-    // (128 workgroups).  bwd_v 11..14 force it with flags 3, 1, 2, 0 (bit 0 VALU remainder columns, bit 1 LDS-staged
-    // epilogue), 21..24 the same with 128-row blocks; 15 / 16 add bit 2 (a wave owns 16 rows and all column tiles: the
-    // two waves of a SIMD no longer form the same A fragments) and bit 3 (coef applied to the accumulators, not to every
-    // fragment element): 66.9 -> 65.3 -> 64.1 us in one alternating run (profiles/r3_lab_call21.json); 16 is the default.
+    // gram_bwd3_kernel (hk_bwd3.h) for the BCNN, signed-sqrt and covariance modes wherever its blocks fill the chip:
+    // 128-row blocks when B C / 128 >= 192, else 64-row blocks when B C / 64 >= 192.  Measured at B = 64, 14 x 14: BCNN
+    // C = 512 64.1 us against 79.1 on the panel kernel; covariance C = 256 20.2 against 27.9.
     if constexpr (MODE == 0 || MODE == 1 || MODE == 3) {
-        const bool forced = (v >= 11 && v <= 16) || (v >= 21 && v <= 24);      // 15 / 16: rows-per-wave split (+ late coef)
-        const bool fill2 = C % 128 == 0 && (long long)B * (C / 128) >= 192;
-        const bool fill1 = (long long)B * nb >= 192;
-        if (forced || (v == 0 && (fill2 || fill1))) {
-            // default: everything on (15); 128-row blocks only - the 64-row form keeps the rows x column-halves split
-            const int f = forced ? v % 10 : 6;
-            const int flags = f == 1 ? 3 : (f == 2 ? 1 : (f == 3 ? 2 : (f == 5 ? 7 : (f == 6 ? 15 : 0))));
+        const bool fill2 = C % 128 == 0 && (long long)Bs * (C / 128) >= 192;
+        const bool fill1 = (long long)Bs * nb >= 192;
+        if (v == 0 && (fill2 || fill1)) {
             int rc = HK_ERR_UNSUPPORTED;
-            if (C % 128 == 0 && (v > 20 || v == 15 || v == 16 || fill2))
-                rc = bwd3_launch<HW, MODE, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
-            if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, MODE, 1>(x, y, dy, inv_norm, dx, tpart, B, C, ex, flags, st);
+            if (fill2) rc = bwd3_launch<HW, MODE, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
+            if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, MODE, 1>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
             if (rc != HK_ERR_UNSUPPORTED) return rc;
         }
     }
-    // compact bilinear: hk_bwd3c.h (P generated from dc in LDS, X by LDS-DMA); shape by cbp_bwd3_shape
+    // compact bilinear: cbp_bwd3_kernel (hk_bwd3c.h: P generated from dc in LDS, X by LDS-DMA); shape by cbp_bwd3_shape
     if constexpr (MODE == 2) {
-        int rb, ksp, nsp;
-        cbp_bwd3_shape(v, B, C, rb, ksp, nsp);
+        int rb = 0, nsp = 1;
+        if (v == 0) cbp_bwd3_shape(B, C, rb, nsp);
         if (rb) {
             int rc = HK_ERR_UNSUPPORTED;
-            if (rb == 2) rc = cbp_bwd3_launch<HW, 2>(x, dx, B, C, ex, ksp, nsp, st);
-            if (rc == HK_ERR_UNSUPPORTED) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, ksp, nsp, st);
-            if (rc == HK_ERR_UNSUPPORTED && nsp == 2) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, 1, 1, st);
+            if (rb == 2) rc = cbp_bwd3_launch<HW, 2>(x, dx, B, C, ex, nsp, st);
+            if (rc == HK_ERR_UNSUPPORTED) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, nsp, st);
+            if (rc == HK_ERR_UNSUPPORTED && nsp == 2) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, 1, st);
             if (rc != HK_ERR_UNSUPPORTED) return rc;
         }
     }
-    if (v != 1 && C % 128 == 0 && (v >= 5 || (long long)B * (C / 128) >= 192)) {
-        if constexpr (MODE == 0 || MODE == 3) {             // LDS-DMA staging (hk_bwd128d.h; forced by bwd_v = 9); bwd_v = 5 asks for the register-staged kernel
-            if (v == 0 || v >= 9) {
-                const int rc = bwd128d_launch<HW, MODE>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
-                if (rc != HK_ERR_UNSUPPORTED) return rc;
-            }
-        }
-        const int rc = bwd128_launch<HW, MODE>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
-        if (rc != HK_ERR_UNSUPPORTED) return rc;
-    }
-    // 64-row blocks on the eight-wave kernel (two waves per SIMD): where the 128-row blocks would not fill the chip but
-    // the 64-row ones do with ONE workgroup per CU (the covariance at C = 256, B = 64: 256 row blocks) - the 4-wave
-    // panel kernel then has one wave per SIMD and nothing covers its staging phases.  bwd_v = 4 forces it.
-    if (v == 4 || (v == 0 && MODE == 1 && (long long)B * nb >= 192 && (long long)B * nb <= 320)) {
-        const int rc = bwd128_launch<HW, MODE, 1>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
-        if (rc != HK_ERR_UNSUPPORTED) return rc;
-    }
+    // small batches (the row blocks do not fill the chip) and forced: the four-wave panel kernel, two workgroups per CU
     hipLaunchKernelGGL((bcnn_bwd_panel_kernel<HW, MODE>), dim3(xcd_grid(B, nb)), dim3(256), 0, st, x, y, dy, inv_norm, dx,
                        tpart, C, nb, B, ex);
     HK_LAUNCH_CHECK();
@@ -585,11 +537,11 @@ int cov_fast_bwd(const float* x, const float* mu, const float* g, float* dx, int
 }
 
 template <int HW>
-static int cbp_bwd3_try(const float* x, float* dx, int B, int C, const BwdExtra& ex, int rb, int ksp, int nsp, hipStream_t st) {
+static int cbp_bwd3_try(const float* x, float* dx, int B, int C, const BwdExtra& ex, int rb, int nsp, hipStream_t st) {
     int rc = HK_ERR_UNSUPPORTED;
-    if (rb == 2) rc = cbp_bwd3_launch<HW, 2>(x, dx, B, C, ex, ksp, nsp, st);
-    if (rc == HK_ERR_UNSUPPORTED) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, ksp, nsp, st);
-    if (rc == HK_ERR_UNSUPPORTED && nsp == 2) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, 1, 1, st);   // odd tile count
+    if (rb == 2) rc = cbp_bwd3_launch<HW, 2>(x, dx, B, C, ex, nsp, st);
+    if (rc == HK_ERR_UNSUPPORTED) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, nsp, st);
+    if (rc == HK_ERR_UNSUPPORTED && nsp == 2) rc = cbp_bwd3_launch<HW, 1>(x, dx, B, C, ex, 1, st);   // odd tile count
     return rc;
 }
 
@@ -599,15 +551,14 @@ int cbp_fast_bwd_fused(const float* x, const int* h1, const int* h2, const float
                        const float* dy, const float* c_raw, const float* inv_norm, int D, float* dx, int B, int C, int HW,
                        hipStream_t st) {
     if (C % 64 != 0 || !aligned16(x) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
-    const int v = tuning().bwd_v;
-    if (!(v == 0 || (v >= 31 && v <= 35))) return HK_ERR_UNSUPPORTED;
+    if (tuning().bwd_v != 0) return HK_ERR_UNSUPPORTED;
     BwdExtra ex = {};
     ex.h1 = h1; ex.h2 = h2; ex.s1 = s1; ex.s2 = s2; ex.dc = nullptr; ex.D = D;
     ex.cy = y; ex.cdy = dy; ex.ccraw = c_raw; ex.cinv = inv_norm;
-    int rb, ksp, nsp;
-    cbp_bwd3_shape(v, B, C, rb, ksp, nsp);
+    int rb, nsp;
+    cbp_bwd3_shape(B, C, rb, nsp);
     if (!rb) return HK_ERR_UNSUPPORTED;
-#define CALL(H) cbp_bwd3_try<H>(x, dx, B, C, ex, rb, ksp, nsp, st)
+#define CALL(H) cbp_bwd3_try<H>(x, dx, B, C, ex, rb, nsp, st)
     HK_HW_SWITCH(CALL)
 #undef CALL
 }
@@ -625,8 +576,3 @@ int cbp_fast_bwd(const float* x, const int* h1, const int* h2, const float* s1, 
 
 }  // namespace hk
 
-#ifdef HK_LAB
-extern "C" int hk_lab_set_stamps(long long* dev_buffer) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hk::g_lab_stamps), &dev_buffer, sizeof(dev_buffer));
-}
-#endif

@@ -259,18 +259,6 @@ __global__ __launch_bounds__(256) void cbp_rowsketch_kernel(const float* __restr
 // so plain read-modify-writes are race-free, and one LDS barrier per row orders the rows - the same per-bin summation
 // order (rows ascending) and the same `c += s1 * r` expression as the row-sketch kernel, hence bit-identical partials,
 // with ~8x less LDS traffic, one barrier per row instead of two and 41 KB of LDS (3 workgroups per CU).
-// HK_LAB builds only (tools/cbp_lab.py): cycle stamps of thread 0 of the workgroups of the first eight images
-#ifdef HK_LAB
-__device__ long long* g_cbp_stamps = nullptr;            // [64 workgroups][32 blocks][8]
-#define CBP_STAMP(blk_, slot_)                                                                         \
-    do {                                                                                              \
-        if (threadIdx.x == 0 && blockIdx.y < 8 && (blk_) < 32 && g_cbp_stamps)                        \
-            g_cbp_stamps[((long long)(blockIdx.y * 8 + blockIdx.x) * 32 + (blk_)) * 8 + (slot_)] =    \
-                (long long)__builtin_amdgcn_s_memtime();                                              \
-    } while (0)
-#else
-#define CBP_STAMP(blk_, slot_) do { } while (0)
-#endif
 
 // rows of G per staged block of the row-scatter kernel, and float4 per thread of one block (C <= 512).  Eight rows: the
 // block's global loads are requested one block ahead, and with four-row blocks (~1 us of work) the ~2 us of HBM latency
@@ -348,9 +336,7 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
     __syncthreads();
     for (int blk = 0; blk < nblk; ++blk) {
         const int cur = blk & 1;
-        CBP_STAMP(blk, 0);
         if (blk + 1 < nblk) HK_BLK_LOAD(blk + 1);
-        CBP_STAMP(blk, 1);
         const float* gcur = gb + cur * CBP_SRB * C;
         const int left = nrows - blk * CBP_SRB;
         const int rmax = left < CBP_SRB ? left : CBP_SRB;
@@ -387,14 +373,13 @@ __global__ __launch_bounds__(256) void cbp_rowscatter_kernel(const float* __rest
 #pragma unroll
                 for (int u = 0; u < NBT; ++u) c[idx[rr][u]] += add[rr][u];
                 HK_LDS_BARRIER();                            // the next row may hit the same bins from other lanes
-                if (rr < 4) CBP_STAMP(blk, 2 + rr);          // (the first four rows of the block)
+                
             }
         }
         if (blk + 1 < nblk) {
             HK_BLK_STORE(cur ^ 1);
             HK_LDS_BARRIER();
         }
-        CBP_STAMP(blk, 6);
     }
 #undef HK_BLK_LOAD
 #undef HK_BLK_STORE
@@ -826,11 +811,3 @@ extern "C" int hk_cbp_bwd(const float* x, const void* plan, const float* y, cons
     return bgemm_launch<true, false>(la, xb, ep, C, HW, C, B, st);
 }
 
-#ifdef HK_LAB
-extern "C" int hk_lab_set_cbf_stamps(long long* dev_buffer) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hk::g_cbf_stamps), &dev_buffer, sizeof(dev_buffer));
-}
-extern "C" int hk_lab_set_cbp_stamps(long long* dev_buffer) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hk::g_cbp_stamps), &dev_buffer, sizeof(dev_buffer));
-}
-#endif

@@ -1,5 +1,5 @@
-// Gram backward, fourth structure:  dX[I rows] = sum_K P(I,K) X(K)  staged by LDS-DMA like hk_bwd128d.h, with what
-// round 2's timing-only builds said that structure still pays for removed:
+// Gram backward:  dX[I rows] = sum_K P(I,K) X(K), every operand staged by LDS-DMA (128-row blocks, eight waves, two LDS
+// stages of 32-channel K-blocks), with what round 2's timing-only builds said that structure paid for removed:
 //
 //   * the 13th column tile.  HW = 196 = 12 x 16 + 4: thirteen 16-column MFMA tiles do 13 / 12.25 of the work, split 7 / 6
 //     over the two waves of a SIMD.  Here the matrix pipe computes columns 0 .. 191 (six tiles per wave: balanced) and
@@ -16,15 +16,39 @@
 //         m[i] += a[i][k] * mu[k],
 //     subtracted from the whole row while the block is copied out - X is staged raw by LDS-DMA, no mean look-ups.
 //
-// LDS tiles, swizzles and the K-block pipeline are those of hk_bwd128d.h (S1 / Y [rows][32 k] with the 16-byte slot
+// LDS tiles and swizzles (S1 / Y [rows][32 k] with the 16-byte slot
 // i * 8 + (k4 ^ (i & 7)); S2 [32 k][rows] with slot i4 ^ 4 ((k >> 2) & 1); X linear; two stages; the pieces of K-block
 // kb + 1 issued behind MFMA groups 0-4 of K-block kb).
 // MODE 0 BCNN   a = (dy_ik + dy_ki) * rcp(y_ik) * inv^2 / (2M)       MODE 3 signed-sqrt BCNN (BCNN.py:23-24)
 // MODE 1 COV    a = (g_ik + g_ki) / M, X centred through the mu column
 #pragma once
-#include "hk_bwd128d.h"
+#include "hk_common.h"
 
 namespace hk {
+
+struct BwdExtra {
+    const float* mu;     // [B][C]      (COV)
+    const int* h1;       // [C]         (CBP)
+    const int* h2;
+    const float* s1;
+    const float* s2;
+    const float* dc;     // [B][D]
+    int D;
+    const float* tb;     // [B][nt]     (signed sqrt: partial sums of t = <y, dy>, added in order)
+    int nt;
+    // CBP, hk_bwd3c.h with dc == nullptr: dc is computed by the kernel itself from the saved forward state
+    const float* cy;     // [B][D]  y
+    const float* cdy;    // [B][D]  dL/dy
+    const float* ccraw;  // [B][D]  bins before the signed square root
+    const float* cinv;   // [B]     1 / max(|u|, 1e-12)
+};
+
+// t = <y, dy> of sample b from its partial sums (every workgroup adds them itself, fixed order)
+__device__ __forceinline__ float bwd_t_of(const BwdExtra& ex, int b) {
+    float t = 0.f;
+    for (int c = 0; c < ex.nt; ++c) t += ex.tb[(long long)b * ex.nt + c];
+    return t;
+}
 
 // RB: 16-row blocks per wave (2: 128-row workgroup blocks, 1: 64-row).  REMV: the HW % 16 == 4 remainder columns on
 // the VALU (false: a last, partly idle MFMA tile like the other kernels).  EPI: LDS-staged 16-byte stores.
@@ -362,11 +386,9 @@ static inline size_t bwd3_lds_bytes(int C) {
 }
 
 // HK_ERR_UNSUPPORTED unless C % (64 RB) == 0 and the operands are 16-byte aligned (the caller then takes another kernel).
-// flags: bit 0 = VALU remainder (where HW % 16 == 4), bit 1 = LDS-staged epilogue, bit 2 = a wave owns 16 rows and all
-// column tiles (128-row blocks with both of the above), bit 3 = coef applied to the accumulators
 template <int HW, int MODE, int RB>
 static int bwd3_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
-                       int B, int C, const BwdExtra& ex, int flags, hipStream_t st) {
+                       int B, int C, const BwdExtra& ex, hipStream_t st) {
     if (C % (64 * RB) != 0 || (long long)C * C >= (1ll << 31) || !aligned16(x) || !aligned16(dy) || !aligned16(dx) ||
         ((MODE == 0 || MODE == 3) && !aligned16(y)))
         return HK_ERR_UNSUPPORTED;
@@ -374,39 +396,14 @@ static int bwd3_launch(const float* x, const float* y, const float* dy, const fl
     if (lds > 160 * 1024) return HK_ERR_UNSUPPORTED;
     const int nI = C / (64 * RB);
     const dim3 grid(xcd_grid(B, nI));
-    constexpr bool CANREM = HW % 16 == 4;
-    const bool remv = CANREM && (flags & 1), epi = flags & 2;
-#define HK_B3_GO(REMV_, EPI_)                                                                                          \
-    do {                                                                                                               \
-        HK_ALLOW_BIG_LDS((&gram_bwd3_kernel<HW, MODE, RB, REMV_, EPI_>), lds);                                         \
-        hipLaunchKernelGGL((gram_bwd3_kernel<HW, MODE, RB, REMV_, EPI_>), grid, dim3(512), lds, st, x, y, dy, inv_norm, \
-                           dx, tpart, C, nI, B, ex);                                                                   \
-    } while (0)
-    if constexpr (CANREM && RB == 2) {
-        if (remv && epi && (flags & 4)) {
-            if (flags & 8) {
-                HK_ALLOW_BIG_LDS((&gram_bwd3_kernel<HW, MODE, RB, true, true, true, true>), lds);
-                hipLaunchKernelGGL((gram_bwd3_kernel<HW, MODE, RB, true, true, true, true>), grid, dim3(512), lds, st, x, y, dy,
-                                   inv_norm, dx, tpart, C, nI, B, ex);
-            } else {
-                HK_ALLOW_BIG_LDS((&gram_bwd3_kernel<HW, MODE, RB, true, true, true, false>), lds);
-                hipLaunchKernelGGL((gram_bwd3_kernel<HW, MODE, RB, true, true, true, false>), grid, dim3(512), lds, st, x, y, dy,
-                                   inv_norm, dx, tpart, C, nI, B, ex);
-            }
-            HK_LAUNCH_CHECK();
-            return HK_OK;
-        }
-    }
-    if constexpr (CANREM) {
-        if (remv && epi) HK_B3_GO(true, true);
-        else if (remv) HK_B3_GO(true, false);
-        else if (epi) HK_B3_GO(false, true);
-        else HK_B3_GO(false, false);
-    } else {
-        if (epi) HK_B3_GO(false, true);
-        else HK_B3_GO(false, false);
-    }
-#undef HK_B3_GO
+    // the shipped form: VALU remainder columns where HW % 16 == 4, LDS-staged epilogue; with 128-row blocks a wave owns 16
+    // rows and all column tiles and the coefficient multiplies the accumulators once (each step
+    // measured - 71.5 -> 66.9 -> 65.3 -> 64.1 us at B = 64, C = 512, 14 x 14)
+    constexpr bool REM = HW % 16 == 4;
+    constexpr bool ROWW = REM && RB == 2;
+    HK_ALLOW_BIG_LDS((&gram_bwd3_kernel<HW, MODE, RB, REM, true, ROWW, ROWW>), lds);
+    hipLaunchKernelGGL((gram_bwd3_kernel<HW, MODE, RB, REM, true, ROWW, ROWW>), grid, dim3(512), lds, st, x, y, dy, inv_norm, dx,
+                       tpart, C, nI, B, ex);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

@@ -11,9 +11,6 @@
 // unsigned byte offsets: no compare / select), two three-way XORs for the signs (sign bits of s1, s2 as masks) and one
 // add.  The A fragment is then a plain ds_read_b128 - no arithmetic in the MFMA stream's own fragment path.
 //
-// ksplit = 2 (small batches): a workgroup takes half of the channels K and ADDS its block to dX with float atomics; dX
-// is zeroed first.  With exactly two addends per element the result does not depend on their order (0 + a + b =
-// 0 + b + a, bit for bit), so the kernel stays reproducible; B = 16, C = 512: 256 workgroups instead of 128.
 #pragma once
 #include "hk_bwd3.h"
 
@@ -23,7 +20,7 @@ namespace hk {
 // stores its own columns: nothing to add up) - how a batch of 16 fills the chip without atomics.
 template <int HW, int RB, bool REMV, int NSPLIT>
 __global__ __launch_bounds__(512, 2) void cbp_bwd3_kernel(const float* __restrict__ x, float* __restrict__ dx, int C, int nI,
-                                                          int B, int ksplit, BwdExtra ex) {
+                                                          int B, BwdExtra ex) {
     static_assert(!REMV || HW % 16 == 4, "VALU remainder: four columns");
     constexpr int NTA = REMV ? HW / 16 : (HW + 15) / 16;  // 16-column MFMA tiles of the row block
     static_assert(NTA % NSPLIT == 0, "column split: an even number of tiles");
@@ -41,8 +38,8 @@ __global__ __launch_bounds__(512, 2) void cbp_bwd3_kernel(const float* __restric
     HK_DYN_LDS16(lds);
 
     int b, w;
-    if (!xcd_map(blockIdx.x, B, nI * NSPLIT * ksplit, b, w)) return;
-    const int I = w / (NSPLIT * ksplit), nh = (w / ksplit) % NSPLIT, ks = w % ksplit;
+    if (!xcd_map(blockIdx.x, B, nI * NSPLIT, b, w)) return;
+    const int I = w / NSPLIT, nh = w % NSPLIT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
@@ -51,8 +48,8 @@ __global__ __launch_bounds__(512, 2) void cbp_bwd3_kernel(const float* __restric
     const int nt0 = nh * NT + half * NH, nloc = (NT % 2 == 0) ? NH : (half ? NT - NH : NH);
     const bool do_rem = REMV && nh == NSPLIT - 1;               // the remainder columns belong to the last column split
     const float* xb = x + (long long)b * C * HW;
-    const int nkbl = (C / KB) / ksplit;                         // K-blocks of this workgroup (even)
-    const int kb0 = ks * nkbl;
+    const int nkbl = C / KB;                                    // K-blocks (even)
+    constexpr int kb0 = 0;
     const unsigned D4 = 4u * (unsigned)ex.D;
 
     f32x4 acc[RB][NH];
@@ -270,8 +267,7 @@ __global__ __launch_bounds__(512, 2) void cbp_bwd3_kernel(const float* __restric
                 rem[i][c] = v;
             }
     }
-    // the block as it lies in HBM (both stages are free: the K loop ended on a barrier), then 16-byte stores - or, with
-    // the channels split over two workgroups, float atomics onto the zeroed dX
+    // the block as it lies in HBM (both stages are free: the K loop ended on a barrier), then 16-byte stores
     float* dxb = dx + (long long)b * C * HW + (long long)I * IB * HW;
     float* O = lds;
 #pragma unroll
@@ -294,13 +290,9 @@ __global__ __launch_bounds__(512, 2) void cbp_bwd3_kernel(const float* __restric
         for (int f = tid; f < IB * w4; f += 512) {
             const int r = f / w4, c = c0 + 4 * (f % w4);
             const f32x4 v = *reinterpret_cast<const f32x4*>(O + r * HW + c);
-            if (ksplit == 1) *reinterpret_cast<f32x4*>(dxb + (long long)r * HW + c) = v;
-            else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) HK_ATOMIC_ADD_F32(dxb + (long long)r * HW + c + t, v[t]);
-            }
+            *reinterpret_cast<f32x4*>(dxb + (long long)r * HW + c) = v;
         }
-    } else if (ksplit == 1) {
+    } else {
         const f32x4* o4 = reinterpret_cast<const f32x4*>(O);
         f32x4* g4 = reinterpret_cast<f32x4*>(dxb);
 #pragma unroll
@@ -308,8 +300,6 @@ __global__ __launch_bounds__(512, 2) void cbp_bwd3_kernel(const float* __restric
             const int f = tid + 512 * u;
             if (f < O4) g4[f] = o4[f];
         }
-    } else {
-        for (int f = tid; f < IB * HW; f += 512) HK_ATOMIC_ADD_F32(dxb + f, O[f]);
     }
 }
 
@@ -321,33 +311,28 @@ static inline size_t cbp_bwd3_lds_bytes(int C, int D) {
     return (loop > image ? loop : image) * sizeof(float);
 }
 
-// HK_ERR_UNSUPPORTED when the shape is not covered.  ksplit 1 or 2 (2: dx is zeroed here, on the stream, first);
-// nsplit 1 or 2 (2: only where the row block has an even number of MFMA column tiles)
+// HK_ERR_UNSUPPORTED when the shape is not covered.  nsplit 1 or 2 (2: only where the row block has an even number of
+// MFMA column tiles)
 template <int HW, int RB>
-static int cbp_bwd3_launch(const float* x, float* dx, int B, int C, const BwdExtra& ex, int ksplit, int nsplit,
-                           hipStream_t st) {
-    if (C % (64 * RB) != 0 || C % (64 * ksplit) != 0 || !aligned16(x) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+static int cbp_bwd3_launch(const float* x, float* dx, int B, int C, const BwdExtra& ex, int nsplit, hipStream_t st) {
+    if (C % (64 * RB) != 0 || !aligned16(x) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
     const size_t lds = cbp_bwd3_lds_bytes<HW, RB>(C, ex.D);
     if (lds > 160 * 1024 || (!ex.dc && ex.D > 512 * 16)) return HK_ERR_UNSUPPORTED;
     constexpr bool REMV = HW % 16 == 4;
     constexpr int NTA = REMV ? HW / 16 : (HW + 15) / 16;
     if (nsplit == 2 && NTA % 2 != 0) return HK_ERR_UNSUPPORTED;
     const int nI = C / (64 * RB);
-    if (ksplit == 2) {
-        const hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * C * HW * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
-    }
-    const dim3 grid(xcd_grid(B, nI * nsplit * ksplit));
+    const dim3 grid(xcd_grid(B, nI * nsplit));
     if constexpr (NTA % 2 == 0) {
         if (nsplit == 2) {
             HK_ALLOW_BIG_LDS((&cbp_bwd3_kernel<HW, RB, REMV, 2>), lds);
-            hipLaunchKernelGGL((cbp_bwd3_kernel<HW, RB, REMV, 2>), grid, dim3(512), lds, st, x, dx, C, nI, B, ksplit, ex);
+            hipLaunchKernelGGL((cbp_bwd3_kernel<HW, RB, REMV, 2>), grid, dim3(512), lds, st, x, dx, C, nI, B, ex);
             HK_LAUNCH_CHECK();
             return HK_OK;
         }
     }
     HK_ALLOW_BIG_LDS((&cbp_bwd3_kernel<HW, RB, REMV, 1>), lds);
-    hipLaunchKernelGGL((cbp_bwd3_kernel<HW, RB, REMV, 1>), grid, dim3(512), lds, st, x, dx, C, nI, B, ksplit, ex);
+    hipLaunchKernelGGL((cbp_bwd3_kernel<HW, RB, REMV, 1>), grid, dim3(512), lds, st, x, dx, C, nI, B, ex);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

@@ -181,18 +181,6 @@ static inline CbfSchedule cbf_schedule(int nb, int B, int ncu = 256) {
 // B2(t + 1); sB / sA are rewritten between B1 and B2, when no M wave reads them.
 // PIPE: the plan guarantees that two consecutive steps of a wave hit disjoint bins (cbf_build_lists = 2): the reads of
 // steps 2 p, 2 p + 1 are issued before their writes - 9 dependent LDS round trips per list instead of 17.
-// HK_LAB builds only (tools/cbf_lab.py): cycle stamps of lane 0 of wave 0 (M, slots 0-3) and wave 4 (N, slots 4-7) of the
-// first 64 workgroups, per tile
-#ifdef HK_LAB
-static __device__ long long* g_cbf_stamps = nullptr;     // [64 workgroups][32 tiles][16 stamps], set by hk_lab_set_cbf_stamps (cbp.hip)
-#define CBF_STAMP(t_, slot_)                                                                             \
-    do {                                                                                                 \
-        if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 64 && (t_) < 32 && g_cbf_stamps)                 \
-            g_cbf_stamps[((long long)blockIdx.x * 32 + (t_)) * 16 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define CBF_STAMP(t_, slot_) do { } while (0)
-#endif
 
 template <int HW, bool PIPE>
 __global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restrict__ x, const unsigned* __restrict__ lists,
@@ -267,7 +255,6 @@ __global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restri
             const bool nxt_is_row = more && t + 1 == c0;
             const int nxt = more ? (nxt_is_row ? tile_I(t + 1) : tile_J(t + 1)) : J;
             f32x4 st[NST];
-            CBF_STAMP(t, 0);
             load_panel(st, nxt);                     // (unconditional: the staging registers stay registers)
             // (pinned: the scheduler otherwise sinks the 13 loads below the MFMA loop - 52 fewer live registers - and the
             //  panel store behind the first barrier starts by waiting for memory)
@@ -282,7 +269,6 @@ __global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restri
             ep.yb = nullptr; ep.C = 0; ep.i0 = ep.j0 = ep.offdiag = 0; ep.inv = ep.inv_m = 0.f; ep.l31 = l31; ep.lh = lh;
             gram_tile<HW, false, NST>(Ap, Bp, acc0, acc1, dummy, ep, lh, st, reinterpret_cast<f32x4*>(sB), false, mt);
             const f32x16 t16 = acc0 + acc1;
-            CBF_STAMP(t, 1);
             // the tile, transposed: T[j][i], four consecutive i per 16-byte store (C layout of the 32x32 MFMA:
             // col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
 #pragma unroll
@@ -291,12 +277,10 @@ __global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restri
                 *reinterpret_cast<f32x4*>(T + (wn * 32 + l31) * CBF_TP + wm * 32 + 8 * g + 4 * lh) = q4;
             }
             HK_LDS_BARRIER();                       // B1
-            CBF_STAMP(t, 2);
             // (a row panel that starts off the diagonal cannot follow: only the first run of an item may, and that one is
             //  loaded by the prologue)
             if (more) store_panel(st, nxt_is_row ? sA : sB);
             HK_LDS_BARRIER();                       // B2
-            CBF_STAMP(t, 3);
         }
     } else {
         // (the younger wave of a SIMD loses the issue arbitration against the MFMA stream of its partner)
@@ -344,20 +328,15 @@ __global__ __launch_bounds__(512, 2) void cbp_fused_kernel(const float* __restri
 #define HK_CBF_NTILE(t_, TB_, CUR0, CUR1, NXT0, NXT1)                                                  \
         do {                                                                                          \
             const int I_ = tile_I(t_), J_ = tile_J(t_);                                               \
-            CBF_STAMP(t_, 4);                                                                         \
             HK_LDS_BARRIER();                       /* B1 */                                          \
             HK_LDS_BARRIER();                       /* B2 */                                          \
-            CBF_STAMP(t_, 5);                                                                         \
             const int tn_ = (t_) + 1 < ntile ? (t_) + 1 : (t_);                                       \
             ldlist(NXT0, tile_I(tn_) * nb + tile_J(tn_));                                             \
             ldlist(NXT1, tile_J(tn_) * nb + tile_I(tn_));                                             \
             __builtin_amdgcn_sched_barrier(0);                                                        \
-            CBF_STAMP(t_, 9);                                                                         \
             bin_list(TB_, CUR0);                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                        \
-            CBF_STAMP(t_, 6);                                                                         \
             if (J_ != I_) bin_list(TB_, CUR1);                                                        \
-            CBF_STAMP(t_, 7);                                                                         \
         } while (0)
         for (int t = 0; t < ntile; t += 2) {
             HK_CBF_NTILE(t, 0, a0, a1, b0, b1);

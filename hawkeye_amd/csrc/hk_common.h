@@ -45,55 +45,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HK_ATOMIC_ADD_F32(p, v) ((void)unsafeAtomicAdd((p), (v)))
 #endif
 
-// Device-coherent (agent scope, `sc1`) 16-byte accesses through a buffer descriptor: a store is written through to memory
-// and leaves the XCD's L2, a load bypasses the CU's L1 - data handed from one workgroup to another INSIDE a launch needs
-// no fences when both sides use these (MI355X_MICROARCH.md, inter-workgroup visibility) and no address is written twice.
-#ifndef HK_COH_RSRC
-namespace hk {
-typedef __amdgpu_buffer_rsrc_t coh_rsrc_t;
-// a pointer the program knows to be wave-uniform, made provably so for the compiler (a descriptor built from anything
-// it cannot prove uniform is applied through a waterfall loop per access)
-template <typename T>
-__device__ __forceinline__ T* uniform_ptr(T* p) {
-    const unsigned long long u = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return (T*)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ coh_rsrc_t coh_rsrc(const float* base, long long floats) {      // base, floats: wave-uniform
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(floats * 4), 0x00020000);
-}
-// (the builtin's own vector type is kept behind `auto` / decltype: converting its result to a user vector typedef makes
-//  the compiler load ONE dword and splat it)
-__device__ __forceinline__ float4 coh_load16(coh_rsrc_t rs, int byte_off) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
-    static_assert(sizeof(v) == 16, "b128");
-    float4 f;
-    __builtin_memcpy(&f, &v, 16);
-    return f;
-}
-__device__ __forceinline__ void coh_store16(coh_rsrc_t rs, int byte_off, float4 f) {
-    decltype(__builtin_amdgcn_raw_buffer_load_b128(rs, 0, 0, 16)) v;
-    __builtin_memcpy(&v, &f, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16);
-}
 // Plain (cached) stores through a buffer descriptor: the hardware drops the lanes whose byte offset lies beyond the
 // descriptor's size - a ragged edge needs no predicate, so the instruction ALWAYS issues (a store under `if (row < n)` is
 // skipped altogether when no lane passes: its place in a counted s_waitcnt vmcnt(n) would then be taken by an older load)
-__device__ __forceinline__ coh_rsrc_t buf_rsrc(const float* base, long long floats) { return coh_rsrc(base, floats); }
-__device__ __forceinline__ void buf_store16(coh_rsrc_t rs, unsigned byte_off, f32x4 f) {
+#ifndef HK_BUF_RSRC
+namespace hk {
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t buf_rsrc(const float* base, long long floats) {      // base, floats: wave-uniform
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(floats * 4), 0x00020000);
+}
+// (the builtin's own vector type is kept behind decltype: converting to a user vector typedef makes the compiler splat ONE dword)
+__device__ __forceinline__ void buf_store16(buf_rsrc_t rs, unsigned byte_off, f32x4 f) {
     decltype(__builtin_amdgcn_raw_buffer_load_b128(rs, 0, 0, 0)) v;
     __builtin_memcpy(&v, &f, 16);
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 0);
 }
-__device__ __forceinline__ void buf_store4(coh_rsrc_t rs, unsigned byte_off, float f) {
+__device__ __forceinline__ void buf_store4(buf_rsrc_t rs, unsigned byte_off, float f) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), rs, (int)byte_off, 0, 0);
 }
-__device__ __forceinline__ int coh_ticket(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int coh_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void coh_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // this wave's stores have left
-__device__ __forceinline__ void coh_nap() { __builtin_amdgcn_s_sleep(8); }
 }  // namespace hk
-#define HK_COH_RSRC 1
+#define HK_BUF_RSRC 1
 #endif
 
 #ifndef HK_WAVE_SYNC
@@ -147,9 +118,8 @@ struct Tuning {
     int roi_bwd = 0;        // HK_ROI_BWD       0: uniform-window ROI-refinement backward (apcnn_roi2.hip), 1: the round-1 table kernel
     int linear_slabs = 0;   // HK_LINEAR_SLABS  0: automatic split-K slab count of hk_linear_fwd
     int ns_tn = 0;          // HK_NS_TN         0: automatic, 64 / 128: forced tile width of the Newton-Schulz products
-    int bwd_v = 0;          // HK_BWD_V         Gram backward: 0 / 1 the 64-row kernel (bcnn_fast.hip), 5 the 128-row kernel (hk_bwd128.h)
+    int bwd_v = 0;          // HK_BWD_V         Gram backward: 0 automatic, 1 the four-wave 64-row panel kernel (bcnn_fast.hip)
     int ns_streams = 1;     // HK_NS_STREAMS    n: the batch runs the Newton-Schulz chain in n + 1 parts on n + 1 HIP queues (default 1: two halves), 0: one queue
-    int ns_flow = 0;        // HK_NS_FLOW       1 / 2: the Newton-Schulz forward as one dataflow launch (hk_nsmm.h, ns_flow_kernel; 2: skewed ticket order), 0: a launch per step
     int ns_sym = 1;         // HK_NS_SYM        1: hk_ns_sqrtm_fwd_sym skips the tiles below the diagonal blocks, 0: it computes every tile
     int lin_walk = -1;      // HK_LIN_WALK      classifier backward: 1: workgroup s walks chunks s, s + S, ..; 0: a contiguous slab per workgroup;
                             //                  -1: the measured winner per kernel (linear_bwd64_kernel 1, linear_bwd16_kernel 0)

@@ -152,8 +152,8 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
         }
         // this lane's rows of the dy tile: sample 16 st + 4 lq + r, features 4 l15 ..+3; of class tile 12: class 192 + 4 lq + r,
         // feature 4 l15 + st (byte offsets; rows beyond B / K lie beyond the descriptor's end: dropped by the hardware)
-        const coh_rsrc_t rs = buf_rsrc(dy, DO_DY ? (long long)B * J : 0);
-        const coh_rsrc_t rs12 = buf_rsrc(dw, DO_DW ? (long long)K * J : 0);
+        const buf_rsrc_t rs = buf_rsrc(dy, DO_DY ? (long long)B * J : 0);
+        const buf_rsrc_t rs12 = buf_rsrc(dw, DO_DW ? (long long)K * J : 0);
         unsigned orow[4], orow12[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
         if (U > 2) { dma(2, 0, 0); dma(2, 0, 1); }
         // this lane's rows of a 16-class output tile: class 4 lq + r of the tile, features 4 l15 ..+3 (byte offsets; classes
         // beyond K lie beyond the descriptor's end)
-        const coh_rsrc_t rs = buf_rsrc(dw, (long long)K * J);
+        const buf_rsrc_t rs = buf_rsrc(dw, (long long)K * J);
         unsigned orow[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) orow[r] = 4u * ((unsigned)(4 * lq + r) * (unsigned)J + 4u * l15);

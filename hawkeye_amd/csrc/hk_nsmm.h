@@ -57,7 +57,6 @@ struct NsProb {
     const float* rout;
     const float* ra;
     float* rpart;
-    const float* tr_src;   // ns_flow_kernel only: s_b = sqrt(trace(tr_src[b])), recomputed by the workgroup
     float* tv;             // nullable: the result's upper triangle, row-major packed [b][d (d + 1) / 2] (Triuvec,
                            // MPNCOV.py:205-230), written next to C by the chain's last forward product
 };
@@ -114,13 +113,9 @@ __host__ __device__ __forceinline__ int ns_tile_count(int tilesM, int tilesN) {
 }
 
 // One workgroup tile (rows m0.., columns n0..) of problem P for sample b; `lds` = NsTileCfg<TN>::LDS_FLOATS floats.
-// COH = true (ns_flow_kernel: the operands were written by other workgroups of the SAME launch): operands are loaded and
-// results stored device-coherently (hk_common.h, coh_*); needs EDGE = false; the trace behind bscale_fn = 1 is
-// recomputed from P.tr_src instead of read (the word another workgroup wrote is not waited for).
-template <int TN, bool EDGE, bool SYM, bool FIRST, bool LAST, bool COH = false>
+template <int TN, bool EDGE, bool SYM, bool FIRST, bool LAST>
 __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int tile, int tiles, int m0, int n0, float* lds) {
     static_assert(!(SYM && EDGE), "the symmetric schedule is for d % 128 == 0");
-    static_assert(!(COH && (EDGE || LAST)), "the dataflow kernel runs the aligned forward products");
     static_assert(!(LAST && (SYM || FIRST)), "the final product of the backward is a general matrix");
     constexpr int TM = 128, BK = 32;
     constexpr int NJ = TN / 64;                 // 32-column MFMA tiles per wave (wave tile = 64 x TN/2)
@@ -153,19 +148,11 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
     const float *pa = nullptr, *pb = nullptr;
     float sg_term = 1.f;                                      // sign of the term being staged
     int k0 = 0;                                               // k offset of the next chunk to stage (EDGE guards)
-    coh_rsrc_t rsa, rsb;                                      // COH: descriptors of the term's operands, per-thread byte offsets
-    int oa = 0, ob = 0;
     auto set_term = [&](int ti) {
         NsTerm T;                                             // by value (a dynamic index would spill the table to scratch,
         if (ti == 0) T = P.t[0];                              //  a reference into a register-resident P likewise)
         else if (ti == 1) T = P.t[1];
         else T = P.t[2];
-        if (COH) {
-            rsa = coh_rsrc(uniform_ptr(T.A + (long long)b * T.sa), (long long)d * d);
-            rsb = coh_rsrc(uniform_ptr(T.B + (long long)b * T.sb), (long long)d * d);
-            oa = ((m0 + ar) * d + ac) * 4;
-            ob = (br * d + n0 + bc) * 4;
-        }
         pa = T.A + (long long)b * T.sa + (long long)(m0 + ar) * d + ac;
         pb = T.B + (long long)b * T.sb + (long long)br * d + n0 + bc;
         sg_term = T.sign;
@@ -184,7 +171,6 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
     R0.sg = 1.f;
     R1 = R0;
     auto lda = [&](int u) -> float4 {
-        if (COH) return coh_load16(rsa, oa + 32 * u * d * 4);
         const float* q = pa + (long long)(32 * u) * d;
         if (!EDGE) return *reinterpret_cast<const float4*>(q);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -198,7 +184,6 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
         return v;
     };
     auto ldb = [&](int u) -> float4 {
-        if (COH) return coh_load16(rsb, ob + BRS * u * d * 4);
         const float* q = pb + (long long)(BRS * u) * d;
         if (!EDGE) return *reinterpret_cast<const float4*>(q);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -222,8 +207,6 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
         if (NLB == 4) { R.b2 = ldb(2); R.b3 = ldb(3); }                    \
         pa += BK;                                                          \
         pb += (long long)BK * d;                                           \
-        oa += BK * 4;                                                      \
-        ob += BK * d * 4;                                                  \
         k0 += BK;                                                          \
         R.sg = sg_term;                                                    \
         ++kc;                                                              \
@@ -330,22 +313,9 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
     // every field of the problem descriptor is read ONCE into a scalar here (P lives in the kernarg segment behind a
     // dynamic index: each mention is a scalar load, and a mention inside a per-element condition becomes a branch)
     float sb_ = 1.0f;
-    if (COH) {
-        if (P.tr_src) {                                       // (uniform) sqrt(trace(a[b])), the summation order of FIRST
-            __shared__ float redt[4];
-            const float* ab = P.tr_src + (long long)b * d * d;
-            float sd = 0.f;
-            for (int i = tid; i < d; i += 256) sd += ab[(long long)i * d + i];
-            sb_ = sqrtf(block_sum<4>(sd, redt));
-        }
-    } else if (P.bscale) {
+    if (P.bscale) {
         const float v_ = P.bscale[b];
         sb_ = P.bscale_fn == 1 ? sqrtf(v_) : (P.bscale_fn == 2 ? 1.0f / v_ : v_);
-    }
-    coh_rsrc_t rsc, rsc2;
-    if (COH) {
-        rsc = coh_rsrc(uniform_ptr(P.C + (long long)b * P.sc), (long long)d * d);
-        rsc2 = coh_rsrc(uniform_ptr((P.C2 ? P.C2 : P.C) + (long long)b * (P.C2 ? P.sc2 : P.sc)), (long long)d * d);
     }
     float rs0 = 0.f, rs1 = 0.f;                               // LAST: this thread's share of the two sums
     const float* rgb = LAST ? P.rg + (long long)b * d * d : nullptr;
@@ -445,9 +415,6 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
                     float* Tw = lds + wave * ((TN / 2) * 68);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) Tw[(j * 32 + 4 * lh + 8 * gq + t) * 68 + i * 32 + l31] = o1[t] * sb_;
-                } else if (COH) {
-                    coh_store16(rsc, (int)(orow + col) * 4, make_float4(o1[0], o1[1], o1[2], o1[3]));
-                    if (has_c2) coh_store16(rsc2, (int)(orow + col) * 4, make_float4(o2[0], o2[1], o2[2], o2[3]));
                 } else if (!EDGE) {
                     *reinterpret_cast<float4*>(Cb + orow + col) = make_float4(o1[0], o1[1], o1[2], o1[3]);
                     if (has_c2) *reinterpret_cast<float4*>(C2b + orow + col) = make_float4(o2[0], o2[1], o2[2], o2[3]);
@@ -475,20 +442,19 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
     static_assert(4 * (TN / 2) * 68 <= 2 * (SA + SB), "the four wave images fit the LDS of the main loop");
     float* Tw = lds + wave * ((TN / 2) * 68);
     const long long moff = (long long)(n0 + wn * (TN / 2)) * d + m0 + wm * 64;
-    auto flush = [&](float* dst, coh_rsrc_t rsd) {
+    auto flush = [&](float* dst) {
         const int q = lane & 15, c4 = lane >> 4;
         HK_WAVE_SYNC();
 #pragma unroll
         for (int c0 = 0; c0 < TN / 2; c0 += 4) {
             const float4 v = *reinterpret_cast<const float4*>(&Tw[(c0 + c4) * 68 + 4 * q]);
-            if (COH) coh_store16(rsd, (int)(moff + (long long)(c0 + c4) * d + 4 * q) * 4, v);
-            else *reinterpret_cast<float4*>(dst + moff + (long long)(c0 + c4) * d + 4 * q) = v;
+            *reinterpret_cast<float4*>(dst + moff + (long long)(c0 + c4) * d + 4 * q) = v;
         }
         HK_WAVE_SYNC();
     };
-    if (LAST && !EDGE) flush(Cb, rsc);
+    if (LAST && !EDGE) flush(Cb);
     if (SYM && mirror) {
-        flush(Cb, rsc);
+        flush(Cb);
         if (FIRST) {                                        // Z_0's mirror: its tile again, from a (L2-hot), through the image
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -505,7 +471,7 @@ __device__ __forceinline__ void nsmm_tile(const NsProb& P, int d, int b, int til
                             Tw[(j * 32 + 4 * lh + 8 * gq + t) * 68 + i * 32 + l31] = fmaf(alpha2, xs[t], 0.f);
                     }
                 }
-            flush(C2b, rsc2);
+            flush(C2b);
         }
     }
 }
@@ -540,130 +506,12 @@ __host__ __device__ static inline NsProb ns_prob(float* C, long long sc, float a
     p.E2 = nullptr; p.se2 = 0; p.e2 = 0.f;
     p.C2 = nullptr; p.sc2 = 0; p.alpha2 = 0.f; p.diag2 = 0.f;
     p.bscale_fn = 0; p.norm_out = nullptr;
-    p.rg = p.rout = p.ra = nullptr; p.rpart = nullptr; p.tr_src = nullptr; p.tv = nullptr;
+    p.rg = p.rout = p.ra = nullptr; p.rpart = nullptr; p.tv = nullptr;
     return p;
 }
 static inline NsProb& operator+=(NsProb& p, const NsTerm& t) {
     p.t[p.nt++] = t;
     return p;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The forward chain as ONE launch: a ticket-ordered queue of (step, sample, problem, tile) tasks.  OPT-IN (knob ns_flow =
-// 1, or 2 for the skewed ticket order): bit-identical to the launch-per-step schedule, measured at B = 64, d = 256 at
-// 238-281 us against 234-235 us for the launches on the same boxes (profiles/r3_lab_call31/32.json) - NOT faster, and
-// with ONE workgroup per CU it runs as fast (250 us) as with two: a task is a latency chain (operand fetch 3 us,
-// 8 us of MFMA, write-through drain 3 us) that the co-resident workgroup does not cover.  Kept as the scaffold for the
-// next step (operand prefetch of task i + 1 behind the MFMAs of task i); the product does not take it.
-// Why: as launches, a step is 192 / 384 tiles per half batch on 256 CUs - half the CUs hold two tiles, the others one,
-// and every launch lasts two tile times (profiles/r3_ns_launch_timeline.csv); the step boundary is global although the
-// dependency is per SAMPLE.  Here 512 resident workgroups (2 per CU) draw tickets; a ticket is a tile of some step of
-// some sample, and it may start as soon as the previous step of THAT sample is complete (a counter per sample and step).
-//   * Tickets are issued in topological order (step-major), so a task only ever waits for tasks with EARLIER tickets:
-//     no deadlock whatever the residency or the dispatch order (on the CPU emulation, one workgroup at a time, nobody
-//     ever waits).  Spins are bounded: a stuck wait sets *err and goes on.
-//   * Hand-off without fences: results are stored write-through (`sc1`), every storing wave drains its stores, one lane
-//     bumps the (sample, step) counter with an agent-scope atomic; consumers poll that one word relaxed and load the
-//     operands with `sc1` loads.  No address is written twice inside the launch (a T buffer per iteration), so no L2 can
-//     hold a stale line of anything it is asked for.
-//   * The 8 XCDs have a ticket counter each and own the samples b = xcd (mod 8) (blockIdx % 8 is the XCD of a workgroup
-//     on this part - an assumption that only costs L2 hits if wrong): the tiles of a sample share their operands in
-//     one L2 as in the launch-per-step schedule.
-constexpr int NS_FLOW_MAXSTEPS = 12;
-struct NsFlowProb {
-    const float* A;
-    const float* B;
-    float* C;
-    long long sa, sb, sc;
-    float alpha, diag;
-};
-struct NsFlowStep {
-    NsFlowProb p[2];
-    int np;                // problems of the step (1 or 2); kind 1: p[1].C / sc = the second result (Z_0)
-    int kind;              // 0 product, 1 the chain's first step (nsmm_tile FIRST), 2 product scaled by sqrt(trace(a))
-};
-struct NsFlow {
-    NsFlowStep s[NS_FLOW_MAXSTEPS];
-    int cum[NS_FLOW_MAXSTEPS + 1];     // problems in the steps before step k
-    int nsteps, B, d, tilesM, tilesN;
-    const float* a;
-    float* norm_out;
-    int* ticket;                       // [NXCD]            zeroed before the launch
-    int* done;                         // [B][nsteps]       zeroed before the launch
-    int* err;                          // [1]
-    int skew;                          // 1: the second half of an XCD's samples runs one step behind the first
-};
-static inline size_t ns_flow_sync_bytes(int B, int nsteps) { return ((size_t)NXCD + (size_t)B * nsteps + 1) * sizeof(int); }
-
-template <int TN, bool SYM>
-__global__ __launch_bounds__(256, 2) void ns_flow_kernel(const NsFlow f) {
-    __shared__ __attribute__((aligned(16))) float lds[NsTileCfg<TN>::LDS_FLOATS];
-    __shared__ int s_t;
-    const int tid = threadIdx.x;
-    const int xcd = blockIdx.x % NXCD;
-    const int tiles = ns_tile_count<TN, SYM>(f.tilesM, f.tilesN);
-    const int nbx = (f.B - xcd + NXCD - 1) / NXCD;            // this XCD's samples: b = xcd + NXCD s
-    // Ticket order: the XCD's samples form two groups, and group 1 runs ONE STEP BEHIND group 0 - window w holds step w
-    // of group 0 followed by step w - 1 of group 1.  A step is 6 (or 12) tiles per sample, i.e. 48 / 96 tasks for the
-    // 64 resident workgroups of an XCD when all 8 samples march together: the workgroups beyond the step's tasks draw
-    // tickets of the NEXT step of the same samples and wait a whole tile time for them (measured: no faster than the
-    // launches).  With the skew a window is a one-problem step of one group + a two-problem step of the other = 72
-    // tasks, and a task's predecessors lie a whole window back.
-    const int ns0 = f.skew ? (nbx + 1) / 2 : nbx, ns1 = nbx - ns0;
-    const int total = nbx * tiles * f.cum[f.nsteps];
-    for (;;) {
-        __syncthreads();                                      // the previous task is done with the LDS (and with s_t)
-        if (tid == 0) s_t = coh_ticket(f.ticket + xcd);
-        __syncthreads();
-        const int t = __builtin_amdgcn_readfirstlane(s_t);
-        if (t >= total) break;
-        int k = 0, grp = 0, r = t;
-        for (int w = 0; w <= f.nsteps; ++w) {                 // find the window, then the group's part of it
-            const int c0 = w < f.nsteps ? ns0 * tiles * f.s[w].np : 0;
-            const int c1 = w > 0 ? ns1 * tiles * f.s[w - 1].np : 0;
-            if (r < c0) { k = w; grp = 0; break; }
-            r -= c0;
-            if (r < c1) { k = w - 1; grp = 1; break; }
-            r -= c1;
-        }
-        const NsFlowStep& S = f.s[k];
-        const int per_sample = S.np * tiles;
-        int si = r / per_sample;
-        r -= si * per_sample;
-        si += grp * ns0;
-        const int pi = r / tiles, tile = r - pi * tiles;
-        const int b = xcd + NXCD * si;
-        if (k > 0) {                                          // the previous step of this sample, all its tiles
-            if (tid == 0) {
-                const int need = f.s[k - 1].np * tiles;
-                const int* w = f.done + (long long)b * f.nsteps + (k - 1);
-                for (int spins = 0; coh_peek(w) < need; ++spins) {
-                    coh_nap();
-                    if (spins > (1 << 21)) { *f.err = 1; break; }
-                }
-            }
-            __syncthreads();
-        }
-        const NsFlowProb& Q = pi == 0 ? S.p[0] : S.p[1];
-        const long long n = (long long)f.d * f.d;
-        NsProb P = ns_prob(Q.C, Q.sc, Q.alpha, Q.diag);
-        P.t[0].A = Q.A; P.t[0].B = Q.B; P.t[0].sa = Q.sa; P.t[0].sb = Q.sb; P.t[0].sign = 1.f;
-        P.nt = 1;
-        int m0, n0;
-        ns_tile_origin<TN, SYM>(tile, f.tilesN, m0, n0);
-        if (S.kind == 1) {
-            P.E1 = f.a; P.se1 = n;
-            P.C2 = S.p[1].C; P.sc2 = S.p[1].sc;
-            P.norm_out = f.norm_out;
-            nsmm_tile<TN, false, SYM, true, false, true>(P, f.d, b, tile, tiles, m0, n0, lds);
-        } else {
-            if (S.kind == 2) P.tr_src = f.a;
-            nsmm_tile<TN, false, SYM, false, false, true>(P, f.d, b, tile, tiles, m0, n0, lds);
-        }
-        coh_drain();                                          // every storing wave: its stores have left the CU
-        __syncthreads();
-        if (tid == 0) coh_ticket(f.done + (long long)b * f.nsteps + k);
-    }
 }
 
 static inline bool ns_prob_aligned(const NsProb& p) {
@@ -748,33 +596,5 @@ static inline int nsmm_launch(const NsGroup& g, int d, int nb, hipStream_t st, i
     return HK_OK;
 }
 
-// Launch of ns_flow_kernel: `sync` = ns_flow_sync_bytes(B, nsteps) bytes of workspace (zeroed here).  Returns
-// HK_ERR_UNSUPPORTED when the chain has to run as launches (ragged d, unaligned operands, small batch, too many steps).
-static inline int ns_flow_launch(NsFlow f, void* sync, bool sym, hipStream_t st) {
-    if (f.d % 128 != 0 || f.B < 2 * NXCD || f.nsteps > NS_FLOW_MAXSTEPS || f.nsteps < 1) return HK_ERR_UNSUPPORTED;
-    if ((long long)f.d * f.d * 4 > 0x7fffffffLL) return HK_ERR_UNSUPPORTED;
-    bool ok = aligned16(f.a);
-    for (int k = 0; k < f.nsteps; ++k)
-        for (int i = 0; i < 2; ++i) {
-            const NsFlowProb& q = f.s[k].p[i];
-            if (i < f.s[k].np) ok = ok && aligned16(q.A) && aligned16(q.B) && q.sa % 4 == 0 && q.sb % 4 == 0;
-            if (i < f.s[k].np || f.s[k].kind == 1) ok = ok && aligned16(q.C) && q.sc % 4 == 0;
-        }
-    if (!ok) return HK_ERR_UNSUPPORTED;
-    f.cum[0] = 0;
-    for (int k = 0; k < f.nsteps; ++k) f.cum[k + 1] = f.cum[k] + f.s[k].np;
-    f.tilesM = f.d / 128;
-    f.tilesN = f.d / 64;
-    f.ticket = (int*)sync;
-    f.done = f.ticket + NXCD;
-    f.err = f.done + (size_t)f.B * f.nsteps;
-    if (hipMemsetAsync(sync, 0, ns_flow_sync_bytes(f.B, f.nsteps), st) != hipSuccess) return HK_ERR_UNSUPPORTED;
-    f.skew = tuning().ns_flow == 2;
-    const dim3 grid(NXCD * 64);                                // two workgroups per CU
-    if (sym) hipLaunchKernelGGL((ns_flow_kernel<64, true>), grid, dim3(256), 0, st, f);
-    else hipLaunchKernelGGL((ns_flow_kernel<64, false>), grid, dim3(256), 0, st, f);
-    HK_LAUNCH_CHECK();
-    return HK_OK;
-}
 
 }  // namespace hk

@@ -99,9 +99,6 @@ __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __re
 //   * the fragments of chunk c + 1 (complete one barrier earlier) are read behind the last MFMAs of chunk c.
 // Partial results [S][B][K] as before, added in slab order by linear_reduce_kernel: deterministic.
 
-#ifdef HK_LAB   // tools/linear_lab.py, timing only (results are wrong): bits 1 = no MFMAs, 2 = no LDS-DMA inside the loop, 4 = no fragment reads
-__device__ int g_lin_lab = 0;
-#endif
 // MT: 16-sample row tiles per workgroup.  4: up to 64 samples, wave w owns row tile w & 3 and one half of the NT class tiles.
 // 1: up to 16 samples (OSME: N = 10) - every wave owns the same 16 rows and NT / 8 of the class tiles; the product is then
 // a pure stream of W (2 KB of LDS-DMA pieces per MFMA-cycle-pair), the matrix pipe idles.
@@ -180,11 +177,6 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
     const int arow = 16 * rb + l15;
     const int aoff = arow * CH, asw = arow & 7;
     const int boff = A_SZ + (16 * nt0 + l15) * CH, bsw = l15 & 7;      // (16 (nt0 + n) is a multiple of 8)
-#ifdef HK_LAB
-    const int labv = __builtin_amdgcn_readfirstlane(g_lin_lab);
-#else
-    constexpr int labv = 0;
-#endif
     // prologue: chunks 0 .. NS - 2 into stages 0 .. NS - 2
     for (int c = 0; c < NS - 1 && c < nch; ++c) { dma(c, c * STAGE, 0); dma(c, c * STAGE, 1); }
     vm_barrier(true);
@@ -198,7 +190,6 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
     auto run = [&](auto nl_tag) {
         constexpr int NL = decltype(nl_tag)::value;
         auto frag = [&](int st, int s, f32x4& a, f32x4 (&b)[NL]) {
-            if (labv & 4) return;
             const float* base = lds + st;
             a = *reinterpret_cast<const f32x4*>(base + aoff + (((4 * s + lq) ^ asw) << 2));
 #pragma unroll
@@ -206,23 +197,18 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
                 b[n] = *reinterpret_cast<const f32x4*>(base + boff + n * 16 * CH + (((4 * s + lq) ^ bsw) << 2));
         };
         auto mma = [&](const f32x4& a, const f32x4 (&b)[NL]) {
-            if (labv & 1) return;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int n = 0; n < NL; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n][t], acc[n], 0, 0, 0);
         };
         f32x4 a0, a1, b0[NL], b1[NL];
-#ifdef HK_LAB
-        a0 = a1 = (f32x4){1.f, 1.f, 1.f, 1.f};
-        for (int n = 0; n < NL; ++n) b0[n] = b1[n] = (f32x4){1.f, 1.f, 1.f, 1.f};
-#endif
         frag(0, 0, a0, b0);
         int cur = 0;                                             // stage of chunk c (float offset), nxt = chunk c + 1
         for (int c = 0; c < nch; ++c) {
             const int nxt = cur + STAGE < NS * STAGE ? cur + STAGE : 0;
             const int dst = cur >= STAGE ? cur - STAGE : (NS - 1) * STAGE;  // stage of chunk c - 1 = chunk c + NS - 1
-            const bool load = c + NS - 1 < nch && !(labv & 2);   // uniform
+            const bool load = c + NS - 1 < nch;                  // uniform
             frag(cur, 1, a1, b1);
             mma(a0, b0);
             if (load) dma(c + NS - 1, dst, 0);
@@ -345,11 +331,6 @@ extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, 
     return HK_OK;
 }
 
-#ifdef HK_LAB
-extern "C" int hk_lab_set_linear_mode(int v) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_lin_lab), &v, sizeof(int)) == hipSuccess ? HK_OK : HK_ERR_UNSUPPORTED;
-}
-#endif
 
 extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, float* dy, float* dw, float* db, int B, int J,
                              int K, hk_stream_t stream) {

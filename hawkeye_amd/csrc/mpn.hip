@@ -278,48 +278,6 @@ static inline dim3 ns_scale_grid(long long n, int B) {
 }
 
 
-// The forward schedule of hk_ns_sqrtm_fwd (iterN >= 2) as the step table of ns_flow_kernel: ws = iterN - 1 T matrices,
-// then [B] floats (unused here), then the task counters.
-static int ns_flow_forward(const float* a, float* out, float* norm_a, float* ysave, float* zsave, int B, int d, int iter_n,
-                           float* ws, bool sym, hipStream_t st) {
-    const long long n = (long long)d * d, bn = (long long)B * n;
-    const int S = iter_n - 1;
-    const long long sbs = (long long)S * n;
-    NsFlow f;
-    memset(&f, 0, sizeof(f));
-    f.B = B; f.d = d; f.a = a; f.norm_out = norm_a;
-    int k = 0;
-    auto prob = [](const float* A, long long sa, const float* Bm, long long sb, float* C, long long sc, float alpha, float diag) {
-        NsFlowProb q;
-        q.A = A; q.B = Bm; q.C = C; q.sa = sa; q.sb = sb; q.sc = sc; q.alpha = alpha; q.diag = diag;
-        return q;
-    };
-    if (2 * iter_n - 1 > NS_FLOW_MAXSTEPS) return HK_ERR_UNSUPPORTED;
-    f.s[k].p[0] = prob(a, n, a, n, ysave, sbs, 1.f, 0.f);                                          // Y0 (and Z0)   :144-154
-    f.s[k].p[1] = prob(nullptr, 0, nullptr, 0, zsave, sbs, 0.f, 0.f);
-    f.s[k].np = 1; f.s[k].kind = 1; ++k;
-    float* T = ws;
-    for (int i = 1; i < iter_n - 1; ++i, T += bn) {                                                 // :156-159
-        const float* Yp = ysave + (long long)(i - 1) * n;
-        const float* Zp = zsave + (long long)(i - 1) * n;
-        f.s[k].p[0] = prob(Zp, sbs, Yp, sbs, T, n, -0.5f, 1.5f);                                   // ZY = .5 (3I - Z Y)
-        f.s[k].np = 1; f.s[k].kind = 0; ++k;
-        f.s[k].p[0] = prob(Yp, sbs, T, n, ysave + (long long)i * n, sbs, 1.f, 0.f);                 // Y' = Y ZY
-        f.s[k].p[1] = prob(T, n, Zp, sbs, zsave + (long long)i * n, sbs, 1.f, 0.f);                 // Z' = ZY Z
-        f.s[k].np = 2; f.s[k].kind = 0; ++k;
-    }
-    const float* Yl = ysave + (long long)(iter_n - 2) * n;
-    const float* Zl = zsave + (long long)(iter_n - 2) * n;
-    f.s[k].p[0] = prob(Zl, sbs, Yl, sbs, T, n, -1.f, 3.f);                                         // 3I - Z Y      :160
-    f.s[k].np = 1; f.s[k].kind = 0; ++k;
-    f.s[k].p[0] = prob(Yl, sbs, T, n, out, n, 0.5f, 0.f);                                          // .5 Y (.) sqrt(normA)
-    f.s[k].np = 1; f.s[k].kind = 2; ++k;
-    f.nsteps = k;
-    const size_t nmat = iter_n - 1 > 2 ? (size_t)(iter_n - 1) : 2;
-    void* sync = (void*)(ws + nmat * bn + B + 64);
-    return ns_flow_launch(f, (void*)(((uintptr_t)sync + 15) & ~(uintptr_t)15), sym, st);
-}
-
 }  // namespace hk
 
 using namespace hk;
@@ -371,10 +329,8 @@ extern "C" size_t hk_ns_sqrtm_ws_bytes(int B, int d, int iter_n, int backward) {
     const size_t nt = (size_t)(d + 31) / 32;
     const size_t small = ((size_t)B + (backward ? 2 * (size_t)B * nt * nt : 0)) * sizeof(float) + 256;
     if (backward) return 10 * mat + small;
-    // forward: A + T for the launch-per-step schedule; a T per iteration + the task counters for the dataflow launch
-    const int nsteps = iter_n >= 2 ? 2 * iter_n - 1 : 1;
-    const size_t nmat = iter_n - 1 > 2 ? (size_t)(iter_n - 1) : 2;
-    return nmat * mat + small + ns_flow_sync_bytes(B, nsteps) + 256;
+    (void)iter_n;
+    return 2 * mat + small + 256;                  // forward: A + T
 }
 
 // Forward schedule at iterN = 5 (MPNCOV.py:137-164): 12 products in 9 launches -
@@ -401,10 +357,6 @@ static int ns_sqrtm_fwd_impl(const float* a, float* out, float* norm_a, float* y
         NsProb p1 = ns_single(A, n, T, n, out, n, 1.0f, 0.f, sq);                                  // :151,:161
         p1.tv = tv;
         return nsmm_launch(ns_group(p1), d, B, st, 0, 0, sym);
-    }
-    if (tuning().ns_flow != 0 && !tv) {              // the whole chain as one ticket-ordered dataflow launch
-        const int rc = ns_flow_forward(a, out, norm_a, ysave, zsave, B, d, iter_n, (float*)ws, sym, st);
-        if (rc != HK_ERR_UNSUPPORTED) return rc;
     }
     // the first launch works on a itself: trace, normalisation, Z0 = ZY and Y0 = A ZY in one kernel         :144-154
     NsDispatch L(d, B, st, sym);

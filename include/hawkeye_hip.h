@@ -51,13 +51,8 @@ const char* hk_version(void);
 /* A/B levers for tests, benchmarks and profiling - never needed by a caller of the ops.  Each knob selects between
  * implementations that produce the same results (bit-identical or to rounding); the defaults are the measured winners.
  *   "bcnn_generic"  1 = generic GEMM path for the Gram / covariance / CBP kernels and the three-kernel CIN forward
- *   "bwd_v"         Gram backward (BCNN, signed sqrt, covariance): 0 automatic (hk_bwd3.h wherever its row blocks fill
- *                   the chip, else the 64-row panel kernel); 1 panel kernel; 4 eight-wave kernel on 64-row blocks;
- *                   5 register-staged 128-row kernel; 9 round 2's LDS-DMA 128-row kernel; 11..14 hk_bwd3.h with
- *                   VALU remainder columns + LDS-staged epilogue / remainder only / epilogue only / neither; 15 adds
- *                   one wave per 16 rows, 16 (= automatic at 128-row blocks) also the late coefficient; 21..24 = 11..14
- *                   forced onto 128-row blocks.  CBP backward: 31..35 force hk_bwd3c.h with (rows, K split, column
- *                   split) = (128,1,1) (64,1,1) (64,2,1) (128,2,1) (64,1,2)
+ *   "bwd_v"         Gram backward (BCNN / signed-sqrt / covariance / CBP): 0 automatic (gram_bwd3_kernel / cbp_bwd3_kernel
+ *                   where their row blocks fill the chip, else the 64-row panel kernel); 1 panel kernel
  *   "cbp_bin"       CBP forward: -1 automatic (the fused Gram + binning kernel where the plan allows it, else by batch
  *                   size), 0 row-sketch, 1 CSR gather, 2 row-scatter, 3 fused, 4 fused without paired tile steps
  *   "roi_bwd"       0 = LDS-staged ROI refinement kernels, 1 = the round-1 table kernels
@@ -65,7 +60,6 @@ const char* hk_version(void);
  *   "ns_tn"         tile width of the Newton-Schulz products (0 automatic, 64, 128)
  *   "ns_streams"    n: the batch runs the Newton-Schulz chain in n + 1 parts on n + 1 HIP queues (default 1, at most 3)
  *   "ns_sym"        1 (default): hk_ns_sqrtm_fwd_sym skips the tiles below the diagonal blocks; 0: it computes all
- *   "ns_flow"       0 (default): a launch per step; 1 / 2: the forward chain as one dataflow launch (same bits)
  *   "lin_walk"      classifier backward: 1 workgroup s walks the 64-feature chunks s, s + S, ..; 0 a contiguous slab per
  *                   workgroup; -1 (default) the measured winner per kernel
  *   "sched_b"       > 0: batch-size dependent work splits behave as if the batch were this (tests)

@@ -410,21 +410,12 @@ inline T __shfl(T v, int srclane, int = 64) {
 #define HK_DYN_LDS16(name) HK_DYN_LDS(name)
 #define HK_FMAC_PINNED(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
 #define HK_PIN_LOADED(v) ((void)0)
-#define HK_COH_RSRC 1      /* coherent accesses: plain ones (one workgroup at a time; a ticket order in which a task only waits for earlier tickets never waits here) */
+#define HK_BUF_RSRC 1      /* buffer-descriptor stores: bounds-checked like the hardware (lanes beyond the descriptor's size are dropped) */
 namespace hk {
-struct coh_rsrc_t { char* p; long long bytes; };
-template <typename T> inline T* uniform_ptr(T* p) { return p; }
-inline coh_rsrc_t coh_rsrc(const float* base, long long floats) { return coh_rsrc_t{(char*)base, floats * 4}; }
-inline coh_rsrc_t buf_rsrc(const float* base, long long floats) { return coh_rsrc(base, floats); }
-// bounds-checked like the hardware: lanes beyond the descriptor's size are dropped
-inline void buf_store16(coh_rsrc_t rs, unsigned off, hipemu::v4f f) { if ((long long)off + 16 <= rs.bytes) memcpy(rs.p + off, &f, 16); }
-inline void buf_store4(coh_rsrc_t rs, unsigned off, float f) { if ((long long)off + 4 <= rs.bytes) memcpy(rs.p + off, &f, 4); }
-inline float4 coh_load16(coh_rsrc_t rs, int off) { return *reinterpret_cast<const float4*>(rs.p + off); }
-inline void coh_store16(coh_rsrc_t rs, int off, float4 f) { *reinterpret_cast<float4*>(rs.p + off) = f; }
-inline int coh_ticket(int* p) { return (*p)++; }
-inline int coh_peek(const int* p) { return *p; }
-inline void coh_drain() {}
-inline void coh_nap() {}
+struct buf_rsrc_t { char* p; long long bytes; };
+inline buf_rsrc_t buf_rsrc(const float* base, long long floats) { return buf_rsrc_t{(char*)base, floats * 4}; }
+inline void buf_store16(buf_rsrc_t rs, unsigned off, hipemu::v4f f) { if ((long long)off + 16 <= rs.bytes) memcpy(rs.p + off, &f, 16); }
+inline void buf_store4(buf_rsrc_t rs, unsigned off, float f) { if ((long long)off + 4 <= rs.bytes) memcpy(rs.p + off, &f, 4); }
 }
 #define HK_WAVE_SYNC() hipemu::wave_barrier()   /* the fibers of a wave are not in lockstep between collectives */
 #define HK_LDS_VOLATILE(p) ((volatile float*)(p))

@@ -79,22 +79,6 @@ def test_trainers_end_to_end_on_emulated_heads(which, tmp_path, monkeypatch):
     assert not os.path.isfile(os.path.join(tr.log_root, f'{which}_epoch_1.pth'))
 
 
-def test_candidates_tool_dry_run():
-    """tools/candidates.py runs unattended inside bench.py on the GPU box: its dry-run mode (tiny shapes on the emulated
-    kernels) must get through every entry point without an error row."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(_here)
-    env = dict(os.environ, HK_CAND_TINY='1')
-    p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'candidates.py')], capture_output=True, text=True,
-                       env=env, timeout=900)
-    assert p.returncode == 0, p.stderr[-800:]
-    rows = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('[')][-1])
-    assert len(rows) > 25 and not [r for r in rows if 'error' in r], [r for r in rows if 'error' in r]
-    assert all(r.get('bit_identical_to_default', True) for r in rows)
-
-
 def test_tester_evaluates_a_trainer_checkpoint(tmp_path, monkeypatch):
     """Trainer -> checkpoint -> Tester (reference test.py flow: strict load of `model.load`, validation pass, top-1)
     and a real image folder through the presets, with the input finalised on the device (uint8 from the workers)."""

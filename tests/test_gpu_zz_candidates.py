@@ -34,137 +34,89 @@ def _golden(name):
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
 
 
-@pytest.mark.parametrize('b,c,hw', [(2, 128, 14), (3, 256, 12), (2, 384, 8), (2, 512, 14), (3, 128, 10)])
-def test_backward_128_row_kernel(F, b, c, hw, tune):
-    """The two structures of the Gram backward - 64-row blocks with a P tile built in LDS (bwd_v=1) and 128-row blocks
-    with raw tiles and the operand formed at fragment-read time (bwd_v=5, hk_bwd128.h; the default once B*C/128 fills
-    the chip) - give the same dX for the BCNN, covariance and CBP modes (to rounding: the 128-row kernel rounds
-    coef/y before the product), and both agree with the oracle.  bwd_v=9: the 128-row kernel staged by LDS-DMA
-    (hk_bwd128d.h, BCNN and signed-sqrt modes; swizzled source / read addresses) - the same arithmetic as bwd_v=5."""
-    gen = torch.Generator().manual_seed(c + hw)
-    x = torch.relu(torch.randn(b, c, hw, hw, generator=gen))
-    plan = F.CbpPlan(*F.sketch_hashes(c, c, 2048), 2048, torch.device(DEV) if DEV != 'cuda'
-                     else torch.device('cuda', torch.cuda.current_device()))
-    res = []
-    for flag in (1, 5, 9, 4):
-        tune('bwd_v', flag)
-        out = []
-        xg = x.clone().to(DEV).requires_grad_(True)
-        y = F.bilinear_pool(xg)
-        (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(DEV)).sum().backward()
-        out.append(xg.grad.clone())
-        xg = x.clone().to(DEV).requires_grad_(True)
-        cv = F.covpool(xg)
-        (cv * torch.randn(cv.shape, generator=torch.Generator().manual_seed(2)).to(DEV)).sum().backward()
-        out.append(xg.grad.clone())
-        xg = x.clone().to(DEV).requires_grad_(True)
-        yc = F.compact_bilinear_pool(xg, plan)
-        (yc * torch.randn(yc.shape, generator=torch.Generator().manual_seed(3)).to(DEV)).sum().backward()
-        out.append(xg.grad.clone())
-        xg = x.clone().to(DEV).requires_grad_(True)
-        ys = F.bilinear_pool(xg, signed_sqrt=True)
-        (ys * torch.randn(ys.shape, generator=torch.Generator().manual_seed(4)).to(DEV)).sum().backward()
-        out.append(xg.grad.clone())
-        res.append(out)
-    for p, q, tol in zip(res[0], res[1], (2e-6, 2e-6, 2e-6, 2e-5)):
-        assert rel(q, p) < tol
-    assert torch.equal(res[0][2], res[1][2])               # CBP: P is gathered, nothing is rounded differently
-    # LDS-DMA staging: the same products.  dX of the GEMM itself is bit-identical (tools/bwd_ab.py compares it); through
-    # the whole backward the scalar t = <y, dy> differs in its last bits (BCNN mode: summed inside the GEMM kernel in a
-    # different order; signed sqrt: t comes from its own kernel, but d - t2 * y is contracted per kernel)
-    for k in (2,):
-        assert rel(res[k][0], res[1][0]) < 1e-6, (k, float(rel(res[k][0], res[1][0])))
-        assert rel(res[k][3], res[1][3]) < 1e-6, (k, float(rel(res[k][3], res[1][3])))
-    # bwd_v=4: the eight-wave kernel on 64-row blocks (the covariance at C = 256 takes it by default)
-    for p, q, tol in zip(res[0], res[3], (2e-6, 2e-6, 2e-6, 2e-5)):
-        assert rel(q, p) < tol
-    assert torch.equal(res[0][2], res[3][2])
-    xo = x.clone().requires_grad_(True)                    # and both agree with the oracle
-    yo = O.bilinear_pool(xo)
-    (yo * torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))).sum().backward()
-    assert rel(res[1][0], xo.grad) < 2e-5 and rel(res[0][0], xo.grad) < 2e-5
-    xo = x.clone().requires_grad_(True)
-    co = O.covpool(xo)
-    (co * torch.randn(co.shape, generator=torch.Generator().manual_seed(2))).sum().backward()
-    assert rel(res[1][1], xo.grad) < 1e-5
+def _fill_batches(c):
+    """sched_b values (the batch size the work-split heuristics see) that select the 128-row and the 64-row blocks of
+    gram_bwd3_kernel / cbp_bwd3_kernel for C channels, and the column-split form of the CBP backward."""
+    out = {}
+    if c % 128 == 0:
+        out['rows128'] = -(-192 * 128 // c)                 # B C / 128 >= 192
+    out['rows64'] = -(-192 * 64 // c)                       # B C / 64 >= 192 > B C / 128
+    out['colsplit'] = max(1, -(-64 * 64 // c))              # 2 B C / 64 >= 128 > ... : column tiles over two workgroups
+    return out
 
 
-@pytest.mark.parametrize('b,c,hw', [(2, 128, 14), (3, 256, 10), (2, 64, 14), (9, 192, 12), (2, 256, 8)])
+@pytest.mark.parametrize('b,c,hw', [(2, 128, 14), (3, 256, 10), (2, 64, 14), (9, 192, 12), (2, 256, 8), (2, 512, 14), (3, 384, 8)])
 def test_backward_bwd3_kernel(F, b, c, hw, tune):
-    """hk_bwd3.h (bwd_v = 11..14: VALU remainder columns and / or the LDS-staged epilogue; 128-row blocks for C % 128 == 0
-    when forced, else 64-row) for the BCNN, signed-sqrt and covariance modes against the 64-row panel kernel (bwd_v = 1)
-    and the oracle.  Columns served by the matrix pipe are the same fma chains as in every other backward kernel; the
-    HW % 16 == 4 remainder columns (14 x 14, 10 x 10 maps) are summed per lq-quarter on the VALU: rounding-level
-    differences there.  The covariance's centring is the mu column: dX = P X - (P mu) 1^T."""
+    """gram_bwd3_kernel (hk_bwd3.h: 128- or 64-row blocks staged by LDS-DMA, VALU remainder columns where HW % 16 == 4,
+    LDS-staged epilogue; with 128-row blocks a wave per 16 rows and the late coefficient) for the BCNN, signed-sqrt and
+    covariance modes against the four-wave 64-row panel kernel (bwd_v = 1) and the oracle.  Which form runs is a
+    function of the batch size only: sched_b makes the decision see a large batch on these small inputs.  Columns served
+    by the matrix pipe are the same fma chains in every backward kernel; the HW % 16 == 4 remainder columns (14 x 14,
+    10 x 10 maps) are summed per lq-quarter on the VALU and the late coefficient rounds once more: rounding-level
+    differences.  The covariance's centring is the mu column: dX = P X - (P mu) 1^T."""
     gen = torch.Generator().manual_seed(c + hw)
     x = torch.relu(torch.randn(b, c, hw, hw, generator=gen))
+    fb = _fill_batches(c)
+    forms = [('panel', 1, 0)] + [(k, 0, fb[k]) for k in ('rows128', 'rows64') if k in fb]
     res = {}
-    flags = (1, 11, 12, 13, 14) + ((21, 23, 15, 16) if c % 128 == 0 else ())      # 21.. : 128-row blocks forced; 15 / 16: a wave per 16 rows (+ late coef)
-    for flag in flags:
-        tune('bwd_v', flag)
+    for name, v, sb in forms:
+        tune('bwd_v', v)
+        tune('sched_b', sb)
         out = []
         for k, fn in enumerate((F.bilinear_pool, F.covpool, lambda t_: F.bilinear_pool(t_, signed_sqrt=True))):
             xg = x.clone().to(DEV).requires_grad_(True)
             y = fn(xg)
             (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(1 + k)).to(DEV)).sum().backward()
             out.append(xg.grad.clone())
-        res[flag] = out
-    for flag in flags[1:]:
+        res[name] = out
+    for name, _, _ in forms[1:]:
         for k, tol in enumerate((2e-6, 2e-6, 2e-5)):
-            assert rel(res[flag][k], res[1][k]) < tol, (flag, k)
-    if c % 128 == 0:        # the block height changes which workgroup adds which t-partial, nothing in the covariance's dX
-        assert torch.equal(res[21][1], res[11][1]) and torch.equal(res[23][1], res[13][1])
-        # which wave owns which rows does not change the MFMA columns either (the remainder columns are summed alike)
-        assert torch.equal(res[15][1], res[21][1])
-    # the epilogue does not change a bit; with the remainder on the VALU only the last HW % 16 columns may differ
-    for k in range(3):
-        assert torch.equal(res[11][k], res[12][k]) and torch.equal(res[13][k], res[14][k]), k
-    nfull = (hw * hw) // 16 * 16
-    if (hw * hw) % 16 == 4:
-        for k in (1,):     # covariance: nothing but the GEMM between dcov and dX (BCNN modes: t = <y, dy> is summed inside)
-            a, r = res[11][k].reshape(b, c, -1), res[13][k].reshape(b, c, -1)
-            assert rel(a[..., nfull:], r[..., nfull:]) < 2e-6 and float(a[..., nfull:].abs().sum()) > 0
+            assert rel(res[name][k], res['panel'][k]) < tol, (name, k)
     xo = x.clone().requires_grad_(True)
     yo = O.bilinear_pool(xo)
     (yo * torch.randn(yo.shape, generator=torch.Generator().manual_seed(1))).sum().backward()
-    assert rel(res[11][0], xo.grad) < 2e-5
-    xo = x.clone().requires_grad_(True)
-    co = O.covpool(xo)
+    xc = x.clone().requires_grad_(True)
+    co = O.covpool(xc)
     (co * torch.randn(co.shape, generator=torch.Generator().manual_seed(2))).sum().backward()
-    assert rel(res[11][1], xo.grad) < 1e-5 and rel(res[14][1], xo.grad) < 1e-5
+    for name, _, _ in forms:
+        assert rel(res[name][0], xo.grad) < 2e-5 and rel(res[name][1], xc.grad) < 1e-5, name
 
 
 @pytest.mark.parametrize('b,c,hw,d', [(2, 128, 14, 2048), (3, 256, 10, 1000), (2, 64, 14, 96), (2, 256, 8, 6000), (3, 128, 12, 500)])
 def test_cbp_backward_bwd3c_kernel(F, b, c, hw, d, tune):
-    """hk_bwd3c.h - the compact-bilinear backward GEMM with P generated from dc in LDS - in its four shapes (bwd_v
-    31..34: 128- / 64-row blocks, channels in one workgroup or split over two with float atomics onto a zeroed dX) against
-    the 64-row panel kernel behind cbp_dc1_kernel (bwd_v = 1).  dc is computed by the kernel itself from the forward's
-    saved state; P is the same two products and one add per element; the split form adds two partial sums - in either
-    order the same bits."""
+    """cbp_bwd3_kernel (hk_bwd3c.h) - the compact-bilinear backward GEMM with P generated from dc in LDS - in its three
+    shapes (128-row blocks, 64-row blocks, 64-row blocks with the column tiles divided between two workgroups; selected by
+    the batch size the heuristics see: sched_b) against the 64-row panel kernel behind cbp_dc1_kernel (bwd_v = 1).  dc is
+    computed by the kernel itself from the forward's saved state; P is the same two products and one add per element, so
+    the three shapes give the same bits."""
     gen = torch.Generator().manual_seed(c + hw + d)
     x = torch.relu(torch.randn(b, c, hw, hw, generator=gen))
     wt = torch.randn(b, d, generator=gen)
     plan = F.CbpPlan(*F.sketch_hashes(c, c, d), d, torch.device(DEV) if DEV != 'cuda'
                      else torch.device('cuda', torch.cuda.current_device()))
+    fb = _fill_batches(c)
+    forms = [('panel', 1, 0)] + [(k, 0, fb[k]) for k in ('rows128', 'rows64', 'colsplit') if k in fb]
     res = {}
-    flags = (1, 32, 33, 35) + ((31, 34) if c % 128 == 0 else ())          # 35: column tiles split over two workgroups
-    for flag in flags:
-        tune('bwd_v', flag)
+    def grad(v, sb):
+        tune('bwd_v', v)
+        tune('sched_b', 0)                      # (the forward's work split sees the real batch: the same y for every form)
         xg = x.clone().to(DEV).requires_grad_(True)
-        (F.compact_bilinear_pool(xg, plan) * wt.to(DEV)).sum().backward()
-        res[flag] = xg.grad.clone()
-        xg2 = x.clone().to(DEV).requires_grad_(True)
-        (F.compact_bilinear_pool(xg2, plan) * wt.to(DEV)).sum().backward()
-        assert torch.equal(xg2.grad, res[flag]), flag              # reproducible, the atomically accumulated form too
-    for flag in flags[1:]:       # (dc is formed inside the kernel: t = <y, dy> is summed in another order than by cbp_dc1_kernel)
-        assert rel(res[flag], res[1]) < 2e-6, flag
-    if c % 128 == 0:             # the block height does not change a bit of the unsplit form
-        assert torch.equal(res[31], res[32])
-    assert torch.equal(res[35], res[32])          # nor does dividing the column tiles between two workgroups
+        loss = (F.compact_bilinear_pool(xg, plan) * wt.to(DEV)).sum()
+        tune('sched_b', sb)
+        loss.backward()
+        return xg.grad.clone()
+    for name, v, sb in forms:
+        res[name] = grad(v, sb)
+        assert torch.equal(grad(v, sb), res[name]), name              # reproducible
+    for name, _, _ in forms[1:]:  # (dc is formed inside the kernel: t = <y, dy> is summed in another order than by cbp_dc1_kernel)
+        assert rel(res[name], res['panel']) < 2e-6, name
+    if 'rows128' in res:         # the block height does not change a bit
+        assert torch.equal(res['rows128'], res['rows64'])
+    assert torch.equal(res['colsplit'], res['rows64'])          # nor does dividing the column tiles between two workgroups
     if d >= 1000:       # (tiny sketches: every bin cancels somewhere - the gradient is ill-conditioned in float32)
         xo = x.clone().double().requires_grad_(True)
         (O.compact_bilinear_pool_gram(xo, d) * wt.double()).sum().backward()
-        assert rel(res[33], xo.grad) < 1e-4 + 50 * rel(res[1], xo.grad)
+        assert rel(res['rows64'], xo.grad) < 1e-4 + 50 * rel(res['panel'], xo.grad)
 
 
 @pytest.mark.parametrize('mode', ['train', 'eval'])
@@ -580,34 +532,6 @@ def test_bcnn_pool_forward_equals_its_stages(F, b, c, hw):
     assert lib.hk_bcnn_gram_norm(ptr(x), ptr(inv2), ptr(y2), b, c, n, stream()) == 0
     assert torch.equal(y1, y2) and torch.equal(inv1, inv2) and torch.equal(cs1, cs2)
     assert rel(y1.reshape(b, c, c), O.bilinear_pool(x.cpu().reshape(b, c, hw, hw)).reshape(b, c, c)) < 1e-5
-
-
-@pytest.mark.parametrize('b,d,itn', [(16, 128, 3), (19, 256, 5), (16, 128, 2), (33, 384, 4)])
-def test_ns_dataflow_forward(F, b, d, itn, tune):
-    """ns_flow = 1: the forward chain as ONE launch (hk_nsmm.h, ns_flow_kernel: tickets over (step, sample, tile), a
-    counter per sample and step, write-through stores + device-coherent loads).  The same tile arithmetic as the
-    launch-per-step schedule at the same tile width: bit-identical results, saved iterates and traces - for both forward
-    entry points, an odd batch (XCDs with different sample counts), two / three / five iterations, repeatedly (a missed
-    dependency or a stale line would change bits), and the backward runs on the iterates it saved."""
-    from hawkeye_amd import _lib
-    x = torch.relu(torch.randn(b, d, 5, 6, generator=torch.Generator().manual_seed(b + d))) + 0.01
-    wt = torch.randn(b, d, d, generator=torch.Generator().manual_seed(3))
-    tune('ns_tn', 64)
-    for symmetric in (True, False):
-        res = []
-        for flow in (0, 1, 2, 1):                 # 2: the skewed ticket order
-            tune('ns_flow', flow)
-            xg = x.clone().to(DEV).requires_grad_(True)
-            y = F.sqrtm(F.covpool(xg), itn, symmetric=symmetric)
-            (y * wt.to(DEV)).sum().backward()
-            res.append((y.detach().clone(), xg.grad.clone()))
-        for y, g in res[1:]:
-            assert torch.equal(y, res[0][0]) and torch.equal(g, res[0][1]), symmetric
-    tune('ns_flow', 0)
-    xo = x.clone().requires_grad_(True)
-    yo = O.sqrtm(O.covpool(xo), itn)
-    (yo * wt).sum().backward()
-    assert rel(res[0][0], yo) < 1e-5 and rel(res[0][1], xo.grad) < 1e-4
 
 
 @pytest.mark.parametrize('b,d,itn', [(2, 128, 3), (17, 256, 5), (3, 70, 4), (2, 64, 1), (2, 33, 2)])
