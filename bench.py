@@ -295,7 +295,7 @@ def other_models(timeout_s=240):
 
 
 LINE_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-             'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+             'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'ddp')
 LINE_MAX = 4096
 
 
@@ -451,8 +451,12 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.image, a.classes)
         if reducer is not None and reducer.trace:
-            detail['ddp_timeline'] = reducer.timeline()
+            tl = reducer.timeline()
+            detail['ddp_timeline'] = tl
             detail['ddp_buckets_mib'] = [mb for _, mb in reducer.describe()]
+            if tl:       # on the line itself: when each gradient bucket's all-reduce was issued inside the backward (ms since zero_grad)
+                res['ddp'] = {'buckets_mib': detail['ddp_buckets_mib'], 'issued_ms': [b[2] for b in tl['buckets']],
+                              'backward_end_ms': tl['backward_end_ms'], 'joined_ms': tl['joined_ms']}
         if world == 1 and not a.no_other_models and a.model == 'BCNN' and not a.force_pg:
             torch.cuda.empty_cache()
             detail['other_models'] = other_models()

@@ -318,9 +318,10 @@ def test_bench_spawns_its_own_ranks(tmp_path, world):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out['n_gpus'] == world and out['config']['global_batch'] == 2 * world and out['scaling'] == 'weak' and out['value'] > 0
-    assert out['ddp_buckets_mib'][0] > out['ddp_buckets_mib'][-1] or len(out['ddp_buckets_mib']) == 1
-    tl = out['ddp_timeline']                   # bucket 0 (the classifier: last layer, first gradient) goes out before backward ends
-    assert tl['buckets'][0][2] is not None and tl['buckets'][0][2] <= tl['backward_end_ms'] <= tl['joined_ms']
+    assert len(lines[0]) < 4096 and p.stdout.rstrip().splitlines()[-1] == lines[0]        # short, and the LAST stdout line
+    d = out['ddp']                             # bucket 0 (the classifier: last layer, first gradient) goes out before backward ends
+    assert d['buckets_mib'][0] > d['buckets_mib'][-1] or len(d['buckets_mib']) == 1
+    assert d['issued_ms'][0] is not None and d['issued_ms'][0] <= d['backward_end_ms'] <= d['joined_ms']
 
 
 def test_trainer_runs_one_synthetic_epoch(tmp_path):
