@@ -33,14 +33,14 @@ __global__ __launch_bounds__(256) void att_pool_fwd_kernel(const float* __restri
             s0 += (v.x + v.y) + (v.z + v.w);
             if (ap) {
                 const float4 a = reinterpret_cast<const float4*>(ap)[i];
-                s1 += (v.x * a.x + v.y * a.y) + (v.z * a.z + v.w * a.w);
+                s1 += fmaf(v.x, a.x, v.y * a.y) + fmaf(v.z, a.z, v.w * a.w);   // (explicit: the same bits in every kernel that forms it)
             }
         }
     } else {
         for (int i = lane; i < HW; i += 64) {
             const float v = fp[i];
             s0 += v;
-            if (ap) s1 += v * ap[i];
+            if (ap) s1 = fmaf(v, ap[i], s1);
         }
     }
     s0 = wave_sum(s0);
@@ -83,22 +83,22 @@ __global__ __launch_bounds__(256) void att_pool_bwd_kernel(const float* __restri
             for (int u = 0; u < 16; ++u) v[u] = fp[(long long)(c + u) * HW];
 #pragma unroll
             for (int u = 0; u < 16; u += 4) {
-                acc0 += ss[c + u] * v[u];
-                acc1 += ss[c + u + 1] * v[u + 1];
-                acc2 += ss[c + u + 2] * v[u + 2];
-                acc3 += ss[c + u + 3] * v[u + 3];
+                acc0 = fmaf(ss[c + u], v[u], acc0);
+                acc1 = fmaf(ss[c + u + 1], v[u + 1], acc1);
+                acc2 = fmaf(ss[c + u + 2], v[u + 2], acc2);
+                acc3 = fmaf(ss[c + u + 3], v[u + 3], acc3);
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) dp[(long long)(c + u) * HW] = (ss[c + u] * a + sg[c + u]) * inv;
+            for (int u = 0; u < 16; ++u) dp[(long long)(c + u) * HW] = fmaf(ss[c + u], a, sg[c + u]) * inv;
         }
         for (; c < C; ++c) {
-            acc0 += ss[c] * fp[(long long)c * HW];
-            dp[(long long)c * HW] = (ss[c] * a + sg[c]) * inv;
+            acc0 = fmaf(ss[c], fp[(long long)c * HW], acc0);
+            dp[(long long)c * HW] = fmaf(ss[c], a, sg[c]) * inv;
         }
         da_s[(long long)b * HW + hw] = ((acc0 + acc1) + (acc2 + acc3)) * inv;
     } else {
 #pragma unroll 8
-        for (int c = 0; c < C; ++c) dp[(long long)c * HW] = (ss[c] * a + sg[c]) * inv;
+        for (int c = 0; c < C; ++c) dp[(long long)c * HW] = fmaf(ss[c], a, sg[c]) * inv;
     }
 }
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void att_pool3_fwd_kernel(AttLevels L, long lo
         const float4 v = reinterpret_cast<const float4*>(fp)[i];
         const float4 a = reinterpret_cast<const float4*>(ap)[i];
         s0 += (v.x + v.y) + (v.z + v.w);
-        s1 += (v.x * a.x + v.y * a.y) + (v.z * a.z + v.w * a.w);
+        s1 += fmaf(v.x, a.x, v.y * a.y) + fmaf(v.z, a.z, v.w * a.w);
     }
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
@@ -188,17 +188,17 @@ __global__ __launch_bounds__(256) void att_pool3_bwd_kernel(AttLevels L, int C) 
         for (int u = 0; u < 16; ++u) v[u] = fp[(long long)(c + u) * HW];
 #pragma unroll
         for (int u = 0; u < 16; u += 4) {
-            acc0 += ss[c + u] * v[u];
-            acc1 += ss[c + u + 1] * v[u + 1];
-            acc2 += ss[c + u + 2] * v[u + 2];
-            acc3 += ss[c + u + 3] * v[u + 3];
+            acc0 = fmaf(ss[c + u], v[u], acc0);
+            acc1 = fmaf(ss[c + u + 1], v[u + 1], acc1);
+            acc2 = fmaf(ss[c + u + 2], v[u + 2], acc2);
+            acc3 = fmaf(ss[c + u + 3], v[u + 3], acc3);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) dp[(long long)(c + u) * HW] = (ss[c + u] * a + sg[c + u]) * inv;
+        for (int u = 0; u < 16; ++u) dp[(long long)(c + u) * HW] = fmaf(ss[c + u], a, sg[c + u]) * inv;
     }
     for (; c < C; ++c) {
-        acc0 += ss[c] * fp[(long long)c * HW];
-        dp[(long long)c * HW] = (ss[c] * a + sg[c]) * inv;
+        acc0 = fmaf(ss[c], fp[(long long)c * HW], acc0);
+        dp[(long long)c * HW] = fmaf(ss[c], a, sg[c]) * inv;
     }
     L.da[lvl][(long long)b * HW + hw] = ((acc0 + acc1) + (acc2 + acc3)) * inv;
 }

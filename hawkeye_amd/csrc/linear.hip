@@ -15,6 +15,7 @@
 
 #include "hk_bgemm.h"
 #include "hk_linear_bwd.h"
+#include "hk_linear_fwd.h"
 #include "../../include/hawkeye_hip.h"
 
 namespace hk {
@@ -84,165 +85,6 @@ __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __re
     if (lane == 0) db[k] = s;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Forward for the WIDE classifiers (BCNN 262 144 -> 200, OSME 100 352 -> 1024): a workgroup owns one slab of features and
-// ALL of its (up to 64) samples x a group of NT 16-column class tiles, so y is read once and W once, through LDS-DMA.
-// The generic split-K path above runs at 133-144 us on the BCNN shape = 1.95 TB/s (profiles/r2_pool_kernels_pmc.csv:
-// 53 % of its wave time parked on loads, y fetched by four class tiles, one chunk of register prefetch); the product is
-// balanced between the matrix pipe and HBM (24 FLOP/B), so both have to be kept busy:
-//   * 512 threads = 8 waves: wave w owns samples 16 (w & 3) .. + 15 and the class tiles of half w >> 2 (7 + 6 of 13, or
-//     8 + 8 of 16), 16x16x4 MFMA, A operand = y rows, B operand = W rows - both tiles are [row][32 features] exactly as
-//     they lie in memory, read back with ds_read_b128 through the XOR swizzle of hk_bwd128d.h (slot row * 8 + (k4 ^ (row & 7)));
-//   * chunks of 32 features, FOUR LDS stages (4 x 34.8 KB for 13 class tiles, 4 x 38.9 KB for 15), the pieces of chunk
-//     c + 3 are issued during chunk c; the barrier that ends a chunk waits with s_waitcnt vmcnt(n) for everything but
-//     the n pieces the wave has just issued, so a piece has two whole chunks to arrive;
-//   * the fragments of chunk c + 1 (complete one barrier earlier) are read behind the last MFMAs of chunk c.
-// Partial results [S][B][K] as before, added in slab order by linear_reduce_kernel: deterministic.
-
-// MT: 16-sample row tiles per workgroup.  4: up to 64 samples, wave w owns row tile w & 3 and one half of the NT class tiles.
-// 1: up to 16 samples (OSME: N = 10) - every wave owns the same 16 rows and NT / 8 of the class tiles; the product is then
-// a pure stream of W (2 KB of LDS-DMA pieces per MFMA-cycle-pair), the matrix pipe idles.
-template <int NT, int MT>
-__global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __restrict__ y, const float* __restrict__ w,
-                                                               float* __restrict__ part, int B, int J, int K, int KS,
-                                                               int S, int ngrp) {
-    static_assert(MT == 4 || (MT == 1 && NT % 8 == 0), "one row tile: the class tiles are dealt to the eight waves");
-    constexpr int NH = MT == 4 ? (NT + 1) / 2 : NT / 8;   // class tiles per wave (at most)
-    constexpr int NS = 4;                                // LDS stages (chunk c + 1 must be complete one barrier early: >= 4)
-    constexpr int CH = 32;                               // features per chunk
-    constexpr int MR = 16 * MT;                          // sample rows per workgroup
-    constexpr int A_SZ = MR * CH, B_SZ = NT * 16 * CH;   // floats
-    constexpr int STAGE = A_SZ + B_SZ;
-    constexpr int NPA = 2 * MT, NPB = NT * 2, NP = NPA + NPB; // 1 KB pieces per chunk: 8 rows x 32 floats each
-    constexpr int PPW = (NP + 7) / 8;                    // pieces per wave (at most)
-    HK_DYN_LDS16(lds);
-
-    int slab, grp;
-    if (!xcd_map(blockIdx.x, S, ngrp, slab, grp)) return;
-    const int rg = blockIdx.y;                                  // group of MR samples
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int rb = MT == 4 ? (wave & 3) : 0, half = wave >> 2;
-    const int nt0 = MT == 4 ? half * NH : wave * NH, nloc = MT == 4 ? (half ? NT - NH : NH) : NH;
-    const long long f0 = (long long)slab * KS;                  // first feature of the slab
-    const int nfeat = (J - f0) < KS ? (int)(J - f0) : KS;       // (a multiple of 32: J % 32 == 0, KS % 32 == 0)
-    const int nch = nfeat / CH;
-
-    // this lane's source offsets (floats, from y / w + f0 + 32 c) in the pieces its wave issues: piece p = wave + 8 u;
-    // p < 8: sample rows 8 p .. 8 p + 7 (clamped to the last sample), else class rows 8 (p - 8) .. (clamped to K - 1);
-    // LDS slot j = lane & 7 of row r holds the feature quad j ^ (r & 7)
-    long long src[PPW];
-    int npc = 0;
-#pragma unroll
-    for (int u = 0; u < PPW; ++u) {
-        const int p = wave + 8 * u;
-        const int r8 = lane >> 3, q4 = 4 * ((lane & 7) ^ (r8 & 7));
-        if (p < NPA) {
-            int row = rg * MR + 8 * p + r8;
-            row = row < B ? row : B - 1;
-            src[u] = (long long)row * J + q4;
-        } else {
-            int n = grp * (NT * 16) + 8 * (p - NPA) + r8;
-            n = n < K ? n : K - 1;
-            src[u] = (long long)n * J + q4;
-        }
-        if (p < NP) ++npc;
-    }
-    // pieces of chunk c into stage st (float offset); part 0 / 1: first / second half of the wave's pieces
-    auto dma = [&](int c, int st, int part) {
-        const long long fo = f0 + (long long)c * CH;
-#pragma unroll
-        for (int u = 0; u < PPW; ++u) {
-            if ((u < (PPW + 1) / 2) != (part == 0)) continue;
-            const int p = wave + 8 * u;
-            if (p < NP) glds16((p < NPA ? y : w) + src[u] + fo, lds + st + 256 * p);
-        }
-    };
-    auto vm_barrier = [&](bool all) {
-        if (all) HK_VM_BARRIER(0);
-        else if (npc == 6) HK_VM_BARRIER(6);
-        else if (npc == 5) HK_VM_BARRIER(5);
-        else if (npc == 4) HK_VM_BARRIER(4);
-        else if (npc == 3) HK_VM_BARRIER(3);
-        else HK_VM_BARRIER(0);
-    };
-
-    f32x4 acc[NH];
-#pragma unroll
-    for (int n = 0; n < NH; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // fragments of feature step s (0 / 1) of the chunk in stage st: a = y[16 rb + l15][16 s + 4 lq ..+3],
-    // b[n] = W[16 (nt0 + n) + l15][same features]
-    const int arow = 16 * rb + l15;
-    const int aoff = arow * CH, asw = arow & 7;
-    const int boff = A_SZ + (16 * nt0 + l15) * CH, bsw = l15 & 7;      // (16 (nt0 + n) is a multiple of 8)
-    // prologue: chunks 0 .. NS - 2 into stages 0 .. NS - 2
-    for (int c = 0; c < NS - 1 && c < nch; ++c) { dma(c, c * STAGE, 0); dma(c, c * STAGE, 1); }
-    vm_barrier(true);
-    // The chunk loop, instantiated per number of class tiles of the wave (NL = 7 / 6 of 13, 8 / 7 of 15): with the tile
-    // count a run-time value the eighth fragment read and every seventh MFMA sat behind a (uniform) branch in the middle
-    // of the MFMA stream (82.4 -> 77.3 us at the BCNN shape in one alternating run, profiles/r3_lab_call25.json).
-    // Within a half chunk the compiler places the seven reads of the NEXT fragments behind the last MFMAs of the
-    // current ones and waits for them at once: the wave parks for one LDS latency per half chunk while the other wave
-    // of its SIMD has the matrix pipe.  Pinning the reads ahead of the MFMAs (no wait left) measured SLOWER - 80.6 us
-    // with the reads before the group, 88.1 us with the reads behind its first seven MFMAs.
-    auto run = [&](auto nl_tag) {
-        constexpr int NL = decltype(nl_tag)::value;
-        auto frag = [&](int st, int s, f32x4& a, f32x4 (&b)[NL]) {
-            const float* base = lds + st;
-            a = *reinterpret_cast<const f32x4*>(base + aoff + (((4 * s + lq) ^ asw) << 2));
-#pragma unroll
-            for (int n = 0; n < NL; ++n)
-                b[n] = *reinterpret_cast<const f32x4*>(base + boff + n * 16 * CH + (((4 * s + lq) ^ bsw) << 2));
-        };
-        auto mma = [&](const f32x4& a, const f32x4 (&b)[NL]) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int n = 0; n < NL; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n][t], acc[n], 0, 0, 0);
-        };
-        f32x4 a0, a1, b0[NL], b1[NL];
-        frag(0, 0, a0, b0);
-        int cur = 0;                                             // stage of chunk c (float offset), nxt = chunk c + 1
-        for (int c = 0; c < nch; ++c) {
-            const int nxt = cur + STAGE < NS * STAGE ? cur + STAGE : 0;
-            const int dst = cur >= STAGE ? cur - STAGE : (NS - 1) * STAGE;  // stage of chunk c - 1 = chunk c + NS - 1
-            const bool load = c + NS - 1 < nch;                  // uniform
-            frag(cur, 1, a1, b1);
-            mma(a0, b0);
-            if (load) dma(c + NS - 1, dst, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            frag(c + 1 < nch ? nxt : cur, 0, a0, b0);            // complete and published by the previous barrier
-            mma(a1, b1);
-            if (load) dma(c + NS - 1, dst, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            vm_barrier(!load);
-            cur = nxt;
-        }
-    };
-    if constexpr (MT == 4 && NT % 2 == 1) {
-        if (nloc == NH) run(std::integral_constant<int, NH>{});
-        else run(std::integral_constant<int, NH - 1>{});
-    } else {
-        run(std::integral_constant<int, NH>{});
-    }
-
-    // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-    float* pb = part + (long long)slab * B * K;
-#pragma unroll
-    for (int n = 0; n < NH; ++n) {
-        const int col = grp * (NT * 16) + 16 * (nt0 + n) + l15;
-        if (n < nloc && col < K) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rg * MR + 16 * rb + 4 * lq + r;
-                if (row < B) pb[(long long)row * K + col] = acc[n][r];
-            }
-        }
-    }
-}
-
 // the wide-classifier plan: slabs of KS features for linear_skinny_kernel; false when the generic path serves the shape
 static inline bool skinny_plan(int B, int J, int K, int& KS, int& S, int& nt, int& ngrp, int& nrg) {
     if (tuning().linear_slabs < 0) return false;                 // knob: -1 forces the generic split-K path
@@ -303,16 +145,17 @@ extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, 
     int nt, ngrp, nrg;
     if (aligned16(y) && aligned16(w) && skinny_plan(B, J, K, KS, S, nt, ngrp, nrg)) {
         const dim3 grid(xcd_grid(S, ngrp), nrg);
+        const int walk = tuning().lin_walk < 0 ? 1 : tuning().lin_walk;          // interleaved chunks (see linear_skinny_kernel)
         const size_t lds = (size_t)4 * ((nt == 16 ? 16 : 64) * 32 + nt * 16 * 32) * sizeof(float);
         if (nt == 13) HK_ALLOW_BIG_LDS((&linear_skinny_kernel<13, 4>), lds);
         else if (nt == 15) HK_ALLOW_BIG_LDS((&linear_skinny_kernel<15, 4>), lds);
         else HK_ALLOW_BIG_LDS((&linear_skinny_kernel<16, 1>), lds);
         if (nt == 13)
-            hipLaunchKernelGGL((linear_skinny_kernel<13, 4>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
+            hipLaunchKernelGGL((linear_skinny_kernel<13, 4>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp, walk);
         else if (nt == 15)
-            hipLaunchKernelGGL((linear_skinny_kernel<15, 4>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
+            hipLaunchKernelGGL((linear_skinny_kernel<15, 4>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp, walk);
         else
-            hipLaunchKernelGGL((linear_skinny_kernel<16, 1>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp);
+            hipLaunchKernelGGL((linear_skinny_kernel<16, 1>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp, walk);
         HK_LAUNCH_CHECK();
         const int BK = B * K;
         hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, out, BK, K, S);

@@ -38,4 +38,24 @@ for rname, wdy, wdw in ROLES:
             torch.cuda.synchronize()
             out[m].append(round(e0.elapsed_time(e1) / 20 * 1e3, 1))
     res[rname] = {name: {'us_median': sorted(out[m])[2], 'us_min': min(out[m])} for m, name in MODES}
+# ---- forward (linear_skinny_kernel<13, 4>)
+lab.hk_probe_linear_fwd.argtypes = [ctypes.c_int, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
+part = torch.empty(256 * B * K, device=dev)
+FMODES = [(0, 'whole kernel'), (1, 'no MFMAs (LDS-DMA stream + fragment reads + barriers)'), (2, 'no loads in the loop (MFMA + fragment reads + barriers)'),
+          (10, 'no loads, no fragment reads (MFMA + barriers)'), (9, 'loads only'), (3, 'fragment reads + barriers only'), (8, 'no fragment reads')]
+FM2 = [(m, n, 1) for m, n in FMODES] + [(0, 'whole kernel, contiguous slabs', 0), (9, 'loads only, contiguous slabs', 0)]
+out = {(m, wk): [] for m, _, wk in FM2}
+for rnd in range(5):
+    for m, _, wk in FM2:
+        fn = lambda: lab.hk_probe_linear_fwd(m, p(y), p(w), p(part), B, J, K, wk, st())
+        for _ in range(3):
+            assert fn() == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[(m, wk)].append(round(e0.elapsed_time(e1) / 20 * 1e3, 1))
+res['forward'] = {name: {'us_median': sorted(out[(m, wk)])[2], 'us_min': min(out[(m, wk)])} for m, name, wk in FM2}
 json.dump(res, sys.stdout, indent=1)

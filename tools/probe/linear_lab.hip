@@ -47,3 +47,35 @@ extern "C" int hk_probe_linear_bwd64(int labv, const float* g, const float* w, c
         default: return -3;
     }
 }
+
+// ---- forward: linear_skinny_kernel<13, 4> at 64 samples x 200 classes (256 slabs of KS features)
+#include "../../hawkeye_amd/csrc/hk_linear_fwd.h"
+
+template <int LABV>
+static int launch_fwd(const float* y, const float* w, float* part, int B, int J, int K, int walk, hipStream_t st) {
+    const int S = 256, KS = ((J / 32 + S - 1) / S) * 32;
+    const size_t ldsb = (size_t)4 * (64 * 32 + 13 * 16 * 32) * sizeof(float);
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_skinny_kernel<13, 4, LABV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return -1;
+        once = true;
+    }
+    hipLaunchKernelGGL((linear_skinny_kernel<13, 4, LABV>), dim3(xcd_grid(S, 1)), dim3(512), ldsb, st, y, w, part, B, J, K, KS, S, 1, walk);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// part: 256 * B * K floats
+extern "C" int hk_probe_linear_fwd(int labv, const float* y, const float* w, float* part, int B, int J, int K, int walk, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (labv) {
+        case 0: return launch_fwd<0>(y, w, part, B, J, K, walk, st);
+        case 1: return launch_fwd<1>(y, w, part, B, J, K, walk, st);
+        case 2: return launch_fwd<2>(y, w, part, B, J, K, walk, st);
+        case 3: return launch_fwd<3>(y, w, part, B, J, K, walk, st);
+        case 8: return launch_fwd<8>(y, w, part, B, J, K, walk, st);
+        case 9: return launch_fwd<9>(y, w, part, B, J, K, walk, st);
+        case 10: return launch_fwd<10>(y, w, part, B, J, K, walk, st);
+        default: return -3;
+    }
+}
