@@ -202,7 +202,7 @@ def kernel_rooflines(B, C, HW, dev):
         ('hk_linear_fwd: linear_skinny_kernel + linear_reduce_kernel (classifier 262144->200)',
          lambda: lib.hk_linear_fwd(ptr(y), ptr(wl), ptr(bl), ptr(ol), B, J, K, ptr(wsl), nwl, stream()),
          lflops, lbytes, lflops * kpad, True),
-        ('hk_linear_bwd: dy = g W, dW = g^T y, db (classifier backward 262144->200)',
+        ('hk_linear_bwd: linear_bwd64_kernel (dy = g W, dW = g^T y, db in one launch; classifier 262144->200)',
          lambda: lib.hk_linear_bwd(ptr(y), ptr(wl), ptr(gl), ptr(dyl), ptr(dwl), ptr(dbl), B, J, K, stream()),
          2 * lflops, 2 * lbytes, lflops * (1.0 + kpad), True),
     ]
@@ -224,7 +224,7 @@ def pmc_traffic(row_name):
     import csv
     import re
     names = re.findall(r'[a-z][a-z0-9_]*_kernel', row_name)
-    for name in ('r4_pool_kernels_pmc.csv', 'r3_pool_kernels_pmc.csv', 'r2_pool_kernels_pmc.csv'):
+    for name in ('r4_pool_kernels_pmc.csv', 'r3_pool_kernels_pmc.csv'):
         try:
             rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', name))))
             total = 0.0
