@@ -30,6 +30,8 @@ SIGNATURES = {
     'hk_bcnn_ssqrt_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'hk_bcnn_ssqrt_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_ssqrt_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_bcnn_ssqrt_pool_fwd_unscaled': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_bcnn_ssqrt_pool_bwd_unscaled': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_colsum_norm': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_gram_norm': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     'hk_bcnn_bwd_gemm': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
@@ -65,6 +67,8 @@ SIGNATURES = {
     'hk_linear_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'hk_linear_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_linear_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    'hk_linear_fwd_scaled': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_linear_bwd_scaled': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     'hk_npairs_ws_bytes': (c_sz, [c_i, c_i]),
     'hk_npairs_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_cin_sci_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
@@ -78,6 +82,9 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+HK_OK, HK_ERR_BAD_ARG, HK_ERR_WORKSPACE, HK_ERR_UNSUPPORTED = 0, -1, -2, -3      # hk_common.h
 
 
 class HawkeyeHipError(RuntimeError):

@@ -275,9 +275,28 @@ __global__ __launch_bounds__(256) void ssqrt_scale_kernel(float* __restrict__ y,
     for (long long e = e0 + threadIdx.x; e < e1; e += 256) p[e] *= inv;
 }
 
+// inv_norm[b] alone (the scale itself is folded into the classifier that consumes u: hk_linear_fwd_scaled)
+__global__ __launch_bounds__(64) void ssqrt_norm_kernel(const float* __restrict__ part, float* __restrict__ inv_norm, int B,
+                                                        int nparts) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int c = 0; c < nparts; ++c) s += part[(long long)b * SS_CHUNKS + c];        // (ssqrt_scale_kernel's order)
+    inv_norm[b] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+}
+
+// The backward on the UNSCALED u (y = inv u): with t = <y, dy> = inv <u, dy> the operand of the GEMM is
+//     (dy + dy^T - 2 t y) / |y| * inv^2 / 2M = (dy + dy^T - 2 (inv^2 <u, dy>) u) / |u| * inv / 2M,
+// i.e. the kernels below run unchanged on u with the t partials scaled by inv^2 and sqrt(inv) in the place of inv.
+__global__ __launch_bounds__(64) void ssqrt_sqrt_inv_kernel(const float* __restrict__ inv_norm, float* __restrict__ sq, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < B) sq[b] = sqrtf(inv_norm[b]);
+}
+
 // part[b][chunk] = sum y * dy over the chunk (t = <y, dy> of the l2-normalisation backward)
 __global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ y, const float* __restrict__ dy,
-                                                          float* __restrict__ part, long long n) {
+                                                          float* __restrict__ part, long long n,
+                                                          const float* __restrict__ inv = nullptr) {
     __shared__ float red[4];
     const int b = blockIdx.y;
     const long long len = (n + SS_CHUNKS - 1) / SS_CHUNKS, e0 = (long long)blockIdx.x * len;
@@ -287,6 +306,7 @@ __global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restric
     float s = 0.f;
     for (long long e = e0 + threadIdx.x; e < e1; e += 256) s += p[e] * q[e];
     s = block_sum<4>(s, red);
+    if (inv) s *= inv[b] * inv[b];                            // (unscaled u: see ssqrt_sqrt_inv_kernel)
     if (threadIdx.x == 0) part[(long long)b * SS_CHUNKS + blockIdx.x] = s;
 }
 
@@ -400,11 +420,11 @@ extern "C" int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy,
 // ------------------------------------------------------------------ signed-sqrt variant
 extern "C" size_t hk_bcnn_ssqrt_ws_bytes(int B, int C, int HW) {
     (void)C; (void)HW;
-    return (size_t)B * SS_CHUNKS * sizeof(float) + 256;
+    return (size_t)B * (SS_CHUNKS + 1) * sizeof(float) + 256;       // partial sums + sqrt(inv_norm) of the unscaled backward
 }
 
-extern "C" int hk_bcnn_ssqrt_pool_fwd(const float* x, float* y, float* inv_norm, int B, int C, int HW, void* ws,
-                                      size_t ws_bytes, hk_stream_t stream) {
+static int ssqrt_pool_fwd_impl(const float* x, float* y, float* inv_norm, int B, int C, int HW, void* ws, size_t ws_bytes,
+                               hk_stream_t stream, bool scale) {
     if (!x || !y || !inv_norm || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_bcnn_ssqrt_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -413,7 +433,8 @@ extern "C" int hk_bcnn_ssqrt_pool_fwd(const float* x, float* y, float* inv_norm,
         int nparts = 0;
         const int rc2 = gram_fast_ssqrt(x, y, (float*)ws, &nparts, B, C, HW, st);
         if (rc2 == HK_OK) {
-            hipLaunchKernelGGL(ssqrt_scale_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (const float*)ws, inv_norm, n, nparts);
+            if (scale) hipLaunchKernelGGL(ssqrt_scale_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (const float*)ws, inv_norm, n, nparts);
+            else hipLaunchKernelGGL(ssqrt_norm_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const float*)ws, inv_norm, B, nparts);
             HK_LAUNCH_CHECK();
             return HK_OK;
         }
@@ -428,19 +449,39 @@ extern "C" int hk_bcnn_ssqrt_pool_fwd(const float* x, float* y, float* inv_norm,
     if (rc != HK_OK) return rc;
     hipLaunchKernelGGL(ssqrt_apply_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (float*)ws, n);
     HK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ssqrt_scale_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (const float*)ws, inv_norm, n, SS_CHUNKS);
+    if (scale) hipLaunchKernelGGL(ssqrt_scale_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, (const float*)ws, inv_norm, n, SS_CHUNKS);
+    else hipLaunchKernelGGL(ssqrt_norm_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const float*)ws, inv_norm, B, SS_CHUNKS);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
 
-extern "C" int hk_bcnn_ssqrt_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx,
-                                      int B, int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream) {
+extern "C" int hk_bcnn_ssqrt_pool_fwd(const float* x, float* y, float* inv_norm, int B, int C, int HW, void* ws,
+                                      size_t ws_bytes, hk_stream_t stream) {
+    return ssqrt_pool_fwd_impl(x, y, inv_norm, B, C, HW, ws, ws_bytes, stream, true);
+}
+
+extern "C" int hk_bcnn_ssqrt_pool_fwd_unscaled(const float* x, float* u, float* inv_norm, int B, int C, int HW, void* ws,
+                                               size_t ws_bytes, hk_stream_t stream) {
+    return ssqrt_pool_fwd_impl(x, u, inv_norm, B, C, HW, ws, ws_bytes, stream, false);
+}
+
+static int ssqrt_pool_bwd_impl(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, int B, int C,
+                               int HW, void* ws, size_t ws_bytes, hk_stream_t stream, bool unscaled) {
     if (!x || !y || !dy || !inv_norm || !dx || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_bcnn_ssqrt_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* tpart = (float*)ws;
-    hipLaunchKernelGGL(dot_partial_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, dy, tpart, (long long)C * C);
-    HK_LAUNCH_CHECK();
+    if (unscaled) {                              // y is u: t partials scaled by inv^2, sqrt(inv) in the place of inv
+        float* sq = tpart + (size_t)B * SS_CHUNKS;
+        hipLaunchKernelGGL(ssqrt_sqrt_inv_kernel, dim3((B + 63) / 64), dim3(64), 0, st, inv_norm, sq, B);
+        HK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dot_partial_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, dy, tpart, (long long)C * C, inv_norm);
+        HK_LAUNCH_CHECK();
+        inv_norm = sq;
+    } else {
+        hipLaunchKernelGGL(dot_partial_kernel, dim3(SS_CHUNKS, B), dim3(256), 0, st, y, dy, tpart, (long long)C * C, (const float*)nullptr);
+        HK_LAUNCH_CHECK();
+    }
     if (!force_generic()) {
         const int rc = bcnn_ssqrt_fast_bwd(x, y, dy, inv_norm, tpart, SS_CHUNKS, dx, B, C, HW, st);
         if (rc != HK_ERR_UNSUPPORTED) return rc;
@@ -453,4 +494,14 @@ extern "C" int hk_bcnn_ssqrt_pool_bwd(const float* x, const float* y, const floa
     pa.tsum = tpart; pa.nt = SS_CHUNKS; pa.t2 = 0.f;
     const LdPlain xb = make_plain(x, (long long)C * HW, HW, C, HW);
     return bgemm_launch<true, false>(pa, xb, make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f), C, HW, C, B, st);
+}
+
+extern "C" int hk_bcnn_ssqrt_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx,
+                                      int B, int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    return ssqrt_pool_bwd_impl(x, y, dy, inv_norm, dx, B, C, HW, ws, ws_bytes, stream, false);
+}
+
+extern "C" int hk_bcnn_ssqrt_pool_bwd_unscaled(const float* x, const float* u, const float* dy, const float* inv_norm, float* dx,
+                                               int B, int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    return ssqrt_pool_bwd_impl(x, u, dy, inv_norm, dx, B, C, HW, ws, ws_bytes, stream, true);
 }

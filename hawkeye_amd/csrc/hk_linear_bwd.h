@@ -48,7 +48,10 @@ template <int NKS, int MODE = 0, int LABV = 0>
 __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                               const float* __restrict__ y, float* __restrict__ dy,
                                                               float* __restrict__ dw, float* __restrict__ db, int B, int J,
-                                                              int K, int CPS, int S, int walk) {
+                                                              int K, int CPS, int S, int walk,
+                                                              const float* __restrict__ row_scale = nullptr) {
+    // row_scale (optional, [B]): dW = (row_scale g)^T y - y is a pooled vector handed over unnormalised and row_scale its
+    // 1 / |z| (hk_linear_bwd_scaled); dy and db are those of the unscaled g
     static_assert(NKS % 2 == 0 && NKS <= 52, "two halves of class steps; up to 208 classes");
     constexpr int CH = 64;                               // features per chunk
     constexpr int NKH = NKS / 2;                         // class steps = 1 KB W pieces per half chunk
@@ -143,6 +146,10 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
                 sum += __shfl_xor(sum, 16, 64);
                 sum += __shfl_xor(sum, 32, 64);
                 if (lq == 0 && 192 + l15 < K) db[192 + l15] = sum;
+            }
+            if (row_scale != nullptr) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) g13[s] *= row_scale[4 * s + lq < B ? 4 * s + lq : B - 1];
             }
         }
         HK_LDS_BARRIER();                                        // ... and read by everybody: stages 2, 3 are free
@@ -293,6 +300,14 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
                 sum += __shfl_xor(sum, 32, 64);
                 const int cls = 16 * (3 * wv + i) + l15;
                 if (lq == 0 && cls < K) db[cls] = sum;
+            }
+        }
+        if (row_scale != nullptr) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float r = row_scale[4 * s + lq < B ? 4 * s + lq : B - 1];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) gt[i][s] *= r;
             }
         }
         HK_LDS_BARRIER();                                        // ... and read by everybody: stages 2, 3 are free

@@ -46,9 +46,11 @@ struct LdSlab {
     }
 };
 
-// out[e] = bias[e % K] + sum_s part[s][e]   (e over B*K; slabs added as 4 interleaved chains combined in fixed order)
+// out[e] = bias[e % K] + rs[e / K] * sum_s part[s][e]   (e over B*K; slabs added as 4 interleaved chains combined in fixed
+// order; rs: optional per-sample scale - the 1 / |z| of a pooled vector handed over unnormalised)
 __global__ __launch_bounds__(256) void linear_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                           float* __restrict__ out, int BK, int K, int S) {
+                                                           const float* __restrict__ rs, float* __restrict__ out, int BK,
+                                                           int K, int S) {
     __shared__ float red[4][64];
     const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + l;
@@ -70,7 +72,10 @@ __global__ __launch_bounds__(256) void linear_reduce_kernel(const float* __restr
     }
     red[g][l] = s;
     __syncthreads();
-    if (g == 0 && e < BK) out[e] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) + (bias ? bias[e % K] : 0.f);
+    if (g == 0 && e < BK) {
+        const float sum = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        out[e] = (rs ? rs[e / K] * sum : sum) + (bias ? bias[e % K] : 0.f);
+    }
 }
 
 // db[k] = sum_b g[b][k]: one wave per class, lanes over the samples, fixed shuffle tree (one thread per class looping over
@@ -134,8 +139,8 @@ extern "C" size_t hk_linear_ws_bytes(int B, int J, int K) {
     return (size_t)S * B * K * sizeof(float) + 256;
 }
 
-extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, float* out, int B, int J, int K, void* ws,
-                             size_t ws_bytes, hk_stream_t stream) {
+extern "C" int hk_linear_fwd_scaled(const float* y, const float* w, const float* bias, const float* row_scale, float* out,
+                                    int B, int J, int K, void* ws, size_t ws_bytes, hk_stream_t stream) {
     if (!y || !w || !out || B <= 0 || J <= 0 || K <= 0) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_linear_ws_bytes(B, J, K)) return HK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -158,7 +163,7 @@ extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, 
             hipLaunchKernelGGL((linear_skinny_kernel<16, 1>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp, walk);
         HK_LAUNCH_CHECK();
         const int BK = B * K;
-        hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, out, BK, K, S);
+        hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, row_scale, out, BK, K, S);
         HK_LAUNCH_CHECK();
         return HK_OK;
     }
@@ -169,14 +174,20 @@ extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, 
     const int rc = bgemm_launch<true, true>(la, lb, ep, B, K, KS, S, st);     // slab = batch ; A [B][KS], B as [K][KS]
     if (rc != HK_OK) return rc;
     const int BK = B * K;
-    hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, out, BK, K, S);
+    hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, row_scale, out, BK, K, S);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
 
+extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, float* out, int B, int J, int K, void* ws,
+                             size_t ws_bytes, hk_stream_t stream) {
+    return hk_linear_fwd_scaled(y, w, bias, nullptr, out, B, J, K, ws, ws_bytes, stream);
+}
 
-extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, float* dy, float* dw, float* db, int B, int J,
-                             int K, hk_stream_t stream) {
+// row_scale != nullptr: dW = (row_scale g)^T y (see linear_bwd64_kernel); only the one-launch kernel supports it -
+// HK_ERR_UNSUPPORTED (nothing launched) for every other shape: the caller then normalises y itself
+static int linear_bwd_impl(const float* y, const float* w, const float* g, const float* row_scale, float* dy, float* dw,
+                           float* db, int B, int J, int K, hk_stream_t stream) {
     if (!y || !w || !g || B <= 0 || J <= 0 || K <= 0) return HK_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     // wide classifier, up to 64 samples and 208 classes: both products in one launch of linear_bwd64_kernel (the knob
@@ -192,7 +203,7 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
     do {                                                                                                       \
         HK_ALLOW_BIG_LDS((&linear_bwd64_kernel<NKS_, MODE_>), ldsb);                                           \
         hipLaunchKernelGGL((linear_bwd64_kernel<NKS_, MODE_>), dim3(S), dim3(512), ldsb, st, g, w, y, dy, dw, db, B, J, K, CPS, \
-                           S, walk);                                                                           \
+                           S, walk, row_scale);                                                                \
     } while (0)
         const int mode = dy && dw ? 0 : (dy ? 1 : 2);            // both products / dy only / dW only
         if (nks == 50) {
@@ -208,6 +219,7 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
         }
         return HK_OK;
     }
+    if (row_scale) return HK_ERR_UNSUPPORTED;
     // up to 16 samples, up to 1024 outputs (OSME): linear_bwd16_kernel, a pure stream of W / dW
     if (B <= 16 && K <= 1024 && K >= 256 && J % 64 == 0 && (long long)J >= 16384 && (dy || dw) && tuning().linear_slabs >= 0 &&
         aligned16(y) && aligned16(w) && aligned16(dy) && aligned16(dw)) {
@@ -253,4 +265,15 @@ extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, flo
         HK_LAUNCH_CHECK();
     }
     return HK_OK;
+}
+
+extern "C" int hk_linear_bwd(const float* y, const float* w, const float* g, float* dy, float* dw, float* db, int B, int J,
+                             int K, hk_stream_t stream) {
+    return linear_bwd_impl(y, w, g, nullptr, dy, dw, db, B, J, K, stream);
+}
+
+extern "C" int hk_linear_bwd_scaled(const float* y, const float* w, const float* g, const float* row_scale, float* dy, float* dw,
+                                    float* db, int B, int J, int K, hk_stream_t stream) {
+    if (!row_scale) return HK_ERR_BAD_ARG;
+    return linear_bwd_impl(y, w, g, row_scale, dy, dw, db, B, J, K, stream);
 }

@@ -748,6 +748,70 @@ class _Linear(torch.autograd.Function):
         return dy, dw, db
 
 
+class _SsqrtPoolLinear(torch.autograd.Function):
+    """Signed-sqrt bilinear pooling (the reference's commented alternative, BCNN.py:23-24) + the classifier on it with the
+    l2 scale folded into the classifier: the pooled vector is handed over as u = sign(G) sqrt(|G| + 1e-10),
+    unnormalised - the scale pass over B x C^2 floats is not launched - and logits = inv_norm[b] (u W^T) + bias."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x, weight = _f32c(x), _f32c(weight)
+        b, c, h, w = x.shape
+        hw, j, k = h * w, c * c, weight.shape[0]
+        if weight.shape[1] != j:
+            raise _lib.HawkeyeHipError(f'ssqrt_pool_linear: weight {tuple(weight.shape)} does not match {c} x {c} pooled features')
+        u = torch.empty(b, j, dtype=torch.float32, device=x.device)
+        inv_norm = torch.empty(b, dtype=torch.float32, device=x.device)
+        nws = lib.hk_bcnn_ssqrt_ws_bytes(b, c, hw)
+        ws = _ws(nws, x.device)
+        check(lib.hk_bcnn_ssqrt_pool_fwd_unscaled(ptr(x), ptr(u), ptr(inv_norm), b, c, hw, ptr(ws), nws, stream()),
+              'hk_bcnn_ssqrt_pool_fwd_unscaled')
+        bias_c = _f32c(bias) if bias is not None else None
+        out = torch.empty(b, k, dtype=torch.float32, device=x.device)
+        nwl = lib.hk_linear_ws_bytes(b, j, k)
+        wsl = _ws(nwl, x.device)
+        check(lib.hk_linear_fwd_scaled(ptr(u), ptr(weight), ptr(bias_c), ptr(inv_norm), ptr(out), b, j, k, ptr(wsl), nwl,
+                                       stream()), 'hk_linear_fwd_scaled')
+        ctx.save_for_backward(x, u, inv_norm, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, u, inv_norm, weight = ctx.saved_tensors
+        g = _f32c(g)
+        b, c, h, w = x.shape
+        hw, j, k = h * w, c * c, weight.shape[0]
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dy = torch.empty_like(u) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(k, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        rc = lib.hk_linear_bwd_scaled(ptr(u), ptr(weight), ptr(g), ptr(inv_norm), ptr(dy), ptr(dw), ptr(db), b, j, k, stream())
+        if rc == _lib.HK_ERR_UNSUPPORTED:      # shapes the one-launch kernel does not serve: dW from the scaled g explicitly
+            gs = g * inv_norm[:, None]
+            check(lib.hk_linear_bwd(ptr(u), ptr(weight), ptr(g), ptr(dy), None, ptr(db), b, j, k, stream()), 'hk_linear_bwd')
+            if need_w:
+                check(lib.hk_linear_bwd(ptr(u), ptr(weight), ptr(gs), None, ptr(dw), None, b, j, k, stream()), 'hk_linear_bwd')
+        else:
+            check(rc, 'hk_linear_bwd_scaled')
+        dx = None
+        if need_x:
+            dx = torch.empty_like(x)
+            nws = lib.hk_bcnn_ssqrt_ws_bytes(b, c, hw)
+            ws = _ws(nws, x.device)
+            check(lib.hk_bcnn_ssqrt_pool_bwd_unscaled(ptr(x), ptr(u), ptr(dy), ptr(inv_norm), ptr(dx), b, c, hw, ptr(ws), nws,
+                                                      stream()), 'hk_bcnn_ssqrt_pool_bwd_unscaled')
+        return dx, dw, db
+
+
+def ssqrt_pool_linear(x, weight, bias=None):
+    """x [B,C,h,w] -> logits [B,K] = Linear(normalize(sign(G) sqrt(|G| + 1e-10))) with the normalisation folded into the
+    classifier's epilogue (the pooled vector is never rescaled in memory)."""
+    return _SsqrtPoolLinear.apply(x, weight, bias)
+
+
 def linear(y, weight, bias=None):
     """y [B,J] @ weight[K,J]^T + bias[K] -> [B,K] on the split-K f32-MFMA path."""
     return _Linear.apply(y, weight, bias)

@@ -59,4 +59,6 @@ class BCNN(nn.Module):
         feats = self.backbone(x)
         if self.stage == 1:
             feats = feats.detach()
+        if self.bilinear_pooling.signed_sqrt:     # pooling + classifier with the l2 scale folded into the classifier
+            return HF.ssqrt_pool_linear(feats, self.classifier.weight, self.classifier.bias)
         return wide_linear(self.classifier, self.bilinear_pooling(feats))

@@ -98,6 +98,15 @@ int hk_bcnn_ssqrt_pool_fwd(const float* x, float* y, float* inv_norm, int B, int
                            hk_stream_t stream);
 int hk_bcnn_ssqrt_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, int B, int C,
                            int HW, void* ws, size_t ws_bytes, hk_stream_t stream);
+/* The same pooling with the l2 scale left to the consumer ("fold the per-sample 1 / |z| into the classifier's
+ * epilogue"): _fwd_unscaled writes u = sign(G) sqrt(|G| + 1e-10) and inv_norm = 1 / max(|u|_2, 1e-12) - the scale pass over
+ * the 4 C^2 bytes per image is not launched; hk_linear_fwd_scaled(u, ..., row_scale = inv_norm) applies it to the
+ * [B, classes] logits.  _bwd_unscaled takes that u and dy = dL/d(inv_norm u) (what hk_linear_bwd_scaled returns).
+ * (The default sqrt(G + 1e-5) variant needs none of this: its norm is known before the Gram is formed.) */
+int hk_bcnn_ssqrt_pool_fwd_unscaled(const float* x, float* u, float* inv_norm, int B, int C, int HW, void* ws, size_t ws_bytes,
+                                    hk_stream_t stream);
+int hk_bcnn_ssqrt_pool_bwd_unscaled(const float* x, const float* u, const float* dy, const float* inv_norm, float* dx, int B,
+                                    int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream);
 
 /* The two stages of each direction, individually callable (hk_bcnn_pool_fwd = colsum_norm + gram_norm,
  * hk_bcnn_pool_bwd = bwd_gemm + bwd_rank1); bench.py times them separately.
@@ -304,6 +313,14 @@ int hk_linear_fwd(const float* y, const float* w, const float* bias, float* out,
                   size_t ws_bytes, hk_stream_t stream);
 int hk_linear_bwd(const float* y, const float* w, const float* g, float* dy, float* dw, float* db, int B, int J, int K,
                   hk_stream_t stream);
+/* With a per-sample scale folded in (row_scale [B], e.g. the 1 / |z| of a pooled vector handed over unnormalised):
+ *   out = row_scale[b] * (y W^T) + bias ;  dy = g W  (= dL/d(row_scale y)) ;  dW = (row_scale g)^T y ;  db = sum_b g.
+ * hk_linear_bwd_scaled is served by the one-launch kernel only (up to 64 samples, up to 208 outputs, J % 64 == 0,
+ * J >= 16384); HK_ERR_UNSUPPORTED - nothing launched - otherwise. */
+int hk_linear_fwd_scaled(const float* y, const float* w, const float* bias, const float* row_scale, float* out, int B, int J,
+                         int K, void* ws, size_t ws_bytes, hk_stream_t stream);
+int hk_linear_bwd_scaled(const float* y, const float* w, const float* g, const float* row_scale, float* dy, float* dw, float* db,
+                         int B, int J, int K, hk_stream_t stream);
 
 /* ------------------------------------------------------ MAMC n-pairs loss (8f-4) ----
  * loss = NPairsLoss(parts, targets) and dx = d loss / d parts in one call.

@@ -125,6 +125,31 @@ def test_bcnn_signed_sqrt_variant(F, shape, seed, tune):
         assert rel(yg, g['y']) < 2e-6 and rel(xg.grad, g['dx']) < 5e-5
 
 
+@pytest.mark.parametrize('b,c,hw,k', [(3, 128, 14, 200), (2, 64, 10, 37), (5, 192, 8, 208)])
+def test_signed_sqrt_pool_with_the_scale_folded_into_the_classifier(F, b, c, hw, k):
+    """F.ssqrt_pool_linear (the per-sample 1 / |z| folded into the classifier's epilogue - the pooled vector
+    stays unnormalised in memory; hk_bcnn_ssqrt_pool_fwd_unscaled / _bwd_unscaled, hk_linear_fwd_scaled / _bwd_scaled)
+    against the unfused pair (F.bilinear_pool(signed_sqrt=True) -> F.linear) and against the oracle: logits and all three
+    gradients.  128 x 128 features = 16384: the one-launch classifier backward; the other shapes its fallback."""
+    xn = rs_signed_channels(700 + c, (b, c, hw, hw))
+    w = t(rs_randn(701, (k, c * c))) / c
+    bias, g = t(rs_randn(702, (k,))), t(rs_randn(703, (b, k)))
+    res = []
+    for fused in (False, True):
+        xg = t(xn).to(DEV).requires_grad_(True)
+        wg, bg = w.clone().to(DEV).requires_grad_(True), bias.clone().to(DEV).requires_grad_(True)
+        out = F.ssqrt_pool_linear(xg, wg, bg) if fused else F.linear(F.bilinear_pool(xg, signed_sqrt=True), wg, bg)
+        (out * g.to(DEV)).sum().backward()
+        res.append((out.detach(), xg.grad, wg.grad, bg.grad))
+    for a, r_ in zip(res[1], res[0]):
+        assert rel(a, r_) < 5e-6
+    xo = t(xn).requires_grad_(True)
+    wo, bo = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    oo = torch.nn.functional.linear(O.bilinear_pool_signed_sqrt(xo), wo, bo)
+    (oo * g).sum().backward()
+    assert rel(res[1][0], oo) < 1e-5 and rel(res[1][1], xo.grad) < 5e-5 and rel(res[1][2], wo.grad) < 1e-5
+
+
 def test_bcnn_signed_sqrt_512_vs_golden(F):
     g = load('bcnn_ssqrt_512')
     xn, wn = rs_signed_channels(1240, (2, 512, 14, 14)), rs_randn(1241, (2, 512 * 512))

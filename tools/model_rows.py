@@ -166,6 +166,22 @@ def apcnn_kernels(B=16, classes=8142):
                0, 8.0 * B * 512 * 3136)
 
 
+def ssqrt_kernels(B=64, C=512, HW=196):
+    """The signed-sqrt variant (BCNN.py:23-24) with and without the l2 scale folded into the classifier."""
+    x = torch.randn(B, C, HW, device=dev); y = E(B, C * C); inv = E(B); dy = R(B, C * C); dx = E(B, C, HW)
+    nws = lib.hk_bcnn_ssqrt_ws_bytes(B, C, HW); ws = E(nws, dtype=torch.uint8)
+    fl, by = 2.0 * B * C * C * HW, 4.0 * B * (C * HW + C * C)
+    kernel_row('BCNN-ssqrt', 'ssqrt pool fwd (Gram with sign-sqrt epilogue + scale pass)',
+               lambda: lib.hk_bcnn_ssqrt_pool_fwd(ptr(x), ptr(y), ptr(inv), B, C, HW, ptr(ws), nws, stream()), fl, by, flops_exec=fl * 36 / 64)
+    kernel_row('BCNN-ssqrt', 'ssqrt pool fwd, unscaled (the 1 / |z| goes into the classifier epilogue: no scale pass)',
+               lambda: lib.hk_bcnn_ssqrt_pool_fwd_unscaled(ptr(x), ptr(y), ptr(inv), B, C, HW, ptr(ws), nws, stream()), fl, by,
+               flops_exec=fl * 36 / 64)
+    kernel_row('BCNN-ssqrt', 'ssqrt pool bwd', lambda: lib.hk_bcnn_ssqrt_pool_bwd(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), B, C, HW, ptr(ws), nws, stream()),
+               fl, 4.0 * B * (2 * C * HW + 2 * C * C))
+    kernel_row('BCNN-ssqrt', 'ssqrt pool bwd, unscaled', lambda: lib.hk_bcnn_ssqrt_pool_bwd_unscaled(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), B, C, HW, ptr(ws), nws, stream()),
+               fl, 4.0 * B * (2 * C * HW + 2 * C * C))
+
+
 def guarded(fn, *args):
     try:
         fn(*args)
@@ -175,6 +191,7 @@ def guarded(fn, *args):
 
 
 if __name__ == '__main__':
+    guarded(ssqrt_kernels)
     guarded(mpn_kernels)
     guarded(cbp_kernels)
     guarded(apcnn_kernels)
