@@ -593,17 +593,8 @@ def osme_scale(x, m):
 # --------------------------------------------------------------------- CIN channel interaction
 # hk_cin_sci_fwd: for C % 64 == 0 and 7x7 / 8x8 / 6x6 maps ONE kernel (cin.hip: two passes over the column blocks, softmax
 # statistics first, then W written once and consumed from registers by the second product) - 297 us at the plugin's shape
-# (B = 20, C = 2048, HW = 49) against 486 us for rocBLAS bmm + softmax + bmm (profiles/r3_lab_*.json).  Other shapes run
-# a three-kernel chain on the generic tile that is slower than the library (706 us at that shape): the forward then
-# takes the library GEMMs; W is produced and saved either way (the contrastive branch and the backward kernels consume
-# it).  Tests set _CIN_SCI_FWD_HIP to True to keep the chain covered.
-_CIN_SCI_FWD_HIP = None          # None: by shape (above); True / False: always / never
-
-
-def _cin_sci_on_hip(c, hw):
-    if _CIN_SCI_FWD_HIP is not None:
-        return bool(_CIN_SCI_FWD_HIP)
-    return c % 64 == 0 and hw in (36, 49, 64)
+# (B = 20, C = 2048, HW = 49) against 486 us for rocBLAS bmm + softmax + bmm.  Other shapes run the three-kernel chain on
+# the generic MFMA tile inside the same entry point (706 us at that shape) - there is no library branch.
 
 
 class _CinSci(torch.autograd.Function):
@@ -615,13 +606,9 @@ class _CinSci(torch.autograd.Function):
         lib = _lib.load()
         x = _f32c(x)
         b, c, hw = x.shape
-        if _cin_sci_on_hip(c, hw):
-            w = torch.empty(b, c, c, dtype=torch.float32, device=x.device)
-            y = torch.empty_like(x)
-            check(lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), b, c, hw, stream()), 'hk_cin_sci_fwd')
-        else:
-            w = torch.softmax(torch.bmm(x, x.transpose(1, 2)).mul_(-1.0 / hw), dim=2)      # CIN.py:31-33
-            y = torch.bmm(w, x)                                                            # CIN.py:34
+        w = torch.empty(b, c, c, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        check(lib.hk_cin_sci_fwd(ptr(x), ptr(w), ptr(y), b, c, hw, stream()), 'hk_cin_sci_fwd')
         ctx.save_for_backward(x, w)
         ctx.set_materialize_grads(False)
         return y, w

@@ -74,14 +74,9 @@ def emulated():
     wl_saved = [m.wide_linear for m in plugs]
     for m in plugs:
         m.wide_linear = _torch_wide_linear
-    # the CIN forward takes the library GEMMs for the shapes its one-kernel form does not cover; on the emulated device
-    # every shape goes through the kernels (there is no library to take, and the chain stays covered)
-    cin_saved = F._CIN_SCI_FWD_HIP
-    F._CIN_SCI_FWD_HIP = True
     try:
         yield F
     finally:
         _lib._lib, F.ptr, F.stream, F._on = saved
-        F._CIN_SCI_FWD_HIP = cin_saved
         for m, f in zip(plugs, wl_saved):
             m.wide_linear = f

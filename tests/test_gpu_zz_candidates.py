@@ -382,9 +382,8 @@ def test_mamc_npairs_loss_larger_batch(F):
 def test_cin_channel_interaction_ops(F, b, c, hw, monkeypatch):
     """hk_cin_sci_* / hk_cin_cci_*  vs torch autograd of the reference's formulas (CIN.py:31-34, 51-54) in
     fp64: forward values, and the gradients through both branches including the one that reaches W_SCI from the
-    contrastive branch and the per-sample weights.  (hk_cin_sci_fwd is forced on: the plugin's default forward takes the
-    library GEMMs, which are faster at its shape.)"""
-    monkeypatch.setattr(F, '_CIN_SCI_FWD_HIP', True)
+    contrastive branch and the per-sample weights: the one-kernel forms at 7x7 / 8x8 / 6x6 maps and C % 64 == 0, the generic
+    chains everywhere else."""
     gen = torch.Generator().manual_seed(b * 100 + c)
     x = torch.relu(torch.randn(b, c, hw, generator=gen))
     wt = torch.randn(b, generator=gen) * 0.7
