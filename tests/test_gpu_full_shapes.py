@@ -208,3 +208,40 @@ def test_apcnn_roi_pipeline_at_batch_16_8142_classes_vs_reference(F, g):
         yo = O.roi_crop_feat(xo, ri, 8, training=(mode == 'train'), drops=[drops[i]])
         (yo * t(wn[i:i + 1])).sum().backward()
         assert rel(y[i:i + 1], yo) < 1e-6 and rel(xg.grad[i:i + 1], xo.grad) < 1e-6
+
+
+def test_classifier_backward_full_shape_is_reproducible_under_memory_pressure():
+    """linear_bwd64_kernel at the metric's shape (64 x 262144 -> 200): the barrier that ends a pipeline unit waits with a
+    COUNTED s_waitcnt vmcnt(n) (everything but the pieces and stores issued since) - if a count were off by one, or if
+    stores did not retire in issue order, a unit would occasionally be consumed before it has landed.  Forty launches, half
+    of them while a side stream hammers HBM with copies (memory latency several times the quiet one): dy, dW and db must be
+    bit-identical every time and agree with fp64."""
+    from hawkeye_amd import _lib
+    from hawkeye_amd._lib import ptr, stream
+    lib = _lib.load()
+    B, J, K = 64, 262144, 200
+    gen = torch.Generator().manual_seed(5)
+    y = torch.randn(B, J, generator=gen).to(DEV)
+    w = (torch.randn(K, J, generator=gen) / 512).to(DEV)
+    g = torch.randn(B, K, generator=gen).to(DEV)
+    ref = None
+    junk_a, junk_b = torch.empty(64 * 1024 * 1024, device=DEV), torch.empty(64 * 1024 * 1024, device=DEV)
+    side = torch.cuda.Stream()
+    for it in range(40):
+        dy = torch.full((B, J), float('nan'), device=DEV)
+        dw = torch.full((K, J), float('nan'), device=DEV)
+        db = torch.full((K,), float('nan'), device=DEV)
+        if it % 2:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    junk_b.copy_(junk_a)
+        assert lib.hk_linear_bwd(ptr(y), ptr(w), ptr(g), ptr(dy), ptr(dw), ptr(db), B, J, K, stream()) == 0
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (dy, dw, db)
+            assert rel(dy, g.double().cpu() @ w.double().cpu()) < 2e-6
+            assert rel(dw, g.double().cpu().t() @ y.double().cpu()) < 2e-6
+            assert rel(db, g.double().cpu().sum(0)) < 2e-6
+        else:
+            assert torch.equal(dy, ref[0]) and torch.equal(dw, ref[1]) and torch.equal(db, ref[2]), it
