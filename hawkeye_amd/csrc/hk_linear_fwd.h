@@ -124,7 +124,8 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
     // profiles/r4_linear_lab.json): the LDS-DMA stream alone takes 44.5 us (6.2 TB/s with the interleaved chunk walk, 50.3
     // with contiguous slabs), MFMAs + fragment reads + barriers alone 55-58 us, the whole kernel 68-71 us.  Reading a chunk's
     // fragments only AFTER the barrier that publishes it (so that the barrier waits for one chunk less and a piece has two
-    // more chunk times to land) measured 78.6 us: memory latency is not what the overlap loses.
+    // more chunk times to land) measured 78.6 us: memory latency is not what the overlap loses; issuing all pieces from the
+    // four waves with one class tile less (6 of 13) instead of from all eight: 71.6 vs 70.2 us - nor is it who issues them.
     auto run = [&](auto nl_tag) {
         constexpr int NL = decltype(nl_tag)::value;
         auto frag = [&](int st, int s, f32x4& a, f32x4 (&b)[NL]) {
