@@ -546,8 +546,13 @@ class _OsmeGap(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
+        lib = _lib.load()
         n, c, h, w = ctx.shape
-        return (dz / float(h * w)).view(n, c, 1, 1).expand(n, c, h, w).contiguous()
+        dz = _f32c(dz)
+        dx = torch.empty(n, c, h, w, dtype=torch.float32, device=dz.device)
+        # dx[b,c,:] = dz[b,c] / HW: the row-parallel GAP backward of the attention pooling (one launch; f is not read)
+        check(lib.hk_att_pool_bwd(ptr(dx), None, ptr(dz), None, ptr(dx), None, n, c, h * w, stream()), 'hk_att_pool_bwd')
+        return dx
 
 
 class _OsmeScale(torch.autograd.Function):
