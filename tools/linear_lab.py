@@ -58,4 +58,21 @@ for rnd in range(5):
         torch.cuda.synchronize()
         out[(m, wk)].append(round(e0.elapsed_time(e1) / 20 * 1e3, 1))
 res['forward'] = {name: {'us_median': sorted(out[(m, wk)])[2], 'us_min': min(out[(m, wk)])} for m, name, wk in FM2}
+# the same kernels on ZERO operands (no data toggling: the chip's power management gives the clock back): if the whole kernel
+# gains much more than its two sides, the overlap loss is power, not structure
+yz, wz = torch.zeros_like(y), torch.zeros_like(w)
+outz = {}
+for rnd in range(5):
+    for m, name in ((0, 'whole kernel'), (9, 'loads only'), (10, 'no loads, no fragment reads (MFMA + barriers)')):
+        fn = lambda: lab.hk_probe_linear_fwd(m, p(yz), p(wz), p(part), B, J, K, 1, st())
+        for _ in range(3):
+            assert fn() == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        outz.setdefault(name, []).append(round(e0.elapsed_time(e1) / 20 * 1e3, 1))
+res['forward, zero operands'] = {k: {'us_median': sorted(v)[2], 'us_min': min(v)} for k, v in outz.items()}
 json.dump(res, sys.stdout, indent=1)
