@@ -615,13 +615,14 @@ _MODEL_CFG = {
 
 
 @pytest.mark.parametrize('b,j,k', [(2, 6000, 200), (2, 32896, 200), (3, 262144, 200), (16, 6000, 8142), (64, 65536, 200),
-                                   (37, 65728, 130), (10, 100352, 1024), (7, 16448, 300), (16, 20032, 1000)])
+                                   (37, 65728, 130), (10, 100352, 1024), (7, 16448, 300), (16, 20032, 1000), (4, 32768, 200),
+                                   (3, 16384, 13), (17, 16384, 208)])
 def test_linear_bwd_direct_at_classifier_shapes(F, b, j, k):
     """hk_linear_bwd on its own at the classifier widths of the plugins (CBCNN 6000: not a multiple of 64, so the
     48-column / 8-deep tails of the tile kernel are exercised; MPN 32896 and BCNN 262144: up to 64 samples and 208 classes
     both products in one launch of linear_bwd64_kernel - full and ragged sample / class tiles, a ragged last slab, 50
-    and 52 class steps; OSME 100352 -> 1024 at N = 10: linear_bwd16_kernel, ragged class blocks and slabs) and the iNat
-    class count:
+    and 52 class steps, one- / two- / many-chunk pipelines, a handful of classes; OSME 100352 -> 1024 at N = 10:
+    linear_bwd16_kernel, ragged class blocks and slabs) and the iNat class count:
     dy = g W, dW = g^T y, db = sum_b g against fp64.  Nothing but the kernel is between the inputs and the check, so a
     failure here is the kernel's."""
     gen = torch.Generator().manual_seed(j + k)
