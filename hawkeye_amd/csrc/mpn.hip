@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void triu_bwd_kernel(const float* __restrict__
 // polynomials in A), so they commute and Z_i Y_i = Y_i Z_i for ANY input, symmetric or not: the backward takes "YZ"
 // and "ZY" (MPNCOV.py:184-185) from ONE product (two results of the same accumulator).  Measured distance from the
 // reference's separate products: 7e-7, the distance of the reference itself from fp64, on covariances and on
-// non-symmetric inputs alike (tests/test_gpu_zz_candidates.py::test_ns_general_input_backward).
+// non-symmetric inputs alike (tests/test_gpu_kernels.py::test_ns_general_input_backward).
 static inline NsGroup ns_group(const NsProb& p0) {
     NsGroup g;
     g.p[0] = p0; g.p[1] = p0; g.p[2] = p0; g.p[3] = p0;

@@ -12,7 +12,7 @@ fill; RandomErasing scale (0.02, 0.33) / ratio (0.3, 3.3), value 0).  Host-side 
 PARITY UNPINNED: torchvision is neither in the build container nor on the GPU box (no wheel, no network), so the
 reference's presets cannot be executed to generate fixtures.  tests/test_transforms_cpu.py checks this file against the
 published definitions only; the device tail `hk_image_finalize` is pinned bit-exactly against this file's own CPU path
-(tests/test_gpu_zz_candidates.py::test_image_finalize_bit_exact).
+(tests/test_gpu_kernels.py::test_image_finalize_bit_exact).
 """
 import math
 import random

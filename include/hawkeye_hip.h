@@ -161,7 +161,7 @@ int hk_ns_sqrtm_triu_fwd(const float* a, float* out, float* tv, float* norm_a, f
  * That is exact for ANY input `a`, symmetric or not: every iterate is a polynomial in the one matrix A = a / tr(a)
  * (Y_0 = A (3I - A)/2, Z_0 = (3I - A)/2, and each step multiplies polynomials in A), and polynomials in one matrix
  * commute.  Measured on non-symmetric inputs: 6.7e-7 from the reference, the same as the 38-product form
- * (tests/test_gpu_zz_candidates.py::test_ns_general_input_backward).  The upstream gradient `dout` may be anything.
+ * (tests/test_gpu_kernels.py::test_ns_general_input_backward).  The upstream gradient `dout` may be anything.
  * hk_ns_sqrtm_bwd_general: same arguments, Z_i Y_i as its own product - all 38 of MPNCOV.py:174-194, literally; kept
  * for A/B checks (it costs four more products). */
 int hk_ns_sqrtm_bwd(const float* a, const float* out, const float* norm_a, const float* ysave,

@@ -13,7 +13,7 @@ from emu.harness import emulated
 
 _here = os.path.dirname(os.path.abspath(__file__))
 _modules = []
-for _file in ('test_gpu_parity.py', 'test_gpu_zz_candidates.py'):
+for _file in ('test_gpu_parity.py', 'test_gpu_kernels.py'):
     _spec = importlib.util.spec_from_file_location('_emu_cases_' + _file[:-3], os.path.join(_here, _file))
     _mod = importlib.util.module_from_spec(_spec)
     _spec.loader.exec_module(_mod)

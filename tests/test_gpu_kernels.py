@@ -1,7 +1,8 @@
-"""GPU parity of the opt-in variants that were written after round 1's GPU budget was spent: validated against the
-oracle on the CPU emulation tier (tests/test_emu_parity.py collects these cases too), first run on a real MI355X
-by the round-end `-m gpu` pass.  The file sorts after the validated suites on purpose.  Each variant is OFF by default
-in the library (environment switch named in the test) until it has a measured number.
+"""GPU parity of the kernels behind the C ABI, second file (the first is tests/test_gpu_parity.py): every shipped form of
+the Gram / compact-bilinear backward, the Newton-Schulz schedules, the classifier kernels at the plugin widths, the SURVEY
+8f rows (n-pairs loss, CIN channel interaction, image finalisation) and the reduced-size models with the kernel classifier.
+Validated against the oracle, fp64 restatements and the reference's goldens; the CPU emulation tier
+(tests/test_emu_parity.py) collects these cases too.
 """
 import numpy as np
 import pytest
