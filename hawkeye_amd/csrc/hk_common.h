@@ -55,10 +55,12 @@ __device__ __forceinline__ buf_rsrc_t buf_rsrc(const float* base, long long floa
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(floats * 4), 0x00020000);
 }
 // (the builtin's own vector type is kept behind decltype: converting to a user vector typedef makes the compiler splat ONE dword)
+// AUX: cache-policy bits of the instruction (0 default; 2 = nt: streamed once, do not keep in L2)
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store16(buf_rsrc_t rs, unsigned byte_off, f32x4 f) {
     decltype(__builtin_amdgcn_raw_buffer_load_b128(rs, 0, 0, 0)) v;
     __builtin_memcpy(&v, &f, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, AUX);
 }
 __device__ __forceinline__ void buf_store4(buf_rsrc_t rs, unsigned byte_off, float f) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), rs, (int)byte_off, 0, 0);
@@ -220,9 +222,10 @@ constexpr int NXCD = 8;
 
 // LDS-DMA: one global_load_lds_dwordx4 - lane l of the wave copies the 16 bytes at ITS global address g to the
 // wave-uniform LDS address l + 16 l (1 KB per wave-instruction, no registers, counted in vmcnt)
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, AUX);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

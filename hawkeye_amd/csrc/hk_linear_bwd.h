@@ -31,6 +31,8 @@ namespace hk {
 //     accumulated in the same registers - on FOUR LDS stages of 33 KB: the pieces of unit u + 3 are issued behind the
 //     first MFMA steps of unit u, so ~100 KB per CU are always on their way (with whole chunks on two stages the next
 //     chunk was requested in a burst and memory idled for the rest of the chunk: 143 us);
+//   * results leave with the nt (streamed, do not keep in L2) policy: 138.7 -> 132.1 us (nt on the LDS-DMA loads as well
+//     gave nothing more: 134);
 //   * nothing but MFMAs between two barriers that is not spread out: fragments are read two (dy) / one (dW) step ahead
 //     of their use, and the results of chunk c leave DURING chunk c + 1, a store behind an MFMA step (16 stores in a burst
 //     behind the barrier kept a wave off the matrix pipe for ~1.6 us per chunk: store issue, not bandwidth);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
         auto dma = [&](int v, int h, int i) __attribute__((always_inline)) {   // piece i of unit v (= chunk v >> 1, half h == v & 1)
             const int p = wave + 4 * i;                          // (4 i + 3 < NKH folds at compile time: only the last i branches)
             if (DO_DY && (4 * i + 3 < NKH || p < NKH))
-                glds16(reinterpret_cast<const float*>(wbase + (long long)(v >> 1) * (fstep * 4) + wo[h][i]),
+                glds16<(LABV & 32) ? 2 : 0>(reinterpret_cast<const float*>(wbase + (long long)(v >> 1) * (fstep * 4) + wo[h][i]),
                        lds + (v & 3) * STAGE + 256 * p);
         };
 #pragma unroll
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
         }
         f32x4 out[4], out13;                                     // the finished rows of the previous chunk
         auto store_row = [&](int c, int r) __attribute__((always_inline)) {       // row r of chunk c's dy tile
-            if (DO_DY && st_ok) buf_store16(rs, orow[r] + 4u * (unsigned)(f0 + (long long)c * fstep), out[r]);
+            if (DO_DY && st_ok) buf_store16<(LABV & 16) ? 0 : 2>(rs, orow[r] + 4u * (unsigned)(f0 + (long long)c * fstep), out[r]);
         };
         auto store_12 = [&](int c, int r) __attribute__((always_inline)) {        // row r of chunk c's quarter of class tile 12
             if (DO_DW && st_ok) buf_store4(rs12, orow12[r] + 4u * (unsigned)(f0 + (long long)c * fstep), out13[r]);
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
         constexpr int PW = DO_DY ? 2 * NPW : 0;                  // pieces issued in two units (by a wave with NPW of them)
         constexpr int SW = 3 * ((DO_DY ? 2 : 0) + (DO_DW ? 2 : 0));   // stores issued in three units
         // unit 0 has landed when all but the pieces of units 1 and 2 have
-        if (U > 2 && !LABV) { if (npc == NPW) HK_VM_BARRIER(PW); else HK_VM_BARRIER(PW >= 2 ? PW - 2 : 0); }
+        if (U > 2 && !(LABV & 15)) { if (npc == NPW) HK_VM_BARRIER(PW); else HK_VM_BARRIER(PW >= 2 ? PW - 2 : 0); }
         else HK_VM_BARRIER(0);
         f32x4 acc[4], acc13;
         // H: half (u & 1); LOAD: unit u + 3 exists; PREV: chunk (u >> 1) - 1 has rows to store; WK: how the end-of-unit wait counts
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
             }
             // younger than the pieces of unit u + 1: the pieces of units u + 2, u + 3 and (WK 2) the stores of the units
             // u - 2, u - 1, u (all of them behind their unit's last piece)
-            if (WK == 0 || LABV) HK_VM_BARRIER(0);
+            if (WK == 0 || (LABV & 15)) HK_VM_BARRIER(0);
             else if (WK == 1) { if (npc == NPW) HK_VM_BARRIER(PW); else HK_VM_BARRIER(PW >= 2 ? PW - 2 : 0); }
             else { if (npc == NPW) HK_VM_BARRIER(PW + SW); else HK_VM_BARRIER(PW >= 2 ? PW - 2 + SW : SW); }
         };
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
             }
         const char* ybase = reinterpret_cast<const char*>(y + f0);
         auto dma = [&](int v, int h, int i) __attribute__((always_inline)) {
-            glds16(reinterpret_cast<const float*>(ybase + (long long)(v >> 1) * (fstep * 4) + yo[h][i]),
+            glds16<(LABV & 32) ? 2 : 0>(reinterpret_cast<const float*>(ybase + (long long)(v >> 1) * (fstep * 4) + yo[h][i]),
                    lds + (v & 3) * STAGE + 256 * (NKH + wv + 4 * i));
         };
         if (DO_DW) {
@@ -323,9 +325,9 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
         auto store_row = [&](int c, int e) __attribute__((always_inline)) {       // store e: tile e / 4, row e % 4
             if (!st_ok) return;
             const unsigned fo = 4u * (unsigned)(f0 + (long long)c * fstep);
-            buf_store16(rs, orow[e % 4] + fo + 4u * (unsigned)(16 * (3 * wv + e / 4)) * (unsigned)J, out[e / 4][e % 4]);
+            buf_store16<(LABV & 16) ? 0 : 2>(rs, orow[e % 4] + fo + 4u * (unsigned)(16 * (3 * wv + e / 4)) * (unsigned)J, out[e / 4][e % 4]);
         };
-        if (U > 2 && !LABV) HK_VM_BARRIER(4); else HK_VM_BARRIER(0);
+        if (U > 2 && !(LABV & 15)) HK_VM_BARRIER(4); else HK_VM_BARRIER(0);
         f32x4 acc[3][4];
         auto unit = [&](int u, auto h_tag, auto load_tag, auto prev_tag, auto wk_tag) __attribute__((always_inline)) {
             constexpr int H = decltype(h_tag)::value, WK = decltype(wk_tag)::value;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
             }
             // younger than the pieces of unit u + 1: two pieces in each of the units u + 2, u + 3 and (WK 2) six stores in
             // each of the units u - 2, u - 1, u
-            if (WK == 0 || LABV) HK_VM_BARRIER(0);
+            if (WK == 0 || (LABV & 15)) HK_VM_BARRIER(0);
             else if (WK == 1) HK_VM_BARRIER(4);
             else HK_VM_BARRIER(22);
         };
@@ -534,7 +536,8 @@ __global__ __launch_bounds__(512, 2) void linear_bwd16_kernel(const float* __res
                         float* o = dw + f0 + (long long)ch * fstep + (long long)cls0 * J;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (cls0 + 4 * lq + r < K) *reinterpret_cast<f32x4*>(o + orow[r]) = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                            if (cls0 + 4 * lq + r < K)
+                                __builtin_nontemporal_store((f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]}, reinterpret_cast<f32x4*>(o + orow[r]));
                         __builtin_amdgcn_sched_barrier(0);       // one output tile at a time (the stream is HBM-bound: registers, not ILP)
                     }
                 }

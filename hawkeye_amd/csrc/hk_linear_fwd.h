@@ -1,7 +1,7 @@
 // Forward of the wide classifiers (replaces nn.Linear.forward at model/methods/BCNN.py:42,54, CBCNN.py:26,34,
 // OSME.py:34,43): linear_skinny_kernel, launched by hk_linear_fwd (linear.hip).
 // LABV (timing-only instances for tools/probe/linear_lab.hip - results are wrong, the product instantiates LABV = 0 only):
-// bit 0 no MFMAs, bit 1 no LDS-DMA inside the chunk loop, bit 3 no fragment reads.
+// bit 0 no MFMAs, bit 1 no LDS-DMA inside the chunk loop, bit 3 no fragment reads, bit 5 nt policy on the LDS-DMA loads.
 #pragma once
 #include <type_traits>
 
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
         for (int u = 0; u < PPW; ++u) {
             if ((u < (PPW + 1) / 2) != (part == 0)) continue;
             const int p = wave + 8 * u;
-            if (p < NP) glds16((p < NPA ? y : w) + src[u] + fo, lds + st + 256 * p);
+            if (p < NP) glds16<(LABV & 32) ? 2 : 0>((p < NPA ? y : w) + src[u] + fo, lds + st + 256 * p);
         }
     };
     auto vm_barrier = [&](bool all) {

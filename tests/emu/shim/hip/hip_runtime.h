@@ -414,6 +414,7 @@ inline T __shfl(T v, int srclane, int = 64) {
 namespace hk {
 struct buf_rsrc_t { char* p; long long bytes; };
 inline buf_rsrc_t buf_rsrc(const float* base, long long floats) { return buf_rsrc_t{(char*)base, floats * 4}; }
+template <int AUX = 0>
 inline void buf_store16(buf_rsrc_t rs, unsigned off, hipemu::v4f f) { if ((long long)off + 16 <= rs.bytes) memcpy(rs.p + off, &f, 16); }
 inline void buf_store4(buf_rsrc_t rs, unsigned off, float f) { if ((long long)off + 4 <= rs.bytes) memcpy(rs.p + off, &f, 4); }
 }

@@ -20,7 +20,7 @@ st = lambda: P(torch.cuda.current_stream().cuda_stream)
 p = lambda t: P(t.data_ptr()) if t is not None else None
 MODES = [(0, 'whole kernel'), (1, 'no MFMAs'), (2, 'no loads in the loop'), (4, 'no stores'), (6, 'no loads, no stores (MFMA + fragment reads + barriers)'),
          (14, 'no loads, no stores, no fragment reads (MFMA + barriers)'), (7, 'barriers + fragment reads only'), (9, 'loads + stores only'),
-         (8, 'no fragment reads')]
+         (8, 'no fragment reads'), (16, 'default-policy stores instead of nt (results correct)'), (32, 'nt LDS-DMA loads (results correct)'), (48, 'default-policy stores + nt loads')]
 ROLES = [('both roles', True, True), ('dy role only', True, False), ('dW role only', False, True)]
 res = {}
 for rname, wdy, wdw in ROLES:
@@ -43,7 +43,7 @@ lab.hk_probe_linear_fwd.argtypes = [ctypes.c_int, P, P, P, ctypes.c_int, ctypes.
 part = torch.empty(256 * B * K, device=dev)
 FMODES = [(0, 'whole kernel'), (1, 'no MFMAs (LDS-DMA stream + fragment reads + barriers)'), (2, 'no loads in the loop (MFMA + fragment reads + barriers)'),
           (10, 'no loads, no fragment reads (MFMA + barriers)'), (9, 'loads only'), (3, 'fragment reads + barriers only'), (8, 'no fragment reads')]
-FM2 = [(m, n, 1) for m, n in FMODES] + [(0, 'whole kernel, contiguous slabs', 0), (9, 'loads only, contiguous slabs', 0)]
+FM2 = [(m, n, 1) for m, n in FMODES] + [(0, 'whole kernel, contiguous slabs', 0), (9, 'loads only, contiguous slabs', 0), (32, 'nt LDS-DMA loads (results correct)', 1)]
 out = {(m, wk): [] for m, _, wk in FM2}
 for rnd in range(5):
     for m, _, wk in FM2:

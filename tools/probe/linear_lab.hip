@@ -44,6 +44,9 @@ extern "C" int hk_probe_linear_bwd64(int labv, const float* g, const float* w, c
         case 9: return launch<9>(g, w, y, dy, dw, db, B, J, K, walk, st);
         case 14: return launch<14>(g, w, y, dy, dw, db, B, J, K, walk, st);
         case 8: return launch<8>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 16: return launch<16>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 32: return launch<32>(g, w, y, dy, dw, db, B, J, K, walk, st);
+        case 48: return launch<48>(g, w, y, dy, dw, db, B, J, K, walk, st);
         default: return -3;
     }
 }
@@ -76,6 +79,7 @@ extern "C" int hk_probe_linear_fwd(int labv, const float* y, const float* w, flo
         case 8: return launch_fwd<8>(y, w, part, B, J, K, walk, st);
         case 9: return launch_fwd<9>(y, w, part, B, J, K, walk, st);
         case 10: return launch_fwd<10>(y, w, part, B, J, K, walk, st);
+        case 32: return launch_fwd<32>(y, w, part, B, J, K, walk, st);
         default: return -3;
     }
 }
