@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     constexpr int N4 = PANEL / 4;
     constexpr int NST = (N4 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float lds[3 * PANEL];
+    __shared__ __attribute__((aligned(16))) float epi_stage[4][512];      // 2 KB per wave: the epilogue's turn-table (GramEpi)
 
     int b, w;
     const int per = pair_mode ? (nb + 1) / 2 : nb;
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     ep.lh = lh;
     ep.i0 = ep.j0 = ep.offdiag = 0;
     ep.ss = 0.f;
+    ep.stg = epi_stage[wave];
+    ep.t0 = ep.t1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     {   // first A panel: all loads in flight at once, then the LDS writes
         const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)rb0 * PANEL);
@@ -210,9 +213,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) prev[r] = ep.direct(prev[r], r);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) ep.mirror(prev, g);
+    for (int s_ = 0; s_ < GramEpi<MODE>::NSTEP; ++s_) ep.step(prev, s_);
     if (MODE == 2) {        // this workgroup's share of |u|^2 (fixed order) -> mu[b][w]  (row stride SSQ_STRIDE)
         __shared__ float reds[4];
         const float tot = block_sum<4>(ep.ss, reds);

@@ -18,22 +18,71 @@ struct GramEpi {
     int offdiag;
     int l31, lh;
     float ss;        // MODE 2
-    __device__ __forceinline__ float direct(float v, int r) {
+    float* stg;      // 512 floats of LDS private to this wave: the sub-tile leaves through it, half at a time
+    f32x4 t0, t1;    // a half on its way from LDS to HBM
+    __device__ __forceinline__ float value(float v) {
         // v_sqrt_f32 (1 ulp, argument >= 1e-5: no denormal/negative handling needed) - parity budget is 1e-4
         float z = MODE == 0 ? __builtin_amdgcn_sqrtf(fmaf(v, inv_m, 1e-5f)) * inv : v * inv;
         if (MODE == 2) {
             z = z == 0.f ? 0.f : copysignf(sqrtf(fabsf(z) + 1e-10f), z);      // (sign(0) = 0, like torch)
             ss = fmaf(offdiag ? 2.f * z : z, z, ss);
         }
-        const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        yb[(long long)i * C + j0 + l31] = z;
         return z;
     }
-    __device__ __forceinline__ void mirror(const f32x16& p, int g) {   // rows 8g+4lh .. +3 of column l31 -> y[j][i..i+3]
-        if (!offdiag) return;
-        const float4 q = make_float4(p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]);
-        *reinterpret_cast<float4*>(&yb[(long long)(j0 + l31) * C + i0 + 8 * g + 4 * lh]) = q;
+    // The finished sub-tile p (C layout of the 32x32 MFMA: lane (l31, lh), register r = row (r & 3) + 8 (r >> 2) + 4 lh of
+    // column l31) leaves in 13 steps spread over the next tile's MFMA steps.  Round 4: every store is a 16-byte store of
+    // a whole 128-byte (direct rows) / 64-byte (mirrored rows) run, the tile turned through 2 KB of wave-private LDS a
+    // half at a time - 8 store instructions per tile and wave instead of 16 four-byte stores + 4 sixteen-byte stores
+    // that covered 32 bytes of a row each.  With four-byte stores the kernel could not go below 28 us at ANY map size
+    // (67 MB of y at 2.4 TB/s: tools/probe/gram_hw.py); the values are the same bits.
+    //   0-3  the 16 values (sqrt, scale)          4 / 6   rows 0-15 / 16-31 of the tile -> LDS [16][32]
+    //   5 / 7  ... read back as 16-byte pieces    6 / 8   ... stored: 8 rows x 128 B per instruction
+    //   8 / 10 columns 0-15 / 16-31 of the MIRRORED tile -> LDS [32][16]; 9 / 11 read back; 10 / 12 stored: 16 rows x 64 B
+    __device__ __forceinline__ void step(f32x16& p, int s) {
+        const int lane = l31 + 32 * lh;
+        if (s < 4) {
+#pragma unroll
+            for (int r = 4 * s; r < 4 * s + 4; ++r) p[r] = value(p[r]);
+            return;
+        }
+        if (s == 6 || s == 8) {                                   // the half read one step ago: rows 16 h .. of the tile
+            const int h = (s - 6) >> 1;
+            float* o = yb + (long long)(i0 + 16 * h + (lane >> 3)) * C + j0 + 4 * (lane & 7);
+            *reinterpret_cast<f32x4*>(o) = t0;
+            *reinterpret_cast<f32x4*>(o + 8ll * C) = t1;
+        }
+        if ((s == 10 || s == 12) && offdiag) {                    // mirrored: rows j0 + .., columns i0 + 16 h ..
+            const int h = (s - 10) >> 1;
+            float* o = yb + (long long)(j0 + (lane >> 2)) * C + i0 + 16 * h + 4 * (lane & 3);
+            *reinterpret_cast<f32x4*>(o) = t0;
+            *reinterpret_cast<f32x4*>(o + 16ll * C) = t1;
+        }
+        if (s == 4 || s == 6) {                                   // rows (r & 3) + 8 (r >> 2) + 4 lh - 16 h, h = registers 8 h ..
+            const int h = (s - 4) >> 1;
+            HK_WAVE_SYNC();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = p[8 * h + r];
+            HK_WAVE_SYNC();
+        }
+        if (s == 5 || s == 7) {
+            t0 = *reinterpret_cast<const f32x4*>(stg + (lane >> 3) * 32 + 4 * (lane & 7));
+            t1 = *reinterpret_cast<const f32x4*>(stg + (8 + (lane >> 3)) * 32 + 4 * (lane & 7));
+        }
+        if ((s == 8 || s == 10) && offdiag) {                     // T[column l31][row 8 g + 4 lh + t - 16 h]
+            const int h = (s - 8) >> 1;
+            HK_WAVE_SYNC();
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                *reinterpret_cast<f32x4*>(stg + l31 * 16 + 8 * g + 4 * lh) =
+                    (f32x4){p[8 * h + 4 * g], p[8 * h + 4 * g + 1], p[8 * h + 4 * g + 2], p[8 * h + 4 * g + 3]};
+            HK_WAVE_SYNC();
+        }
+        if ((s == 9 || s == 11) && offdiag) {
+            t0 = *reinterpret_cast<const f32x4*>(stg + (lane >> 2) * 16 + 4 * (lane & 3));
+            t1 = *reinterpret_cast<const f32x4*>(stg + (16 + (lane >> 2)) * 16 + 4 * (lane & 3));
+        }
     }
+    static constexpr int NSTEP = 13;
 };
 
 // One 64x64 tile step for this wave's 32x32 sub-tile.  K is split over TWO independent accumulator chains (the two
@@ -70,24 +119,22 @@ __device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[1], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], q[3], acc1, 0, 0, 0);
         if (HASPREV) {
-            if (s < 16) prev[s] = ep.direct(prev[s], s);
-            else if (s < 20) ep.mirror(prev, s - 16);
+            if (s < EPI::NSTEP) ep.step(prev, s);
         }
         a = an;
         q = qn;
     }
     if (HW % 8 == 4) {   // k = 8*KS .. +3: lanes 0-31 take the first two, lanes 32-63 the last two
-        const float2 a = *reinterpret_cast<const float2*>(Ap + 8 * KS - 2 * lh);
-        const float2 q = *reinterpret_cast<const float2*>(Bp + 8 * KS - 2 * lh);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, acc1, 0, 0, 0);
+        // (ext-vector loads, not float2: a struct-typed LDS load carries alias info and the wait-count pass then
+        // parks it behind every LDS-DMA in flight - vmcnt(0) - in kernels that prefetch by LDS-DMA)
+        const f32x2 a = *reinterpret_cast<const f32x2*>(Ap + 8 * KS - 2 * lh);
+        const f32x2 q = *reinterpret_cast<const f32x2*>(Bp + 8 * KS - 2 * lh);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], q[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[1], acc1, 0, 0, 0);
     }
     if (HASPREV) {
 #pragma unroll
-        for (int s = KS; s < 20; ++s) {
-            if (s < 16) prev[s] = ep.direct(prev[s], s);
-            else ep.mirror(prev, s - 16);
-        }
+        for (int s = KS; s < EPI::NSTEP; ++s) ep.step(prev, s);
     }
 }
 
