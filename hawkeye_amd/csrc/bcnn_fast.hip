@@ -150,6 +150,12 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     }
 
     int a_idx = 0, b_idx = 0;
+    // HW = 64 (row pitch 256 B: every row starts in the same LDS bank): this wave's A rows are held in registers for the
+    // whole row block (hk_gram_tile.h, 28.6 -> 23.4 us at B = 64, C = 512); at the other sizes it measured level
+    // (HW = 100, 144) or 0.6 us slower (196), and they keep reading A from the panel.
+    constexpr bool AREG = HW == 64;
+    GramAReg<AREG ? HW : 8> areg;
+    if (AREG) areg.load(lds + (wm * 32 + l31) * HW + 4 * lh, lh);
     f32x16 prev;
 #pragma unroll
     for (int i = 0; i < 16; ++i) prev[i] = 0.f;
@@ -190,8 +196,13 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
             f32x4* dst = reinterpret_cast<f32x4*>(lds + n_idx * PANEL);
-            if (has_prev) gram_tile<HW, true, NST>(Ap, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
-            else gram_tile<HW, false, NST>(Ap, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
+            if constexpr (AREG) {
+                if (has_prev) gram_tile_ra<HW, true, NST>(areg, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
+                else gram_tile_ra<HW, false, NST>(areg, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
+            } else {
+                if (has_prev) gram_tile<HW, true, NST>(Ap, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
+                else gram_tile<HW, false, NST>(Ap, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
+            }
             prev = acc0 + acc1;
             ep.i0 = I * 64 + wm * 32;
             ep.j0 = J * 64 + wn * 32;
@@ -206,6 +217,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
                         center_panel<HW>(lds + n_idx * PANEL, mub + rb1 * 64, tid);
                         HK_LDS_BARRIER();
                     }
+                    if (AREG) areg.load(lds + a_idx * PANEL + (wm * 32 + l31) * HW + 4 * lh, lh);
                 } else {
                     b_idx = n_idx;
                 }

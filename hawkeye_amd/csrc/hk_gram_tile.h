@@ -138,4 +138,56 @@ __device__ __forceinline__ void gram_tile(const float* Ap, const float* Bp, f32x
     }
 }
 
+// The same tile step with the A operand in REGISTERS (round 4).  A wave's A rows are the same for every tile of a row
+// block: its 32 rows x the k it feeds to the MFMAs (lane (l31, lh): k = 8 s + 4 lh + t) are HW / 2 floats per lane,
+// read from the LDS panel once per row block instead of once per tile - half of the fragment traffic.  Used where the
+// panel's row pitch makes the fragment reads collide (HW = 64); elsewhere it measured no gain (bcnn_fast.hip).
+template <int HW>
+struct GramAReg {
+    static constexpr int KS = HW / 8;
+    f32x4 a[KS];
+    f32x2 tail;
+    __device__ __forceinline__ void load(const float* Ap, int lh) {      // Ap = panel + row * HW + 4 lh, as gram_tile takes it
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const f32x4*>(Ap + 8 * s);
+        if (HW % 8 == 4) tail = *reinterpret_cast<const f32x2*>(Ap + 8 * KS - 2 * lh);
+    }
+};
+template <int HW, bool HASPREV, int NST, class EPI>
+__device__ __forceinline__ void gram_tile_ra(const GramAReg<HW>& ar, const float* Bp, f32x16& acc0, f32x16& acc1,
+                                             f32x16& prev, EPI& ep, int lh, const f32x4 (&st)[NST], f32x4* dst,
+                                             bool do_write, int tid) {
+    constexpr int KS = HW / 8;
+    constexpr int N4 = 16 * HW;
+    constexpr int WS = (KS - NST - 1) > 0 ? (KS - NST - 1) : 0;   // first step that writes
+    f32x4 q = *reinterpret_cast<const f32x4*>(Bp);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f32x4 qn = q;
+        if (s + 1 < KS) qn = *reinterpret_cast<const f32x4*>(Bp + 8 * (s + 1));
+        if (s >= WS && s - WS < NST) {
+            const int f = tid + 256 * (s - WS);
+            if (do_write && f < N4) dst[f] = st[s - WS];
+        }
+        const f32x4 a = ar.a[s];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], q[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], q[2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], q[3], acc1, 0, 0, 0);
+        if (HASPREV) {
+            if (s < EPI::NSTEP) ep.step(prev, s);
+        }
+        q = qn;
+    }
+    if (HW % 8 == 4) {   // k = 8*KS .. +3: lanes 0-31 take the first two, lanes 32-63 the last two
+        const f32x2 qt = *reinterpret_cast<const f32x2*>(Bp + 8 * KS - 2 * lh);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar.tail[0], qt[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar.tail[1], qt[1], acc1, 0, 0, 0);
+    }
+    if (HASPREV) {
+#pragma unroll
+        for (int s = KS; s < EPI::NSTEP; ++s) ep.step(prev, s);
+    }
+}
+
 }  // namespace hk
