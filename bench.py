@@ -317,12 +317,14 @@ def final_line(res):
 def emit(res, detail):
     """Detail -> gpurun_out/bench_detail.json + a short table on stderr; then the final line, last on stdout."""
     if detail:
+        # (HAWKEYE_BENCH_DETAIL: where the tests' own bench runs put theirs - not over the record of the real one)
+        path = os.environ.get('HAWKEYE_BENCH_DETAIL') or os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')
         try:
-            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-            with open(os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'), 'w') as f:
+            os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+            with open(path, 'w') as f:
                 json.dump({'headline': {k: res[k] for k in LINE_KEYS if k in res}, **detail}, f, indent=1)
         except OSError as e:
-            print(f'[bench] could not write gpurun_out/bench_detail.json: {e}', file=sys.stderr)
+            print(f'[bench] could not write {path}: {e}', file=sys.stderr)
         for k in detail.get('kernels', []):
             print(f"[bench] {k['us']:9.2f} us  {k['bound']:4s} frac {k['frac']:.3f}  {k['kernel'][:100]}", file=sys.stderr)
         om = detail.get('other_models')

@@ -70,6 +70,7 @@ def test_final_line_survives_oversized_strings():
 def test_emit_prints_the_line_last_on_stdout_and_detail_elsewhere(tmp_path, monkeypatch):
     res, detail = canned()
     monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    monkeypatch.delenv('HAWKEYE_BENCH_DETAIL', raising=False)
     out, err = io.StringIO(), io.StringIO()
     with redirect_stdout(out), redirect_stderr(err):
         bench.emit(res, detail)

@@ -310,6 +310,7 @@ def test_bench_spawns_its_own_ranks(tmp_path, world):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['HAWKEYE_BENCH_DETAIL'] = str(tmp_path / 'bench_detail.json')
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--share-gpu', '--backend', 'gloo',
                         '--steps', '2', '--warmup', '1', '--batch', '2', '--image', '64'],
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
