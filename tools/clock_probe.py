@@ -80,10 +80,12 @@ st = stream
 # nothing but MFMAs (32x32x2, 8 waves per CU)
 src, out = torch.randn(65536, device=dev), torch.empty(512 * 512, device=dev)
 nm = [0]
-def mfma_only():
-    nm[0] = probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), 2, 256, 512, 2000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-mfma_only()
-rows.append(measure('MFMA only: v_mfma_f32_32x32x2_f32 back to back, 8 waves per CU', mfma_only, flops=nm[0] * 4096.0 * 256 * 8))
+for kind, nm_, fl in ((2, 'v_mfma_f32_32x32x2_f32', 4096.0), (0, 'v_mfma_f32_16x16x4_f32', 2048.0)):
+    def mfma_only():
+        nm[0] = probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), kind, 256, 512, 2000 if kind == 2 else 1000,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    mfma_only()
+    rows.append(measure(f'MFMA only: {nm_} back to back, 8 waves per CU', mfma_only, flops=nm[0] * fl * 256 * 8))
 # an HBM copy
 big_a, big_b = torch.empty(1 << 28, device=dev), torch.empty(1 << 28, device=dev)
 rows.append(measure('HBM copy 1 GiB -> 1 GiB (torch copy_)', lambda: big_b.copy_(big_a)))

@@ -66,6 +66,8 @@ rows = [{'kernel': 'idle', 'rocm_smi': [smi()]}]
 src, out = torch.randn(65536, device=dev), torch.empty(512 * 512, device=dev)
 rows.append(run('MFMA only (32x32x2, 8 waves per CU)',
                 lambda: probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), 2, 256, 512, 400, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))))
+rows.append(run('MFMA only (16x16x4, 8 accumulators, 8 waves per CU)',
+                lambda: probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), 0, 256, 512, 200, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))))
 B, C, HW = 64, 512, 196
 x = torch.relu(torch.randn(B, C, HW, device=dev)); y = torch.empty(B, C * C, device=dev); dy = torch.randn(B, C * C, device=dev)
 dx = torch.empty_like(x); inv = torch.rand(B, device=dev) + 0.5; tp = torch.empty(B, C // 64, device=dev)
