@@ -126,6 +126,9 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
     // fragments only AFTER the barrier that publishes it (so that the barrier waits for one chunk less and a piece has two
     // more chunk times to land) measured 78.6 us: memory latency is not what the overlap loses; issuing all pieces from the
     // four waves with one class tile less (6 of 13) instead of from all eight: 71.6 vs 70.2 us - nor is it who issues them.
+    // Halving the fragment reads - a wave takes TWO sample tiles x its class half on ONE of the chunk's two feature steps
+    // (9 reads per 56 MFMAs instead of 16; the steps meet through LDS after the loop) - measured 96 vs 84 us in one
+    // alternating run (7 + 7 / 6 + 6 class tiles on the two waves of a SIMD instead of 7 + 6 explains half of it): removed.
     auto run = [&](auto nl_tag) {
         constexpr int NL = decltype(nl_tag)::value;
         auto frag = [&](int st, int s, f32x4& a, f32x4 (&b)[NL]) {
