@@ -44,3 +44,25 @@ def test_streamed_cin_product_counts_its_requests(tmp_path):
     # every wait leaves the newest chunk's requests in flight: none is vmcnt(0), none waits into the newest set
     assert min(waits) >= n_req - 2, (waits, n_req)
     assert not any('s_cbranch' in l for l in loop[1:-1]), 'a branch inside the chunk loop'
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='no hipcc')
+def test_gram_forward_leaves_in_16_byte_stores_and_never_spills(tmp_path):
+    """bcnn_gram_panel_kernel (bcnn_fast.hip, hk_gram_tile.h): every element of y - direct and mirrored - leaves in a
+    16-byte store (the epilogue turns each sub-tile through wave-private LDS for that), nothing goes to scratch, and the
+    150 KB of panels + 8 KB of turn-tables fit the 160 KB of a CU."""
+    src = os.path.join(ROOT, 'hawkeye_amd', 'csrc', 'bcnn_fast.hip')
+    out = str(tmp_path / 'bcnn_fast.s')
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-o', out, src],
+                   check=True, capture_output=True, timeout=900)
+    txt = open(out).read()
+    seen = 0
+    for m in re.finditer(r'^(_ZN2hk22bcnn_gram_panel_kernelILi(\d+)ELi(\d)ELb(\d)\w*):.*?\n(.*?)\.end_amdhsa_kernel', txt, re.S | re.M):
+        body = m.group(5)
+        seen += 1
+        assert 'scratch_' not in body, m.group(1)
+        assert len(re.findall(r'global_store_dwordx4', body)) >= 16, m.group(1)
+        # the only narrow stores: the norm / colsum / partial-norm words of the prologue and tail (not y)
+        assert len(re.findall(r'global_store_dword ', body)) <= 3, m.group(1)
+        assert int(re.search(r'group_segment_fixed_size (\d+)', body).group(1)) <= 160 * 1024, m.group(1)
+    assert seen == 16                                              # 4 map sizes x (BCNN, signed sqrt, covariance centred / raw)
