@@ -80,9 +80,10 @@ st = stream
 # nothing but MFMAs (32x32x2, 8 waves per CU)
 src, out = torch.randn(65536, device=dev), torch.empty(512 * 512, device=dev)
 nm = [0]
-for kind, nm_, fl in ((2, 'v_mfma_f32_32x32x2_f32', 4096.0), (0, 'v_mfma_f32_16x16x4_f32', 2048.0)):
+for kind, nm_, fl in ((2, 'v_mfma_f32_32x32x2_f32', 4096.0), (3, 'v_mfma_f32_32x32x2_f32, operands changing every instruction', 4096.0),
+                      (0, 'v_mfma_f32_16x16x4_f32', 2048.0)):
     def mfma_only():
-        nm[0] = probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), kind, 256, 512, 2000 if kind == 2 else 1000,
+        nm[0] = probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), kind, 256, 512, 2000 if kind >= 2 else 1000,
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     mfma_only()
     rows.append(measure(f'MFMA only: {nm_} back to back, 8 waves per CU', mfma_only, flops=nm[0] * fl * 256 * 8))

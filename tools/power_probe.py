@@ -66,6 +66,8 @@ rows = [{'kernel': 'idle', 'rocm_smi': [smi()]}]
 src, out = torch.randn(65536, device=dev), torch.empty(512 * 512, device=dev)
 rows.append(run('MFMA only (32x32x2, 8 waves per CU)',
                 lambda: probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), 2, 256, 512, 400, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))))
+rows.append(run('MFMA only (32x32x2, operands changing every instruction)',
+                lambda: probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), 3, 256, 512, 400, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))))
 rows.append(run('MFMA only (16x16x4, 8 accumulators, 8 waves per CU)',
                 lambda: probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), 0, 256, 512, 200, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))))
 B, C, HW = 64, 512, 196
