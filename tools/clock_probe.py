@@ -87,6 +87,21 @@ for kind, nm_, fl in ((2, 'v_mfma_f32_32x32x2_f32', 4096.0), (3, 'v_mfma_f32_32x
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     mfma_only()
     rows.append(measure(f'MFMA only: {nm_} back to back, 8 waves per CU', mfma_only, flops=nm[0] * fl * 256 * 8))
+for thr, mode, tiles, what in ((256, 0, 400, 'nothing else'), (512, 0, 400, 'nothing else'),
+                               (256, 1, 400, '+ a workgroup barrier per tile (24 steps)'),
+                               (256, 3, 400, '+ barrier + the epilogue arithmetic (sum, sqrt, fma; accumulators restart)'),
+                               (256, 7, 400, '+ barrier + epilogue + 64 B per lane stored per tile'),
+                               (256, 7, 40, '+ barrier + epilogue + stores, 40 tiles per launch'),
+                               (256, 7, 9, '+ barrier + epilogue + stores, 9 tiles per launch (the Gram forward\'s length)'),
+                               (256, 0, 9, 'nothing else, 9 tiles per launch'),
+                               (256, 9, 400, '+ barrier + the next panel staged (13 x 16 B loads per thread from L2, written to LDS inside the MFMA steps)'),
+                               (256, 15, 400, '+ barrier + epilogue + stores + panel staging'),
+                               (256, 15, 9, '+ barrier + epilogue + stores + panel staging, 9 tiles per launch')):
+    def mfma_lds():
+        nm[0] = probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), 4 + mode, 256, thr, 24 * tiles, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    mfma_lds()
+    rows.append(measure(f'MFMA fed from LDS (32x32x2, one ds_read_b128 per two MFMAs: the Gram kernels\' diet), {thr // 64} waves per CU, {what}',
+                        mfma_lds, flops=nm[0] * 4096.0 * 256 * (thr // 64)))
 # an HBM copy
 big_a, big_b = torch.empty(1 << 28, device=dev), torch.empty(1 << 28, device=dev)
 rows.append(measure('HBM copy 1 GiB -> 1 GiB (torch copy_)', lambda: big_b.copy_(big_a)))

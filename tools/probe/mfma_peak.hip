@@ -79,14 +79,94 @@ __global__ __launch_bounds__(512, 2) void mfma32v_kernel(const float* __restrict
     out[t] = r;
 }
 
+// 32x32x2 fed from LDS the way the Gram kernels feed it: per four MFMAs two ds_read_b128 (one A, one B fragment of a
+// [64 rows][196 floats] panel, read one step ahead), two accumulator chains, nothing else - no barriers, no global
+// traffic.  What an LDS-fed fp32 MFMA loop can reach, and at which clock.
+// mode bit 0: a workgroup barrier after every 24 steps (a "tile"); bit 1: the tile's accumulators are summed, sent through
+// sqrt / fma (the Gram epilogue's VALU work) and restarted from zero; bit 2: ... and stored (16 B per lane x 4, a
+// 32-bit offset that walks 64 MB); bit 3: the next panel's staging - 13 global loads of 16 B per thread (L2 hits) at the
+// top of a tile, written to a third LDS panel from inside its MFMA steps: each adds one ingredient of the real kernel
+// to the bare loop.
+__global__ __launch_bounds__(512, 1) void mfma32lds_kernel(const float* __restrict__ in, float* __restrict__ out, int iters,
+                                                           int mode, float* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * 64 * 196];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // operands: one value of `in` per thread, varied arithmetically (no memory-bound fill in front of a short launch)
+        const float base = in[(blockIdx.x * 512 + tid) & 65535];
+        for (int i = tid; i < 2 * 64 * 196; i += blockDim.x) lds[i] = base + 0.001f * (float)(i & 1023);
+    }
+    __syncthreads();
+    const int l31 = lane & 31, lh = lane >> 5, wm = (wave >> 1) & 1, wn = wave & 1;
+    const float* Ap = lds + (wm * 32 + l31) * 196 + 4 * lh;
+    const float* Bp = lds + 64 * 196 + (wn * 32 + l31) * 196 + 4 * lh;
+    f32x16 acc0, acc1, keep;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; keep[r] = 0.f; }
+    unsigned so = (unsigned)t * 16u;
+    for (int it = 0; it < iters; it += 24) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(Ap), q = *reinterpret_cast<const f32x4*>(Bp);
+        f32x4 stg[13];
+        if (mode & 8) {                       // the next 50 KB panel: 13 x 16 B per thread from an L2-resident buffer (in[], 256 KB)
+            const f32x4* src = reinterpret_cast<const f32x4*>(in) + ((it * 64 + blockIdx.x * 3136) & 8191);
+#pragma unroll
+            for (int u = 0; u < 13; ++u) stg[u] = src[(tid + 256 * u) & 4095];
+        }
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            f32x4 an = a, qn = q;
+            if (s + 1 < 24) {
+                an = *reinterpret_cast<const f32x4*>(Ap + 8 * (s + 1));
+                qn = *reinterpret_cast<const f32x4*>(Bp + 8 * (s + 1));
+            }
+            if ((mode & 8) && s >= 10 && s < 23) {
+                const int f = tid + 256 * (s - 10);
+                if (f < 3136) reinterpret_cast<f32x4*>(lds + 2 * 64 * 196)[f] = stg[s - 10];
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], q[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], q[2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], q[3], acc1, 0, 0, 0);
+            a = an;
+            q = qn;
+        }
+        asm volatile("" ::: "memory");
+        if (mode & 2) {
+            f32x16 p = acc0 + acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_sqrtf(fmaf(fabsf(p[r]), 0.0051f, 1e-5f)) * 0.37f; acc0[r] = 0.f; acc1[r] = 0.f; }
+            if (mode & 4) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(sink) + ((so + (unsigned)g * 8388608u) & 67108863u)) =
+                        (f32x4){p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]};
+                so += 16u * 131072u;
+            }
+            keep += p;
+        }
+        if (mode & 1) __syncthreads();
+    }
+    const f32x16 sres = acc0 + acc1 + keep;
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += sres[i];
+    out[t] = r;
+}
+
 // kind 0: 16x16x4, 8 accumulators per wave; 1: 16x16x4, 16 accumulators; 2: 32x32x2, 4 accumulators;
-// 3: 32x32x2, 4 accumulators, operands changing every instruction (iters a multiple of 4).
+// 3: 32x32x2, 4 accumulators, operands changing every instruction (iters a multiple of 4);
+// 4 + mode: 32x32x2 fed from LDS (iters a multiple of 24; returns iters * 4 MFMAs per wave); mode bits: 1 barrier per
+// tile, 2 epilogue arithmetic, 4 stores.
 // Returns the MFMA count per wave (so the caller computes FLOPs: 2048 per 16x16x4, 4096 per 32x32x2), < 0 on error.
+static float* g_sink = nullptr;        // 64 MB target of the LDS-fed loop's store mode
 extern "C" long long hk_probe_mfma(const float* in, float* out, int kind, int blocks, int threads, int iters, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (kind == 0) hipLaunchKernelGGL(mfma16_kernel<8>, dim3(blocks), dim3(threads), 0, st, in, out, iters);
     else if (kind == 1) hipLaunchKernelGGL(mfma16_kernel<16>, dim3(blocks), dim3(threads), 0, st, in, out, iters);
-    else if (kind == 3) hipLaunchKernelGGL(mfma32v_kernel, dim3(blocks), dim3(threads), 0, st, in, out, iters);
+    else if (kind >= 4 && kind < 20) {          // 4 + mode
+        if (!g_sink && hipMalloc(&g_sink, 64u << 20) != hipSuccess) return -1;
+        hipLaunchKernelGGL(mfma32lds_kernel, dim3(blocks), dim3(threads), 0, st, in, out, iters, kind - 4, g_sink);
+        return hipGetLastError() != hipSuccess ? -1 : (long long)iters * 4;
+    } else if (kind == 3) hipLaunchKernelGGL(mfma32v_kernel, dim3(blocks), dim3(threads), 0, st, in, out, iters);
     else hipLaunchKernelGGL(mfma32_kernel, dim3(blocks), dim3(threads), 0, st, in, out, iters);
     if (hipGetLastError() != hipSuccess) return -1;
     return (long long)iters * 4 * (kind == 0 ? 8 : kind == 1 ? 16 : 4);
