@@ -43,3 +43,15 @@ def test_cpu_tensors_are_refused():
         F.bilinear_pool(torch.rand(1, 8, 2, 2))
     with pytest.raises(HawkeyeHipError):
         F.covpool(torch.rand(1, 8, 2, 2))
+
+
+def test_a_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
+    """No CPU path behind the ops: without the built extension every op raises (and says how to build it)."""
+    from hawkeye_amd import _lib
+    import hawkeye_amd.functional as F
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'libhawkeye_hip.so'))
+    with pytest.raises(_lib.HawkeyeHipError, match='no CPU fallback'):
+        _lib.load()
+    with pytest.raises(_lib.HawkeyeHipError):
+        F.bilinear_pool(torch.rand(1, 8, 2, 2))
