@@ -102,6 +102,12 @@ for thr, mode, tiles, what in ((256, 0, 400, 'nothing else'), (512, 0, 400, 'not
     mfma_lds()
     rows.append(measure(f'MFMA fed from LDS (32x32x2, one ds_read_b128 per two MFMAs: the Gram kernels\' diet), {thr // 64} waves per CU, {what}',
                         mfma_lds, flops=nm[0] * 4096.0 * 256 * (thr // 64)))
+for tiles in (400, 9):
+    def mfma_lds8():
+        nm[0] = probe.hk_probe_mfma(src.data_ptr(), out.data_ptr(), 30, 256, 512, 24 * tiles, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    mfma_lds8()
+    rows.append(measure(f'MFMA fed from LDS, EIGHT waves (K split between the two waves of a SIMD, partial sums exchanged through LDS), barrier + epilogue + stores + panel staging, {tiles} tiles per launch',
+                        mfma_lds8, flops=nm[0] * 4096.0 * 256 * 8))
 # an HBM copy
 big_a, big_b = torch.empty(1 << 28, device=dev), torch.empty(1 << 28, device=dev)
 rows.append(measure('HBM copy 1 GiB -> 1 GiB (torch copy_)', lambda: big_b.copy_(big_a)))
