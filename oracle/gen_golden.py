@@ -402,26 +402,125 @@ def gen_models_448():
     """The same three reference models at the CONFIGS' input size: two 448 x 448 images -> 14 x 14 feature maps, where the
     plugins dispatch the panel / fused kernels (bcnn_gram_panel_kernel<196>, cbp_fused_kernel<196>, the covariance panel
     kernel + nsmm chain at d = 256) and the wide-classifier kernels at their real widths (262144 / 6000 / 32896 -> 200).
-    Pins eval logits, and - through a cross-entropy on targets (3, 77) - the classifier's own gradients."""
+    Pins eval logits, and - through a cross-entropy on targets (3, 77) - the classifier's own gradients, and the gradient
+    AT THE HEAD'S INPUT as the reference's autograd produces it in-model (`*_feat_grad`: d loss / d backbone(x); for MPN
+    also `MPN_dr_grad`, the gradient at the covariance's input behind the 1x1 reduction) - the pool's dX at 14 x 14 maps
+    without MIOpen's backward in between.  The same model is also run in float64; the float32 run's distance from it is
+    stored per tensor (`*_e32_feat_grad`) as the yardstick of what float32 can pin.
+    `BCNN_S1*`: the reference BCNN with `stage=1` (BCNN.py:45-52: frozen trunk, features detached) - logits and the
+    classifier's gradients; no parameter of the trunk may receive a gradient."""
     from inputs import seeded_init
     models = gen_keys()
     res = {}
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+
+    def run(m, dt):
+        keep = {}
+        hooks = [m.backbone.register_forward_hook(lambda _m, _i, o: (o.retain_grad(), keep.__setitem__('feat', o))[0])]
+        if hasattr(m, 'pool'):
+            hooks.append(m.pool.conv_dr_block.register_forward_hook(
+                lambda _m, _i, o: (o.retain_grad(), keep.__setitem__('dr', o))[0]))
+        m = m.to(dt)
+        m.zero_grad()
+        x = t(rs_randn(931, (2, 3, 448, 448))).to(dt)
+        y = m(x)
+        torch.nn.functional.cross_entropy(y, torch.tensor([3, 77])).backward()
+        for h in hooks:
+            h.remove()
+        return y.detach(), {k: v.grad.clone() for k, v in keep.items()}
+
     for name in ('BCNN', 'CBCNN', 'MPN'):
         m = models[name]
         seeded_init(m, 930)
         m.eval()
-        x = t(rs_randn(931, (2, 3, 448, 448)))
         for p_ in m.parameters():
             p_.requires_grad_(True)
-        y = m(x)
-        torch.nn.functional.cross_entropy(y, torch.tensor([3, 77])).backward()
-        res[name] = y.detach()
+        y, g32 = run(m, torch.float32)
+        res[name] = y
         res[name + '_cls_w_grad'] = sub(m.classifier.weight.grad, 1009)
         res[name + '_cls_w_grad_abs'] = m.classifier.weight.grad.abs().sum().reshape(1)
         res[name + '_cls_b_grad'] = m.classifier.bias.grad.clone()
         w0 = next(m.backbone.parameters())
         res[name + '_conv0_grad'] = w0.grad.clone()
+        res[name + '_feat_grad'] = sub(g32['feat'], 7)
+        res[name + '_feat_grad_abs'] = g32['feat'].double().abs().sum().reshape(1)
+        if 'dr' in g32:
+            res[name + '_dr_grad'] = sub(g32['dr'], 3)
+            res[name + '_dr_grad_abs'] = g32['dr'].double().abs().sum().reshape(1)
+        if name == 'CBCNN':                        # sketch matrices are plain attributes: cast by hand
+            m.bilinear_pooling.sparse_sketch_matrix1 = m.bilinear_pooling.sparse_sketch_matrix1.double()
+            m.bilinear_pooling.sparse_sketch_matrix2 = m.bilinear_pooling.sparse_sketch_matrix2.double()
+        y64, g64 = run(m, torch.float64)
+        res[name + '_e32_feat_grad'] = np.array([rel(g32['feat'], g64['feat'])])
+        res[name + '_e32_logits'] = np.array([rel(y, y64)])
+        res[name + '_feat_grad64'] = sub(g64['feat'], 7).float()
+        if 'dr' in g32:
+            res[name + '_e32_dr_grad'] = np.array([rel(g32['dr'], g64['dr'])])
+        print(name, 'fp32 reference vs fp64 reference: logits', rel(y, y64), 'feat grad', rel(g32['feat'], g64['feat']),
+              ('dr grad %g' % rel(g32['dr'], g64['dr'])) if 'dr' in g32 else '')
+        models[name] = None
+        del m
+
+    # BCNN stage 1 (BASELINE configs[0]): BCNN.py:45-52
+    from yacs.config import CfgNode as CN
+    m = MODEL.get('BCNN')(CN(dict(stage=1, num_classes=200)))
+    seeded_init(m, 930)
+    m.eval()
+    y = m(t(rs_randn(931, (2, 3, 448, 448))))
+    torch.nn.functional.cross_entropy(y, torch.tensor([3, 77])).backward()
+    assert all(p_.grad is None for p_ in m.backbone.parameters())
+    res['BCNN_S1'] = y.detach()
+    res['BCNN_S1_cls_w_grad'] = sub(m.classifier.weight.grad, 1009)
+    res['BCNN_S1_cls_w_grad_abs'] = m.classifier.weight.grad.abs().sum().reshape(1)
+    res['BCNN_S1_cls_b_grad'] = m.classifier.bias.grad.clone()
     save('model_logits_448', **res)
+
+
+APCNN_448_TRAIN_BATCH = 4
+
+
+def gen_apcnn_448():
+    """AP-CNN as configs[4] runs it: 448 x 448 input, num_classes = 8142 -> hidden_num = 256 (APCNN.py:360-363) and the
+    0.1 - 0.9 border band of get_att_roi (APCNN.py:451-455).  Eval mode on two images (out_mean, the 8 logits, mask_cat,
+    the three ROI tables: APCNN.py:540-599) and train mode at batch 4 with the python-`random` drop block seeded (as
+    gen_apcnn_train: pinned in float64, the float32 run's own distance stored as the yardstick)."""
+    import random
+    from inputs import seeded_init
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    m = M_AP.resnet50(8142)
+    seeded_init(m, 940)
+    m.eval()
+    with torch.no_grad():
+        out_mean, out_list, mask_cat, roi_list = m(t(rs_randn(941, (2, 3, 448, 448))), None)
+    res = dict(out_mean=sub(out_mean, 1), out_list=torch.stack(out_list), mask_cat=sub(mask_cat, 13),
+               roi3=roi_list[0], roi4=roi_list[1], roi5=roi_list[2])
+    print('eval rois', [tuple(r.shape) for r in roi_list], 'argmax', out_mean.argmax(1).tolist())
+    runs = {}
+    nb = APCNN_448_TRAIN_BATCH
+    for dt in (torch.float64, torch.float32):
+        m = M_AP.resnet50(8142)
+        seeded_init(m, 940)
+        m = m.to(dt).train()
+        x = t(rs_randn(942, (nb, 3, 448, 448))).to(dt)
+        wt = t(rs_randn(943, (nb, 8142))).to(dt)
+        random.seed(5)
+        om, ol, _mc, rl = m(x, None)
+        (om * wt).sum().backward()
+        runs[dt] = (om.detach(), torch.stack(ol).detach(), rl,
+                    {n: p.grad for n, p in m.named_parameters() if p.grad is not None})
+    om, ol, rois, grads = runs[torch.float64]
+    om32, ol32, rois32, grads32 = runs[torch.float32]
+    assert all(torch.equal(a[:, :5].float(), b[:, :5]) for a, b in zip(rois, rois32)), 'fp32 / fp64 picked different ROIs'
+    keep = ['conv1.weight', 'layer2.0.conv1.weight', 'layer4.2.conv3.weight', 'cls_concate.1.weight', 'cls3.6.weight']
+    stride = lambda k: max(7, grads[k].numel() // 2000 | 1)
+    res.update(t_out_mean=om, t_out_list=ol, t_roi3=rois[0].float(), t_roi4=rois[1].float(), t_roi5=rois[2].float(),
+               t_e32_out_list=np.array([rel(ol32[i], ol[i]) for i in range(8)]), t_e32_out_mean=np.array([rel(om32, om)]),
+               t_grad_names=np.array(keep), **{'t_g%d' % i: sub(grads[k], stride(k)) for i, k in enumerate(keep)},
+               **{'t_gn%d' % i: grads[k].norm().reshape(1) for i, k in enumerate(keep)},
+               t_e32_g=np.array([rel(grads32[k], grads[k]) for k in keep]))
+    print('train: fp32 reference vs fp64 reference: out_list', [rel(ol32[i], ol[i]) for i in range(8)],
+          'grads', [rel(grads32[k], grads[k]) for k in keep])
+    save('model_apcnn_448', **res)
 
 
 APCNN_TRAIN_BATCH = 8
