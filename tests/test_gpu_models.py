@@ -36,9 +36,12 @@ def build(name, **kw):
     return MODEL.get(name)(CfgNode(dict(name=name, **kw)))
 
 
-# AP-CNN train-mode bound, in units of the reference's OWN float32-vs-float64 distance per tensor (train-mode BatchNorm
-# amplifies rounding).  Measured on the MI355X (MIOpen convolutions, another summation order): see the printed `worst`.
-APCNN_TRAIN_K = 20.0
+# AP-CNN train-mode bounds, in units of the reference's OWN float32-vs-float64 distance per tensor (train-mode BatchNorm
+# amplifies rounding).  Measured on the MI355X (MIOpen convolutions, another summation order; profiles/r5_parity_edges.log):
+# worst 1.52 at 224 x 224 / batch 8 / 200 classes, 5.43 at 448 x 448 / batch 4 / 8142 classes (torch CPU: 1.06 / 1.09);
+# the bounds are about twice that (round 4 allowed 20).
+APCNN_TRAIN_K = 4.0
+APCNN_TRAIN_K_448 = 12.0
 
 CFG = {
     'BCNN': dict(stage=2, num_classes=200),
@@ -294,7 +297,7 @@ def test_apcnn_at_config_shape_train_vs_reference():
         got = got.cpu().numpy()
         assert got.shape == g[key].shape
         np.testing.assert_array_equal(got[:, :5], g[key][:, :5])
-    k = APCNN_TRAIN_K
+    k = APCNN_TRAIN_K_448
     worst = 0.0
     for i, o in enumerate(out_list):
         r = float(rel(o, g['t_out_list'][i])) / max(float(g['t_e32_out_list'][i]), 1e-5)
