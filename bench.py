@@ -80,6 +80,28 @@ def free_port():
     return port
 
 
+def host_threads_per_rank(world):
+    return max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
+
+
+def device_identity(dev):
+    """What tells two GPUs apart on one node: PCI domain:bus:device and the uuid (torch's device properties)."""
+    p = torch.cuda.get_device_properties(dev)
+    pci = ':'.join(f'{getattr(p, k):x}' for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id') if hasattr(p, k))
+    return {'index': dev.index, 'pci': pci or None, 'uuid': str(getattr(p, 'uuid', '')) or None, 'name': p.name}
+
+
+def gather_rank_devices(rank, world, dev):
+    """N > 1: every rank's host pid and device identity, gathered to all ranks - the first multi-GPU run then says by
+    itself whether N ranks really sat on N different GPUs (`distinct_devices` == N unless --share-gpu)."""
+    me = dict(rank=rank, pid=os.getpid(), **device_identity(dev))
+    seen = [None] * world
+    torch.distributed.all_gather_object(seen, me)
+    ids = {(d['pci'], d['uuid']) if (d['pci'] or d['uuid']) else ('index', d['index']) for d in seen}
+    return {'ranks_seen': sorted(d['rank'] for d in seen), 'distinct_devices': len(ids),
+            'devices': [d['pci'] or d['uuid'] or str(d['index']) for d in sorted(seen, key=lambda d: d['rank'])]}
+
+
 def respawn_one_rank_per_gpu(a):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: become
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` (one process per
@@ -89,7 +111,11 @@ def respawn_one_rank_per_gpu(a):
                  f'(--share-gpu --backend gloo runs the ranks on one GPU for a functional check)')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    os.execv(sys.executable, cmd)
+    env = dict(os.environ)
+    # host threads: N ranks x (all cores) OpenMP threads oversubscribe the host (the optimiser's foreach kernels and the
+    # pinned-memory copies run on them); give each rank its share before torch is imported in the children
+    env.setdefault('OMP_NUM_THREADS', str(host_threads_per_rank(a.gpus)))
+    os.execve(sys.executable, cmd, env)
 
 
 def build_model(name, classes):
@@ -185,6 +211,14 @@ def kernel_rooflines(B, C, HW, dev):
     wsl = torch.empty(nwl, dtype=torch.uint8, device=dev)
     lflops, lbytes = 2.0 * B * J * K, 4.0 * (K * J + B * J + B * K)
     kpad = (K + 15) // 16 * 16 / float(K)
+    # the backward's kernel by the library's own dispatch rule (bcnn_fast.hip bwd_launch: 128-row blocks when they fill
+    # the chip, else 64-row blocks, else the four-wave panel kernel; the generic tiles outside the fast shapes)
+    if C % 64 == 0 and HW in (196, 144, 100, 64):
+        rb = 2 if (C % 128 == 0 and B * (C // 128) >= 192) else (1 if B * nb >= 192 else 0)
+        bwd_name = f'gram_bwd3_kernel<{HW},0,{rb}>' if rb else f'bcnn_bwd_panel_kernel<{HW},0>'
+    else:
+        bwd_name = 'bgemm_kernel (generic tiles: not a fast shape)'
+    gram_name = f'bcnn_gram_panel_kernel<{HW}>' if C % 64 == 0 and HW in (196, 144, 100, 64) else 'bgemm_kernel (generic tiles)'
     stages = [
         ('bcnn_colsum_partial4_kernel + finalize (stage entry point)',
          lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream()),
@@ -192,9 +226,9 @@ def kernel_rooflines(B, C, HW, dev):
         ('hk_bcnn_pool_fwd, whole (two launches: colsum partials + Gram with the norm in its prologue)',
          lambda: lib.hk_bcnn_pool_fwd(ptr(x), ptr(y), ptr(inv), ptr(cs), B, C, HW, ptr(wsc), nwsc, stream()),
          flops, 8.0 * B * C * HW + 4.0 * B * C * C, flops * sym, False),
-        ('bcnn_gram_panel_kernel<196>', lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
+        (gram_name, lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
          flops, 4.0 * B * C * HW + 4.0 * B * C * C, flops * sym, True),
-        ('gram_bwd3_kernel<196,0,2>',
+        (bwd_name,
          lambda: lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream()),
          flops, 8.0 * B * C * C + 8.0 * B * C * HW, None, True),
         ('bcnn_rank1_fix_kernel', lambda: lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream()),
@@ -224,7 +258,7 @@ def pmc_traffic(row_name):
     import csv
     import re
     names = re.findall(r'[a-z][a-z0-9_]*_kernel', row_name)
-    for name in ('r4_pool_kernels_pmc.csv', 'r3_pool_kernels_pmc.csv'):
+    for name in ('r5_pool_kernels_pmc.csv', 'r4_pool_kernels_pmc.csv'):
         try:
             rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', name))))
             total = 0.0
@@ -357,6 +391,15 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    rank_devices = None
+    if world > 1:
+        torch.set_num_threads(min(torch.get_num_threads(), host_threads_per_rank(world)))
+        # the communicator the gradients will cross must span exactly the ranks the metric counts
+        assert torch.distributed.is_initialized() and torch.distributed.get_world_size() == a.gpus == world, \
+            (torch.distributed.get_world_size(), a.gpus, world)
+        rank_devices = gather_rank_devices(rank, world, dev)
+        if not a.share_gpu:
+            assert rank_devices['distinct_devices'] == world, f'{world} ranks on {rank_devices}'
     torch.backends.cudnn.benchmark = bool(a.miopen_find)   # MIOpen find mode: pick the fastest conv algorithm once
     torch.manual_seed(0)
 
@@ -442,7 +485,9 @@ def main():
             ks = kernel_rooflines(a.batch, 512, (a.image // 32) ** 2, dev)
             # the step's longest single hand-written launch sequence (stage entry points and multi-launch sums excluded)
             dom = max((k for k in ks if k['shipped_kernel']), key=lambda k: k['us'])
-            tr_bytes, tr_src = pmc_traffic(dom['kernel'])
+            # (the committed counters were taken at the metric's shape: another shape gets no traffic figure)
+            at_profiled_shape = (a.batch, a.image, a.classes) == (64, 448, 200)
+            tr_bytes, tr_src = pmc_traffic(dom['kernel']) if at_profiled_shape else (None, None)
             res['roofline'] = {'bound': dom['bound'], 'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
                                'frac': dom['frac'], 'traffic': tr_bytes, 'kernel': dom['kernel'][:96], 'us': dom['us'],
                                'flops_algorithmic': dom['flops_algorithmic'], 'flops_executed': dom['flops_executed'],
@@ -459,6 +504,11 @@ def main():
             if tl:       # on the line itself: when each gradient bucket's all-reduce was issued inside the backward (ms since zero_grad)
                 res['ddp'] = {'buckets_mib': detail['ddp_buckets_mib'], 'issued_ms': [b[2] for b in tl['buckets']],
                               'backward_end_ms': tl['backward_end_ms'], 'joined_ms': tl['joined_ms']}
+        if rank_devices is not None:     # who actually ran: ranks, distinct GPUs, backend, host threads per rank
+            res.setdefault('ddp', {}).update(
+                ranks_seen=rank_devices['ranks_seen'], distinct_devices=rank_devices['distinct_devices'],
+                devices=rank_devices['devices'][:8], backend=torch.distributed.get_backend(),
+                comm_size=torch.distributed.get_world_size(), host_threads_per_rank=torch.get_num_threads())
         if world == 1 and not a.no_other_models and a.model == 'BCNN' and not a.force_pg:
             torch.cuda.empty_cache()
             detail['other_models'] = other_models()

@@ -623,8 +623,11 @@ extern "C" int hk_att_pool3_bwd(const float* f0, const float* f1, const float* f
 
 extern "C" int hk_att_pool_bwd(const float* f, const float* a_s, const float* dgap, const float* dsgap, float* df,
                                float* da_s, int B, int C, int HW, hk_stream_t stream) {
-    if (!f || !df || B <= 0 || C <= 0 || HW <= 0 || (!dgap && !dsgap)) return HK_ERR_BAD_ARG;
-    if (!a_s && dgap) {                          // plain GAP: row-parallel broadcast
+    if (!df || B <= 0 || C <= 0 || HW <= 0 || (!dgap && !dsgap)) return HK_ERR_BAD_ARG;
+    // without a spatial gate there is no sgap: only dgap can arrive, and F itself is not needed (f may be NULL)
+    if (!a_s && (!dgap || dsgap)) return HK_ERR_BAD_ARG;
+    if (a_s && !f) return HK_ERR_BAD_ARG;
+    if (!a_s) {                                  // plain GAP: row-parallel broadcast
         const long long rows = (long long)B * C;
         const dim3 grid((unsigned)((rows + 3) / 4));
         if (HW % 4 == 0 && aligned16(df))

@@ -19,7 +19,7 @@ const Knob kKnobs[] = {
     {"ns_tn", "HK_NS_TN", &Tuning::ns_tn},                      {"bwd_v", "HK_BWD_V", &Tuning::bwd_v},
     {"ns_streams", "HK_NS_STREAMS", &Tuning::ns_streams},        {"sched_b", "HK_SCHED_B", &Tuning::sched_b},
     {"ns_sym", "HK_NS_SYM", &Tuning::ns_sym},
-    {"lin_walk", "HK_LIN_WALK", &Tuning::lin_walk},
+    {"lin_walk", "HK_LIN_WALK", &Tuning::lin_walk},           {"bwd_fold", "HK_BWD_FOLD", &Tuning::bwd_fold},
 };
 Tuning from_env() {
     Tuning t;

@@ -32,32 +32,51 @@ namespace hk {
 
 // ----------------------------------------------------------------------------- forward
 // (GramEpi and gram_tile: hk_gram_tile.h)
-// Covariance (CENTER): centre the 64 x HW row panel `p` (LDS) in place and write the 64 row means to mu_out.  Four lanes
-// per row, each sums the float4s q, q + 4, .. of its row in order, then a two-step butterfly: a fixed order, so the
+// Covariance (CENTER): centre the 64 x HW row panel `p` (LDS) in place and write the 64 row means to mu_out.  Sixteen
+// lanes per row (a wave takes four rows at a time, four times): lane q of row r owns the 16-byte slots
+// ((q - r R4) mod 16) + 16 k of the row, k = 0, 1, .. - ROTATED by the row's own start slot, so that the sixteen lanes a
+// ds_read_b128 / the eight lanes a ds_write_b128 serves together always fall on different slots of the 256-byte bank row,
+// whatever the row pitch (round 4: four lanes per row in place, 23.6 % of the kernel's LDS cycles were conflict cycles).
+// Each lane adds its slots in k order, then a four-step butterfly over the row's sixteen lanes: a fixed order, so the
 // means do not depend on which workgroup computes them.  Called between two barriers.
 template <int HW>
 __device__ __forceinline__ void center_panel(float* p, float* __restrict__ mu_out, int tid) {
-    constexpr int R4 = HW / 4;                       // float4 per row
-    constexpr int NK = (R4 + 3) / 4;
-    const int r = tid >> 2, q = tid & 3;
-    f32x4* row = reinterpret_cast<f32x4*>(p + r * HW);
-    f32x4 v[NK];
-    float s = 0.f;
+    constexpr int R4 = HW / 4;                       // 16-byte slots per row
+    constexpr int NK = (R4 + 15) / 16;
+    const int wave = tid >> 6, lane = tid & 63, q = lane & 15, rr = lane >> 4;
+    f32x4 v[4][NK];
+    float s[4];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int f = q + 4 * k;
-        v[k] = f < R4 ? row[f] : (f32x4){0.f, 0.f, 0.f, 0.f};
-        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    const float m = s / (float)HW;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = 16 * wave + 4 * pass + rr;
+        const int q0 = (q - r * R4) & 15;
+        const f32x4* row = reinterpret_cast<const f32x4*>(p + r * HW);
+        s[pass] = 0.f;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int f = q + 4 * k;
-        if (f < R4) row[f] = v[k] - m;
+        for (int k = 0; k < NK; ++k) {
+            const int f = q0 + 16 * k;
+            v[pass][k] = f < R4 ? row[f] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s[pass] += (v[pass][k][0] + v[pass][k][1]) + (v[pass][k][2] + v[pass][k][3]);
+        }
     }
-    if (q == 0) mu_out[r] = m;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = 16 * wave + 4 * pass + rr;
+        const int q0 = (q - r * R4) & 15;
+        float t = s[pass];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        const float m = t / (float)HW;
+        f32x4* row = reinterpret_cast<f32x4*>(p + r * HW);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int f = q0 + 16 * k;
+            if (f < R4) row[f] = v[pass][k] - m;
+        }
+        if (q == 0) mu_out[r] = m;
+    }
 }
 
 // CENTER (covariance, MPNCOV.py:115-117: cov = X Ibar X^T = (1/M) (X - mu 1^T) X^T): the row panel (the A operand) is
@@ -524,6 +543,66 @@ int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* 
     if (C % 64 != 0 || !aligned16(x) || !aligned16(y) || !aligned16(dy) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
     BwdExtra ex = {};
 #define CALL(H) bwd_launch<H, 0>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
+// The BCNN backward in ONE launch (hk_bwd3.h, TK): the rank-1 term folded into the GEMM kernel.
+//   tdot != nullptr: t = <y, dy> is known as sum_k ta[b][k] (tb[b][k] - tc[k]) (TK 1: applied in the epilogue);
+//   else           : last-arriver pass per image (TK 2); tpart [B][C / 64] receives the partial sums.
+// HK_ERR_UNSUPPORTED - nothing launched - where gram_bwd3_kernel does not run (other map sizes, batches whose row blocks
+// do not fill the chip, the bwd_v knob): the caller then takes the two-launch route.
+// Arrival counters of the TK 2 launches: TICKET_SLOTS rows of TICKET_MAXB counters in device memory, zero when the module
+// is loaded and left zero by every launch (atomicInc wraps); consecutive launches take consecutive rows, so that two
+// launches in flight on different queues never share a counter.
+constexpr int TICKET_SLOTS = 32, TICKET_MAXB = 2048;
+__device__ unsigned g_bwd_tickets[TICKET_SLOTS * TICKET_MAXB];
+
+static unsigned* next_ticket_row() {
+    static std::mutex mu;
+    static unsigned* base[32] = {nullptr};
+    static unsigned next = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!base[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_bwd_tickets)) != hipSuccess) return nullptr;
+        base[dev] = (unsigned*)p;
+    }
+    return base[dev] + (size_t)(next++ % TICKET_SLOTS) * TICKET_MAXB;
+}
+
+template <int HW>
+static int bwd_fold_launch(const float* x, const float* y, const float* dy, const float* inv_norm, const float* colsum,
+                           const float* ta, const float* tb, const float* tc, int tK, float* dx, float* tpart, int B, int C,
+                           hipStream_t st) {
+    const int nb = C / 64, Bs = sched_batch(B);
+    const bool fill2 = C % 128 == 0 && (long long)Bs * (C / 128) >= 192;
+    const bool fill1 = (long long)Bs * nb >= 192;
+    if (tuning().bwd_v != 0 || !(fill2 || fill1)) return HK_ERR_UNSUPPORTED;
+    BwdExtra ex = {};
+    ex.colsum = colsum;
+    int rc = HK_ERR_UNSUPPORTED;
+    if (ta) {
+        ex.ta = ta; ex.tb2 = tb; ex.tc = tc; ex.tK = tK;
+        if (fill2) rc = bwd3_launch<HW, 0, 2, 1>(x, y, dy, inv_norm, dx, nullptr, B, C, ex, st);
+        if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, 0, 1, 1>(x, y, dy, inv_norm, dx, nullptr, B, C, ex, st);
+        return rc;
+    }
+    if (B > TICKET_MAXB || !tpart) return HK_ERR_UNSUPPORTED;
+    ex.ticket = next_ticket_row();
+    if (!ex.ticket) return HK_ERR_UNSUPPORTED;
+    if (fill2) rc = bwd3_launch<HW, 0, 2, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
+    if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, 0, 1, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
+    return rc;
+}
+
+int bcnn_fast_bwd_fold(const float* x, const float* y, const float* dy, const float* inv_norm, const float* colsum,
+                       const float* ta, const float* tb, const float* tc, int tK, float* dx, float* tpart, int B, int C,
+                       int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(y) || !aligned16(dy) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+#define CALL(H) bwd_fold_launch<H>(x, y, dy, inv_norm, colsum, ta, tb, tc, tK, dx, tpart, B, C, st)
     HK_HW_SWITCH(CALL)
 #undef CALL
 }

@@ -27,6 +27,9 @@ int bcnn_fast_gram_norm(const float* x, const float* part, int G, float* colsum,
                         int HW, hipStream_t st);
 int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart, int B,
                   int C, int HW, hipStream_t st);
+int bcnn_fast_bwd_fold(const float* x, const float* y, const float* dy, const float* inv_norm, const float* colsum,
+                       const float* ta, const float* tb, const float* tc, int tK, float* dx, float* tpart, int B, int C,
+                       int HW, hipStream_t st);
 int gram_fast_raw(const float* x, float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
 int bcnn_ssqrt_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, const float* tpart, int nt,
                         float* dx, int B, int C, int HW, hipStream_t st);
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void bcnn_rank1_fix_kernel(float* __restrict__
     float* d = dx + (long long)b * per_sample;
     const float* cs = colsum + (long long)b * HW;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < per_sample; e += (long long)gridDim.x * 256)
-        d[e] -= k * cs[e % HW];
+        d[e] = fmaf(-k, cs[e % HW], d[e]);
 }
 
 // ----------------------------------------------------------------------------- signed-sqrt variant (BCNN.py:23-24)
@@ -412,8 +415,51 @@ extern "C" int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy,
                                 hk_stream_t stream) {
     if (!x || !y || !dy || !inv_norm || !colsum || !dx || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_bcnn_pool_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
+    // one launch where the 128- / 64-row GEMM kernel runs: the last workgroup of an image applies the rank-1 term (TK 2)
+    if (!force_generic() && tuning().bwd_fold >= 0) {
+        const int rc1 = bcnn_fast_bwd_fold(x, y, dy, inv_norm, colsum, nullptr, nullptr, nullptr, 0, dx, (float*)ws, B, C, HW,
+                                           (hipStream_t)stream);
+        if (rc1 != HK_ERR_UNSUPPORTED) return rc1;
+    }
     int rc = hk_bcnn_bwd_gemm(x, y, dy, inv_norm, dx, (float*)ws, B, C, HW, stream);
     if (rc != HK_OK) return rc;
+    return hk_bcnn_bwd_rank1(dx, (const float*)ws, inv_norm, colsum, B, C, HW, stream);
+}
+
+// The same with t = <y, dy> handed over as a dot product of two small operands: t[b] = sum_k ta[b][k] (tb[b][k] - tc[k])
+// (tc nullable).  When dy = g W is the input gradient of a linear layer on y, <y, dy> = sum_k g_k (logit_k - bias_k):
+// ta = g, tb = the layer's output, tc = its bias, K its width.  One launch, no second pass over dX, no partial sums in
+// the K loop.  Shapes the fast kernel does not serve: t is formed by a tiny kernel into ws and the two-launch route runs.
+__global__ __launch_bounds__(64) void bcnn_tdot_kernel(const float* __restrict__ ta, const float* __restrict__ tb,
+                                                       const float* __restrict__ tc, float* __restrict__ tpart, int K,
+                                                       int slots) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float p = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const long long o = (long long)b * K + k;
+        p = fmaf(ta[o], tb[o] - (tc ? tc[k] : 0.f), p);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m, 64);
+    for (int i = lane; i < slots; i += 64) tpart[(long long)b * slots + i] = i == 0 ? p : 0.f;
+}
+
+extern "C" int hk_bcnn_pool_bwd_tdot(const float* x, const float* y, const float* dy, const float* inv_norm,
+                                     const float* colsum, const float* ta, const float* tb, const float* tc, int K,
+                                     float* dx, int B, int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    if (!x || !y || !dy || !inv_norm || !colsum || !ta || !tb || !dx || K <= 0 || B <= 0 || C <= 0 || HW <= 0)
+        return HK_ERR_BAD_ARG;
+    if (!ws || ws_bytes < hk_bcnn_pool_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
+    if (!force_generic() && tuning().bwd_fold >= 0) {
+        const int rc1 = bcnn_fast_bwd_fold(x, y, dy, inv_norm, colsum, ta, tb, tc, K, dx, nullptr, B, C, HW, (hipStream_t)stream);
+        if (rc1 != HK_ERR_UNSUPPORTED) return rc1;
+    }
+    // (the GEMM launch below overwrites ws with ITS partial sums of t: they are ignored - the dot product goes in after it)
+    int rc = hk_bcnn_bwd_gemm(x, y, dy, inv_norm, dx, (float*)ws, B, C, HW, stream);
+    if (rc != HK_OK) return rc;
+    const int slots = (C + 63) / 64;
+    hipLaunchKernelGGL(bcnn_tdot_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ta, tb, tc, (float*)ws, K, slots);
+    HK_LAUNCH_CHECK();
     return hk_bcnn_bwd_rank1(dx, (const float*)ws, inv_norm, colsum, B, C, HW, stream);
 }
 

@@ -41,6 +41,13 @@ struct BwdExtra {
     const float* cdy;    // [B][D]  dL/dy
     const float* ccraw;  // [B][D]  bins before the signed square root
     const float* cinv;   // [B]     1 / max(|u|, 1e-12)
+    // BCNN, rank-1 term folded into the GEMM kernel (TK != 0 below)
+    const float* colsum; // [B][HW]  column sums of X (the forward's)
+    const float* ta;     // TK 1: t[b] = sum_k ta[b][k] (tb2[b][k] - tc[k]), tK terms (tc nullable)
+    const float* tb2;
+    const float* tc;
+    int tK;
+    unsigned* ticket;    // TK 2: [>= B] arrival counters of the launch, zero before and after it
 };
 
 // t = <y, dy> of sample b from its partial sums (every workgroup adds them itself, fixed order)
@@ -58,7 +65,17 @@ __device__ __forceinline__ float bwd_t_of(const BwdExtra& ex, int b) {
 // matrix pipe, so the duplicated fragment arithmetic cost ~4 % of a K-block; the price is one ds_read per MFMA instead
 // of one per two.  COEFL: the factor inv^2 / 2M multiplies the accumulators once instead of every fragment element
 // (rounding-level difference from the other backward kernels).
-template <int HW, int MODE, int RB, bool REMV, bool EPI, bool ROWW = false, bool COEFL = false>
+// TK (BCNN only): where the rank-1 term of the backward, dX -= (t inv^2 / M) 1 colsum^T with t = <y, dy>, is applied.
+//   0: not here - the t partials go to tpart and bcnn_rank1_fix_kernel makes a second pass over dX (the stage entry points);
+//   1: t is KNOWN before the launch, as a dot product of two small operands (ex.ta / tb2 / tc): when dy = g W comes out
+//      of a linear layer on y, <y, dy> = sum_k g_k (logit_k - bias_k).  Every workgroup forms t in its prologue (fixed
+//      order) and subtracts its rows' share while the block is copied out: no second pass, no partial sums of y dy in
+//      the K loop (7 VALU ops per fragment quad less next to the MFMAs);
+//   2: t is not known: the workgroups of an image take a ticket when their block and their partial sum are out, and
+//      the LAST to arrive adds the partials (slot order - the same value whoever is last) and makes the pass over the
+//      image's 4 C HW bytes itself, from the L2 they were just written to: one launch less and the 51 MB of the second
+//      kernel's HBM traffic gone.  Nobody waits for anybody: no forward-progress assumption.
+template <int HW, int MODE, int RB, bool REMV, bool EPI, bool ROWW = false, bool COEFL = false, int TK = 0>
 __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy,
                                                            const float* __restrict__ inv_norm, float* __restrict__ dx,
@@ -69,6 +86,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     constexpr bool HAS_Y = MODE == 0 || MODE == 3;
     constexpr bool MUCOL = MODE == 1;
     static_assert(!ROWW || RB == 2, "row-per-wave split: 128-row blocks");
+    static_assert(TK == 0 || (MODE == 0 && EPI && HW % 4 == 0), "rank-1 fold: BCNN, LDS-staged epilogue");
     constexpr int NT = REMV ? HW / 16 : (HW + 15) / 16;   // 16-column MFMA tiles
     constexpr int NH = ROWW ? NT : (NT + 1) / 2;          // tiles of a wave (of the first column half)
     constexpr int RW = ROWW ? 1 : RB;                     // 16-row blocks of a wave
@@ -84,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     constexpr int STAGE = NTILE * T_SZ + X_SZ;
     constexpr int O4 = IB * HW / 4;                       // float4 of the output block
     static_assert(NXP <= 32, "X pieces are dealt to the 8 waves four deep");
-    static_assert(IB * HW + IB <= 2 * STAGE, "the output image + the mu column fit the two stages");
+    static_assert(IB * HW + IB + HW <= 2 * STAGE, "the output image + the mu column + the column sums fit the two stages");
     HK_DYN_LDS16(lds);
 
     int b, I;
@@ -124,6 +142,22 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     float* mus = lds + 2 * STAGE;
     if (MUCOL) {
         for (int e = tid; e < C; e += 512) mus[e] = ex.mu[(long long)b * C + e];
+    }
+    // TK 1: t = sum_k ta[b][k] (tb2[b][k] - tc[k]) by wave 0 - lane l takes k = l, l + 64, .. in order, then a fixed
+    // butterfly - into the word behind the two stages (published by the prologue's barrier)
+    float csr = 0.f;                                            // TK 1: this thread's column sum, fetched here, used in the epilogue
+    if (TK == 1) {
+        if (wave == 0) {
+            float p = 0.f;
+            for (int k = lane; k < ex.tK; k += 64) {
+                const long long o = (long long)b * ex.tK + k;
+                p = fmaf(ex.ta[o], ex.tb2[o] - (ex.tc ? ex.tc[k] : 0.f), p);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m, 64);
+            if (lane == 0) mus[0] = p;
+        }
+        if (tid < HW) csr = ex.colsum[(long long)b * HW + tid];
     }
 
     // ---- this lane's 16 bytes in the pieces its wave issues (32-bit offsets; bases advance with kb)
@@ -181,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             f32x4 d1_ = *reinterpret_cast<const f32x4*>(S1 + sl_);                                             \
             f32x4 yv_ = (f32x4){1.f, 1.f, 1.f, 1.f};                                                           \
             if (HAS_Y) yv_ = *reinterpret_cast<const f32x4*>(Yt + sl_);                                        \
-            if (MODE == 0 && do_t)                                                                             \
+            if (MODE == 0 && do_t && TK != 1)                                                                  \
                 tacc += (yv_[0] * d1_[0] + yv_[1] * d1_[1]) + (yv_[2] * d1_[2] + yv_[3] * d1_[3]);             \
             if (MODE == 3) d1_ -= t2 * yv_;                                                                    \
             const float* s2p_ = S2 + (16 * (s_) + 4 * lq) * IB + ((((row_ >> 2) ^ ((lq & 1) << 2))) << 2) + (row_ & 3); \
@@ -256,6 +290,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
 #pragma unroll
     for (int part = 0; part < 5; ++part) HK_B3_DMA(0, 0, part);
     __syncthreads();
+    const float kfix1 = TK == 1 ? mus[0] * inv_norm[b] * inv_norm[b] / (float)HW : 0.f;      // (bcnn_rank1_fix_kernel's k)
     int kb = 0;
     for (; kb + 2 < nkb; kb += 2) {                                     // steady state, two K-blocks per trip
         HK_B3_KBLOCK(kb, 0, true);
@@ -322,6 +357,8 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             }
             if (MUCOL && do_t && lq == 0) CM[wrow + i * 16 + l15] = mcol[i];
         }
+        float* CS = CM + IB;                                                // [HW] k colsum (TK 1)
+        if (TK == 1 && tid < HW) CS[tid] = kfix1 * csr;
         __syncthreads();
         const f32x4* o4 = reinterpret_cast<const f32x4*>(O);
         f32x4* g4 = reinterpret_cast<f32x4*>(dxb);
@@ -331,6 +368,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             if (f < O4) {
                 f32x4 v = o4[f];
                 if (MUCOL) v -= CM[(4 * f) / HW];
+                if (TK == 1) v -= reinterpret_cast<const f32x4*>(CS)[f % (HW / 4)];
                 g4[f] = v;
             }
         }
@@ -364,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             }
         }
     }
-    if (MODE == 0) {                                           // t partials: C / 64 slots per image (zero-filled for RB = 2)
+    if (MODE == 0 && TK != 1) {                                // t partials: C / 64 slots per image (zero-filled for RB = 2)
         __syncthreads();
         const float tsum = block_sum<8>(tacc, lds);
         if (tid == 0) {
@@ -376,17 +414,56 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             }
         }
     }
+    if (TK == 2) {
+        // this block of dX and this partial sum are out (release), then the ticket; the last of the image's nI workgroups
+        // sees everybody's (acquire) and finishes the image.  atomicInc wraps at nI - 1: the counter is zero again.
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) lds[16] = __builtin_bit_cast(float, atomicInc(ex.ticket + b, (unsigned)(nI - 1)));
+        __syncthreads();
+        if (__builtin_bit_cast(unsigned, lds[16]) != (unsigned)(nI - 1)) return;
+        __threadfence();
+        const int nslot = RB == 2 ? 2 * nI : nI;
+        float t = 0.f;
+        for (int i = 0; i < nslot; ++i) t += tpart[(long long)b * nslot + i];        // (bcnn_rank1_fix_kernel's order)
+        const float in = inv_norm[b];
+        const float kf = t * in * in / (float)HW;
+        float* CS = lds + 32;
+        if (tid < HW) CS[tid] = ex.colsum[(long long)b * HW + tid];
+        __syncthreads();
+        f32x4* d4 = reinterpret_cast<f32x4*>(dx + (long long)b * C * HW);
+        const int n4 = C * (HW / 4);
+        constexpr int UN = 7;                                   // 16-byte loads in flight per thread
+        for (int f0 = tid; f0 < n4; f0 += 512 * UN) {
+            f32x4 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int f = f0 + 512 * u;
+                v[u] = d4[f < n4 ? f : n4 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int f = f0 + 512 * u;
+                if (f < n4) {
+                    const f32x4 c4 = reinterpret_cast<const f32x4*>(CS)[f % (HW / 4)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = fmaf(-kf, c4[e], v[u][e]);
+                    d4[f] = v[u];
+                }
+            }
+        }
+    }
 }
 
 template <int HW, int MODE, int RB>
 static inline size_t bwd3_lds_bytes(int C) {
     constexpr int nxp = (32 * HW / 4 + 63) / 64;
     constexpr int ntile = (MODE == 0 || MODE == 3) ? 3 : 2;
-    return ((size_t)2 * (ntile * 64 * RB * 32 + nxp * 256) + (MODE == 1 ? (size_t)C : 0)) * sizeof(float);
+    return ((size_t)2 * (ntile * 64 * RB * 32 + nxp * 256) + (MODE == 1 ? (size_t)C : 4)) * sizeof(float);
 }
 
 // HK_ERR_UNSUPPORTED unless C % (64 RB) == 0 and the operands are 16-byte aligned (the caller then takes another kernel).
-template <int HW, int MODE, int RB>
+template <int HW, int MODE, int RB, int TK = 0>
 static int bwd3_launch(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart,
                        int B, int C, const BwdExtra& ex, hipStream_t st) {
     if (C % (64 * RB) != 0 || (long long)C * C >= (1ll << 31) || !aligned16(x) || !aligned16(dy) || !aligned16(dx) ||
@@ -401,8 +478,8 @@ static int bwd3_launch(const float* x, const float* y, const float* dy, const fl
     // measured - 71.5 -> 66.9 -> 65.3 -> 64.1 us at B = 64, C = 512, 14 x 14)
     constexpr bool REM = HW % 16 == 4;
     constexpr bool ROWW = REM && RB == 2;
-    HK_ALLOW_BIG_LDS((&gram_bwd3_kernel<HW, MODE, RB, REM, true, ROWW, ROWW>), lds);
-    hipLaunchKernelGGL((gram_bwd3_kernel<HW, MODE, RB, REM, true, ROWW, ROWW>), grid, dim3(512), lds, st, x, y, dy, inv_norm, dx,
+    HK_ALLOW_BIG_LDS((&gram_bwd3_kernel<HW, MODE, RB, REM, true, ROWW, ROWW, TK>), lds);
+    hipLaunchKernelGGL((gram_bwd3_kernel<HW, MODE, RB, REM, true, ROWW, ROWW, TK>), grid, dim3(512), lds, st, x, y, dy, inv_norm, dx,
                        tpart, C, nI, B, ex);
     HK_LAUNCH_CHECK();
     return HK_OK;

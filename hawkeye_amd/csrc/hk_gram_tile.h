@@ -52,8 +52,8 @@ struct GramEpi {
             *reinterpret_cast<f32x4*>(o + 8ll * C) = t1;
         }
         if ((s == 10 || s == 12) && offdiag) {                    // mirrored: rows j0 + .., columns i0 + 16 h ..
-            const int h = (s - 10) >> 1;
-            float* o = yb + (long long)(j0 + (lane >> 2)) * C + i0 + 16 * h + 4 * (lane & 3);
+            const int h = (s - 10) >> 1;                          // (the piece this lane read back is slot msw of its row)
+            float* o = yb + (long long)(j0 + (lane >> 2)) * C + i0 + 16 * h + 4 * ((lane & 3) ^ ((lane >> 3) & 3));
             *reinterpret_cast<f32x4*>(o) = t0;
             *reinterpret_cast<f32x4*>(o + 16ll * C) = t1;
         }
@@ -69,11 +69,18 @@ struct GramEpi {
             t1 = *reinterpret_cast<const f32x4*>(stg + (8 + (lane >> 3)) * 32 + 4 * (lane & 7));
         }
         if ((s == 8 || s == 10) && offdiag) {                     // T[column l31][row 8 g + 4 lh + t - 16 h]
+            // A row of T is 64 bytes = four 16-byte slots; a ds_write_b128 is served in groups of 8 consecutive lanes and
+            // its banks repeat every 128 bytes, so with the slots in place lanes l31 = 0, 2, 4, 6 of a group landed on the
+            // same four banks (4-way: 17 % of the kernel's LDS cycles were conflict cycles, round 4).  Slot k of row l31
+            // is kept at k ^ ((l31 >> 1) & 3): the eight lanes of a group cover eight different slots of a bank row; the
+            // linear read-back below stays conflict-free (a row's four slots are permuted among themselves) and the
+            // store above undoes the permutation in its column offset.
             const int h = (s - 8) >> 1;
+            const int sw = (l31 >> 1) & 3;
             HK_WAVE_SYNC();
 #pragma unroll
             for (int g = 0; g < 2; ++g)
-                *reinterpret_cast<f32x4*>(stg + l31 * 16 + 8 * g + 4 * lh) =
+                *reinterpret_cast<f32x4*>(stg + l31 * 16 + 4 * ((2 * g + lh) ^ sw)) =
                     (f32x4){p[8 * h + 4 * g], p[8 * h + 4 * g + 1], p[8 * h + 4 * g + 2], p[8 * h + 4 * g + 3]};
             HK_WAVE_SYNC();
         }

@@ -192,7 +192,10 @@ static int linear_bwd_impl(const float* y, const float* w, const float* g, const
     hipStream_t st = (hipStream_t)stream;
     // wide classifier, up to 64 samples and 208 classes: both products in one launch of linear_bwd64_kernel (the knob
     // linear_slabs = -1 keeps the generic tiles)
-    if (B <= 64 && K <= 208 && J % 64 == 0 && (long long)J >= 16384 && (long long)K * J < (1ll << 30) && (dy || dw) &&
+    // (the kernels address W / dW [K][J] and y / dy [B][J] through 32-bit byte offsets of buffer descriptors: both must
+    //  stay below 2^30 elements - a wider problem takes the generic tiles)
+    if (B <= 64 && K <= 208 && J % 64 == 0 && (long long)J >= 16384 && (long long)K * J < (1ll << 30) &&
+        (long long)B * J < (1ll << 30) && (dy || dw) &&
         tuning().linear_slabs >= 0 && aligned16(y) && aligned16(w) && aligned16(dy) && aligned16(dw)) {
         const int nchunk = J / 64;
         const int CPS = (nchunk + 255) / 256, S = (nchunk + CPS - 1) / CPS;      // one workgroup per CU
@@ -221,7 +224,8 @@ static int linear_bwd_impl(const float* y, const float* w, const float* g, const
     }
     if (row_scale) return HK_ERR_UNSUPPORTED;
     // up to 16 samples, up to 1024 outputs (OSME): linear_bwd16_kernel, a pure stream of W / dW
-    if (B <= 16 && K <= 1024 && K >= 256 && J % 64 == 0 && (long long)J >= 16384 && (dy || dw) && tuning().linear_slabs >= 0 &&
+    if (B <= 16 && K <= 1024 && K >= 256 && J % 64 == 0 && (long long)J >= 16384 && (long long)K * J < (1ll << 30) &&
+        (long long)B * J < (1ll << 30) && (dy || dw) && tuning().linear_slabs >= 0 &&
         aligned16(y) && aligned16(w) && aligned16(dy) && aligned16(dw)) {
         const int nchunk = J / 64;
         const int CPS = (nchunk + 255) / 256, S = (nchunk + CPS - 1) / CPS;

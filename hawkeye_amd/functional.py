@@ -550,8 +550,9 @@ class _OsmeGap(torch.autograd.Function):
         n, c, h, w = ctx.shape
         dz = _f32c(dz)
         dx = torch.empty(n, c, h, w, dtype=torch.float32, device=dz.device)
-        # dx[b,c,:] = dz[b,c] / HW: the row-parallel GAP backward of the attention pooling (one launch; f is not read)
-        check(lib.hk_att_pool_bwd(ptr(dx), None, ptr(dz), None, ptr(dx), None, n, c, h * w, stream()), 'hk_att_pool_bwd')
+        # dx[b,c,:] = dz[b,c] / HW: the row-parallel GAP backward of the attention pooling (one launch; without a gate
+        # the entry point takes no F)
+        check(lib.hk_att_pool_bwd(None, None, ptr(dz), None, ptr(dx), None, n, c, h * w, stream()), 'hk_att_pool_bwd')
         return dx
 
 
@@ -796,6 +797,67 @@ class _SsqrtPoolLinear(torch.autograd.Function):
             check(lib.hk_bcnn_ssqrt_pool_bwd_unscaled(ptr(x), ptr(u), ptr(dy), ptr(inv_norm), ptr(dx), b, c, hw, ptr(ws), nws,
                                                       stream()), 'hk_bcnn_ssqrt_pool_bwd_unscaled')
         return dx, dw, db
+
+
+class _BilinearPoolLinear(torch.autograd.Function):
+    """BilinearPooling + the classifier on it (model/methods/BCNN.py:13-27 + :54) as ONE autograd node.  Forward: the two
+    entry points back to back (the l2 scale is already free in the Gram epilogue: nothing to fold).  Backward: because
+    dy = g W is produced here, the inner product <y, dy> that F.normalize's backward needs is known in closed form,
+        t[b] = sum_j y[b,j] sum_k g[b,k] W[k,j] = sum_k g[b,k] (logits[b,k] - bias[k]),
+    so hk_bcnn_pool_bwd_tdot runs the Gram backward as one launch with the rank-1 term applied while dX is written -
+    no partial sums of y * dy, no second pass over dX."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x, weight = _f32c(x), _f32c(weight)
+        b, c, h, w = x.shape
+        hw, j, k = h * w, c * c, weight.shape[0]
+        if weight.shape[1] != j:
+            raise _lib.HawkeyeHipError(f'bilinear_pool_linear: weight {tuple(weight.shape)} does not match {c} x {c} pooled features')
+        y = torch.empty(b, j, dtype=torch.float32, device=x.device)
+        inv_norm = torch.empty(b, dtype=torch.float32, device=x.device)
+        colsum = torch.empty(b, hw, dtype=torch.float32, device=x.device)
+        nws = lib.hk_bcnn_pool_ws_bytes(b, c, hw)
+        ws = _ws(nws, x.device)
+        check(lib.hk_bcnn_pool_fwd(ptr(x), ptr(y), ptr(inv_norm), ptr(colsum), b, c, hw, ptr(ws), nws, stream()),
+              'hk_bcnn_pool_fwd')
+        bias_c = _f32c(bias) if bias is not None else None
+        out = torch.empty(b, k, dtype=torch.float32, device=x.device)
+        nwl = lib.hk_linear_ws_bytes(b, j, k)
+        wsl = _ws(nwl, x.device)
+        check(lib.hk_linear_fwd(ptr(y), ptr(weight), ptr(bias_c), ptr(out), b, j, k, ptr(wsl), nwl, stream()), 'hk_linear_fwd')
+        ctx.save_for_backward(x, y, inv_norm, colsum, weight, bias_c if bias_c is not None else x.new_empty(0), out)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, y, inv_norm, colsum, weight, bias_c, out = ctx.saved_tensors
+        g = _f32c(g)
+        b, c, h, w = x.shape
+        hw, j, k = h * w, c * c, weight.shape[0]
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dy = torch.empty_like(y) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(k, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if dy is not None or dw is not None or db is not None:
+            check(lib.hk_linear_bwd(ptr(y), ptr(weight), ptr(g), ptr(dy), ptr(dw), ptr(db), b, j, k, stream()), 'hk_linear_bwd')
+        dx = None
+        if need_x:
+            dx = torch.empty_like(x)
+            nws = lib.hk_bcnn_pool_ws_bytes(b, c, hw)
+            ws = _ws(nws, x.device)
+            check(lib.hk_bcnn_pool_bwd_tdot(ptr(x), ptr(y), ptr(dy), ptr(inv_norm), ptr(colsum), ptr(g), ptr(out),
+                                            ptr(bias_c) if ctx.has_bias else None, k, ptr(dx), b, c, hw, ptr(ws), nws,
+                                            stream()), 'hk_bcnn_pool_bwd_tdot')
+        return dx, dw, db
+
+
+def bilinear_pool_linear(x, weight, bias=None):
+    """x [B,C,h,w] -> logits [B,K] = Linear(BilinearPooling(x)) (BCNN.py:13-27,54) as one node: see _BilinearPoolLinear."""
+    return _BilinearPoolLinear.apply(x, weight, bias)
 
 
 def ssqrt_pool_linear(x, weight, bias=None):

@@ -9,7 +9,7 @@ import torch.nn as nn
 from ... import functional as HF
 from ..backbone import vgg16
 from ..registry import MODEL
-from ..utils import initialize_weights, wide_linear
+from ..utils import initialize_weights, pooled_classifier
 
 
 FEATURE_CHANNELS = 512          # VGG-16 conv5_3 width: the bilinear descriptor has 512 x 512 entries
@@ -59,6 +59,7 @@ class BCNN(nn.Module):
         feats = self.backbone(x)
         if self.stage == 1:
             feats = feats.detach()
-        if self.bilinear_pooling.signed_sqrt:     # pooling + classifier with the l2 scale folded into the classifier
-            return HF.ssqrt_pool_linear(feats, self.classifier.weight, self.classifier.bias)
-        return wide_linear(self.classifier, self.bilinear_pooling(feats))
+        # pooling + classifier as one autograd node (model/utils.py::pooled_classifier): the classifier's backward knows
+        # <y, dy>, so the pooling's backward is one launch; `self.bilinear_pooling` stays the parameter-free module the
+        # reference has (and what PeerLearningNet / user code may call on its own)
+        return pooled_classifier(self, feats)

@@ -51,3 +51,17 @@ def wide_linear(layer, x):
     initialisers and optimiser groups are untouched.  There is no switch back to the library GEMMs."""
     from .. import functional as F        # hawkeye_amd.functional
     return F.linear(x, layer.weight, layer.bias)
+
+
+def pooled_classifier(model, feats):
+    """`model.classifier(model.bilinear_pooling(feats))` (model/methods/BCNN.py:53-54) as ONE autograd node of two kernels
+    each way: the default sqrt(G + 1e-5) pooling with the classifier behind it - whose backward hands <y, dy> to the Gram
+    backward in closed form (hk_bcnn_pool_bwd_tdot: one launch, no second pass over dX) - or, for
+    BilinearPooling(signed_sqrt=True), the reference's commented alternative (BCNN.py:23-24) with the l2 scale folded
+    into the classifier.  The modules stay what the reference has - `bilinear_pooling` parameter-free and
+    callable on its own, `classifier` an nn.Linear holding the parameters."""
+    from .. import functional as F
+    layer = model.classifier
+    if model.bilinear_pooling.signed_sqrt:
+        return F.ssqrt_pool_linear(feats, layer.weight, layer.bias)
+    return F.bilinear_pool_linear(feats, layer.weight, layer.bias)

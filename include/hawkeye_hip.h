@@ -85,6 +85,14 @@ int hk_bcnn_pool_fwd(const float* x, float* y, float* inv_norm, float* colsum, i
 int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm,
                      const float* colsum, float* dx, int B, int C, int HW, void* ws, size_t ws_bytes,
                      hk_stream_t stream);
+/* The same backward when dy is the input gradient of a linear layer ON y (BCNN.py:54: logits = classifier(y)), i.e.
+ * dy = g W: the inner product t = <y, dy> the normalisation's backward needs (autograd of F.normalize, BCNN.py:26) is then
+ *     t[b] = sum_k ta[b,k] * (tb[b,k] - tc[k])          ta = g [B,K], tb = logits [B,K], tc = bias [K] (nullable)
+ * - B*K multiply-adds instead of a pass over the 2 x 4 C^2 bytes per image of y and dy: one launch, the rank-1 term applied
+ * while dX is written.  Any (ta, tb, tc) with that property may be passed; with another it computes dX for THAT t. */
+int hk_bcnn_pool_bwd_tdot(const float* x, const float* y, const float* dy, const float* inv_norm,
+                          const float* colsum, const float* ta, const float* tb, const float* tc, int K,
+                          float* dx, int B, int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream);
 
 /* Signed-sqrt variant - the second normalisation the reference keeps (commented out) next to the one it runs:
  *     G = X X^T / HW ; u = sign(G) sqrt(|G| + 1e-10) ; y = u / max(|u|_2, 1e-12)
@@ -222,7 +230,8 @@ int hk_cbp_bwd(const float* x, const void* plan, const float* y, const float* c_
  */
 int hk_att_pool_fwd(const float* f, const float* a_s, float* gap, float* sgap, int B, int C, int HW,
                     hk_stream_t stream);
-/* df [B,C,HW] = (dsgap*a_s + dgap)/HW ; da_s [B,HW] = sum_c dsgap*F / HW (nullable with a_s) */
+/* df [B,C,HW] = (dsgap*a_s + dgap)/HW ; da_s [B,HW] = sum_c dsgap*F / HW (nullable with a_s).
+ * a_s == NULL (plain GAP backward, df = dgap / HW): dsgap must be NULL too and f is not read (may be NULL). */
 int hk_att_pool_bwd(const float* f, const float* a_s, const float* dgap, const float* dsgap, float* df,
                     float* da_s, int B, int C, int HW, hk_stream_t stream);
 

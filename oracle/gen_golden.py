@@ -354,14 +354,15 @@ def gen_keys():
         'APCNN_8142': M_AP.resnet50(8142),
         'OSMENet': MODEL.get('OSMENet')(CN(dict(num_attention=2, num_classes=200))),
     }
-    keys = {}
+    keys_path = os.path.join(OUT, 'state_dict_keys.json')
+    keys = json.load(open(keys_path)) if os.path.isfile(keys_path) else {}       # (gen_cin_model adds its own entry: keep it)
     for name, m in models.items():
         keys[name] = {
             'state_dict': [[k, list(v.shape)] for k, v in m.state_dict().items()],
             'children': [n for n, _ in m.named_children()],
             'n_params': sum(p.numel() for p in m.parameters()),
         }
-    with open(os.path.join(OUT, 'state_dict_keys.json'), 'w') as f:
+    with open(keys_path, 'w') as f:
         json.dump(keys, f)
     print('wrote state_dict_keys.json', {k: len(v['state_dict']) for k, v in keys.items()})
     return models

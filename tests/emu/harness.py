@@ -45,21 +45,38 @@ def _torch_wide_linear(layer, x):
     return layer(x)
 
 
-def set_wide_linear(kernel):
-    """Test lever: the plugins' classifier on the kernels (True: hawkeye_amd.model.utils.wide_linear, the product's only
-    path) or on torch's nn.Linear (False: the yardstick some tests compare against).  Returns the previous bindings for
-    restore_wide_linear()."""
+def _torch_pooled_classifier(model, feats):
+    return model.classifier(model.bilinear_pooling(feats))
+
+
+def _unfused_pooled_classifier(model, feats):
     from hawkeye_amd.model.utils import wide_linear
+    return wide_linear(model.classifier, model.bilinear_pooling(feats))
+
+
+def set_wide_linear(kernel, fused=True):
+    """Test lever: the plugins' classifier on the kernels (True: hawkeye_amd.model.utils.wide_linear / pooled_classifier,
+    the product's only path) or on torch's nn.Linear (False: the yardstick some tests compare against).  fused=False (with
+    kernel=True): BCNN's pooling and classifier as two autograd nodes (the round-4 composition) instead of the fused
+    node - the pooled vector is then visible to module hooks.  Returns the previous bindings for restore_wide_linear()."""
+    from hawkeye_amd.model.utils import wide_linear
+    from hawkeye_amd.model.utils import pooled_classifier
     plugs = _plugin_modules()
-    saved = [m.wide_linear for m in plugs]
+    saved = [(getattr(m, 'wide_linear', None), getattr(m, 'pooled_classifier', None)) for m in plugs]
     for m in plugs:
-        m.wide_linear = wide_linear if kernel else _torch_wide_linear
+        if hasattr(m, 'wide_linear'):
+            m.wide_linear = wide_linear if kernel else _torch_wide_linear
+        if hasattr(m, 'pooled_classifier'):
+            m.pooled_classifier = (pooled_classifier if fused else _unfused_pooled_classifier) if kernel else _torch_pooled_classifier
     return saved
 
 
 def restore_wide_linear(saved):
-    for m, f in zip(_plugin_modules(), saved):
-        m.wide_linear = f
+    for m, (f, g) in zip(_plugin_modules(), saved):
+        if f is not None:
+            m.wide_linear = f
+        if g is not None:
+            m.pooled_classifier = g
 
 
 @contextlib.contextmanager
@@ -70,13 +87,9 @@ def emulated():
     # the plugins route their wide classifier through hk_linear_fwd / bwd; emulating a 262144-feature GEMM takes
     # minutes, so whole-model cases run `layer(x)` (torch CPU) here unless a test puts the real wide_linear back
     # (torch_classifier() below does the same for a GPU test that wants the library as its yardstick)
-    plugs = _plugin_modules()
-    wl_saved = [m.wide_linear for m in plugs]
-    for m in plugs:
-        m.wide_linear = _torch_wide_linear
+    wl_saved = set_wide_linear(False)
     try:
         yield F
     finally:
         _lib._lib, F.ptr, F.stream, F._on = saved
-        for m, f in zip(plugs, wl_saved):
-            m.wide_linear = f
+        restore_wide_linear(wl_saved)

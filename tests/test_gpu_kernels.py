@@ -83,6 +83,45 @@ def test_backward_bwd3_kernel(F, b, c, hw, tune):
         assert rel(res[name][0], xo.grad) < 2e-5 and rel(res[name][1], xc.grad) < 1e-5, name
 
 
+@pytest.mark.parametrize('b,c,hw,k,bias', [(2, 128, 14, 7, True), (3, 256, 10, 20, True), (2, 64, 14, 70, False), (3, 192, 12, 5, True),
+                                           (2, 256, 8, 13, True), (2, 512, 14, 200, True)])
+def test_bcnn_backward_in_one_launch(F, b, c, hw, k, bias, tune):
+    """The BCNN backward with the rank-1 term folded into gram_bwd3_kernel (hk_bwd3.h, TK):
+      * hk_bcnn_pool_bwd = ONE launch (TK 2: the last workgroup of an image adds the partial sums of <y, dy> in slot order
+        and makes the pass over the image's dX itself) - bit-identical to the two-launch route (bwd_fold = -1: GEMM kernel
+        + bcnn_rank1_fix_kernel), whichever workgroup arrives last;
+      * hk_bcnn_pool_bwd_tdot (TK 1; F.bilinear_pool_linear: pooling + classifier as one autograd node): <y, dy> taken as
+        sum_k g_k (logit_k - bias_k) - equal to the two-node composition up to the rounding of that scalar - and the
+        classifier's own gradients and the logits bit-identical to it;
+    in the 128-row and the 64-row form of the kernel (sched_b), and where the kernel does not run (small batch: the
+    two-launch fallbacks inside both entry points)."""
+    gen = torch.Generator().manual_seed(3 * c + hw + k)
+    x = torch.relu(torch.randn(b, c, hw, hw, generator=gen)).to(DEV)
+    w = (torch.randn(k, c * c, generator=gen) * 0.05).to(DEV)
+    bs = (torch.randn(k, generator=gen) * 0.1).to(DEV) if bias else None
+    tgt = torch.randint(0, k, (b,), generator=gen).to(DEV)
+    fb = _fill_batches(c)
+    for form, sb in [('small', 0)] + [(f_, fb[f_]) for f_ in ('rows128', 'rows64') if f_ in fb]:
+        tune('sched_b', sb)
+        res = {}
+        for name, fold, fused in (('two', -1, False), ('ticket', 0, False), ('tdot', 0, True)):
+            tune('bwd_fold', fold)
+            xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            bg = bs.clone().requires_grad_(True) if bias else None
+            out = F.bilinear_pool_linear(xg, wg, bg) if fused else F.linear(F.bilinear_pool(xg), wg, bg)
+            torch.nn.functional.cross_entropy(out, tgt).backward()
+            res[name] = (out.detach().clone(), xg.grad.clone(), wg.grad.clone(), bg.grad.clone() if bias else None)
+        assert torch.equal(res['ticket'][1], res['two'][1]), form                      # last-arriver pass: the same bits
+        for i in (0, 2) + ((3,) if bias else ()):
+            assert torch.equal(res['tdot'][i], res['two'][i]), (form, i)               # logits, dW, db
+        e = rel(res['tdot'][1], res['two'][1])
+        assert e < 2e-6, (form, e)
+        xo = x.detach().cpu().clone().requires_grad_(True)
+        yo = torch.nn.functional.linear(O.bilinear_pool(xo), w.cpu(), bs.cpu() if bias else None)
+        torch.nn.functional.cross_entropy(yo, tgt.cpu()).backward()
+        assert rel(res['tdot'][1], xo.grad) < 2e-5 and rel(res['ticket'][1], xo.grad) < 2e-5, form
+
+
 @pytest.mark.parametrize('b,c,hw,d', [(2, 128, 14, 2048), (3, 256, 10, 1000), (2, 64, 14, 96), (2, 256, 8, 6000), (3, 128, 12, 500)])
 def test_cbp_backward_bwd3c_kernel(F, b, c, hw, d, tune):
     """cbp_bwd3_kernel (hk_bwd3c.h) - the compact-bilinear backward GEMM with P generated from dc in LDS - in its three
@@ -717,7 +756,7 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
     runs = []
     from emu.harness import restore_wide_linear, set_wide_linear
     for flag in ('0', '0', '1'):
-        saved_wl = set_wide_linear(flag == '1')
+        saved_wl = set_wide_linear(flag == '1', fused=False)       # (two nodes: the pooled vector is visible to the hook)
         m.zero_grad()
         y = m(x)
         assert rel(y, g[name]) < 1e-4 and y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
@@ -757,6 +796,27 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
         assert direct_f < max(1e-3, 2e4 * d01), (direct_f, d01)
     # the trunk (MIOpen): no gross disagreement; what linear propagation explains is printed above
     assert direct < max(50 * noise, 2e-2), (direct, noise, resid)
+    if name == 'BCNN':
+        # the product's path: pooling + classifier as ONE node (model/utils.py::pooled_classifier), whose backward takes
+        # t = <y, dy> = sum_k g_k (logit_k - bias_k) instead of adding up y * dy (hk_bcnn_pool_bwd_tdot).  Same logits bit
+        # for bit, same classifier gradients bit for bit, and the gradient at the feature map equal to the two-node
+        # composition's up to the rounding of t.
+        fk = []
+        hb = m.backbone.register_forward_hook(lambda _m, _i, o: (o.retain_grad(), fk.append(o))[0])
+        outs = []
+        for fused in (False, True):
+            saved_wl = set_wide_linear(True, fused=fused)
+            m.zero_grad()
+            y = m(x)
+            torch.nn.functional.cross_entropy(y, target).backward()
+            outs.append((y.detach().clone(), m.classifier.weight.grad.clone(), fk[-1].grad.clone()))
+            restore_wide_linear(saved_wl)
+        hb.remove()
+        (y_u, cw_u, f_u), (y_f, cw_f, f_f) = outs
+        assert torch.equal(y_u, y_f) and torch.equal(cw_u, cw_f)
+        ef = rel(f_f, f_u)
+        print(f'[fused pool + classifier] feature-map gradient, one node vs two: {ef:.2e}')
+        assert ef < 1e-5, ef
 
 
 def test_cin_model_matches_reference(F):

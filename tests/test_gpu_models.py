@@ -432,6 +432,11 @@ def test_bench_spawns_its_own_ranks(tmp_path, world):
     d = out['ddp']                             # bucket 0 (the classifier: last layer, first gradient) goes out before backward ends
     assert d['buckets_mib'][0] > d['buckets_mib'][-1] or len(d['buckets_mib']) == 1
     assert d['issued_ms'][0] is not None and d['issued_ms'][0] <= d['backward_end_ms'] <= d['joined_ms']
+    # who ran: every rank reported in, the communicator spans them, and (here: --share-gpu) they sat on ONE device -
+    # on the scaling node the same keys must read distinct_devices == world, which bench.py asserts by itself
+    assert d['ranks_seen'] == list(range(world)) and d['comm_size'] == world and d['backend'] == 'gloo'
+    assert d['distinct_devices'] == 1 and len(d['devices']) == min(world, 8)
+    assert 1 <= d['host_threads_per_rank'] <= max(1, (os.cpu_count() or 1) // world)
 
 
 def test_trainer_runs_one_synthetic_epoch(tmp_path):

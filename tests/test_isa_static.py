@@ -62,7 +62,8 @@ def test_gram_forward_leaves_in_16_byte_stores_and_never_spills(tmp_path):
         seen += 1
         assert 'scratch_' not in body, m.group(1)
         assert len(re.findall(r'global_store_dwordx4', body)) >= 16, m.group(1)
-        # the only narrow stores: the norm / colsum / partial-norm words of the prologue and tail (not y)
-        assert len(re.findall(r'global_store_dword ', body)) <= 3, m.group(1)
+        # the only narrow stores: the norm / colsum / partial-norm words of the prologue and tail (not y); the centred
+        # (covariance) instance also writes its channel means, four rows per wave and call site of center_panel
+        assert len(re.findall(r'global_store_dword ', body)) <= (3 if m.group(4) == '0' else 16), m.group(1)
         assert int(re.search(r'group_segment_fixed_size (\d+)', body).group(1)) <= 160 * 1024, m.group(1)
     assert seen == 16                                              # 4 map sizes x (BCNN, signed sqrt, covariance centred / raw)
