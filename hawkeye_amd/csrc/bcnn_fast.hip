@@ -547,35 +547,13 @@ int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* 
 #undef CALL
 }
 
-// The BCNN backward in ONE launch (hk_bwd3.h, TK): the rank-1 term folded into the GEMM kernel.
-//   tdot != nullptr: t = <y, dy> is known as sum_k ta[b][k] (tb[b][k] - tc[k]) (TK 1: applied in the epilogue);
-//   else           : last-arriver pass per image (TK 2); tpart [B][C / 64] receives the partial sums.
-// HK_ERR_UNSUPPORTED - nothing launched - where gram_bwd3_kernel does not run (other map sizes, batches whose row blocks
-// do not fill the chip, the bwd_v knob): the caller then takes the two-launch route.
-// Arrival counters of the TK 2 launches: TICKET_SLOTS rows of TICKET_MAXB counters in device memory, zero when the module
-// is loaded and left zero by every launch (atomicInc wraps); consecutive launches take consecutive rows, so that two
-// launches in flight on different queues never share a counter.
-constexpr int TICKET_SLOTS = 32, TICKET_MAXB = 2048;
-__device__ unsigned g_bwd_tickets[TICKET_SLOTS * TICKET_MAXB];
-
-static unsigned* next_ticket_row() {
-    static std::mutex mu;
-    static unsigned* base[32] = {nullptr};
-    static unsigned next = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!base[dev]) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_bwd_tickets)) != hipSuccess) return nullptr;
-        base[dev] = (unsigned*)p;
-    }
-    return base[dev] + (size_t)(next++ % TICKET_SLOTS) * TICKET_MAXB;
-}
-
+// The BCNN backward in ONE launch (hk_bwd3.h, TK 1): t = <y, dy> is known as sum_k ta[b][k] (tb[b][k] - tc[k]) and the
+// rank-1 term is applied in the GEMM kernel's epilogue.  HK_ERR_UNSUPPORTED - nothing launched - where gram_bwd3_kernel
+// does not run (other map sizes, batches whose row blocks do not fill the chip, the bwd_v knob): the caller then takes
+// the two-launch route.
 template <int HW>
 static int bwd_fold_launch(const float* x, const float* y, const float* dy, const float* inv_norm, const float* colsum,
-                           const float* ta, const float* tb, const float* tc, int tK, float* dx, float* tpart, int B, int C,
+                           const float* ta, const float* tb, const float* tc, int tK, float* dx, int B, int C,
                            hipStream_t st) {
     const int nb = C / 64, Bs = sched_batch(B);
     const bool fill2 = C % 128 == 0 && (long long)Bs * (C / 128) >= 192;
@@ -583,26 +561,18 @@ static int bwd_fold_launch(const float* x, const float* y, const float* dy, cons
     if (tuning().bwd_v != 0 || !(fill2 || fill1)) return HK_ERR_UNSUPPORTED;
     BwdExtra ex = {};
     ex.colsum = colsum;
+    ex.ta = ta; ex.tb2 = tb; ex.tc = tc; ex.tK = tK;
     int rc = HK_ERR_UNSUPPORTED;
-    if (ta) {
-        ex.ta = ta; ex.tb2 = tb; ex.tc = tc; ex.tK = tK;
-        if (fill2) rc = bwd3_launch<HW, 0, 2, 1>(x, y, dy, inv_norm, dx, nullptr, B, C, ex, st);
-        if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, 0, 1, 1>(x, y, dy, inv_norm, dx, nullptr, B, C, ex, st);
-        return rc;
-    }
-    if (B > TICKET_MAXB || !tpart) return HK_ERR_UNSUPPORTED;
-    ex.ticket = next_ticket_row();
-    if (!ex.ticket) return HK_ERR_UNSUPPORTED;
-    if (fill2) rc = bwd3_launch<HW, 0, 2, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
-    if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, 0, 1, 2>(x, y, dy, inv_norm, dx, tpart, B, C, ex, st);
+    if (fill2) rc = bwd3_launch<HW, 0, 2, 1>(x, y, dy, inv_norm, dx, nullptr, B, C, ex, st);
+    if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, 0, 1, 1>(x, y, dy, inv_norm, dx, nullptr, B, C, ex, st);
     return rc;
 }
 
 int bcnn_fast_bwd_fold(const float* x, const float* y, const float* dy, const float* inv_norm, const float* colsum,
-                       const float* ta, const float* tb, const float* tc, int tK, float* dx, float* tpart, int B, int C,
-                       int HW, hipStream_t st) {
-    if (C % 64 != 0 || !aligned16(x) || !aligned16(y) || !aligned16(dy) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
-#define CALL(H) bwd_fold_launch<H>(x, y, dy, inv_norm, colsum, ta, tb, tc, tK, dx, tpart, B, C, st)
+                       const float* ta, const float* tb, const float* tc, int tK, float* dx, int B, int C, int HW,
+                       hipStream_t st) {
+    if (C % 64 != 0 || !ta || !tb || !aligned16(x) || !aligned16(y) || !aligned16(dy) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+#define CALL(H) bwd_fold_launch<H>(x, y, dy, inv_norm, colsum, ta, tb, tc, tK, dx, B, C, st)
     HK_HW_SWITCH(CALL)
 #undef CALL
 }

@@ -28,8 +28,8 @@ int bcnn_fast_gram_norm(const float* x, const float* part, int G, float* colsum,
 int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, float* tpart, int B,
                   int C, int HW, hipStream_t st);
 int bcnn_fast_bwd_fold(const float* x, const float* y, const float* dy, const float* inv_norm, const float* colsum,
-                       const float* ta, const float* tb, const float* tc, int tK, float* dx, float* tpart, int B, int C,
-                       int HW, hipStream_t st);
+                       const float* ta, const float* tb, const float* tc, int tK, float* dx, int B, int C, int HW,
+                       hipStream_t st);
 int gram_fast_raw(const float* x, float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
 int bcnn_ssqrt_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, const float* tpart, int nt,
                         float* dx, int B, int C, int HW, hipStream_t st);
@@ -415,12 +415,6 @@ extern "C" int hk_bcnn_pool_bwd(const float* x, const float* y, const float* dy,
                                 hk_stream_t stream) {
     if (!x || !y || !dy || !inv_norm || !colsum || !dx || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_bcnn_pool_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
-    // one launch where the 128- / 64-row GEMM kernel runs: the last workgroup of an image applies the rank-1 term (TK 2)
-    if (!force_generic() && tuning().bwd_fold >= 0) {
-        const int rc1 = bcnn_fast_bwd_fold(x, y, dy, inv_norm, colsum, nullptr, nullptr, nullptr, 0, dx, (float*)ws, B, C, HW,
-                                           (hipStream_t)stream);
-        if (rc1 != HK_ERR_UNSUPPORTED) return rc1;
-    }
     int rc = hk_bcnn_bwd_gemm(x, y, dy, inv_norm, dx, (float*)ws, B, C, HW, stream);
     if (rc != HK_OK) return rc;
     return hk_bcnn_bwd_rank1(dx, (const float*)ws, inv_norm, colsum, B, C, HW, stream);
@@ -451,7 +445,7 @@ extern "C" int hk_bcnn_pool_bwd_tdot(const float* x, const float* y, const float
         return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_bcnn_pool_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
     if (!force_generic() && tuning().bwd_fold >= 0) {
-        const int rc1 = bcnn_fast_bwd_fold(x, y, dy, inv_norm, colsum, ta, tb, tc, K, dx, nullptr, B, C, HW, (hipStream_t)stream);
+        const int rc1 = bcnn_fast_bwd_fold(x, y, dy, inv_norm, colsum, ta, tb, tc, K, dx, B, C, HW, (hipStream_t)stream);
         if (rc1 != HK_ERR_UNSUPPORTED) return rc1;
     }
     // (the GEMM launch below overwrites ws with ITS partial sums of t: they are ignored - the dot product goes in after it)

@@ -47,7 +47,6 @@ struct BwdExtra {
     const float* tb2;
     const float* tc;
     int tK;
-    unsigned* ticket;    // TK 2: [>= B] arrival counters of the launch, zero before and after it
 };
 
 // t = <y, dy> of sample b from its partial sums (every workgroup adds them itself, fixed order)
@@ -71,10 +70,11 @@ __device__ __forceinline__ float bwd_t_of(const BwdExtra& ex, int b) {
 //      of a linear layer on y, <y, dy> = sum_k g_k (logit_k - bias_k).  Every workgroup forms t in its prologue (fixed
 //      order) and subtracts its rows' share while the block is copied out: no second pass, no partial sums of y dy in
 //      the K loop (7 VALU ops per fragment quad less next to the MFMAs);
-//   2: t is not known: the workgroups of an image take a ticket when their block and their partial sum are out, and
-//      the LAST to arrive adds the partials (slot order - the same value whoever is last) and makes the pass over the
-//      image's 4 C HW bytes itself, from the L2 they were just written to: one launch less and the 51 MB of the second
-//      kernel's HBM traffic gone.  Nobody waits for anybody: no forward-progress assumption.
+// (Measured and removed, round 5: TK 2, t unknown - the workgroups of an image take a ticket when their block and partial
+//  sum are out and the last to arrive makes the pass over the image's dX from L2.  Correct by the device-scope release /
+//  acquire recipe, bit-identical to the two-launch route - and slower than it: 85.2 vs 81.4 us at B = 64 (the release
+//  writes back 25 MB of freshly dirtied L2 lines and one workgroup streams 2 x 401 KB alone at the end; with
+//  __threadfence() in every thread it was 132 us).)
 template <int HW, int MODE, int RB, bool REMV, bool EPI, bool ROWW = false, bool COEFL = false, int TK = 0>
 __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy,
@@ -411,45 +411,6 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
                 tpart[(long long)b * (2 * nI) + 2 * I + 1] = 0.f;
             } else {
                 tpart[(long long)b * nI + I] = tsum;
-            }
-        }
-    }
-    if (TK == 2) {
-        // this block of dX and this partial sum are out (release), then the ticket; the last of the image's nI workgroups
-        // sees everybody's (acquire) and finishes the image.  atomicInc wraps at nI - 1: the counter is zero again.
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) lds[16] = __builtin_bit_cast(float, atomicInc(ex.ticket + b, (unsigned)(nI - 1)));
-        __syncthreads();
-        if (__builtin_bit_cast(unsigned, lds[16]) != (unsigned)(nI - 1)) return;
-        __threadfence();
-        const int nslot = RB == 2 ? 2 * nI : nI;
-        float t = 0.f;
-        for (int i = 0; i < nslot; ++i) t += tpart[(long long)b * nslot + i];        // (bcnn_rank1_fix_kernel's order)
-        const float in = inv_norm[b];
-        const float kf = t * in * in / (float)HW;
-        float* CS = lds + 32;
-        if (tid < HW) CS[tid] = ex.colsum[(long long)b * HW + tid];
-        __syncthreads();
-        f32x4* d4 = reinterpret_cast<f32x4*>(dx + (long long)b * C * HW);
-        const int n4 = C * (HW / 4);
-        constexpr int UN = 7;                                   // 16-byte loads in flight per thread
-        for (int f0 = tid; f0 < n4; f0 += 512 * UN) {
-            f32x4 v[UN];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int f = f0 + 512 * u;
-                v[u] = d4[f < n4 ? f : n4 - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int f = f0 + 512 * u;
-                if (f < n4) {
-                    const f32x4 c4 = reinterpret_cast<const f32x4*>(CS)[f % (HW / 4)];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[u][e] = fmaf(-kf, c4[e], v[u][e]);
-                    d4[f] = v[u];
-                }
             }
         }
     }

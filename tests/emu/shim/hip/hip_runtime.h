@@ -62,9 +62,6 @@ inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-#define HIP_SYMBOL(x) (&(x))
-template <class T>
-inline hipError_t hipGetSymbolAddress(void** p, T* sym) { *p = (void*)sym; return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
     memcpy(d, s, n);
     return hipSuccess;
@@ -392,8 +389,6 @@ inline void global_load_lds(const void* g, void* l, unsigned size, int off) {
 
 // LDS / global integer atomics: the fibers of a workgroup are switched only at barriers and wave-wide collectives, so a
 // read-modify-write between two switch points is atomic by construction (and min / max do not depend on the order)
-inline unsigned atomicInc(unsigned* p, unsigned wrap) { const unsigned o = *p; *p = o >= wrap ? 0u : o + 1u; return o; }
-inline void __threadfence() {}
 inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
 inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
 

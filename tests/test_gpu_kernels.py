@@ -86,15 +86,12 @@ def test_backward_bwd3_kernel(F, b, c, hw, tune):
 @pytest.mark.parametrize('b,c,hw,k,bias', [(2, 128, 14, 7, True), (3, 256, 10, 20, True), (2, 64, 14, 70, False), (3, 192, 12, 5, True),
                                            (2, 256, 8, 13, True), (2, 512, 14, 200, True)])
 def test_bcnn_backward_in_one_launch(F, b, c, hw, k, bias, tune):
-    """The BCNN backward with the rank-1 term folded into gram_bwd3_kernel (hk_bwd3.h, TK):
-      * hk_bcnn_pool_bwd = ONE launch (TK 2: the last workgroup of an image adds the partial sums of <y, dy> in slot order
-        and makes the pass over the image's dX itself) - bit-identical to the two-launch route (bwd_fold = -1: GEMM kernel
-        + bcnn_rank1_fix_kernel), whichever workgroup arrives last;
-      * hk_bcnn_pool_bwd_tdot (TK 1; F.bilinear_pool_linear: pooling + classifier as one autograd node): <y, dy> taken as
-        sum_k g_k (logit_k - bias_k) - equal to the two-node composition up to the rounding of that scalar - and the
-        classifier's own gradients and the logits bit-identical to it;
-    in the 128-row and the 64-row form of the kernel (sched_b), and where the kernel does not run (small batch: the
-    two-launch fallbacks inside both entry points)."""
+    """The BCNN backward with the rank-1 term folded into gram_bwd3_kernel (hk_bwd3.h, TK 1): hk_bcnn_pool_bwd_tdot
+    (F.bilinear_pool_linear: pooling + classifier as one autograd node) takes <y, dy> as sum_k g_k (logit_k - bias_k) and
+    applies the term while dX is written - equal to the two-node composition (GEMM kernel + bcnn_rank1_fix_kernel on the
+    summed y * dy) up to the rounding of that scalar, with the logits and the classifier's own gradients bit-identical
+    to it; in the 128-row and the 64-row form of the kernel (sched_b), where the kernel does not run (small batch: the
+    three-launch fallback inside the entry point) and with the fold switched off (bwd_fold = -1)."""
     gen = torch.Generator().manual_seed(3 * c + hw + k)
     x = torch.relu(torch.randn(b, c, hw, hw, generator=gen)).to(DEV)
     w = (torch.randn(k, c * c, generator=gen) * 0.05).to(DEV)
@@ -104,22 +101,21 @@ def test_bcnn_backward_in_one_launch(F, b, c, hw, k, bias, tune):
     for form, sb in [('small', 0)] + [(f_, fb[f_]) for f_ in ('rows128', 'rows64') if f_ in fb]:
         tune('sched_b', sb)
         res = {}
-        for name, fold, fused in (('two', -1, False), ('ticket', 0, False), ('tdot', 0, True)):
+        for name, fold, fused in (('two', 0, False), ('tdot_off', -1, True), ('tdot', 0, True)):
             tune('bwd_fold', fold)
             xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
             bg = bs.clone().requires_grad_(True) if bias else None
             out = F.bilinear_pool_linear(xg, wg, bg) if fused else F.linear(F.bilinear_pool(xg), wg, bg)
             torch.nn.functional.cross_entropy(out, tgt).backward()
             res[name] = (out.detach().clone(), xg.grad.clone(), wg.grad.clone(), bg.grad.clone() if bias else None)
-        assert torch.equal(res['ticket'][1], res['two'][1]), form                      # last-arriver pass: the same bits
         for i in (0, 2) + ((3,) if bias else ()):
-            assert torch.equal(res['tdot'][i], res['two'][i]), (form, i)               # logits, dW, db
-        e = rel(res['tdot'][1], res['two'][1])
-        assert e < 2e-6, (form, e)
+            assert torch.equal(res['tdot'][i], res['two'][i]) and torch.equal(res['tdot_off'][i], res['two'][i]), (form, i)   # logits, dW, db
+        e, eo = rel(res['tdot'][1], res['two'][1]), rel(res['tdot_off'][1], res['two'][1])
+        assert e < 2e-6 and eo < 2e-6, (form, e, eo)
         xo = x.detach().cpu().clone().requires_grad_(True)
         yo = torch.nn.functional.linear(O.bilinear_pool(xo), w.cpu(), bs.cpu() if bias else None)
         torch.nn.functional.cross_entropy(yo, tgt.cpu()).backward()
-        assert rel(res['tdot'][1], xo.grad) < 2e-5 and rel(res['ticket'][1], xo.grad) < 2e-5, form
+        assert rel(res['tdot'][1], xo.grad) < 2e-5 and rel(res['tdot_off'][1], xo.grad) < 2e-5, form
 
 
 @pytest.mark.parametrize('b,c,hw,d', [(2, 128, 14, 2048), (3, 256, 10, 1000), (2, 64, 14, 96), (2, 256, 8, 6000), (3, 128, 12, 500)])
@@ -813,10 +809,11 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
             restore_wide_linear(saved_wl)
         hb.remove()
         (y_u, cw_u, f_u), (y_f, cw_f, f_f) = outs
-        assert torch.equal(y_u, y_f) and torch.equal(cw_u, cw_f)
-        ef = rel(f_f, f_u)
-        print(f'[fused pool + classifier] feature-map gradient, one node vs two: {ef:.2e}')
-        assert ef < 1e-5, ef
+        # (not torch.equal: two forward passes of the MIOpen trunk are not bit-identical on the GPU; the kernels' own bit
+        #  identity - logits, dW, db - is test_bcnn_backward_in_one_launch's, on inputs without a trunk in front)
+        ey, ew, ef = rel(y_f, y_u), rel(cw_f, cw_u), rel(f_f, f_u)
+        print(f'[fused pool + classifier] one node vs two: logits {ey:.2e}, classifier gradient {ew:.2e}, feature-map gradient {ef:.2e}')
+        assert ey < 1e-6 and ew < 1e-5 and ef < 1e-4, (ey, ew, ef)
 
 
 def test_cin_model_matches_reference(F):
