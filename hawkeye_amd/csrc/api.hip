@@ -20,6 +20,7 @@ const Knob kKnobs[] = {
     {"ns_streams", "HK_NS_STREAMS", &Tuning::ns_streams},        {"sched_b", "HK_SCHED_B", &Tuning::sched_b},
     {"ns_sym", "HK_NS_SYM", &Tuning::ns_sym},
     {"lin_walk", "HK_LIN_WALK", &Tuning::lin_walk},           {"bwd_fold", "HK_BWD_FOLD", &Tuning::bwd_fold},
+    {"fwd_fold", "HK_FWD_FOLD", &Tuning::fwd_fold},
 };
 Tuning from_env() {
     Tuning t;

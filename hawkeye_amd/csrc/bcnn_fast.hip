@@ -90,11 +90,70 @@ __device__ __forceinline__ void center_panel(float* p, float* __restrict__ mu_ou
 // the finalize launch (4.5 us between two 6 us / 42 us kernels) is gone.
 constexpr int SSQ_STRIDE = 64;         // MODE 2: partial sums per image in the caller's buffer (= SS_CHUNKS of bcnn_pool.hip)
 struct GramNormSrc {
-    const float* part;      // [B][G][HW], nullable: then inv_norm is read
+    const float* part;      // [B][G][HW], nullable: then inv_norm is read - or, `direct`, the sums are formed here from x
     float* colsum;          // [B][HW]
     float* inv_out;         // [B]
     int G;
+    int direct;             // 1: no partials from another launch - the workgroup adds up the sample's columns itself
 };
+
+// NormSrc.direct (round 5: hk_bcnn_pool_fwd in ONE launch).  Every workgroup of a sample forms the sample's column sums
+// itself from x - 4 C HW bytes, read from HBM once per sample (its workgroups run side by side on one XCD: the others
+// hit the L2) - with exactly the arithmetic of bcnn_colsum_partial4_kernel + bcnn_norm_finalize_kernel (bcnn_pool.hip):
+// per 64-channel group, thread (r, q) adds rows r, r + R, .. of column quad q in order, the R phase sums of a quad
+// are added in phase order, the groups in group order - so colsum, 1 / |z| and y are the bits of the two-launch route.
+// The loads of NG groups are in flight together (the A panel's loads were issued before them and are consumed first);
+// `scr` = the two free panel buffers.  Returns 1 / |z|; the workgroup of row block 0 writes colsum / inv_norm.
+template <int HW>
+__device__ __forceinline__ float gram_direct_norm(const float* __restrict__ xb, int C, int nb, float* scr, float* red4,
+                                                  const GramNormSrc& ns, int b, bool writer, int tid) {
+    constexpr int Q = HW / 4, R = 256 / Q, NRW = (64 + R - 1) / R, NG = 4;
+    static_assert(HW % 4 == 0 && Q <= 64, "column quads");
+    const int q = tid % Q, r = tid / Q;
+    const bool act = r < R;
+    f32x4* red = reinterpret_cast<f32x4*>(scr);                      // [nb][256] phase sums
+    for (int g0 = 0; g0 < nb; g0 += NG) {
+        f32x4 v[NG][NRW];
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = g0 + gi < nb ? g0 + gi : nb - 1;
+            const f32x4* xg = reinterpret_cast<const f32x4*>(xb + (long long)g * 64 * HW);
+#pragma unroll
+            for (int i = 0; i < NRW; ++i) {
+                int c = (act ? r : 0) + i * R;
+                c = c < 64 ? c : 63;
+                v[gi][i] = xg[c * Q + q];
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NRW; ++i)
+                if (act && r + i * R < 64) sacc += v[gi][i];
+            if (g0 + gi < nb) red[(g0 + gi) * 256 + tid] = sacc;
+        }
+    }
+    __syncthreads();
+    // column hw of this thread: the quad's phase sums in phase order per group, then the groups in order
+    float ssq = 0.f;
+    for (int hw = tid; hw < HW; hw += 256) {
+        const int qq = hw >> 2, e = hw & 3;
+        float cs = 0.f;
+        for (int g = 0; g < nb; ++g) {
+            float t = red[g * 256 + qq][e];
+            for (int k = 1; k < R; ++k) t += red[g * 256 + qq + k * Q][e];
+            cs += t;
+        }
+        if (writer) ns.colsum[(long long)b * HW + hw] = cs;
+        ssq += cs * cs;
+    }
+    const float tot = block_sum<4>(ssq, red4);
+    const float n2 = tot / (float)HW + (float)C * (float)C * 1e-5f;
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    if (writer && tid == 0) ns.inv_out[b] = inv;
+    return inv;
+}
 template <int HW, int MODE, bool CENTER>
 __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ inv_norm,
@@ -122,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     GramEpi<MODE> ep;
     ep.yb = y + (long long)b * C * C;
     ep.C = C;
-    ep.inv = MODE == 0 ? (ns.part ? 0.f : inv_norm[b]) : alpha;
+    ep.inv = MODE == 0 ? ((ns.part || ns.direct) ? 0.f : inv_norm[b]) : alpha;
     float* mub = CENTER ? mu + (long long)b * C : nullptr;
     ep.inv_m = 1.0f / (float)HW;
     ep.l31 = l31;
@@ -140,7 +199,19 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
             const int f = tid + 256 * u, fc = f < N4 ? f : N4 - 1;
             st0[u] = src[fc];
         }
-        if (MODE == 0 && ns.part) {                       // (uniform) the sample's norm, while the panel loads are in flight
+        if (MODE == 0 && ns.direct) {                     // (uniform) one launch: the column sums from x itself
+            __shared__ float redd[4];
+            f32x4* dst0 = reinterpret_cast<f32x4*>(lds);
+            // (the A panel first - its loads are the oldest in flight - so that the tile loop's operand is in place while
+            //  the column loads are still arriving)
+            const float inv_d = gram_direct_norm<HW>(xb, C, nb, lds + PANEL, redd, ns, b, w == 0, tid);
+#pragma unroll
+            for (int u = 0; u < NST; ++u) {
+                const int f = tid + 256 * u;
+                if (f < N4) dst0[f] = st0[u];
+            }
+            ep.inv = inv_d;
+        } else if (MODE == 0 && ns.part) {                // (uniform) the sample's norm, while the panel loads are in flight
             __shared__ float redn[4];
             const float* pp = ns.part + (long long)b * ns.G * HW;
             float ssq = 0.f;
@@ -155,11 +226,13 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
             ep.inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
             if (w == 0 && tid == 0) ns.inv_out[b] = ep.inv;
         }
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        if (!(MODE == 0 && ns.direct)) {
+            f32x4* dst = reinterpret_cast<f32x4*>(lds);
 #pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int f = tid + 256 * u;
-            if (f < N4) dst[f] = st0[u];
+            for (int u = 0; u < NST; ++u) {
+                const int f = tid + 256 * u;
+                if (f < N4) dst[f] = st0[u];
+            }
         }
     }
     __syncthreads();
@@ -418,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
 
 template <int HW, int MODE, bool CENTER>
 static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, float* mu, float alpha,
-                       hipStream_t st, GramNormSrc ns = GramNormSrc{nullptr, nullptr, nullptr, 0}) {
+                       hipStream_t st, GramNormSrc ns = GramNormSrc{nullptr, nullptr, nullptr, 0, 0}) {
     const int nb = C / 64;
     const int pair_mode = ((long long)B * nb > 256) ? 1 : 0;
     const int per = pair_mode ? (nb + 1) / 2 : nb;
@@ -505,7 +578,8 @@ int bcnn_fast_gram(const float* x, const float* inv_norm, float* y, int B, int C
 int bcnn_fast_gram_norm(const float* x, const float* part, int G, float* colsum, float* inv_norm, float* y, int B, int C,
                         int HW, hipStream_t st) {
     if (C % 64 != 0 || G != C / 64 || !aligned16(x) || !aligned16(y)) return HK_ERR_UNSUPPORTED;
-    const GramNormSrc ns{part, colsum, inv_norm, G};
+    const GramNormSrc ns{part, colsum, inv_norm, G, part ? 0 : 1};       // no partials: the kernel adds up the columns itself
+    if (!part && (size_t)G * 256 * 16 > (size_t)2 * 64 * HW * sizeof(float)) return HK_ERR_UNSUPPORTED;   // phase sums in two panel buffers
 #define CALL(H) gram_launch<H, 0, false>(x, nullptr, y, B, C, nullptr, 1.f, st, ns)
     HK_HW_SWITCH(CALL)
 #undef CALL

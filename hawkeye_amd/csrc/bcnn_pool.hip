@@ -363,9 +363,16 @@ extern "C" int hk_bcnn_gram_norm(const float* x, const float* inv_norm, float* y
 extern "C" int hk_bcnn_pool_fwd(const float* x, float* y, float* inv_norm, float* colsum, int B, int C, int HW,
                                 void* ws, size_t ws_bytes, hk_stream_t stream) {
     if (!x || !y || !inv_norm || !colsum || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
-    // panel-resident Gram: two launches - the 64-channel-group column sums, then the Gram kernel, which forms the norm
-    // from them in its prologue and writes colsum / inv_norm (bcnn_fast.hip, GramNormSrc)
     const int G = (C + 63) / 64;
+    // panel-resident Gram in ONE launch: every workgroup adds up its sample's columns itself (from the XCD's L2 for all
+    // but the first of a sample's workgroups) with the arithmetic of the two kernels below - the same bits - and row
+    // block 0 writes colsum / inv_norm (bcnn_fast.hip, GramNormSrc.direct; fwd_fold = -1: the two-launch route)
+    if (!force_generic() && tuning().fwd_fold >= 0 && C % 64 == 0 && G > 1 && HW % 4 == 0 && HW / 4 <= 64 && aligned16(x)) {
+        const int rc = bcnn_fast_gram_norm(x, nullptr, G, colsum, inv_norm, y, B, C, HW, (hipStream_t)stream);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
+    // two launches - the 64-channel-group column sums, then the Gram kernel, which forms the norm from them in its
+    // prologue and writes colsum / inv_norm
     if (!force_generic() && C % 64 == 0 && G > 1 && ws && ws_bytes >= (size_t)B * G * HW * sizeof(float) && HW % 4 == 0 &&
         HW / 4 <= 64 && aligned16(x) && aligned16(ws)) {
         hipLaunchKernelGGL(bcnn_colsum_partial4_kernel, dim3(G, B), dim3(256), 0, (hipStream_t)stream, x, (float*)ws, C, HW, G);

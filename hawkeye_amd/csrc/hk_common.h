@@ -121,6 +121,8 @@ struct Tuning {
     int ns_sym = 1;         // HK_NS_SYM        1: hk_ns_sqrtm_fwd_sym skips the tiles below the diagonal blocks, 0: it computes every tile
     int lin_walk = -1;      // HK_LIN_WALK      classifier backward: 1: workgroup s walks chunks s, s + S, ..; 0: a contiguous slab per workgroup;
                             //                  -1: the measured winner per kernel (linear_bwd64_kernel 1, linear_bwd16_kernel 0)
+    int fwd_fold = 0;       // HK_FWD_FOLD      hk_bcnn_pool_fwd: 0: one launch (the Gram kernel adds up the sample's columns itself), -1: the
+                            //                  column-sum kernel + the Gram kernel
     int bwd_fold = 0;       // HK_BWD_FOLD      hk_bcnn_pool_bwd_tdot: 0: the rank-1 term in the GEMM kernel's epilogue where that kernel runs
                             //                  (one launch), -1: always GEMM + dot product + bcnn_rank1_fix_kernel
     int sched_b = 0;        // HK_SCHED_B       > 0: work-split heuristics that depend on the batch size behave as if it were this (tests: the

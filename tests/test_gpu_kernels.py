@@ -547,11 +547,12 @@ def test_ns_symmetric_forward(F, b, d, itn, tune):
 
 
 @pytest.mark.parametrize('b,c,hw', [(3, 128, 14), (5, 512, 14), (2, 192, 10), (2, 64, 14), (2, 128, 7)])
-def test_bcnn_pool_forward_equals_its_stages(F, b, c, hw):
-    """hk_bcnn_pool_fwd runs two launches (64-channel-group column sums; Gram kernel that forms the norm from them in its
-    prologue and writes colsum / inv_norm) where the stage entry points run three (partials, finalize, Gram): the same
-    arithmetic in the same order - y, inv_norm and colsum bit for bit, also where the fused form does not apply (one
-    channel group, a map size outside the panel kernel's list)."""
+def test_bcnn_pool_forward_equals_its_stages(F, b, c, hw, tune):
+    """hk_bcnn_pool_fwd is ONE launch (round 5: every workgroup of the Gram kernel adds up its sample's columns itself,
+    GramNormSrc.direct) - or, fwd_fold = -1, two (64-channel-group column sums; Gram kernel that forms the norm from them
+    in its prologue) - where the stage entry points run three (partials, finalize, Gram): the same arithmetic in the same
+    order - y, inv_norm and colsum bit for bit, also where the fused forms do not apply (one channel group, a map size
+    outside the panel kernel's list)."""
     from hawkeye_amd import _lib
     lib = _lib.load()
     ptr, stream = F.ptr, F.stream                      # (the emulation tier swaps these for CPU-tensor versions)
@@ -560,13 +561,19 @@ def test_bcnn_pool_forward_equals_its_stages(F, b, c, hw):
     n = hw * hw
     nws = lib.hk_bcnn_pool_ws_bytes(b, c, n)
     ws = torch.zeros(max(nws, 16), dtype=torch.uint8, device=dev)
-    y1, inv1, cs1 = torch.empty(b, c * c, device=dev), torch.empty(b, device=dev), torch.empty(b, n, device=dev)
-    y2, inv2, cs2 = torch.empty_like(y1), torch.empty_like(inv1), torch.empty_like(cs1)
-    assert lib.hk_bcnn_pool_fwd(ptr(x), ptr(y1), ptr(inv1), ptr(cs1), b, c, n, ptr(ws), nws, stream()) == 0
+    y2, inv2, cs2 = torch.empty(b, c * c, device=dev), torch.empty(b, device=dev), torch.empty(b, n, device=dev)
     assert lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs2), ptr(inv2), b, c, n, ptr(ws), nws, stream()) == 0
     assert lib.hk_bcnn_gram_norm(ptr(x), ptr(inv2), ptr(y2), b, c, n, stream()) == 0
-    assert torch.equal(y1, y2) and torch.equal(inv1, inv2) and torch.equal(cs1, cs2)
-    assert rel(y1.reshape(b, c, c), O.bilinear_pool(x.cpu().reshape(b, c, hw, hw)).reshape(b, c, c)) < 1e-5
+    for fold in (0, -1):
+        tune('fwd_fold', fold)
+        y1, inv1, cs1 = torch.full_like(y2, -1.0), torch.full_like(inv2, -1.0), torch.full_like(cs2, -1.0)
+        assert lib.hk_bcnn_pool_fwd(ptr(x), ptr(y1), ptr(inv1), ptr(cs1), b, c, n, ptr(ws), nws, stream()) == 0
+        assert torch.equal(y1, y2) and torch.equal(inv1, inv2) and torch.equal(cs1, cs2), fold
+        if fold == 0 and c % 64 == 0 and c > 64 and n in (196, 144, 100, 64):      # the one-launch form needs no workspace
+            y1.fill_(-1.0)
+            assert lib.hk_bcnn_pool_fwd(ptr(x), ptr(y1), ptr(inv1), ptr(cs1), b, c, n, None, 0, stream()) == 0
+            assert torch.equal(y1, y2), fold
+    assert rel(y2.reshape(b, c, c), O.bilinear_pool(x.cpu().reshape(b, c, hw, hw)).reshape(b, c, c)) < 1e-5
 
 
 @pytest.mark.parametrize('b,d,itn', [(2, 128, 3), (17, 256, 5), (3, 70, 4), (2, 64, 1), (2, 33, 2)])

@@ -17,6 +17,7 @@ import r4_lab as L
 from r4_lab import dev, lib, p, st
 
 L.DEFAULTS['bwd_fold'] = 0
+L.DEFAULTS['fwd_fold'] = 0
 
 
 def g_pool():
@@ -37,7 +38,8 @@ def g_pool():
     gemm = lambda: lib.hk_bcnn_bwd_gemm(p(x), p(y), p(dy), p(inv), p(dx), p(ws), B, C, HW, st())
     tdot = lambda: lib.hk_bcnn_pool_bwd_tdot(p(x), p(y), p(dy), p(inv), p(cs), p(g), p(lo), p(bi), K, p(dx), B, C, HW, p(ws), nws, st())
     fwd()
-    items = [('hk_bcnn_pool_fwd (entry point)', {}, fwd, fl * 36 / 64, by_f),
+    items = [('hk_bcnn_pool_fwd (entry point: one launch)', {}, fwd, fl * 36 / 64, by_f),
+             ('hk_bcnn_pool_fwd, two launches (fwd_fold=-1)', dict(fwd_fold=-1), fwd, fl * 36 / 64, by_f),
              ('hk_bcnn_gram_norm (Gram kernel alone)', {}, gram, fl * 36 / 64, by_f),
              ('hk_bcnn_pool_bwd, two launches', {}, bwd, fl, by_b),
              ('hk_bcnn_bwd_gemm (GEMM kernel alone, t partials out)', {}, gemm, fl, by_b),
