@@ -103,7 +103,36 @@ struct GramNormSrc {
 // per 64-channel group, thread (r, q) adds rows r, r + R, .. of column quad q in order, the R phase sums of a quad
 // are added in phase order, the groups in group order - so colsum, 1 / |z| and y are the bits of the two-launch route.
 // The loads of NG groups are in flight together (the A panel's loads were issued before them and are consumed first);
-// `scr` = the two free panel buffers.  Returns 1 / |z|; the workgroup of row block 0 writes colsum / inv_norm.
+// `scr` = the two free panel buffers.  46.0 us against 48.5 in two launches and 40.1 for the Gram kernel alone: what
+// it costs is L2 BANDWIDTH - every workgroup reads its whole sample, 103 MB chip-wide - not latency: the same sums
+// streamed behind the MFMA steps of the first tile (40 loads per thread in flight, the head of the stream issued in the
+// prologue) measured 45.95 us and are not kept.
+// the phase sums red [nb][256] (16-byte pieces, in LDS) -> colsum, 1 / |z|: bcnn_colsum_partial4_kernel's phase order, then
+// bcnn_norm_finalize_kernel's group order and norm.  Starts with a barrier (the phase sums are published).
+template <int HW>
+__device__ __forceinline__ float gram_norm_from_phase_sums(const f32x4* red, int C, int nb, float* red4, const GramNormSrc& ns,
+                                                           int b, bool writer, int tid) {
+    constexpr int Q = HW / 4, R = 256 / Q;
+    __syncthreads();
+    float ssq = 0.f;
+    for (int hw = tid; hw < HW; hw += 256) {
+        const int qq = hw >> 2, e = hw & 3;
+        float cs = 0.f;
+        for (int g = 0; g < nb; ++g) {
+            float t = red[g * 256 + qq][e];
+            for (int k = 1; k < R; ++k) t += red[g * 256 + qq + k * Q][e];
+            cs += t;
+        }
+        if (writer) ns.colsum[(long long)b * HW + hw] = cs;
+        ssq += cs * cs;
+    }
+    const float tot = block_sum<4>(ssq, red4);
+    const float n2 = tot / (float)HW + (float)C * (float)C * 1e-5f;
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    if (writer && tid == 0) ns.inv_out[b] = inv;
+    return inv;
+}
+
 template <int HW>
 __device__ __forceinline__ float gram_direct_norm(const float* __restrict__ xb, int C, int nb, float* scr, float* red4,
                                                   const GramNormSrc& ns, int b, bool writer, int tid) {
@@ -134,26 +163,9 @@ __device__ __forceinline__ float gram_direct_norm(const float* __restrict__ xb, 
             if (g0 + gi < nb) red[(g0 + gi) * 256 + tid] = sacc;
         }
     }
-    __syncthreads();
-    // column hw of this thread: the quad's phase sums in phase order per group, then the groups in order
-    float ssq = 0.f;
-    for (int hw = tid; hw < HW; hw += 256) {
-        const int qq = hw >> 2, e = hw & 3;
-        float cs = 0.f;
-        for (int g = 0; g < nb; ++g) {
-            float t = red[g * 256 + qq][e];
-            for (int k = 1; k < R; ++k) t += red[g * 256 + qq + k * Q][e];
-            cs += t;
-        }
-        if (writer) ns.colsum[(long long)b * HW + hw] = cs;
-        ssq += cs * cs;
-    }
-    const float tot = block_sum<4>(ssq, red4);
-    const float n2 = tot / (float)HW + (float)C * (float)C * 1e-5f;
-    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
-    if (writer && tid == 0) ns.inv_out[b] = inv;
-    return inv;
+    return gram_norm_from_phase_sums<HW>(red, C, nb, red4, ns, b, writer, tid);
 }
+
 template <int HW, int MODE, bool CENTER>
 __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ inv_norm,
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
             const int f = tid + 256 * u, fc = f < N4 ? f : N4 - 1;
             st0[u] = src[fc];
         }
-        if (MODE == 0 && ns.direct) {                     // (uniform) one launch: the column sums from x itself
+        if (MODE == 0 && ns.direct == 1) {                // (uniform) one launch: the column sums from x itself
             __shared__ float redd[4];
             f32x4* dst0 = reinterpret_cast<f32x4*>(lds);
             // (the A panel first - its loads are the oldest in flight - so that the tile loop's operand is in place while
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
             ep.inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
             if (w == 0 && tid == 0) ns.inv_out[b] = ep.inv;
         }
-        if (!(MODE == 0 && ns.direct)) {
+        if (!(MODE == 0 && ns.direct == 1)) {
             f32x4* dst = reinterpret_cast<f32x4*>(lds);
 #pragma unroll
             for (int u = 0; u < NST; ++u) {
@@ -251,7 +263,6 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     f32x16 prev;
 #pragma unroll
     for (int i = 0; i < 16; ++i) prev[i] = 0.f;
-    bool has_prev = false;
 
     // Column blocks of a row block.  Paired rows (pair_mode 1: rows w and nb - 1 - w, nb + 1 tiles per workgroup) walk
     // J = I .. nb - 1.  A single row (pair_mode 0) walks CYCLICALLY, J = I, I + 1, .. (mod nb), nb / 2 + 1 columns for
@@ -259,62 +270,65 @@ __global__ __launch_bounds__(256, 1) void bcnn_gram_panel_kernel(const float* __
     // produced once (tile (I, J) and its mirror are both written) and no workgroup has more than nb / 2 + 1 tiles -
     // the triangular walk gave row 0 nb tiles and row nb - 1 one.
     const int cyc = pair_mode ? 0 : ((nb & 1) ? (nb + 1) / 2 : (rb0 < nb / 2 ? nb / 2 + 1 : nb / 2));
+    // One tile of the walk.  FIRST (compile time): the workgroup's first tile - no previous tile's epilogue to interleave;
+    // peeled out of the loop below, so that every other tile is the HASPREV form without a branch.
+    auto tile_step = [&](auto first_tag, int ri, int I, int cnt, int tt) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        int J = I + tt;
+        if (J >= nb) J -= nb;
+        int next_blk = -1;
+        bool newrow = false;
+        if (tt + 1 < cnt) next_blk = (J + 1 < nb) ? J + 1 : 0;
+        else if (ri + 1 < nrb) { next_blk = rb1; newrow = true; }
+        const int n_idx = (a_idx == b_idx) ? (a_idx + 1) % 3 : 3 - a_idx - b_idx;
+
+        f32x4 st[NST];
+        {   // unconditional (index-clamped) loads keep st[] in registers; on the last tile they re-read a panel
+            const int lb = next_blk >= 0 ? next_blk : J;
+            const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)lb * PANEL);
+#pragma unroll
+            for (int u = 0; u < NST; ++u) {
+                const int f = tid + 256 * u, fc = f < N4 ? f : N4 - 1;
+                st[u] = src[fc];
+            }
+        }
+
+        const float* Ap = lds + a_idx * PANEL + (wm * 32 + l31) * HW + 4 * lh;
+        const float* Bp = lds + b_idx * PANEL + (wn * 32 + l31) * HW + 4 * lh;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        f32x4* dst = reinterpret_cast<f32x4*>(lds + n_idx * PANEL);
+        if constexpr (AREG) gram_tile_ra<HW, !FIRST, NST>(areg, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
+        else gram_tile<HW, !FIRST, NST>(Ap, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
+        prev = acc0 + acc1;
+        ep.i0 = I * 64 + wm * 32;
+        ep.j0 = J * 64 + wn * 32;
+        ep.offdiag = (I != J);
+        // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for every epilogue store of this tile
+        HK_LDS_BARRIER();
+        if (next_blk >= 0) {
+            if (newrow) {
+                a_idx = n_idx; b_idx = n_idx;
+                if (CENTER) {                                         // the second row block of the pair: its panel just landed
+                    center_panel<HW>(lds + n_idx * PANEL, mub + rb1 * 64, tid);
+                    HK_LDS_BARRIER();
+                }
+                if (AREG) areg.load(lds + a_idx * PANEL + (wm * 32 + l31) * HW + 4 * lh, lh);
+            } else {
+                b_idx = n_idx;
+            }
+        }
+    };
     for (int ri = 0; ri < nrb; ++ri) {
         const int I = ri == 0 ? rb0 : rb1;
         const int cnt = pair_mode ? nb - I : cyc;
-        for (int tt = 0; tt < cnt; ++tt) {
-            int J = I + tt;
-            if (J >= nb) J -= nb;
-            int next_blk = -1;
-            bool newrow = false;
-            if (tt + 1 < cnt) next_blk = (J + 1 < nb) ? J + 1 : 0;
-            else if (ri + 1 < nrb) { next_blk = rb1; newrow = true; }
-            const int n_idx = (a_idx == b_idx) ? (a_idx + 1) % 3 : 3 - a_idx - b_idx;
-
-            f32x4 st[NST];
-            {   // unconditional (index-clamped) loads keep st[] in registers; on the last tile they re-read a panel
-                const int lb = next_blk >= 0 ? next_blk : J;
-                const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)lb * PANEL);
-#pragma unroll
-                for (int u = 0; u < NST; ++u) {
-                    const int f = tid + 256 * u, fc = f < N4 ? f : N4 - 1;
-                    st[u] = src[fc];
-                }
-            }
-
-            const float* Ap = lds + a_idx * PANEL + (wm * 32 + l31) * HW + 4 * lh;
-            const float* Bp = lds + b_idx * PANEL + (wn * 32 + l31) * HW + 4 * lh;
-            f32x16 acc0, acc1;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-            f32x4* dst = reinterpret_cast<f32x4*>(lds + n_idx * PANEL);
-            if constexpr (AREG) {
-                if (has_prev) gram_tile_ra<HW, true, NST>(areg, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
-                else gram_tile_ra<HW, false, NST>(areg, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
-            } else {
-                if (has_prev) gram_tile<HW, true, NST>(Ap, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
-                else gram_tile<HW, false, NST>(Ap, Bp, acc0, acc1, prev, ep, lh, st, dst, next_blk >= 0, tid);
-            }
-            prev = acc0 + acc1;
-            ep.i0 = I * 64 + wm * 32;
-            ep.j0 = J * 64 + wn * 32;
-            ep.offdiag = (I != J);
-            has_prev = true;
-            // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for every epilogue store of this tile
-            HK_LDS_BARRIER();
-            if (next_blk >= 0) {
-                if (newrow) {
-                    a_idx = n_idx; b_idx = n_idx;
-                    if (CENTER) {                                     // the second row block of the pair: its panel just landed
-                        center_panel<HW>(lds + n_idx * PANEL, mub + rb1 * 64, tid);
-                        HK_LDS_BARRIER();
-                    }
-                    if (AREG) areg.load(lds + a_idx * PANEL + (wm * 32 + l31) * HW + 4 * lh, lh);
-                } else {
-                    b_idx = n_idx;
-                }
-            }
+        int tt = 0;
+        if (ri == 0) {
+            tile_step(std::true_type{}, ri, I, cnt, 0);
+            tt = 1;
         }
+        for (; tt < cnt; ++tt) tile_step(std::false_type{}, ri, I, cnt, tt);
     }
 #pragma unroll
     for (int s_ = 0; s_ < GramEpi<MODE>::NSTEP; ++s_) ep.step(prev, s_);
