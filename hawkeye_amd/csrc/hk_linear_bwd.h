@@ -40,7 +40,7 @@ namespace hk {
 //     wave has issued since (two units of pieces, three units of stores; vmcnt retires in issue order).  The count is
 //     exact because every store ALWAYS issues: ragged sample / class edges are cut by the buffer descriptor's bounds
 //     check (buf_store16), not by a branch around the instruction.
-// The last class tile (classes 192 ..) is dealt to the four DY waves by output column quarter (wave i: columns {4 n + i},
+// The last class tile (classes 192 ..) is dealt to the four DY waves by output column quarter (wave i: columns 16 i .. 16 i + 15,
 // one more MFMA in eight of its 25 steps, 4-byte stores: 4 % of dW) - the dW waves hold 48 resident fragments, 48
 // accumulators and the 48 finished values of the previous chunk, the dy waves have room.  db = sum_b g falls out of the
 // resident fragments in the workgroup of chunk 0.  Deterministic: no atomics, fixed summation order.
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
     const float* gi = lds + 2 * STAGE;
 
     if (role_dy) {
-        const int st = wave;                                     // sample tile; also the column quarter of class tile 12
+        const int st = wave;                                     // sample tile; also the column quarter (16 st ..) of class tile 12
         // pieces p = wave + 4 i of a W half tile: class row 4 (h NKH + p) + lq (clamped to K - 1), features 4 l15 ..+3
         // (byte offsets from the chunk's base: K J 4 < 4 GB is checked by the launcher)
         unsigned wo[2][NPW];
@@ -160,14 +160,14 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
             for (int i = 0; i < NPW; ++i) dma(2, 0, i);
         }
         // this lane's rows of the dy tile: sample 16 st + 4 lq + r, features 4 l15 ..+3; of class tile 12: class 192 + 4 lq + r,
-        // feature 4 l15 + st (byte offsets; rows beyond B / K lie beyond the descriptor's end: dropped by the hardware)
+        // feature 16 st + l15 (byte offsets; rows beyond B / K lie beyond the descriptor's end: dropped by the hardware)
         const buf_rsrc_t rs = buf_rsrc(dy, DO_DY ? (long long)B * J : 0);
         const buf_rsrc_t rs12 = buf_rsrc(dw, DO_DW ? (long long)K * J : 0);
         unsigned orow[4], orow12[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             orow[r] = 4u * ((unsigned)(16 * st + 4 * lq + r) * (unsigned)J + 4u * l15);
-            orow12[r] = 4u * ((unsigned)(192 + 4 * lq + r) * (unsigned)J + 4u * l15 + st);
+            orow12[r] = 4u * ((unsigned)(192 + 4 * lq + r) * (unsigned)J + 16u * st + l15);
         }
         f32x4 out[4], out13;                                     // the finished rows of the previous chunk
         auto store_row = [&](int c, int r) __attribute__((always_inline)) {       // row r of chunk c's dy tile
@@ -187,7 +187,12 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
             constexpr int H = decltype(h_tag)::value, WK = decltype(wk_tag)::value;
             constexpr bool LOAD = decltype(load_tag)::value != 0, PREV = decltype(prev_tag)::value != 0;
             const float* T = Lf + (u & 3) * STAGE;
-            const float* T1 = T + 256 * NKH + st;                // y[32 H + 4 s + lq][4 l15 + st] at + 256 s
+            // class tile 12: y[32 H + 4 s + lq][16 st + l15] at + 256 s (row 4 s + lq of piece s is 64 lq floats into it).
+            // Round 5: the wave takes the 16 CONSECUTIVE features 16 st .. of the tile, not every fourth one (4 l15 + st):
+            // the 32 lanes of a ds_read_b32 group then fall on 16 banks twice (2-way) instead of 8 banks four times -
+            // these reads were the kernel's 25.8 % LDS conflict cycles - and its stores are 64-byte runs of a dW row
+            // instead of every fourth word of a 256-byte run shared with the three other waves.  Same sums, same bits.
+            const float* T1 = lds + (u & 3) * STAGE + 256 * NKH + 64 * lq + 16 * st + l15;
             if (H == 0) {
                 acc13 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll

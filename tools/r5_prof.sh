@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 kernel-trace statistics + separate PMC passes (never combined with other trace domains) of one command:
-#     gpurun -- 'bash tools/r4_prof.sh <tag> python tools/run_cbp.py 64 5'
-# writes gpurun_out/r4prof/<tag>_kernel_stats.csv and <tag>_pmc.csv
+#     gpurun -- 'bash tools/r5_prof.sh <tag> python tools/run_cbp.py 64 5'
+# writes gpurun_out/r5prof/<tag>_kernel_stats.csv and <tag>_pmc.csv
 set -u
 ROOT=$PWD
 TAG=$1; shift
-OUT=$ROOT/gpurun_out/r4prof
+OUT=$ROOT/gpurun_out/r5prof
 mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 CMD="$@"

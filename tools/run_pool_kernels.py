@@ -21,11 +21,17 @@ cs = torch.empty(B, HW, device=dev)
 tp = torch.empty(B, C // 64, device=dev)
 nwsc = lib.hk_bcnn_pool_ws_bytes(B, C, HW)
 wsc = torch.empty(nwsc, dtype=torch.uint8, device=dev)
+gk, lo, bi = torch.randn(B, 200, device=dev), torch.randn(B, 200, device=dev), torch.randn(200, device=dev)
 for _ in range(reps):
     lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream())
     lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream())
     lib.hk_bcnn_bwd_gemm(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), ptr(tp), B, C, HW, stream())
     lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream())
+    # round 5: the one-launch entry points (forward with the column sums in the Gram kernel; backward with t = <y, dy> handed
+    # over as a dot product and the rank-1 term in the GEMM kernel's epilogue)
+    lib.hk_bcnn_pool_fwd(ptr(x), ptr(y), ptr(inv), ptr(cs), B, C, HW, ptr(wsc), nwsc, stream())
+    lib.hk_bcnn_pool_bwd_tdot(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(cs), ptr(gk), ptr(lo), ptr(bi), 200, ptr(dx), B, C, HW,
+                              ptr(wsc), nwsc, stream())
 torch.cuda.synchronize()
 print('ok', flush=True)
 
