@@ -328,6 +328,19 @@ def other_models(timeout_s=240):
         return {'error': repr(e)[:300]}
 
 
+def graph_rows(timeout_s=200):
+    """Every pooling head, forward + backward, captured in a hipGraph and replayed (tools/graph_rows.py): bit identity with
+    the eager run and eager-vs-replay time per head.  Subprocess after the headline; detail file only."""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'graph_rows.py'), '--quick'], capture_output=True, text=True,
+                           cwd=ROOT, timeout=timeout_s)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('[')]
+        return json.loads(lines[-1]) if p.returncode == 0 and lines else {'error': f'rc={p.returncode}', 'stderr_tail': p.stderr[-300:]}
+    except Exception as e:  # noqa: BLE001
+        return {'error': repr(e)[:300]}
+
+
 LINE_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'ddp')
 LINE_MAX = 4096
@@ -371,6 +384,13 @@ def emit(res, detail):
                       f"{k.get('train_step')}", file=sys.stderr)
         if isinstance(om, dict):
             print(f'[bench] other_models: {om}', file=sys.stderr)
+        gr = detail.get('graph_rows')
+        for k in (gr if isinstance(gr, list) else []):
+            if 'us_eager' in k:
+                print(f"[bench] hipGraph {k['head'][:60]:60s} eager {k['us_eager']:8.1f} us  replay {k['us_graph_replay']:8.1f} us  "
+                      f"bit-identical {k['bit_identical_to_eager']}", file=sys.stderr)
+            else:
+                print(f'[bench] hipGraph {k}', file=sys.stderr)
         sys.stderr.flush()
     sys.stdout.flush()
     print(final_line(res), flush=True)
@@ -512,6 +532,7 @@ def main():
         if world == 1 and not a.no_other_models and a.model == 'BCNN' and not a.force_pg:
             torch.cuda.empty_cache()
             detail['other_models'] = other_models()
+            detail['graph_rows'] = graph_rows()
         emit(res, detail)
     if world > 1:
         torch.distributed.destroy_process_group()

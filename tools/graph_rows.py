@@ -117,6 +117,8 @@ def run_head(name, build, iters=20):
     loss = step()
     torch.cuda.synchronize()
     ref = [loss.detach().clone()] + [t.grad.detach().clone() for t in leaves]
+    del loss      # (an eager loss kept alive keeps its AccumulateGrad nodes - bound to the default stream - alive: the captured
+                  #  backward would then synchronise with the default stream inside the capture, and end-capture crashes)
     us_eager = time_loop(step, iters)
     for t in leaves:
         t.grad = None
@@ -141,15 +143,23 @@ def run_head(name, build, iters=20):
 
 
 if __name__ == '__main__':
+    only = [a[7:] for a in sys.argv[1:] if a.startswith('--head=')]
+    if only:                                        # child: one head
+        name = [n for n in HEADS if n.startswith(only[0])][0]
+        print('ROW ' + json.dumps(run_head(name, HEADS[name], iters=5 if QUICK else 20)), flush=True)
+        sys.exit(0)
+    # parent: every head in a process of its own (a capture that fails must not take the others with it)
+    import subprocess
     rows = []
-    for name, build in HEADS.items():
-        try:
-            rows.append(run_head(name, build, iters=5 if QUICK else 20))
-        except Exception as e:  # noqa: BLE001
-            rows.append({'head': name, 'error': repr(e)[:400]})
-        torch.cuda.empty_cache()
-    txt = json.dumps(rows)
-    print(txt)
+    for name in HEADS:
+        cmd = [sys.executable, '-X', 'faulthandler', os.path.abspath(__file__), '--head=' + name.split(' ')[0]] + (['--quick'] if QUICK else [])
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        got = [ln for ln in p.stdout.splitlines() if ln.startswith('ROW ')]
+        if p.returncode == 0 and got:
+            rows.append(json.loads(got[-1][4:]))
+        else:
+            rows.append({'head': name, 'error': f'rc={p.returncode}', 'stderr_tail': p.stderr[-1500:]})
+    print(json.dumps(rows))
     if os.path.isdir(os.path.join(ROOT, 'gpurun_out')):
         with open(os.path.join(ROOT, 'gpurun_out', 'r5_graph_rows.json'), 'w') as f:
             json.dump(rows, f, indent=1)
