@@ -589,6 +589,137 @@ struct LdCbpDG {
     }
 };
 
+
+// ------------------------------------------------------------------ the parts of CompactBilinearPooling Hawkeye's own
+// CBCNN never takes (CBCNN.py:96-102 two DIFFERENT inputs; :127-130 sum_pool = False) - same count-sketch identity:
+//   two inputs:       c[b,k]   = sum_{(i,j) -> k} s1_i s2_j (X1 X2^T)[b,i,j]          a binning of the CROSS Gram
+//   per location:     c[b,p,k] = sum_{(i,j) -> k} s1_i s2_j x1[b,i,p] x2[b,j,p]       no sum over the map
+// Plain kernels (fixed summation orders, no atomics); the signed square root and F.normalize behind them are left to
+// the caller (hawkeye_amd/model/methods/CBCNN.py keeps the reference's own two lines for them).
+
+// dG[b,i,j] = s1_i s2_j dc[b, (h1_i + h2_j) mod D]
+__global__ __launch_bounds__(256) void cbp_unbin_kernel(const float* __restrict__ dc, const int* __restrict__ h1,
+                                                        const int* __restrict__ h2, const float* __restrict__ s1,
+                                                        const float* __restrict__ s2, float* __restrict__ dG, int C, int D) {
+    const int b = blockIdx.z, i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= C) return;
+    int k = h1[i] + h2[j];
+    if (k >= D) k -= D;
+    dG[((long long)b * C + i) * C + j] = s1[i] * s2[j] * dc[(long long)b * D + k];
+}
+
+// one workgroup per (location p, sample b): the two channel columns in LDS, thread t owns bins t, t + 256, ..; a bin's
+// entries in the plan's (i, j)-ascending order
+__global__ __launch_bounds__(256) void cbp_loc_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                          const int* __restrict__ off, const unsigned* __restrict__ ent,
+                                                          float* __restrict__ c, int C, int HW, int D) {
+    HK_DYN_LDS(sm);                                    // [2][C]
+    const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < C; i += 256) {
+        sm[i] = x1[((long long)b * C + i) * HW + p];
+        sm[C + i] = x2[((long long)b * C + i) * HW + p];
+    }
+    __syncthreads();
+    const float rc = 1.0f / (float)C;
+    float* cp = c + ((long long)b * HW + p) * D;
+    for (int k = tid; k < D; k += 256) {
+        float s = 0.f;
+        for (int e = off[k]; e < off[k + 1]; ++e) {
+            const unsigned u = ent[e];
+            const int idx = (int)(u & 0x7fffffffu);
+            const int i = (int)(((float)idx + 0.5f) * rc);          // idx / C, exact for C <= 1024 (entry point checks)
+            const float v = sm[i] * sm[C + idx - i * C];
+            s += (u >> 31) ? -v : v;
+        }
+        cp[k] = s;
+    }
+}
+
+// dx1[b,i,p] = s1_i sum_j s2_j dc[b,p,bin(i,j)] x2[b,j,p] ; dx2[b,j,p] = s2_j sum_i s1_i dc[b,p,bin(i,j)] x1[b,i,p]
+// one workgroup per (p, b): dc[b,p,:], the two columns and the hashes in LDS; thread per channel, j (i) ascending
+__global__ __launch_bounds__(256) void cbp_loc_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                          const float* __restrict__ dc, const int* __restrict__ h1,
+                                                          const int* __restrict__ h2, const float* __restrict__ s1,
+                                                          const float* __restrict__ s2, float* __restrict__ dx1,
+                                                          float* __restrict__ dx2, int C, int HW, int D) {
+    HK_DYN_LDS(sm);                                    // dc [D] | x1 s1 [C] | x2 s2 [C] | h1 [C] | h2 [C]
+    const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    float* sd = sm;
+    float* a1 = sm + D;
+    float* a2 = a1 + C;
+    int* g1 = reinterpret_cast<int*>(a2 + C);
+    int* g2 = g1 + C;
+    const float* dcp = dc + ((long long)b * HW + p) * D;
+    for (int k = tid; k < D; k += 256) sd[k] = dcp[k];
+    for (int i = tid; i < C; i += 256) {
+        a1[i] = s1[i] * x1[((long long)b * C + i) * HW + p];
+        a2[i] = s2[i] * x2[((long long)b * C + i) * HW + p];
+        g1[i] = h1[i];
+        g2[i] = h2[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < C; i += 256) {
+        const int hi = g1[i], hj = g2[i];
+        float acc1 = 0.f, acc2 = 0.f;
+        for (int j = 0; j < C; ++j) {
+            int k1 = hi + g2[j];
+            if (k1 >= D) k1 -= D;
+            acc1 += sd[k1] * a2[j];                    // row i of dG against x2
+            int k2 = g1[j] + hj;
+            if (k2 >= D) k2 -= D;
+            acc2 += sd[k2] * a1[j];                    // column i of dG against x1
+        }
+        if (dx1) dx1[((long long)b * C + i) * HW + p] = s1[i] * acc1;
+        if (dx2) dx2[((long long)b * C + i) * HW + p] = s2[i] * acc2;
+    }
+}
+
+}  // namespace hk
+
+using namespace hk;
+
+extern "C" int hk_cbp_bin_matrix(const float* G, const void* plan, float* c_raw, int B, int C, int D, hk_stream_t stream) {
+    if (!G || !plan || !c_raw || B <= 0 || C <= 0 || D <= 0) return HK_ERR_BAD_ARG;
+    const CbpPlan pl = cbp_view(plan, C, D);
+    hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, G, pl.off, pl.ent, c_raw, C * C, D);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_cbp_unbin_matrix(const float* dc, const void* plan, float* dG, int B, int C, int D, hk_stream_t stream) {
+    if (!dc || !plan || !dG || B <= 0 || C <= 0 || D <= 0) return HK_ERR_BAD_ARG;
+    if (B > 65535 || C > 65535) return HK_ERR_UNSUPPORTED;
+    const CbpPlan pl = cbp_view(plan, C, D);
+    hipLaunchKernelGGL(cbp_unbin_kernel, dim3((C + 255) / 256, C, B), dim3(256), 0, (hipStream_t)stream, dc, pl.h1, pl.h2, pl.s1,
+                       pl.s2, dG, C, D);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_cbp_loc_fwd(const float* x1, const float* x2, const void* plan, float* c, int B, int C, int HW, int D,
+                              hk_stream_t stream) {
+    if (!x1 || !x2 || !plan || !c || B <= 0 || C <= 0 || HW <= 0 || D <= 0) return HK_ERR_BAD_ARG;
+    if (C > 1024 || B > 65535) return HK_ERR_UNSUPPORTED;
+    const CbpPlan pl = cbp_view(plan, C, D);
+    hipLaunchKernelGGL(cbp_loc_fwd_kernel, dim3(HW, B), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream, x1, x2,
+                       pl.off, pl.ent, c, C, HW, D);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_cbp_loc_bwd(const float* x1, const float* x2, const float* dc, const void* plan, float* dx1, float* dx2, int B,
+                              int C, int HW, int D, hk_stream_t stream) {
+    if (!x1 || !x2 || !dc || !plan || (!dx1 && !dx2) || B <= 0 || C <= 0 || HW <= 0 || D <= 0) return HK_ERR_BAD_ARG;
+    const size_t lds = ((size_t)D + 4 * (size_t)C) * sizeof(float);
+    if (lds > 64 * 1024 || B > 65535) return HK_ERR_UNSUPPORTED;
+    const CbpPlan pl = cbp_view(plan, C, D);
+    hipLaunchKernelGGL(cbp_loc_bwd_kernel, dim3(HW, B), dim3(256), lds, (hipStream_t)stream, x1, x2, dc, pl.h1, pl.h2, pl.s1, pl.s2,
+                       dx1, dx2, C, HW, D);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+namespace hk {
 }  // namespace hk
 
 using namespace hk;

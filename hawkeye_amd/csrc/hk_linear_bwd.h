@@ -192,7 +192,11 @@ __global__ __launch_bounds__(512, 2) void linear_bwd64_kernel(const float* __res
             // the 32 lanes of a ds_read_b32 group then fall on 16 banks twice (2-way) instead of 8 banks four times -
             // these reads were the kernel's 25.8 % LDS conflict cycles - and its stores are 64-byte runs of a dW row
             // instead of every fourth word of a 256-byte run shared with the three other waves.  Same sums, same bits.
-            const float* T1 = lds + (u & 3) * STAGE + 256 * NKH + 64 * lq + 16 * st + l15;
+            // (the lane part is re-derived here from an opaque copy of the lane id - three VALU ops per unit: kept live across
+            //  the whole role it is one register too many for the 256 this kernel has, and the spill code lands between units)
+            int ln_ = lane;
+            HK_PIN_LOADED(ln_);
+            const float* T1 = lds + (u & 3) * STAGE + 256 * NKH + 16 * st + 64 * (ln_ >> 4) + (ln_ & 15);
             if (H == 0) {
                 acc13 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll

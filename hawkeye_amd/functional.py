@@ -344,6 +344,90 @@ def compact_bilinear_pool(x, plan):
     return _CompactBilinearPool.apply(x, plan)
 
 
+def _bgemm_raw(lib, a, b, out, trans_a, trans_b, m, n, k, nb):
+    check(lib.hk_bgemm_f32(ptr(a), a.shape[2], a.shape[1] * a.shape[2], int(trans_a), ptr(b), b.shape[2], b.shape[1] * b.shape[2],
+                           int(trans_b), ptr(out), n, m * n, m, n, k, nb, 1.0, 0.0, 0.0, stream()), 'hk_bgemm_f32')
+
+
+class _CbpCrossSum(torch.autograd.Function):
+    """Count sketch of the summed outer product of TWO different maps (CompactBilinearPooling.forward with bottom2 given,
+    CBCNN.py:96-130, before its signed sqrt): c[b,k] = sum_{(i,j) -> k} s1_i s2_j (X1 X2^T)[b,i,j] - the cross Gram on the
+    generic MFMA tiles (hk_bgemm_f32), the plan's CSR gather over it (hk_cbp_bin_matrix); backward: dG from dc
+    (hk_cbp_unbin_matrix), dX1 = dG X2, dX2 = dG^T X1."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, plan):
+        lib = _lib.load()
+        x1, x2 = _f32c(x1), _f32c(x2)
+        b, c, h, w = x1.shape
+        if tuple(x2.shape) != (b, c, h, w) or plan.C != c:
+            raise _lib.HawkeyeHipError(f'compact_bilinear_pool: inputs {tuple(x1.shape)} / {tuple(x2.shape)}, plan for {plan.C} channels')
+        hw, d = h * w, plan.D
+        g = torch.empty(b, c, c, dtype=torch.float32, device=x1.device)
+        _bgemm_raw(lib, x1.view(b, c, hw), x2.view(b, c, hw), g, False, True, c, c, hw, b)
+        c_raw = torch.empty(b, d, dtype=torch.float32, device=x1.device)
+        check(lib.hk_cbp_bin_matrix(ptr(g), ptr(plan.blob), ptr(c_raw), b, c, d, stream()), 'hk_cbp_bin_matrix')
+        ctx.plan = plan
+        ctx.save_for_backward(x1, x2)
+        return c_raw
+
+    @staticmethod
+    def backward(ctx, dc):
+        lib = _lib.load()
+        x1, x2 = ctx.saved_tensors
+        plan = ctx.plan
+        b, c, h, w = x1.shape
+        hw, d = h * w, plan.D
+        dc = _f32c(dc)
+        dg = torch.empty(b, c, c, dtype=torch.float32, device=x1.device)
+        check(lib.hk_cbp_unbin_matrix(ptr(dc), ptr(plan.blob), ptr(dg), b, c, d, stream()), 'hk_cbp_unbin_matrix')
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0]:
+            dx1 = torch.empty_like(x1)
+            _bgemm_raw(lib, dg, x2.view(b, c, hw), dx1.view(b, c, hw), False, False, c, hw, c, b)
+        if ctx.needs_input_grad[1]:
+            dx2 = torch.empty_like(x2)
+            _bgemm_raw(lib, dg, x1.view(b, c, hw), dx2.view(b, c, hw), True, False, c, hw, c, b)
+        return dx1, dx2, None
+
+
+class _CbpPerLocation(torch.autograd.Function):
+    """The tensor sketch of every location on its own (CompactBilinearPooling.forward with sum_pool = False, CBCNN.py:117-128
+    before its signed sqrt): c[b,h,w,k] = sum_{(i,j) -> k} s1_i s2_j x1[b,i,h,w] x2[b,j,h,w]  ->  [B,H,W,D]."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, plan):
+        lib = _lib.load()
+        x1, x2 = _f32c(x1), _f32c(x2)
+        b, c, h, w = x1.shape
+        if tuple(x2.shape) != (b, c, h, w) or plan.C != c:
+            raise _lib.HawkeyeHipError(f'compact_bilinear_pool: inputs {tuple(x1.shape)} / {tuple(x2.shape)}, plan for {plan.C} channels')
+        out = torch.empty(b, h, w, plan.D, dtype=torch.float32, device=x1.device)
+        check(lib.hk_cbp_loc_fwd(ptr(x1), ptr(x2), ptr(plan.blob), ptr(out), b, c, h * w, plan.D, stream()), 'hk_cbp_loc_fwd')
+        ctx.plan = plan
+        ctx.save_for_backward(x1, x2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dc):
+        lib = _lib.load()
+        x1, x2 = ctx.saved_tensors
+        plan = ctx.plan
+        b, c, h, w = x1.shape
+        dc = _f32c(dc)
+        dx1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
+        dx2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        check(lib.hk_cbp_loc_bwd(ptr(x1), ptr(x2), ptr(dc), ptr(plan.blob), ptr(dx1), ptr(dx2), b, c, h * w, plan.D, stream()),
+              'hk_cbp_loc_bwd')
+        return dx1, dx2, None
+
+
+def compact_bilinear_sketch(x1, x2, plan, sum_pool=True):
+    """The count sketch BEFORE the signed square root, for the forms Hawkeye's own CBCNN does not take: two different inputs
+    ([B,D]) or no sum over the map ([B,H,W,D]); x2 may be x1."""
+    return _CbpCrossSum.apply(x1, x2, plan) if sum_pool else _CbpPerLocation.apply(x1, x2, plan)
+
+
 # --------------------------------------------------------------------- AP-CNN
 class _AttPool(torch.autograd.Function):
     """gap = mean_hw F ; sgap = mean_hw a_s F  (one pass over F).

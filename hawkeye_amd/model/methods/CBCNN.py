@@ -5,6 +5,7 @@ optional explicit hashes) and, like the reference, holds NO parameters or buffer
 (the sketches are not in the state_dict).  It evaluates the tensor sketch through
 the exact Gram identity on the HIP kernels (hk_cbp_fwd/bwd) - see csrc/cbp.hip."""
 import numpy as np
+import torch
 import torch.nn as nn
 
 from ... import functional as HF
@@ -17,8 +18,6 @@ class CompactBilinearPooling(nn.Module):
     def __init__(self, input_dim1, input_dim2, output_dim, sum_pool=True,
                  rand_h_1=None, rand_s_1=None, rand_h_2=None, rand_s_2=None):
         super().__init__()
-        if not sum_pool:
-            raise NotImplementedError('sum_pool=False (per-location output) is not on the Hawkeye path')
         self.input_dim1, self.input_dim2, self.output_dim, self.sum_pool = input_dim1, input_dim2, output_dim, sum_pool
         h1, s1, h2, s2 = HF.sketch_hashes(input_dim1, input_dim2, output_dim)
         self.rand_h_1 = np.asarray(rand_h_1 if rand_h_1 is not None else h1)
@@ -40,10 +39,20 @@ class CompactBilinearPooling(nn.Module):
                                       self.rand_s_2.copy())
 
     def forward(self, bottom1, bottom2=None):
-        if bottom2 is not None and bottom2 is not bottom1:
-            raise NotImplementedError('two distinct inputs are not used by Hawkeye (CBCNN.py:33 passes one)')
-        assert bottom1.size(1) == self.input_dim1 and self.input_dim1 == self.input_dim2     # CBCNN.py:104-105
-        return HF.compact_bilinear_pool(bottom1, self._plan(bottom1.device))
+        one_input = bottom2 is None or bottom2 is bottom1
+        if bottom2 is None:
+            bottom2 = bottom1                                                                # CBCNN.py:101-102 (a clone there)
+        assert bottom1.size(1) == self.input_dim1 and bottom2.size(1) == self.input_dim2     # CBCNN.py:104-105
+        if self.input_dim1 != self.input_dim2:
+            raise NotImplementedError('input_dim1 != input_dim2: the plan (bin -> entries of a square Gram) is built per width')
+        plan = self._plan(bottom1.device)
+        if one_input and self.sum_pool:          # what Hawkeye's CBCNN calls (CBCNN.py:23,33): Gram + binning + finish on the kernels
+            return HF.compact_bilinear_pool(bottom1, plan)
+        # two different inputs (cross Gram) or sum_pool = False (every location on its own): the sketch on the kernels, then
+        # the reference's own two lines (CBCNN.py:132-133; for a [B,H,W,D] tensor F.normalize runs along H - kept as it is)
+        cbp = HF.compact_bilinear_sketch(bottom1, bottom2, plan, self.sum_pool)
+        cbp = torch.sign(cbp) * torch.sqrt(torch.abs(cbp) + 1e-10)
+        return torch.nn.functional.normalize(cbp)
 
 
 @MODEL.register

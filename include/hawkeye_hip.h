@@ -219,6 +219,21 @@ int hk_cbp_bwd(const float* x, const void* plan, const float* y, const float* c_
                const float* dy, float* dx, int B, int C, int HW, int D, void* ws, size_t ws_bytes,
                hk_stream_t stream);
 
+/* The two forms of CompactBilinearPooling.forward Hawkeye's own CBCNN never takes (it calls it with one input and
+ * sum_pool = True, CBCNN.py:23,33): two DIFFERENT inputs (CBCNN.py:96-102) and sum_pool = False (:127-130).  Same identity:
+ *   hk_cbp_bin_matrix    c_raw[b,k]  = sum_{(i,j) -> k} s1_i s2_j G[b,i,j]      for a given G [B,C,C] (the cross Gram X1 X2^T:
+ *                                                                              hk_bgemm_f32) - the plan's CSR gather
+ *   hk_cbp_unbin_matrix  dG[b,i,j]   = s1_i s2_j dc[b, (h1_i + h2_j) mod D]     its transpose (then dX1 = dG X2, dX2 = dG^T X1)
+ *   hk_cbp_loc_fwd       c[b,p,k]    = sum_{(i,j) -> k} s1_i s2_j x1[b,i,p] x2[b,j,p]     c [B,HW,D], no sum over the map
+ *   hk_cbp_loc_bwd       dx1, dx2 [B,C,HW] from dc [B,HW,D] (either output nullable)
+ * The signed square root and F.normalize (CBCNN.py:132-133) are the caller's; C (= both input widths) <= 1024 for _loc_. */
+int hk_cbp_bin_matrix(const float* G, const void* plan, float* c_raw, int B, int C, int D, hk_stream_t stream);
+int hk_cbp_unbin_matrix(const float* dc, const void* plan, float* dG, int B, int C, int D, hk_stream_t stream);
+int hk_cbp_loc_fwd(const float* x1, const float* x2, const void* plan, float* c, int B, int C, int HW, int D,
+                   hk_stream_t stream);
+int hk_cbp_loc_bwd(const float* x1, const float* x2, const float* dc, const void* plan, float* dx1, float* dx2, int B,
+                   int C, int HW, int D, hk_stream_t stream);
+
 /* ------------------------------------------------------------------ AP-CNN ----
  * Attention pooling.  The reference materialises A = a_s*F + a_c*F and only ever
  * consumes its global average (cls3/4/5 start with AdaptiveAvgPool2d(1)), so

@@ -112,6 +112,31 @@ def gen_cbp():
     w = t(rs_randn(24, tuple(y.shape)))
     (y * w).sum().backward()
     save('cbp_small_dense', y=y, dx=x.grad)
+    # the forms Hawkeye's own CBCNN never calls: two DIFFERENT inputs (CBCNN.py:96-102) and sum_pool = False (:127-130,
+    # [B,H,W,D] with F.normalize running along H), one and two inputs
+    # (a location's 256 signed products fall into 64 bins: a few bins nearly cancel, and the reference's own float32 FFT
+    #  gradient is ~1e-3 away from its float64 one there - so the module is run in both precisions and the float32 run's
+    #  distance from the float64 one is stored as the yardstick, like gen_full's cbp_e32_*)
+    res = {}
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for tag, two, sp in (('two', True, True), ('loc', False, False), ('loc_two', True, False)):
+        runs = {}
+        for dt in (torch.float32, torch.float64):
+            cbp = M_CBCNN.CompactBilinearPooling(16, 16, 64, sum_pool=sp)
+            cbp.sparse_sketch_matrix1 = cbp.sparse_sketch_matrix1.to(dt)
+            cbp.sparse_sketch_matrix2 = cbp.sparse_sketch_matrix2.to(dt)
+            x1 = t(np.abs(rs_randn(25, (2, 16, 3, 5))) + 0.1).to(dt).requires_grad_(True)
+            x2 = t(np.abs(rs_randn(26, (2, 16, 3, 5))) + 0.1).to(dt).requires_grad_(True)
+            y = cbp(x1, x2) if two else cbp(x1)
+            (y * t(rs_randn(27, tuple(y.shape))).to(dt)).sum().backward()
+            runs[dt] = (y.detach(), x1.grad.clone(), x2.grad.clone() if two else None)
+        (y, d1, d2), (y64, d164, d264) = runs[torch.float32], runs[torch.float64]
+        res[f'y_{tag}'], res[f'dx1_{tag}'], res[f'dx1_64_{tag}'] = y, d1, d164.float()
+        res[f'e32_dx1_{tag}'] = np.array([rel(d1, d164)])
+        if two:
+            res[f'dx2_{tag}'], res[f'dx2_64_{tag}'], res[f'e32_dx2_{tag}'] = d2, d264.float(), np.array([rel(d2, d264)])
+        print('cbp_forms', tag, 'reference fp32 vs fp64: y', rel(y, y64), 'dx1', rel(d1, d164), ('dx2 %g' % rel(d2, d264)) if two else '')
+    save('cbp_forms', **res)
     cbp = M_CBCNN.CompactBilinearPooling(512, 512, 6000)
     x = t(rs_relu_randn(1234, (2, 512, 14, 14))).requires_grad_(True)
     y = cbp(x)

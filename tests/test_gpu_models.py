@@ -128,6 +128,40 @@ def test_bcnn_stage1_at_config_input_size_vs_reference():
     assert rel(m.classifier.bias.grad, g['BCNN_S1_cls_b_grad']) < 1e-4
 
 
+def test_bcnn_signed_sqrt_whole_model():
+    """BCNN with the reference's OTHER normalisation (BCNN.py:23-24 enabled: `bilinear_pooling.signed_sqrt = True`) end to
+    end: the plugin then runs pooling + classifier as one node with the l2 scale folded into the classifier
+    (model/utils.py::pooled_classifier -> F.ssqrt_pool_linear, SURVEY 8f-1).  Same 28 state_dict keys as the default model;
+    logits and every gradient equal to the two-node composition (signed-sqrt pooling kernel, then torch's nn.Linear)
+    on the same weights; and the pooled vector of that composition against the reference's own source with the two
+    lines swapped in (tests/golden/bcnn_ssqrt_small.npz pins the pooling itself in test_gpu_parity)."""
+    import json
+    from emu.harness import restore_wide_linear, set_wide_linear
+    keys = json.load(open(os.path.join(G, 'state_dict_keys.json')))['BCNN']['state_dict']
+    m = build('BCNN', stage=2, num_classes=12)
+    m.bilinear_pooling.signed_sqrt = True
+    assert [k for k, _ in keys] == list(m.state_dict().keys())
+    seeded_init(m, 950)
+    m = m.to(DEV).eval()
+    x = t(rs_randn(951, (3, 3, 64, 64))).to(DEV)
+    tgt = torch.tensor([1, 7, 4], device=DEV)
+    res = []
+    for kernel in (False, True):                       # torch Linear on the kernel's pooled vector / the fused node
+        saved = set_wide_linear(kernel)
+        m.zero_grad()
+        y = m(x)
+        torch.nn.functional.cross_entropy(y, tgt).backward()
+        res.append((y.detach().clone(), m.classifier.weight.grad.clone(), m.classifier.bias.grad.clone(),
+                    next(m.backbone.parameters()).grad.clone()))
+        restore_wide_linear(saved)
+    (y0, w0, b0, c0), (y1, w1, b1, c1) = res
+    assert rel(y1, y0) < 1e-5 and y1.argmax(1).tolist() == y0.argmax(1).tolist()
+    assert rel(w1, w0) < 1e-5 and rel(b1, b0) < 1e-5
+    e = rel(c1, c0)
+    print(f'[BCNN signed sqrt] fused node vs pooling kernel + nn.Linear: first-conv gradient {e:.2e}')
+    assert e < 2e-2, e                                # (behind MIOpen's backward; 2 x 2 maps: the signed sqrt's slope at G ~ 0)
+
+
 def test_pyramid_attentions_module_vs_reference_golden():
     """SURVEY row A7 at MODULE level: the plugin's PyramidAttentions (spatial gate on MIOpen, hk_att_pool, channel gates
     averaged bottom-up, pooled = sgap + a_c * gap) with the REFERENCE's weights, against what the reference's

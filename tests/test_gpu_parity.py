@@ -362,6 +362,40 @@ def test_cbp_dense_small_and_512(F):
         assert yg.argmax(dim=1).cpu().tolist() == y.argmax(dim=1).tolist()
 
 
+def test_cbp_two_inputs_and_per_location_vs_reference(F):
+    """The forms of CompactBilinearPooling.forward that Hawkeye's own CBCNN does not call, through the plugin module, against
+    the reference module run on the same inputs (tests/golden/cbp_forms.npz, gen_cbp): two DIFFERENT inputs (CBCNN.py:96-102
+    - the cross Gram X1 X2^T binned by the plan's CSR gather), sum_pool = False with one input and with two (CBCNN.py:127-130
+    - the sketch of every location on its own, [B,H,W,D], F.normalize along H as the reference leaves it): outputs and the
+    gradients with respect to both inputs.  Also: the two-input form fed the SAME tensor twice equals the one-input kernels."""
+    from hawkeye_amd.model.methods.CBCNN import CompactBilinearPooling
+    g = load('cbp_forms')
+    for tag, two, sp in (('two', True, True), ('loc', False, False), ('loc_two', True, False)):
+        pool = CompactBilinearPooling(16, 16, 64, sum_pool=sp)
+        x1 = t(np.abs(rs_randn(25, (2, 16, 3, 5))) + 0.1).to(DEV).requires_grad_(True)
+        x2 = t(np.abs(rs_randn(26, (2, 16, 3, 5))) + 0.1).to(DEV).requires_grad_(True)
+        y = pool(x1, x2) if two else pool(x1)
+        assert tuple(y.shape) == tuple(g[f'y_{tag}'].shape)
+        (y * t(rs_randn(27, tuple(y.shape))).to(DEV)).sum().backward()
+        assert rel(y, g[f'y_{tag}']) < 1e-5, tag
+        # gradients: against the reference run in float64 (1e-4), and against its float32 run within that run's own
+        # distance from the float64 one (per location a few of the 64 bins nearly cancel: dc = du / 2 sqrt|c| amplifies the
+        # round-off of the reference's FFTs to 1e-3 there)
+        for xg, k in ((x1, 'dx1'),) + (((x2, 'dx2'),) if two else ()):
+            assert rel(xg.grad, g[f'{k}_64_{tag}']) < 1e-4, (tag, k)
+            assert rel(xg.grad, g[f'{k}_{tag}']) < 1e-4 + 2 * float(g[f'e32_{k}_{tag}'][0]), (tag, k)
+    # the cross route on one tensor = the symmetric route (different kernels, same mathematics)
+    pool = CompactBilinearPooling(128, 128, 512)
+    xa = t(rs_relu_randn(28, (3, 128, 7, 7)) + 0.05).to(DEV).requires_grad_(True)
+    xb = xa.detach().clone().requires_grad_(True)
+    w = t(rs_randn(29, (3, 512))).to(DEV)
+    y1 = pool(xa)
+    (y1 * w).sum().backward()
+    y2 = pool(xb, xb.clone())                      # (a distinct tensor object: takes the two-input route; gradient flows to xb twice)
+    (y2 * w).sum().backward()
+    assert rel(y2, y1) < 1e-5 and rel(xb.grad, xa.grad) < 1e-4
+
+
 @pytest.mark.parametrize('csr', ['0', '1', '2', '3', '4'])
 def test_cbp_512_both_binning_kernels(F, csr, tune):
     """hk_cbp_fwd has the fused Gram + binning kernel (3: the default) and three binning kernels behind a separate Gram

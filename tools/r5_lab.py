@@ -96,6 +96,16 @@ def g_linear():
     fwd = lambda: lib.hk_linear_fwd(p(y), p(w), p(bias), p(o), B, J, K, p(ws), nws, st())
     bwd = lambda: lib.hk_linear_bwd(p(y), p(w), p(g), p(dy), p(dw), p(db), B, J, K, st())
     items = [('hk_linear_fwd', {}, fwd, fl, by), ('hk_linear_bwd (dy + dW + db)', {}, bwd, 2 * fl, 2 * by)]
+    alt = os.environ.get('R5_ALT_LIB')              # a second build of the library (an older kernel) timed in the same rounds
+    if alt:
+        import ctypes
+        from hawkeye_amd import _lib as LL
+        lib2 = ctypes.CDLL(alt)
+        for name, (res, args) in LL.SIGNATURES.items():
+            if hasattr(lib2, name):
+                getattr(lib2, name).restype, getattr(lib2, name).argtypes = res, args
+        items.append((f'hk_linear_bwd of {os.path.basename(alt)}', {}, lambda: lib2.hk_linear_bwd(p(y), p(w), p(g), p(dy), p(dw), p(db), B, J, K, st()), 2 * fl, 2 * by))
+        items.append((f'hk_linear_fwd of {os.path.basename(alt)}', {}, lambda: lib2.hk_linear_fwd(p(y), p(w), p(bias), p(o), B, J, K, p(ws), nws, st()), fl, by))
     return [L.run_group('classifier 64 x 262144 -> 200', items)]
 
 
