@@ -191,6 +191,60 @@ def test_trivial_augment_wide_op_table_known_answers():
     assert (_arr(out) == np.where(_arr(img) < 127.5, _arr(img), 255 - _arr(img))).all()
 
 
+def test_preset_tail_known_answers(monkeypatch):
+    """Hand-derived answers for the rest of the preset parameter paths (dataset/transforms.py:26-46,63-69), labelled for what
+    they are: checks against torchvision's PUBLISHED definitions, not against torchvision itself (unpinned: DESIGN.md
+    section 4).  PILToTensor + ConvertImageDtype = value / 255; Normalize = (v - mean_c) / std_c per channel; the erase
+    box is zeroed AFTER the normalisation (RandomErasing value = 0 on the normalised tensor); RandomHorizontalFlip mirrors
+    the columns; Resize(int) takes the SHORTER side to `resize_size` and the longer to int(size * long / short) (truncated);
+    CenterCrop's offsets are int(round((side - crop) / 2))."""
+    # normalisation constants on a constant image: (200 / 255 - mean) / std per channel
+    img = Image.fromarray(np.full((8, 8, 3), 200, dtype=np.uint8))
+    out = T.normalize(T.to_float_tensor(img))
+    want = [(200.0 / 255.0 - m) / s_ for m, s_ in zip((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))]
+    assert out.shape == (3, 8, 8)
+    for c in range(3):
+        assert math.isclose(float(out[c, 3, 5]), want[c], rel_tol=1e-6)
+    assert math.isclose(want[0], 1.3070474, rel_tol=1e-6) and math.isclose(want[2], 1.6813944, rel_tol=1e-6)   # (by hand)
+    # black / white pixels: -mean / std and (1 - mean) / std
+    bw = np.zeros((2, 2, 3), dtype=np.uint8)
+    bw[0, 0] = 255
+    o2 = T.normalize(T.to_float_tensor(Image.fromarray(bw)))
+    assert math.isclose(float(o2[1, 1, 1]), -0.456 / 0.224, rel_tol=1e-6) and math.isclose(float(o2[1, 0, 0]), 0.544 / 0.224, rel_tol=1e-6)
+    # eval preset geometry: 500 x 375 (w x h), resize 510, crop 448 -> shorter side (h) 510, w = int(510 * 500 / 375) = 680;
+    # offsets int(round((680 - 448) / 2)) = 116 and int(round((510 - 448) / 2)) = 31.  A ramp image whose value encodes
+    # its column makes the crop window visible.
+    ramp = np.tile((np.arange(500) // 2).astype(np.uint8)[None, :, None], (375, 1, 3))
+    ev = T.ClassificationPresetEval(448, 510, device_finalize=True)(Image.fromarray(ramp))['u8'].numpy()
+    assert ev.shape == (448, 448, 3)
+    # column x of the crop = column 116 + x of the 680-wide resize = source column ~ (116 + x + 0.5) * 500 / 680 - 0.5
+    for x in (0, 200, 447):
+        src = (116 + x + 0.5) * 500.0 / 680.0 - 0.5
+        assert abs(float(ev[100, x, 0]) - src / 2.0) <= 1.0, (x, ev[100, x, 0], src / 2.0)
+    # portrait: 300 x 400 -> w is the shorter side: 510 x int(510 * 400 / 300) = 510 x 680; left 31, top 116
+    ramp_v = np.tile((np.arange(400) // 2).astype(np.uint8)[:, None, None], (1, 300, 3))
+    ev = T.ClassificationPresetEval(448, 510, device_finalize=True)(Image.fromarray(ramp_v))['u8'].numpy()
+    for y in (0, 447):
+        src = (116 + y + 0.5) * 400.0 / 680.0 - 0.5
+        assert abs(float(ev[y, 10, 0]) - src / 2.0) <= 1.0
+    # train preset with every draw scripted: the crop box (whole image), a flip, no augmentation, an erase box.
+    # 64 x 64 ramp -> crop (0, 0, 64, 64) resized to 32: column x holds source columns 2x, 2x + 1; flipped: 63 - ...
+    rampc = np.tile((np.arange(64) * 4).astype(np.uint8)[None, :, None], (64, 1, 3))
+    monkeypatch.setattr(T, 'random_resized_crop_box', lambda w, h: (0, 0, w, h))
+    monkeypatch.setattr(T, 'random_erasing_box', lambda h, w: (4, 6, 5, 7))            # (top, left, h, w)
+    draws = iter([0.2, 0.05])                               # flip (0.2 < 0.5), erase (0.05 < 0.1)
+    monkeypatch.setattr(T.random, 'random', lambda: next(draws))
+    tr = T.ClassificationPresetTrain(32, auto_augment_policy=None, random_erase_prob=0.1)(Image.fromarray(rampc))
+    assert tr.shape == (3, 32, 32)
+    assert float(tr[:, 4:9, 6:13].abs().max()) == 0.0       # the erased box: zeros in NORMALISED space
+    px = lambda v, c: (v / 255.0 - (0.485, 0.456, 0.406)[c]) / (0.229, 0.224, 0.225)[c]
+    # flipped ramp: output column x shows source columns 63 - 2x, 62 - 2x (mean 62.5 - 2x, times 4 grey levels per column)
+    for x in (0, 20, 31):
+        got = float(tr[1, 20, x])
+        assert abs(got - px((62.5 - 2 * x) * 4.0, 1)) <= 3.0 / 255.0 / 0.224, (x, got)
+    assert float(tr[1, 20, 0]) > float(tr[1, 20, 31])       # mirrored: bright on the left
+
+
 def test_presets_against_torchvision_fixtures_when_present():
     """tests/golden/transforms_tv.npz is written by oracle/gen_transform_fixtures.py wherever torchvision is installed (it
     is not in this image nor on the GPU box: DESIGN.md section 4, 'parity unpinned'); when the file exists the eval preset
