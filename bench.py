@@ -223,7 +223,7 @@ def kernel_rooflines(B, C, HW, dev):
         ('bcnn_colsum_partial4_kernel + finalize (stage entry point)',
          lambda: lib.hk_bcnn_colsum_norm(ptr(x), ptr(cs), ptr(inv), B, C, HW, ptr(wsc), nwsc, stream()),
          0.0, 4.0 * B * C * HW, None, False),
-        ('hk_bcnn_pool_fwd, whole (two launches: colsum partials + Gram with the norm in its prologue)',
+        ('hk_bcnn_pool_fwd, whole (ONE launch: the Gram kernel adds up the sample\'s columns in its prologue)',
          lambda: lib.hk_bcnn_pool_fwd(ptr(x), ptr(y), ptr(inv), ptr(cs), B, C, HW, ptr(wsc), nwsc, stream()),
          flops, 8.0 * B * C * HW + 4.0 * B * C * C, flops * sym, False),
         (gram_name, lambda: lib.hk_bcnn_gram_norm(ptr(x), ptr(inv), ptr(y), B, C, HW, stream()),
@@ -233,6 +233,13 @@ def kernel_rooflines(B, C, HW, dev):
          flops, 8.0 * B * C * C + 8.0 * B * C * HW, None, True),
         ('bcnn_rank1_fix_kernel', lambda: lib.hk_bcnn_bwd_rank1(ptr(dx), ptr(tp), ptr(inv), ptr(cs), B, C, HW, stream()),
          0.0, 8.0 * B * C * HW, None, True),
+        ('hk_bcnn_pool_bwd, whole (two launches: GEMM kernel + rank-1 pass; dy from anywhere)',
+         lambda: lib.hk_bcnn_pool_bwd(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(cs), ptr(dx), B, C, HW, ptr(wsc), nwsc, stream()),
+         flops, 8.0 * B * C * C + 8.0 * B * C * HW, None, False),
+        ('hk_bcnn_pool_bwd_tdot, whole (ONE launch: <y, dy> from the classifier, rank-1 term in the GEMM epilogue; what BCNN runs)',
+         lambda: lib.hk_bcnn_pool_bwd_tdot(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(cs), ptr(gl), ptr(ol), ptr(bl), K, ptr(dx), B, C, HW,
+                                           ptr(wsc), nwsc, stream()),
+         flops, 8.0 * B * C * C + 8.0 * B * C * HW, None, False),
         ('hk_linear_fwd: linear_skinny_kernel + linear_reduce_kernel (classifier 262144->200)',
          lambda: lib.hk_linear_fwd(ptr(y), ptr(wl), ptr(bl), ptr(ol), B, J, K, ptr(wsl), nwl, stream()),
          lflops, lbytes, lflops * kpad, True),

@@ -33,7 +33,7 @@ def canned():
         'roofline': {'bound': dom['bound'], 'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
                      'frac': dom['frac'], 'traffic': 303269365, 'kernel': dom['kernel'][:96], 'us': dom['us'],
                      'flops_algorithmic': dom['flops_algorithmic'], 'flops_executed': dom['flops_executed'],
-                     'bytes_algorithmic': dom['bytes_algorithmic'], 'traffic_source': 'profiles/r3_pool_kernels_pmc.csv'},
+                     'bytes_algorithmic': dom['bytes_algorithmic'], 'traffic_source': 'profiles/r5_pool_kernels_pmc.csv'},
         'cpu_baseline': {'value': 2.35, 'unit': 'images/sec', 'cores': 32, 'kind': 'port',
                          'sample': 'BCNN stage-2 train step, batch 4, 448x448, best of 3 after 1 warm-up, torch CPU fp32, 32 '
                                    'threads of 256 host cores'},
