@@ -10,14 +10,13 @@
 // Binning a tile deterministically, without atomics, with four waves in parallel: it is a GATHER.  For every ordered
 // pair of 64-row blocks (I, J) the plan holds the 4096 entries (i in I, j in J) -> bin (h1_i + h2_j) mod D, sign
 // s1_i s2_j, sorted by bin and cut into FOUR runs, one per binning wave: wave w owns the bins [w D / 4, (w + 1) D / 4) in
-// every list, so no bin is ever touched by two waves, whatever their relative progress.  Lane t of a wave owns 18
-// consecutive entries of its run (18 x 64 = 1152 >= 1024 + 4.6 sigma of the run length; padded with entries that add 0
-// to a dump bin; the plan build fails over to the unfused path if a run does not fit), and in step e every lane adds
-// one of its entries:
+// every list, so no bin is ever touched by two waves, whatever their relative progress.  A run has 18 x 64 = 1152
+// (step, lane) slots (>= 1024 + 4.6 sigma of the run length; padded with entries that add 0 to a dump bin; the plan build
+// fails over to the unfused path if a run does not fit), and in step e every lane adds one entry:
 //     c[bin] += +-T[idx]           T = the tile in LDS
-// The 64 entries of a step are 18 apart in sorted order, so they hit distinct bins unless a bin held more than 18
-// entries of the tile (the plan build checks: at C = 512, D = 6000 the largest count is 7); later steps of a wave may
-// hit the same bin from neighbouring lanes - LDS instructions of one wave execute in order, and a step's (pair of
+// The plan build deals the entries so that the 64 entries of a step (and, for the paired form, of a pair of steps) hit
+// distinct bins - and, round 5, so that the 32 addresses a half wave presents per LDS access fall on different banks;
+// later steps of a wave may hit the same bin again - LDS instructions of one wave execute in order, and a step's (pair of
 // steps') read-modify-write is complete in the instruction stream before the next one's read is issued.  A computed
 // tile (I, J), I < J, feeds two lists: (I, J) and (J, I) (G_ji = G_ij, other bin); a diagonal tile one.  Per bin the
 // additions happen in a fixed order (tile order of the workgroup, position within a list): bit-reproducible.
@@ -30,6 +29,7 @@
 // so that B x items fills the chip (B = 16, C = 512: 16 items per sample = 256 workgroups).
 #pragma once
 #include <vector>
+#include <array>
 #include <algorithm>
 #include "hk_gram_tile.h"
 
@@ -58,12 +58,10 @@ struct CbfSchedule {
 __host__ __device__ __forceinline__ unsigned cbf_pack(int idx, int bin, int neg) { return (unsigned)(4 * idx) | ((unsigned)(4 * bin) << 16) | ((unsigned)neg << 31); }
 __host__ __device__ __forceinline__ int cbf_bin_of(unsigned w) { return (int)((w >> 16) & 0x7fffu) / 4; }
 
-// Host: the nb x nb lists of (C, D, hashes).  Returns 0 when the fused path cannot be used for these hashes (a bin with
-// more than CBF_LSTEPS entries in one tile, a run that does not fit its padding, D too large for the entry word), 1 when
-// it can, 2 when in addition the two steps of every PAIR (2 p, 2 p + 1) of a wave hit disjoint bins - the kernel then
-// issues the reads of a pair before its writes.  A lane's 18 sorted entries are dealt to its steps with stride 7 (step q
-// takes sorted offset 7 q mod 18), so consecutive steps of a lane - and of its neighbours - are >= 7 apart in sorted
-// order: disjoint unless a bin holds more than 7 entries of the tile (C = 512, D = 6000: at most 7).
+// Host: the nb x nb lists of (C, D, hashes).  Returns 0 when the fused path cannot be used for these hashes (a run that
+// does not fit its padding, an entry no step can take, D too large for the entry word), 1 when it can, 2 when in addition
+// the two steps of every PAIR (2 p, 2 p + 1) of a wave hit disjoint bins - the kernel then issues the reads of a pair
+// before its writes.  How the entries of a run are dealt to its (step, lane) slots: see the loop over the waves below.
 static inline int cbf_build_lists(const int* h1, const float* s1, const int* h2, const float* s2, int C, int D,
                                   std::vector<unsigned>& out) {
     if (C % 64 != 0 || D + 1 > CBF_DMAX) return 0;
@@ -100,12 +98,149 @@ static inline int cbf_build_lists(const int* h1, const float* s1, const int* h2,
             for (int w = 0; w < 4; ++w) {
                 const int n = cut[w + 1] - cut[w];
                 if (n > CBF_WLEN || n < 0) return 0;
-                // lane t owns sorted positions [18 t, 18 t + 18) of the run, offset o in step (o * 13) mod 18 (the inverse
-                // of q -> 7 q mod 18); word (step q, lane t) at (w * 18 + q) * 64 + t
-                for (int q = 0; q < n; ++q) {
-                    const E& e = es[cut[w] + q];
-                    const int t = q / CBF_LSTEPS, o = q % CBF_LSTEPS, st = (o * 13) % CBF_LSTEPS;
-                    L[(w * CBF_LSTEPS + st) * 64 + t] = cbf_pack(e.idx, e.bin, e.neg);
+                // The run's n entries are dealt to its 18 x 64 (step, lane) slots; word (step q, lane t) at (w * 18 + q) * 64 + t.
+                // Any deal is correct as long as one instruction never touches a bin twice (a step's 64 read-modify-writes;
+                // for the paired form also the partner step's) - a bin's additions then happen in step order, fixed by the
+                // plan.  Round 5 uses that freedom against LDS bank conflicts (round 3 dealt sorted runs of 18 to the lanes
+                // with a stride-7 step pattern: the 32 addresses a half wave presents per 4-byte LDS access fell on random
+                // banks, 3.3-way on average - 45 % of the kernel's LDS cycles were conflict cycles).  An entry has a gather
+                // bank (idx mod 32) and a bin bank (bin mod 32): the entries of one half-step are chosen as a MATCHING of
+                // the bipartite multigraph gather banks <-> bin banks (Kuhn's augmenting paths, busiest banks first), i.e.
+                // 32 entries whose gather banks are all different AND whose bin banks are all different (two entries of one
+                // bin share a bin bank, so a matching never holds a bin twice); bins already in the other half of the step
+                // or in the partner step are excluded.  What the 36 matchings leave over goes to the free slots with the
+                // fewest collisions.
+                {
+                    const E* el = &es[cut[w]];
+                    std::vector<char> left(n, 1);
+                    std::vector<int> slot(CBF_LSTEPS * 64, -1);                  // entry index per (step, lane)
+                    std::vector<std::vector<int>> binsOf(CBF_LSTEPS);            // bins placed per step
+                    auto in_step = [&](int q, int bin) {
+                        for (int b_ : binsOf[q]) if (b_ == bin) return true;
+                        return false;
+                    };
+                    for (int q = 0; q < CBF_LSTEPS; ++q)
+                        for (int half = 0; half < 2; ++half) {
+                            // candidate edges by gather bank; degrees for the "busiest first" order
+                            std::vector<int> adj[32];
+                            int degT[32] = {}, degB[32] = {};
+                            std::vector<int> remBin(n, 0);                       // entries of the same bin still to place (sorted: neighbours)
+                            for (int e = 0; e < n;) {
+                                int f = e, c = 0;
+                                while (f < n && el[f].bin == el[e].bin) { c += left[f]; ++f; }
+                                for (int g_ = e; g_ < f; ++g_) remBin[g_] = c;
+                                e = f;
+                            }
+                            for (int e = 0; e < n; ++e) {
+                                if (!left[e]) continue;
+                                degT[el[e].idx & 31]++;
+                                degB[el[e].bin & 31]++;
+                                if (in_step(q, el[e].bin) || in_step(q ^ 1, el[e].bin)) continue;
+                                adj[el[e].idx & 31].push_back(e);
+                            }
+                            // edge order of a gather bank: entries of the bins with the most entries still to place first (a
+                            // bin with c entries needs c steps no two of which are partners: the heavy ones must not be left
+                            // for the end), then the busier bin bank
+                            for (int tb = 0; tb < 32; ++tb)
+                                std::stable_sort(adj[tb].begin(), adj[tb].end(), [&](int a_, int b_) {
+                                    if (remBin[a_] != remBin[b_]) return remBin[a_] > remBin[b_];
+                                    return degB[el[a_].bin & 31] > degB[el[b_].bin & 31];
+                                });
+                            int order[32];
+                            for (int tb = 0; tb < 32; ++tb) order[tb] = tb;
+                            std::stable_sort(order, order + 32, [&](int a_, int b_) { return degT[a_] > degT[b_]; });
+                            int matchB[32], matchT[32];                          // bin bank -> entry, gather bank -> entry
+                            for (int k = 0; k < 32; ++k) matchB[k] = matchT[k] = -1;
+                            bool seen[32];
+                            auto augment = [&](auto&& self, int tb) -> bool {
+                                for (int e : adj[tb]) {
+                                    const int bb = el[e].bin & 31;
+                                    if (seen[bb]) continue;
+                                    seen[bb] = true;
+                                    if (matchB[bb] < 0 || self(self, el[matchB[bb]].idx & 31)) {
+                                        matchB[bb] = e;
+                                        matchT[tb] = e;
+                                        return true;
+                                    }
+                                }
+                                return false;
+                            };
+                            for (int k = 0; k < 32; ++k) {
+                                for (int z = 0; z < 32; ++z) seen[z] = false;
+                                augment(augment, order[k]);
+                            }
+                            int lane = 32 * half;
+                            for (int tb = 0; tb < 32; ++tb) {
+                                const int e = matchT[tb];
+                                if (e < 0 || matchB[el[e].bin & 31] != e) continue;          // (an augmenting path may have re-matched it)
+                                slot[q * 64 + lane++] = e;
+                                left[e] = 0;
+                                binsOf[q].push_back(el[e].bin);
+                            }
+                        }
+                    // leftovers: the free slot with the fewest bank collisions whose step (and partner step) does not hold the bin
+                    for (int e = 0; e < n; ++e) {
+                        if (!left[e]) continue;
+                        int best = -1;
+                        long long bc = 0;
+                        for (int q = 0; q < CBF_LSTEPS; ++q) {
+                            if (in_step(q, el[e].bin) || in_step(q ^ 1, el[e].bin)) continue;
+                            for (int half = 0; half < 2; ++half) {
+                                int freeLane = -1, coll = 0;
+                                for (int t = 32 * half; t < 32 * half + 32; ++t) {
+                                    const int o = slot[q * 64 + t];
+                                    if (o < 0) { if (freeLane < 0) freeLane = t; continue; }
+                                    coll += ((el[o].idx & 31) == (el[e].idx & 31)) + ((el[o].bin & 31) == (el[e].bin & 31));
+                                }
+                                if (freeLane >= 0 && (best < 0 || coll < bc)) { best = q * 64 + freeLane; bc = coll; }
+                            }
+                        }
+                        if (best < 0) {
+                            // every admissible step is full: move one of its occupants to a free slot IT may take, and take its place
+                            auto drop_bin = [&](int q, int bin) {
+                                for (size_t z = 0; z < binsOf[q].size(); ++z)
+                                    if (binsOf[q][z] == bin) { binsOf[q].erase(binsOf[q].begin() + z); return; }
+                            };
+                            for (int q = 0; q < CBF_LSTEPS && best < 0; ++q) {
+                                if (in_step(q, el[e].bin) || in_step(q ^ 1, el[e].bin)) continue;
+                                for (int t = 0; t < 64 && best < 0; ++t) {
+                                    const int o = slot[q * 64 + t];
+                                    if (o < 0) continue;
+                                    for (int q2 = 0; q2 < CBF_LSTEPS && best < 0; ++q2) {
+                                        if (q2 == q || in_step(q2, el[o].bin)) continue;
+                                        if (q2 != (q ^ 1) && in_step(q2 ^ 1, el[o].bin)) continue;
+                                        if (q2 == (q ^ 1)) continue;             // (o itself sits in q: its bin would meet itself across the pair)
+                                        for (int t2 = 0; t2 < 64; ++t2)
+                                            if (slot[q2 * 64 + t2] < 0) {
+                                                slot[q2 * 64 + t2] = o;
+                                                binsOf[q2].push_back(el[o].bin);
+                                                drop_bin(q, el[o].bin);
+                                                slot[q * 64 + t] = -1;
+                                                best = q * 64 + t;
+                                                break;
+                                            }
+                                    }
+                                }
+                            }
+                        }
+                        if (best < 0) {                                          // only steps that break the PAIRED form are left: take one
+                            for (int q = 0; q < CBF_LSTEPS && best < 0; ++q) {
+                                if (in_step(q, el[e].bin)) continue;
+                                for (int t = 0; t < 64; ++t)
+                                    if (slot[q * 64 + t] < 0) { best = q * 64 + t; break; }
+                            }
+                            if (best < 0) return 0;
+                        }
+                        slot[best] = e;
+                        left[e] = 0;
+                        binsOf[best / 64].push_back(el[e].bin);
+                    }
+                    for (int q = 0; q < CBF_LSTEPS; ++q)
+                        for (int t = 0; t < 64; ++t)
+                            if (slot[q * 64 + t] >= 0) {
+                                const E& e = el[slot[q * 64 + t]];
+                                L[(w * CBF_LSTEPS + q) * 64 + t] = cbf_pack(e.idx, e.bin, e.neg);
+                            }
                 }
                 // the 64 entries of a step must hit distinct bins (the dump bin may repeat); two consecutive steps too
                 // for the pipelined form

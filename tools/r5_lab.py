@@ -62,24 +62,39 @@ def g_cov():
 
 
 def g_cbp():
+    """hk_cbp_fwd / hk_cbp_bwd through the C ABI at B = 64 and the yaml batch 16; with R5_ALT_LIB also the same calls into a
+    second build of the library (its own plan: the gather lists are built by hk_cbp_plan_build) in the same rounds."""
+    import ctypes
     import hawkeye_amd.functional as F
+    from hawkeye_amd import _lib as LL
     out = []
-    plan = F.CbpPlan(*F.sketch_hashes(512, 512, 6000), 6000, dev)
+    C, D, HW = 512, 6000, 196
+    h1, s1, h2, s2 = F.sketch_hashes(C, C, D)
+    libs = [('', lib)]
+    alt = os.environ.get('R5_ALT_LIB')
+    if alt:
+        lib2 = ctypes.CDLL(alt)
+        for name, (res, args) in LL.SIGNATURES.items():
+            if hasattr(lib2, name):
+                getattr(lib2, name).restype, getattr(lib2, name).argtypes = res, args
+        libs.append((' of ' + os.path.basename(alt), lib2))
+    plans = []
+    for tag, lb in libs:
+        blob = torch.empty(lb.hk_cbp_plan_bytes(C, D), dtype=torch.uint8, device=dev)
+        assert lb.hk_cbp_plan_build(h1.ctypes.data, s1.ctypes.data, h2.ctypes.data, s2.ctypes.data, C, D, p(blob), st()) == 0
+        plans.append(blob)
     for B in (64, 16):
-        x = torch.relu(torch.randn(B, 512, 14, 14, device=dev)).requires_grad_(True)
-        w = torch.randn(B, 6000, device=dev)
-        y = F.compact_bilinear_pool(x, plan)
-        fl = 2.0 * B * 512 * 512 * 196
-
-        def fwd():
-            with torch.no_grad():
-                F.compact_bilinear_pool(x, plan)
-
-        def fb():
-            x.grad = None
-            (F.compact_bilinear_pool(x, plan) * w).sum().backward()
-        items = [('cbp fwd (through the autograd wrapper: + host overhead)', {}, fwd, fl * 36 / 64, None),
-                 ('cbp fwd + bwd + a mul / sum (autograd)', {}, fb, 2 * fl, None)]
+        x = torch.relu(torch.randn(B, C, HW, device=dev))
+        y, craw, inv = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev), torch.empty(B, device=dev)
+        dy, dx = torch.randn(B, D, device=dev), torch.empty_like(x)
+        nws = lib.hk_cbp_ws_bytes(B, C, HW, D)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        fl = 2.0 * B * C * C * HW
+        items = []
+        for (tag, lb), blob in zip(libs, plans):
+            items.append(('hk_cbp_fwd' + tag, {}, (lambda lb=lb, blob=blob: lb.hk_cbp_fwd(p(x), p(blob), p(y), p(craw), p(inv), B, C, HW, D, p(ws), nws, st())), fl * 36 / 64, None))
+            items.append(('hk_cbp_bwd' + tag, {}, (lambda lb=lb, blob=blob: lb.hk_cbp_bwd(p(x), p(blob), p(y), p(craw), p(inv), p(dy), p(dx), B, C, HW, D, p(ws), nws, st())), fl, None))
+        items[0][2]()
         out.append(L.run_group(f'compact bilinear pooling B = {B}', items))
     return out
 
