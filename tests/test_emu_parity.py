@@ -39,6 +39,7 @@ _HEAVY = {'test_cbp_rowsketch_equals_csr[512-6000-40]', 'test_models_with_hip_cl
           'test_sqrtm_triuvec_in_one_chain[17-256-5]',
           'test_backward_bwd3_kernel[2-512-14]', 'test_bcnn_backward_in_one_launch[2-512-14-200-True]',
           'test_bcnn_backward_in_one_launch[3-256-10-20-True]', 'test_bcnn_backward_in_one_launch[2-256-8-13-True]',
+          'test_bcnn_backward_in_one_launch[3-192-12-5-True]',
           'test_linear_bwd_direct_at_classifier_shapes[64-65536-200]', 'test_linear_bwd_direct_at_classifier_shapes[37-65728-130]',
           'test_linear_bwd_single_products[9-16384-260]', 'test_linear_bwd_single_products[64-16384-193]',
           'test_signed_sqrt_pool_with_the_scale_folded_into_the_classifier[5-192-8-208]', 'test_ns_symmetric_forward[1-384-2]', 'test_linear_bwd_direct_at_classifier_shapes[10-100352-1024]',
