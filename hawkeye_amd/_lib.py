@@ -31,6 +31,7 @@ SIGNATURES = {
     'hk_bcnn_ssqrt_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'hk_bcnn_ssqrt_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_ssqrt_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_bcnn_ssqrt_pool_bwd_tdot': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_ssqrt_pool_fwd_unscaled': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_ssqrt_pool_bwd_unscaled': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_colsum_norm': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),

@@ -665,6 +665,32 @@ int bcnn_fast_bwd_fold(const float* x, const float* y, const float* dy, const fl
 #undef CALL
 }
 
+// signed-sqrt variant with t = <y, dy> handed over as a dot product (the classifier's backward knows it: hk_bwd3.h TK 1):
+// no pass over y and dy for the partial sums.  t_inv2: y is the un-normalised u (inv_norm = the true 1 / |u|): the
+// coefficient carries one factor inv less, t one more.  HK_ERR_UNSUPPORTED where gram_bwd3_kernel does not run.
+template <int HW>
+static int ssqrt_tdot_launch(const float* x, const float* y, const float* dy, const float* inv_norm, const float* ta,
+                             const float* tb, const float* tc, int tK, int t_inv2, float* dx, int B, int C, hipStream_t st) {
+    const int nb = C / 64, Bs = sched_batch(B);
+    const bool fill2 = C % 128 == 0 && (long long)Bs * (C / 128) >= 192;
+    const bool fill1 = (long long)Bs * nb >= 192;
+    if (tuning().bwd_v != 0 || !(fill2 || fill1)) return HK_ERR_UNSUPPORTED;
+    BwdExtra ex = {};
+    ex.ta = ta; ex.tb2 = tb; ex.tc = tc; ex.tK = tK; ex.t_inv2 = t_inv2;
+    int rc = HK_ERR_UNSUPPORTED;
+    if (fill2) rc = bwd3_launch<HW, 3, 2, 1>(x, y, dy, inv_norm, dx, nullptr, B, C, ex, st);
+    if (rc == HK_ERR_UNSUPPORTED) rc = bwd3_launch<HW, 3, 1, 1>(x, y, dy, inv_norm, dx, nullptr, B, C, ex, st);
+    return rc;
+}
+int bcnn_ssqrt_fast_bwd_tdot(const float* x, const float* y, const float* dy, const float* inv_norm, const float* ta,
+                             const float* tb, const float* tc, int tK, int t_inv2, float* dx, int B, int C, int HW,
+                             hipStream_t st) {
+    if (C % 64 != 0 || !ta || !tb || !aligned16(x) || !aligned16(y) || !aligned16(dy) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+#define CALL(H) ssqrt_tdot_launch<H>(x, y, dy, inv_norm, ta, tb, tc, tK, t_inv2, dx, B, C, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
 // signed-sqrt variant (BCNN.py:23-24): P = (dy + dy^T - 2 t y) / |y| * inv^2 / (2M), t from its partial sums
 int bcnn_ssqrt_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, const float* tpart, int nt,
                         float* dx, int B, int C, int HW, hipStream_t st) {

@@ -30,6 +30,9 @@ int bcnn_fast_bwd(const float* x, const float* y, const float* dy, const float* 
 int bcnn_fast_bwd_fold(const float* x, const float* y, const float* dy, const float* inv_norm, const float* colsum,
                        const float* ta, const float* tb, const float* tc, int tK, float* dx, int B, int C, int HW,
                        hipStream_t st);
+int bcnn_ssqrt_fast_bwd_tdot(const float* x, const float* y, const float* dy, const float* inv_norm, const float* ta,
+                             const float* tb, const float* tc, int tK, int t_inv2, float* dx, int B, int C, int HW,
+                             hipStream_t st);
 int gram_fast_raw(const float* x, float* mu, float alpha, float* g, int B, int C, int HW, hipStream_t st);
 int bcnn_ssqrt_fast_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, const float* tpart, int nt,
                         float* dx, int B, int C, int HW, hipStream_t st);
@@ -541,6 +544,26 @@ static int ssqrt_pool_bwd_impl(const float* x, const float* y, const float* dy, 
     pa.tsum = tpart; pa.nt = SS_CHUNKS; pa.t2 = 0.f;
     const LdPlain xb = make_plain(x, (long long)C * HW, HW, C, HW);
     return bgemm_launch<true, false>(pa, xb, make_affine(dx, (long long)C * HW, HW, 1.0f, nullptr, 0.f, 0.f), C, HW, C, B, st);
+}
+
+// The signed-sqrt backward when dy = g W comes from a linear layer on the (normalised) pooled vector: t = <y, dy> =
+// sum_k ta[b,k] (tb[b,k] - tc[k]) (ta = g, tb = logits, tc = bias) - the 2 x 4 C^2 bytes per image pass for its partial sums
+// (dot_partial_kernel) is not launched.  unscaled != 0: `y` is the un-normalised u of hk_bcnn_ssqrt_pool_fwd_unscaled and dy
+// the gradient hk_linear_bwd_scaled returned.  Shapes the one-launch kernel does not serve fall back to the entry points
+// above (which add up y * dy themselves).
+extern "C" int hk_bcnn_ssqrt_pool_bwd_tdot(const float* x, const float* y, const float* dy, const float* inv_norm,
+                                           const float* ta, const float* tb, const float* tc, int K, int unscaled, float* dx,
+                                           int B, int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    if (!x || !y || !dy || !inv_norm || !ta || !tb || !dx || K <= 0 || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    if (!ws || ws_bytes < hk_bcnn_ssqrt_ws_bytes(B, C, HW)) return HK_ERR_WORKSPACE;
+    if (!force_generic() && tuning().bwd_fold >= 0) {
+        hipStream_t st = (hipStream_t)stream;
+        // (unscaled: (dy + dy^T - 2 t inv u) / (inv |u|) inv^2 / 2M = (dy + dy^T - 2 (t inv) u) / |u| inv / 2M - the kernel takes
+        //  the true inv_norm and applies it once to the coefficient and once to t: one launch, nothing in front of it)
+        const int rc = bcnn_ssqrt_fast_bwd_tdot(x, y, dy, inv_norm, ta, tb, tc, K, unscaled ? 1 : 0, dx, B, C, HW, st);
+        if (rc != HK_ERR_UNSUPPORTED) return rc;
+    }
+    return ssqrt_pool_bwd_impl(x, y, dy, inv_norm, dx, B, C, HW, ws, ws_bytes, stream, unscaled != 0);
 }
 
 extern "C" int hk_bcnn_ssqrt_pool_bwd(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx,

@@ -47,6 +47,8 @@ struct BwdExtra {
     const float* tb2;
     const float* tc;
     int tK;
+    int t_inv2;          // signed sqrt, TK 1: `y` is the UN-normalised u = y / inv (inv_norm = the true 1 / |u|): the coefficient
+                         // carries one factor inv less and the kernel's t is inv times the dot product
 };
 
 // t = <y, dy> of sample b from its partial sums (every workgroup adds them itself, fixed order)
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     constexpr bool HAS_Y = MODE == 0 || MODE == 3;
     constexpr bool MUCOL = MODE == 1;
     static_assert(!ROWW || RB == 2, "row-per-wave split: 128-row blocks");
-    static_assert(TK == 0 || (MODE == 0 && EPI && HW % 4 == 0), "rank-1 fold: BCNN, LDS-staged epilogue");
+    static_assert(TK == 0 || ((MODE == 0 || MODE == 3) && EPI && HW % 4 == 0), "t handed over: BCNN / signed sqrt, LDS-staged epilogue");
     constexpr int NT = REMV ? HW / 16 : (HW + 15) / 16;   // 16-column MFMA tiles
     constexpr int NH = ROWW ? NT : (NT + 1) / 2;          // tiles of a wave (of the first column half)
     constexpr int RW = ROWW ? 1 : RB;                     // 16-row blocks of a wave
@@ -121,10 +123,11 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
     float coef = 1.0f / (float)HW;
     if (HAS_Y) {
         const float in = inv_norm[b];
-        coef = in * in / (2.0f * (float)HW);
+        coef = ((MODE == 3 && TK == 1 && ex.t_inv2) ? in : in * in) / (2.0f * (float)HW);
     }
     const float cfrag = COEFL ? 1.0f : coef;                    // factor applied per fragment element
-    const float t2 = MODE == 3 ? 2.0f * bwd_t_of(ex, b) : 0.f;
+    // signed sqrt: t = <y, dy> from its partial sums - or (TK 1) from the dot product wave 0 forms below
+    float t2 = (MODE == 3 && TK != 1) ? 2.0f * bwd_t_of(ex, b) : 0.f;
 
     f32x4 acc[RW][NH];
     float rem[RW][NR], mcol[RW];
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m, 64);
             if (lane == 0) mus[0] = p;
         }
-        if (tid < HW) csr = ex.colsum[(long long)b * HW + tid];
+        if (MODE == 0 && tid < HW) csr = ex.colsum[(long long)b * HW + tid];
     }
 
     // ---- this lane's 16 bytes in the pieces its wave issues (32-bit offsets; bases advance with kb)
@@ -290,7 +293,8 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
 #pragma unroll
     for (int part = 0; part < 5; ++part) HK_B3_DMA(0, 0, part);
     __syncthreads();
-    const float kfix1 = TK == 1 ? mus[0] * inv_norm[b] * inv_norm[b] / (float)HW : 0.f;      // (bcnn_rank1_fix_kernel's k)
+    const float kfix1 = (TK == 1 && MODE == 0) ? mus[0] * inv_norm[b] * inv_norm[b] / (float)HW : 0.f;      // (bcnn_rank1_fix_kernel's k)
+    if (TK == 1 && MODE == 3) t2 = 2.0f * mus[0] * (ex.t_inv2 ? inv_norm[b] : 1.0f);
     int kb = 0;
     for (; kb + 2 < nkb; kb += 2) {                                     // steady state, two K-blocks per trip
         HK_B3_KBLOCK(kb, 0, true);
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             if (MUCOL && do_t && lq == 0) CM[wrow + i * 16 + l15] = mcol[i];
         }
         float* CS = CM + IB;                                                // [HW] k colsum (TK 1)
-        if (TK == 1 && tid < HW) CS[tid] = kfix1 * csr;
+        if (TK == 1 && MODE == 0 && tid < HW) CS[tid] = kfix1 * csr;
         __syncthreads();
         const f32x4* o4 = reinterpret_cast<const f32x4*>(O);
         f32x4* g4 = reinterpret_cast<f32x4*>(dxb);
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void gram_bwd3_kernel(const float* __restri
             if (f < O4) {
                 f32x4 v = o4[f];
                 if (MUCOL) v -= CM[(4 * f) / HW];
-                if (TK == 1) v -= reinterpret_cast<const f32x4*>(CS)[f % (HW / 4)];
+                if (TK == 1 && MODE == 0) v -= reinterpret_cast<const f32x4*>(CS)[f % (HW / 4)];
                 g4[f] = v;
             }
         }

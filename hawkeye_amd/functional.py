@@ -850,14 +850,14 @@ class _SsqrtPoolLinear(torch.autograd.Function):
         wsl = _ws(nwl, x.device)
         check(lib.hk_linear_fwd_scaled(ptr(u), ptr(weight), ptr(bias_c), ptr(inv_norm), ptr(out), b, j, k, ptr(wsl), nwl,
                                        stream()), 'hk_linear_fwd_scaled')
-        ctx.save_for_backward(x, u, inv_norm, weight)
+        ctx.save_for_backward(x, u, inv_norm, weight, bias_c if bias_c is not None else x.new_empty(0), out)
         ctx.has_bias = bias is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, u, inv_norm, weight = ctx.saved_tensors
+        x, u, inv_norm, weight, bias_c, out = ctx.saved_tensors
         g = _f32c(g)
         b, c, h, w = x.shape
         hw, j, k = h * w, c * c, weight.shape[0]
@@ -878,8 +878,10 @@ class _SsqrtPoolLinear(torch.autograd.Function):
             dx = torch.empty_like(x)
             nws = lib.hk_bcnn_ssqrt_ws_bytes(b, c, hw)
             ws = _ws(nws, x.device)
-            check(lib.hk_bcnn_ssqrt_pool_bwd_unscaled(ptr(x), ptr(u), ptr(dy), ptr(inv_norm), ptr(dx), b, c, hw, ptr(ws), nws,
-                                                      stream()), 'hk_bcnn_ssqrt_pool_bwd_unscaled')
+            # <y, dy> = sum_k g_k (logit_k - bias_k): the classifier's operands instead of a pass over u and dy
+            check(lib.hk_bcnn_ssqrt_pool_bwd_tdot(ptr(x), ptr(u), ptr(dy), ptr(inv_norm), ptr(g), ptr(out),
+                                                  ptr(bias_c) if ctx.has_bias else None, k, 1, ptr(dx), b, c, hw, ptr(ws), nws,
+                                                  stream()), 'hk_bcnn_ssqrt_pool_bwd_tdot')
         return dx, dw, db
 
 

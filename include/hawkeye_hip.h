@@ -115,6 +115,13 @@ int hk_bcnn_ssqrt_pool_fwd_unscaled(const float* x, float* u, float* inv_norm, i
                                     hk_stream_t stream);
 int hk_bcnn_ssqrt_pool_bwd_unscaled(const float* x, const float* u, const float* dy, const float* inv_norm, float* dx, int B,
                                     int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream);
+/* Either backward when dy = g W comes from a linear layer on the normalised pooled vector: the inner product <y, dy> of the
+ * l2-normalisation's backward is then t[b] = sum_k ta[b,k] (tb[b,k] - tc[k]) (ta = g, tb = logits, tc = bias, nullable) and the
+ * pass over y and dy that adds it up (2 x 4 C^2 bytes per image) is not launched.  unscaled = 0: y as hk_bcnn_ssqrt_pool_fwd
+ * returned it; != 0: the u / dy of the _unscaled pair. */
+int hk_bcnn_ssqrt_pool_bwd_tdot(const float* x, const float* y, const float* dy, const float* inv_norm, const float* ta,
+                                const float* tb, const float* tc, int K, int unscaled, float* dx, int B, int C, int HW,
+                                void* ws, size_t ws_bytes, hk_stream_t stream);
 
 /* The two stages of each direction, individually callable (hk_bcnn_pool_fwd = colsum_norm + gram_norm,
  * hk_bcnn_pool_bwd = bwd_gemm + bwd_rank1); bench.py times them separately.

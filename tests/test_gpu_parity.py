@@ -126,28 +126,38 @@ def test_bcnn_signed_sqrt_variant(F, shape, seed, tune):
 
 
 @pytest.mark.parametrize('b,c,hw,k', [(3, 128, 14, 200), (2, 64, 10, 37), (5, 192, 8, 208)])
-def test_signed_sqrt_pool_with_the_scale_folded_into_the_classifier(F, b, c, hw, k):
+def test_signed_sqrt_pool_with_the_scale_folded_into_the_classifier(F, b, c, hw, k, tune):
     """F.ssqrt_pool_linear (the per-sample 1 / |z| folded into the classifier's epilogue - the pooled vector
-    stays unnormalised in memory; hk_bcnn_ssqrt_pool_fwd_unscaled / _bwd_unscaled, hk_linear_fwd_scaled / _bwd_scaled)
-    against the unfused pair (F.bilinear_pool(signed_sqrt=True) -> F.linear) and against the oracle: logits and all three
-    gradients.  128 x 128 features = 16384: the one-launch classifier backward; the other shapes its fallback."""
+    stays unnormalised in memory; hk_bcnn_ssqrt_pool_fwd_unscaled, hk_linear_fwd_scaled / _bwd_scaled) against the unfused
+    pair (F.bilinear_pool(signed_sqrt=True) -> F.linear) and against the oracle: logits and all three gradients.
+    128 x 128 features = 16384: the one-launch classifier backward; the other shapes its fallback.
+    Round 5: the pooling's backward takes <y, dy> = sum_k g_k (logit_k - bias_k) from the node (hk_bcnn_ssqrt_pool_bwd_tdot:
+    no pass over u and dy for its partial sums) - in the 128- and 64-row form of gram_bwd3_kernel (sched_b), where that
+    kernel does not run (small batch: the entry point adds up u * dy itself) and with the hand-over off (bwd_fold = -1)."""
     xn = rs_signed_channels(700 + c, (b, c, hw, hw))
     w = t(rs_randn(701, (k, c * c))) / c
     bias, g = t(rs_randn(702, (k,))), t(rs_randn(703, (b, k)))
-    res = []
-    for fused in (False, True):
-        xg = t(xn).to(DEV).requires_grad_(True)
-        wg, bg = w.clone().to(DEV).requires_grad_(True), bias.clone().to(DEV).requires_grad_(True)
-        out = F.ssqrt_pool_linear(xg, wg, bg) if fused else F.linear(F.bilinear_pool(xg, signed_sqrt=True), wg, bg)
-        (out * g.to(DEV)).sum().backward()
-        res.append((out.detach(), xg.grad, wg.grad, bg.grad))
-    for a, r_ in zip(res[1], res[0]):
-        assert rel(a, r_) < 5e-6
     xo = t(xn).requires_grad_(True)
     wo, bo = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     oo = torch.nn.functional.linear(O.bilinear_pool_signed_sqrt(xo), wo, bo)
     (oo * g).sum().backward()
-    assert rel(res[1][0], oo) < 1e-5 and rel(res[1][1], xo.grad) < 5e-5 and rel(res[1][2], wo.grad) < 1e-5
+    forms = {'small': 0, 'rows64': -(-192 * 64 // c)}
+    if c % 128 == 0:
+        forms['rows128'] = -(-192 * 128 // c)
+    for form, sb in forms.items():
+        tune('sched_b', sb)
+        res = []
+        for fused, fold in ((False, 0), (True, 0), (True, -1)):
+            tune('bwd_fold', fold)
+            xg = t(xn).to(DEV).requires_grad_(True)
+            wg, bg = w.clone().to(DEV).requires_grad_(True), bias.clone().to(DEV).requires_grad_(True)
+            out = F.ssqrt_pool_linear(xg, wg, bg) if fused else F.linear(F.bilinear_pool(xg, signed_sqrt=True), wg, bg)
+            (out * g.to(DEV)).sum().backward()
+            res.append((out.detach(), xg.grad, wg.grad, bg.grad))
+        for r1 in res[1:]:
+            for a, r_ in zip(r1, res[0]):
+                assert rel(a, r_) < 5e-6, form
+            assert rel(r1[0], oo) < 1e-5 and rel(r1[1], xo.grad) < 5e-5 and rel(r1[2], wo.grad) < 1e-5, form
 
 
 def test_bcnn_signed_sqrt_512_vs_golden(F):

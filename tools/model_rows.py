@@ -180,6 +180,11 @@ def ssqrt_kernels(B=64, C=512, HW=196):
                fl, 4.0 * B * (2 * C * HW + 2 * C * C))
     kernel_row('BCNN-ssqrt', 'ssqrt pool bwd, unscaled', lambda: lib.hk_bcnn_ssqrt_pool_bwd_unscaled(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), B, C, HW, ptr(ws), nws, stream()),
                fl, 4.0 * B * (2 * C * HW + 2 * C * C))
+    g, lo, bi = R(B, 200), R(B, 200), R(200)
+    kernel_row('BCNN-ssqrt', 'ssqrt pool bwd, unscaled, <y, dy> handed over by the classifier (hk_bcnn_ssqrt_pool_bwd_tdot: what the fused node runs)',
+               lambda: lib.hk_bcnn_ssqrt_pool_bwd_tdot(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(g), ptr(lo), ptr(bi), 200, 1, ptr(dx), B, C, HW,
+                                                       ptr(ws), nws, stream()),
+               fl, 4.0 * B * (2 * C * HW + 2 * C * C))
 
 
 def guarded(fn, *args):
