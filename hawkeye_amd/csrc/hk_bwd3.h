@@ -66,12 +66,14 @@ __device__ __forceinline__ float bwd_t_of(const BwdExtra& ex, int b) {
 // matrix pipe, so the duplicated fragment arithmetic cost ~4 % of a K-block; the price is one ds_read per MFMA instead
 // of one per two.  COEFL: the factor inv^2 / 2M multiplies the accumulators once instead of every fragment element
 // (rounding-level difference from the other backward kernels).
-// TK (BCNN only): where the rank-1 term of the backward, dX -= (t inv^2 / M) 1 colsum^T with t = <y, dy>, is applied.
-//   0: not here - the t partials go to tpart and bcnn_rank1_fix_kernel makes a second pass over dX (the stage entry points);
+// TK: where t = <y, dy>, the scalar of the l2-normalisation's backward, comes from.
+//   0: BCNN: the kernel adds up its partial sums (-> tpart) and bcnn_rank1_fix_kernel applies the rank-1 term
+//      dX -= (t inv^2 / M) 1 colsum^T in a second pass over dX; signed sqrt: from the partial sums ex.tb of a pass over y, dy;
 //   1: t is KNOWN before the launch, as a dot product of two small operands (ex.ta / tb2 / tc): when dy = g W comes out
-//      of a linear layer on y, <y, dy> = sum_k g_k (logit_k - bias_k).  Every workgroup forms t in its prologue (fixed
-//      order) and subtracts its rows' share while the block is copied out: no second pass, no partial sums of y dy in
-//      the K loop (7 VALU ops per fragment quad less next to the MFMAs);
+//      of a linear layer on y, <y, dy> = sum_k g_k (logit_k - bias_k).  Every workgroup forms t in its prologue (wave 0,
+//      fixed order).  BCNN: it subtracts its rows' share of the rank-1 term while the block is copied out - no second
+//      pass, no partial sums of y dy in the K loop (7 VALU ops per fragment quad less next to the MFMAs); signed sqrt
+//      (t sits inside the operand P): no pass over y and dy in front of the kernel.
 // (Measured and removed, round 5: TK 2, t unknown - the workgroups of an image take a ticket when their block and partial
 //  sum are out and the last to arrive makes the pass over the image's dX from L2.  Correct by the device-scope release /
 //  acquire recipe, bit-identical to the two-launch route - and slower than it: 85.2 vs 81.4 us at B = 64 (the release
