@@ -515,6 +515,17 @@ extern "C" int hk_bcnn_ssqrt_pool_fwd_unscaled(const float* x, float* u, float* 
     return ssqrt_pool_fwd_impl(x, u, inv_norm, B, C, HW, ws, ws_bytes, stream, false);
 }
 
+// The same u with the norm left ENTIRELY to the consumer: ONE launch - the Gram kernel with the signed sqrt in its epilogue -
+// that writes u and, per image, *nparts partial sums of u^2 (ss_part [B][64], fixed order); hk_linear_fwd_ssq adds them up
+// in its reduce launch (ssqrt_norm_kernel's order: the same inv_norm bits) and applies 1 / |u| to the logits.
+// HK_ERR_UNSUPPORTED - nothing launched - outside the panel kernel's shapes: take hk_bcnn_ssqrt_pool_fwd_unscaled.
+extern "C" int hk_bcnn_ssqrt_pool_fwd_parts(const float* x, float* u, float* ss_part, int* nparts, int B, int C, int HW,
+                                            hk_stream_t stream) {
+    if (!x || !u || !ss_part || !nparts || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;
+    if (force_generic()) return HK_ERR_UNSUPPORTED;
+    return gram_fast_ssqrt(x, u, ss_part, nparts, B, C, HW, (hipStream_t)stream);
+}
+
 static int ssqrt_pool_bwd_impl(const float* x, const float* y, const float* dy, const float* inv_norm, float* dx, int B, int C,
                                int HW, void* ws, size_t ws_bytes, hk_stream_t stream, bool unscaled) {
     if (!x || !y || !dy || !inv_norm || !dx || B <= 0 || C <= 0 || HW <= 0) return HK_ERR_BAD_ARG;

@@ -24,7 +24,9 @@ struct GramEpi {
         // v_sqrt_f32 (1 ulp, argument >= 1e-5: no denormal/negative handling needed) - parity budget is 1e-4
         float z = MODE == 0 ? __builtin_amdgcn_sqrtf(fmaf(v, inv_m, 1e-5f)) * inv : v * inv;
         if (MODE == 2) {
-            z = z == 0.f ? 0.f : copysignf(sqrtf(fabsf(z) + 1e-10f), z);      // (sign(0) = 0, like torch)
+            // (sign(0) = 0, like torch; v_sqrt_f32 like MODE 0 - 1 ulp, argument >= 1e-10: the IEEE sqrtf expansion was ~12
+            //  VALU instructions per element next to the MFMA stream)
+            z = z == 0.f ? 0.f : copysignf(__builtin_amdgcn_sqrtf(fabsf(z) + 1e-10f), z);
             ss = fmaf(offdiag ? 2.f * z : z, z, ss);
         }
         return z;

@@ -48,9 +48,12 @@ struct LdSlab {
 
 // out[e] = bias[e % K] + rs[e / K] * sum_s part[s][e]   (e over B*K; slabs added as 4 interleaved chains combined in fixed
 // order; rs: optional per-sample scale - the 1 / |z| of a pooled vector handed over unnormalised)
+// ssq (optional, [B][64]): the row scale is not given but formed here - 1 / max(sqrt(sum of the sample's nssq partial sums of
+// u^2), 1e-12), added in ssqrt_norm_kernel's order - and written to rs_out [B] by the thread that holds output (b, 0).
 __global__ __launch_bounds__(256) void linear_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                            const float* __restrict__ rs, float* __restrict__ out, int BK,
-                                                           int K, int S) {
+                                                           int K, int S, const float* __restrict__ ssq = nullptr, int nssq = 0,
+                                                           float* __restrict__ rs_out = nullptr) {
     __shared__ float red[4][64];
     const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + l;
@@ -74,7 +77,14 @@ __global__ __launch_bounds__(256) void linear_reduce_kernel(const float* __restr
     __syncthreads();
     if (g == 0 && e < BK) {
         const float sum = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-        out[e] = (rs ? rs[e / K] * sum : sum) + (bias ? bias[e % K] : 0.f);
+        float sc = rs ? rs[e / K] : 1.0f;
+        if (ssq) {
+            float t = 0.f;
+            for (int c = 0; c < nssq; ++c) t += ssq[(long long)(e / K) * 64 + c];
+            sc = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+            if (e % K == 0) rs_out[e / K] = sc;
+        }
+        out[e] = ((rs || ssq) ? sc * sum : sum) + (bias ? bias[e % K] : 0.f);
     }
 }
 
@@ -139,8 +149,8 @@ extern "C" size_t hk_linear_ws_bytes(int B, int J, int K) {
     return (size_t)S * B * K * sizeof(float) + 256;
 }
 
-extern "C" int hk_linear_fwd_scaled(const float* y, const float* w, const float* bias, const float* row_scale, float* out,
-                                    int B, int J, int K, void* ws, size_t ws_bytes, hk_stream_t stream) {
+static int linear_fwd_impl(const float* y, const float* w, const float* bias, const float* row_scale, const float* ssq, int nssq,
+                           float* rs_out, float* out, int B, int J, int K, void* ws, size_t ws_bytes, hk_stream_t stream) {
     if (!y || !w || !out || B <= 0 || J <= 0 || K <= 0) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_linear_ws_bytes(B, J, K)) return HK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -163,7 +173,7 @@ extern "C" int hk_linear_fwd_scaled(const float* y, const float* w, const float*
             hipLaunchKernelGGL((linear_skinny_kernel<16, 1>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp, walk);
         HK_LAUNCH_CHECK();
         const int BK = B * K;
-        hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, row_scale, out, BK, K, S);
+        hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, row_scale, out, BK, K, S, ssq, nssq, rs_out);
         HK_LAUNCH_CHECK();
         return HK_OK;
     }
@@ -174,9 +184,22 @@ extern "C" int hk_linear_fwd_scaled(const float* y, const float* w, const float*
     const int rc = bgemm_launch<true, true>(la, lb, ep, B, K, KS, S, st);     // slab = batch ; A [B][KS], B as [K][KS]
     if (rc != HK_OK) return rc;
     const int BK = B * K;
-    hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, row_scale, out, BK, K, S);
+    hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, row_scale, out, BK, K, S, ssq, nssq, rs_out);
     HK_LAUNCH_CHECK();
     return HK_OK;
+}
+
+extern "C" int hk_linear_fwd_scaled(const float* y, const float* w, const float* bias, const float* row_scale, float* out,
+                                    int B, int J, int K, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    return linear_fwd_impl(y, w, bias, row_scale, nullptr, 0, nullptr, out, B, J, K, ws, ws_bytes, stream);
+}
+
+// out = (1 / |u|) (u W^T) + bias with |u|^2 handed over as nparts partial sums per sample (ss_part [B][64], from
+// hk_bcnn_ssqrt_pool_fwd_parts); inv_norm [B] is WRITTEN (the backward's operand).
+extern "C" int hk_linear_fwd_ssq(const float* u, const float* w, const float* bias, const float* ss_part, int nparts,
+                                 float* inv_norm, float* out, int B, int J, int K, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    if (!ss_part || !inv_norm || nparts <= 0 || nparts > 64) return HK_ERR_BAD_ARG;
+    return linear_fwd_impl(u, w, bias, nullptr, ss_part, nparts, inv_norm, out, B, J, K, ws, ws_bytes, stream);
 }
 
 extern "C" int hk_linear_fwd(const float* y, const float* w, const float* bias, float* out, int B, int J, int K, void* ws,

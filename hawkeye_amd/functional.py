@@ -842,14 +842,24 @@ class _SsqrtPoolLinear(torch.autograd.Function):
         inv_norm = torch.empty(b, dtype=torch.float32, device=x.device)
         nws = lib.hk_bcnn_ssqrt_ws_bytes(b, c, hw)
         ws = _ws(nws, x.device)
-        check(lib.hk_bcnn_ssqrt_pool_fwd_unscaled(ptr(x), ptr(u), ptr(inv_norm), b, c, hw, ptr(ws), nws, stream()),
-              'hk_bcnn_ssqrt_pool_fwd_unscaled')
         bias_c = _f32c(bias) if bias is not None else None
         out = torch.empty(b, k, dtype=torch.float32, device=x.device)
         nwl = lib.hk_linear_ws_bytes(b, j, k)
         wsl = _ws(nwl, x.device)
-        check(lib.hk_linear_fwd_scaled(ptr(u), ptr(weight), ptr(bias_c), ptr(inv_norm), ptr(out), b, j, k, ptr(wsl), nwl,
-                                       stream()), 'hk_linear_fwd_scaled')
+        # two launches + the classifier's reduce: the Gram kernel leaves partial sums of u^2 and the reduce launch forms 1 / |u|
+        import ctypes
+        nparts = ctypes.c_int(0)
+        rc = lib.hk_bcnn_ssqrt_pool_fwd_parts(ptr(x), ptr(u), ptr(ws), ctypes.byref(nparts), b, c, hw, stream())
+        if rc == _lib.HK_OK:
+            check(lib.hk_linear_fwd_ssq(ptr(u), ptr(weight), ptr(bias_c), ptr(ws), nparts.value, ptr(inv_norm), ptr(out), b, j, k,
+                                        ptr(wsl), nwl, stream()), 'hk_linear_fwd_ssq')
+        else:
+            if rc != _lib.HK_ERR_UNSUPPORTED:
+                check(rc, 'hk_bcnn_ssqrt_pool_fwd_parts')
+            check(lib.hk_bcnn_ssqrt_pool_fwd_unscaled(ptr(x), ptr(u), ptr(inv_norm), b, c, hw, ptr(ws), nws, stream()),
+                  'hk_bcnn_ssqrt_pool_fwd_unscaled')
+            check(lib.hk_linear_fwd_scaled(ptr(u), ptr(weight), ptr(bias_c), ptr(inv_norm), ptr(out), b, j, k, ptr(wsl), nwl,
+                                           stream()), 'hk_linear_fwd_scaled')
         ctx.save_for_backward(x, u, inv_norm, weight, bias_c if bias_c is not None else x.new_empty(0), out)
         ctx.has_bias = bias is not None
         return out

@@ -115,6 +115,10 @@ int hk_bcnn_ssqrt_pool_fwd_unscaled(const float* x, float* u, float* inv_norm, i
                                     hk_stream_t stream);
 int hk_bcnn_ssqrt_pool_bwd_unscaled(const float* x, const float* u, const float* dy, const float* inv_norm, float* dx, int B,
                                     int C, int HW, void* ws, size_t ws_bytes, hk_stream_t stream);
+/* ... and with the norm left entirely to the consumer: ONE launch that writes u and *nparts partial sums of u^2 per image
+ * (ss_part [B, 64]); hk_linear_fwd_ssq (below) adds them up in its reduce launch, applies 1 / |u| to the logits and writes
+ * inv_norm.  HK_ERR_UNSUPPORTED (nothing launched) outside the panel kernel's shapes. */
+int hk_bcnn_ssqrt_pool_fwd_parts(const float* x, float* u, float* ss_part, int* nparts, int B, int C, int HW, hk_stream_t stream);
 /* Either backward when dy = g W comes from a linear layer on the normalised pooled vector: the inner product <y, dy> of the
  * l2-normalisation's backward is then t[b] = sum_k ta[b,k] (tb[b,k] - tc[k]) (ta = g, tb = logits, tc = bias, nullable) and the
  * pass over y and dy that adds it up (2 x 4 C^2 bytes per image) is not launched.  unscaled = 0: y as hk_bcnn_ssqrt_pool_fwd
@@ -352,6 +356,10 @@ int hk_linear_fwd_scaled(const float* y, const float* w, const float* bias, cons
                          int K, void* ws, size_t ws_bytes, hk_stream_t stream);
 int hk_linear_bwd_scaled(const float* y, const float* w, const float* g, const float* row_scale, float* dy, float* dw, float* db,
                          int B, int J, int K, hk_stream_t stream);
+/* hk_linear_fwd_scaled with the scale formed in the reduce launch: 1 / max(sqrt(sum of ss_part[b, 0 .. nparts)), 1e-12), written
+ * to inv_norm [B] (the partial sums of |u|^2 of hk_bcnn_ssqrt_pool_fwd_parts: no launch in between). */
+int hk_linear_fwd_ssq(const float* u, const float* w, const float* bias, const float* ss_part, int nparts, float* inv_norm,
+                      float* out, int B, int J, int K, void* ws, size_t ws_bytes, hk_stream_t stream);
 
 /* ------------------------------------------------------ MAMC n-pairs loss (8f-4) ----
  * loss = NPairsLoss(parts, targets) and dx = d loss / d parts in one call.

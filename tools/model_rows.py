@@ -180,6 +180,24 @@ def ssqrt_kernels(B=64, C=512, HW=196):
                fl, 4.0 * B * (2 * C * HW + 2 * C * C))
     kernel_row('BCNN-ssqrt', 'ssqrt pool bwd, unscaled', lambda: lib.hk_bcnn_ssqrt_pool_bwd_unscaled(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(dx), B, C, HW, ptr(ws), nws, stream()),
                fl, 4.0 * B * (2 * C * HW + 2 * C * C))
+    import ctypes
+    w = R(200, C * C); out = E(B, 200); bi0 = R(200)
+    nwl = lib.hk_linear_ws_bytes(B, C * C, 200); wsl = E(nwl, dtype=torch.uint8)
+    npart = ctypes.c_int(0)
+
+    def pair_norm():
+        lib.hk_bcnn_ssqrt_pool_fwd_unscaled(ptr(x), ptr(y), ptr(inv), B, C, HW, ptr(ws), nws, stream())
+        return lib.hk_linear_fwd_scaled(ptr(y), ptr(w), ptr(bi0), ptr(inv), ptr(out), B, C * C, 200, ptr(wsl), nwl, stream())
+
+    def pair_parts():
+        lib.hk_bcnn_ssqrt_pool_fwd_parts(ptr(x), ptr(y), ptr(ws), ctypes.byref(npart), B, C, HW, stream())
+        return lib.hk_linear_fwd_ssq(ptr(y), ptr(w), ptr(bi0), ptr(ws), npart.value, ptr(inv), ptr(out), B, C * C, 200, ptr(wsl), nwl,
+                                     stream())
+    flp = fl + 2.0 * B * C * C * 200
+    byp = by + 4.0 * (B * C * C + 200 * C * C)
+    kernel_row('BCNN-ssqrt', 'ssqrt pool fwd unscaled + classifier fwd (4 launches: Gram, norm, GEMM, reduce)', pair_norm, flp, byp, flops_exec=flp - fl * 28 / 64)
+    kernel_row('BCNN-ssqrt', 'ssqrt pool fwd parts + classifier fwd (3 launches: the norm formed in the reduce launch: what the fused node runs)',
+               pair_parts, flp, byp, flops_exec=flp - fl * 28 / 64)
     g, lo, bi = R(B, 200), R(B, 200), R(200)
     kernel_row('BCNN-ssqrt', 'ssqrt pool bwd, unscaled, <y, dy> handed over by the classifier (hk_bcnn_ssqrt_pool_bwd_tdot: what the fused node runs)',
                lambda: lib.hk_bcnn_ssqrt_pool_bwd_tdot(ptr(x), ptr(y), ptr(dy), ptr(inv), ptr(g), ptr(lo), ptr(bi), 200, 1, ptr(dx), B, C, HW,
@@ -197,6 +215,9 @@ def guarded(fn, *args):
 
 if __name__ == '__main__':
     guarded(ssqrt_kernels)
+    if '--ssqrt-only' in sys.argv:
+        print(json.dumps(rows), flush=True)
+        sys.exit(0)
     guarded(mpn_kernels)
     guarded(cbp_kernels)
     guarded(apcnn_kernels)
