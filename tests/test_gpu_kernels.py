@@ -576,6 +576,46 @@ def test_bcnn_pool_forward_equals_its_stages(F, b, c, hw, tune):
     assert rel(y2.reshape(b, c, c), O.bilinear_pool(x.cpu().reshape(b, c, hw, hw)).reshape(b, c, c)) < 1e-5
 
 
+@pytest.mark.parametrize('b,c,hw,k', [(3, 128, 14, 20), (5, 512, 14, 7), (2, 64, 14, 5), (2, 192, 10, 9)])
+def test_signed_sqrt_norm_formed_in_the_classifier_reduce(F, b, c, hw, k):
+    """hk_bcnn_ssqrt_pool_fwd_parts + hk_linear_fwd_ssq (three launches) against hk_bcnn_ssqrt_pool_fwd_unscaled +
+    hk_linear_fwd_scaled (four): u, inv_norm and the logits bit for bit; outside the panel kernel's shapes the parts entry
+    point declines with HK_ERR_UNSUPPORTED before launching anything; the consumer rejects a partial count outside 1..64."""
+    import ctypes
+    from hawkeye_amd import _lib
+    lib = _lib.load()
+    ptr, stream = F.ptr, F.stream
+    dev = torch.device(DEV)
+    n, j = hw * hw, c * c
+    g = torch.Generator().manual_seed(c + k)
+    x = torch.randn(b, c, n, generator=g).to(dev)
+    w = (torch.randn(k, j, generator=g) * 0.05).to(dev)
+    bias = torch.randn(k, generator=g).to(dev)
+    nws = lib.hk_bcnn_ssqrt_ws_bytes(b, c, n)
+    ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
+    nwl = lib.hk_linear_ws_bytes(b, j, k)
+    wsl = torch.zeros(max(nwl, 16), dtype=torch.uint8, device=dev)
+    u2, inv2, o2 = torch.empty(b, j, device=dev), torch.empty(b, device=dev), torch.empty(b, k, device=dev)
+    assert lib.hk_bcnn_ssqrt_pool_fwd_unscaled(ptr(x), ptr(u2), ptr(inv2), b, c, n, ptr(ws), nws, stream()) == 0
+    assert lib.hk_linear_fwd_scaled(ptr(u2), ptr(w), ptr(bias), ptr(inv2), ptr(o2), b, j, k, ptr(wsl), nwl, stream()) == 0
+    u1, inv1, o1 = torch.full_like(u2, -1.0), torch.full_like(inv2, -1.0), torch.full_like(o2, -1.0)
+    npart = ctypes.c_int(0)
+    assert lib.hk_bcnn_ssqrt_pool_fwd_parts(ptr(x), ptr(u1), ptr(ws), ctypes.byref(npart), b, c, n, stream()) == 0
+    assert 1 <= npart.value <= 64
+    assert lib.hk_linear_fwd_ssq(ptr(u1), ptr(w), ptr(bias), ptr(ws), npart.value, ptr(inv1), ptr(o1), b, j, k, ptr(wsl), nwl,
+                                 stream()) == 0
+    assert torch.equal(u1, u2) and torch.equal(inv1, inv2) and torch.equal(o1, o2)
+    for bad in (0, 65):
+        assert lib.hk_linear_fwd_ssq(ptr(u1), ptr(w), ptr(bias), ptr(ws), bad, ptr(inv1), ptr(o1), b, j, k, ptr(wsl), nwl,
+                                     stream()) == _lib.HK_ERR_BAD_ARG
+    xr = torch.randn(2, 48, 25, generator=g).to(dev)                 # 48 channels: not a panel-kernel shape
+    ur = torch.full((2, 48 * 48), -1.0, device=dev)
+    assert lib.hk_bcnn_ssqrt_pool_fwd_parts(ptr(xr), ptr(ur), ptr(ws), ctypes.byref(npart), 2, 48, 25, stream()) == _lib.HK_ERR_UNSUPPORTED
+    assert bool((ur == -1.0).all())
+    oo = torch.nn.functional.linear(O.bilinear_pool_signed_sqrt(x.cpu().reshape(b, c, hw, hw)), w.cpu(), bias.cpu())
+    assert rel(o1, oo) < 1e-5
+
+
 @pytest.mark.parametrize('b,d,itn', [(2, 128, 3), (17, 256, 5), (3, 70, 4), (2, 64, 1), (2, 33, 2)])
 def test_sqrtm_triuvec_in_one_chain(F, b, d, itn):
     """hk_ns_sqrtm_triu_fwd (what the MPN head calls): the chain's last product writes the packed upper triangle next to
