@@ -503,11 +503,12 @@ __global__ __launch_bounds__(256, 2) void bcnn_bwd_panel_kernel(const float* __r
     }
 }
 
+// pair: -1 = the rule the pooling heads were tuned on (row blocks in pairs once there are more than 256 of them); 0 / 1 = the caller's choice
 template <int HW, int MODE, bool CENTER>
 static int gram_launch(const float* x, const float* inv_norm, float* y, int B, int C, float* mu, float alpha,
-                       hipStream_t st, GramNormSrc ns = GramNormSrc{nullptr, nullptr, nullptr, 0, 0}) {
+                       hipStream_t st, GramNormSrc ns = GramNormSrc{nullptr, nullptr, nullptr, 0, 0}, int pair = -1) {
     const int nb = C / 64;
-    const int pair_mode = ((long long)B * nb > 256) ? 1 : 0;
+    const int pair_mode = pair >= 0 ? pair : (((long long)B * nb > 256) ? 1 : 0);
     const int per = pair_mode ? (nb + 1) / 2 : nb;
     hipLaunchKernelGGL((bcnn_gram_panel_kernel<HW, MODE, CENTER>), dim3(xcd_grid(B, per)), dim3(256), 0, st, x, inv_norm,
                        y, C, nb, B, pair_mode, mu, alpha, ns);
@@ -622,6 +623,20 @@ int gram_fast_raw(const float* x, float* mu, float alpha, float* g, int B, int C
 #undef CALL
     }
 #define CALL(H) gram_launch<H, 1, false>(x, nullptr, g, B, C, nullptr, alpha, st)
+    HK_HW_SWITCH(CALL)
+#undef CALL
+}
+
+// G = alpha X X^T for a caller outside the pooling heads (CIN's interaction matrix at 14 x 14 maps: C = 2048, 32 row blocks per
+// sample).  The row blocks go singly or in pairs, whichever leaves the shorter longest queue of 64 x 64 tiles on the 256 CUs
+// (one workgroup per CU: 150 KB of LDS): B = 20, C = 2048 -> 640 single blocks of <= 17 tiles in 3 rounds against 320 pairs of
+// 33 tiles in 2.
+int gram_fast_scaled(const float* x, float alpha, float* g, int B, int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(g)) return HK_ERR_UNSUPPORTED;
+    const long long nb = C / 64;
+    const long long single = ((B * nb + 255) / 256) * (nb / 2 + 1), paired = ((B * ((nb + 1) / 2) + 255) / 256) * (nb + 1);
+    const int pair = paired < single ? 1 : 0;
+#define CALL(H) gram_launch<H, 1, false>(x, nullptr, g, B, C, nullptr, alpha, st, GramNormSrc{nullptr, nullptr, nullptr, 0, 0}, pair)
     HK_HW_SWITCH(CALL)
 #undef CALL
 }

@@ -19,6 +19,9 @@
 
 namespace hk {
 
+// bcnn_fast.hip: g = alpha X X^T on the Gram panel kernel (every tile of the symmetric matrix computed once, both halves written)
+int gram_fast_scaled(const float* x, float alpha, float* g, int B, int C, int HW, hipStream_t st);
+
 // in place: row <- softmax(row), n columns
 __global__ __launch_bounds__(256) void cin_softmax_rows_kernel(float* __restrict__ w, int n) {
     __shared__ float red[4];
@@ -611,6 +614,272 @@ static int cin_sci_flash(const float* x, float* w, float* y, int B, int C, int H
     return HK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// SCI forward for 14 x 14 / 12 x 12 / 10 x 10 maps (a 448^2 input: HW = 196).  With K = HW = 196 the Gram is no longer cheap
+// to recompute (two passes of the one-kernel form above would issue three 2 C^2 HW products where the chain issues two),
+// so S = -X X^T / HW is MATERIALISED - by the Gram panel kernel of bcnn_fast.hip, which computes every 64 x 64 tile of the
+// symmetric matrix once and writes it and its mirror image - and then
+//   cin_row_stats_kernel    one wave per row: m_i = max_j S_ij, l_i = sum_j exp(S_ij - m_i), the row held in registers between
+//                           the two sweeps, fixed order; parked in the first two floats of the row's own Y storage;
+//   cin_softmax_pv_kernel   a workgroup owns 32 rows of one sample and walks the 64-row blocks X_j (LDS-DMA, three stages);
+//                           wave q takes columns 16 q .. + 15 of every block: it loads its 32 x 16 piece of S in the A-operand
+//                           layout of the 32x32x2 MFMA (lane = row, 16-byte loads), turns it into P = exp(S - m) / l in
+//                           registers, writes P over S - W is written ONCE and never read back - and issues Y += P X_j from
+//                           the same registers; the four partial Y tiles meet in LDS at the end (fixed order).
+// Against the chain on the generic tile (S written, read and rewritten by the row softmax, read again by the second product:
+// 1.3 GB) this moves 1.0 GB and runs both products on kernels built for their shapes.  32-row workgroups: B C / 32 = 1280 at
+// the plugin's batch of 20 - five full rounds of the 256 CUs (150 KB of LDS: one workgroup per CU, ONE wave per SIMD: every
+// latency is covered by the pipeline below, not by other waves); 64-row ones would be 2.5 rounds.
+// Measured at B = 20, C = 2048, 14 x 14 (rocprofv3, MI355X): Gram 196 us + statistics 81 us + this kernel 384 us; the chain on
+// the generic tile 588 + 225 + 549 us; rocBLAS bmm + softmax + bmm 940 us end to end (tools/cin_rows.py).  What each step of
+// the way to 384 us was worth: operands of MFMA group r + 1 requested before group r issues - nothing on its own (535 us);
+// eighths of the sample-major list per XCD instead of whole samples 535 -> 453; three stages and the piece of S three blocks
+// ahead in untracked registers 453 -> 460 (no gain: the wait was never latency); the step's 17 vector-memory instructions
+// dealt over the MFMA groups instead of issued in one burst 460 -> 407; the last four columns of Y on the vector ALU 407 ->
+// 384.  Without S and W traffic the same loop takes 330 us (= 0.62 of the matrix pipe's nominal peak, where the other fp32
+// MFMA kernels of this library sit); streaming hints on the loads of S / stores of W changed nothing (382 vs 385 us).
+// NV > 0: C = 256 NV - the row stays in registers between the two sweeps (one read of S); NV = 0: any C % 4 == 0, the second
+// sweep re-reads the row (from L2)
+template <int NV>
+__global__ __launch_bounds__(256) void cin_row_stats_kernel(const float* __restrict__ s, float* __restrict__ y, int C, int HW,
+                                                            long long rows) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const f32x4* p = reinterpret_cast<const f32x4*>(s + row * C);
+    float m = -3.402823466e38f, l = 0.f;
+    auto vmax = [](float a, const f32x4& v) { return fmaxf(fmaxf(a, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); };
+    auto vsum = [&](const f32x4& v) {
+        return (__builtin_amdgcn_exp2f((v[0] - m) * LOG2E) + __builtin_amdgcn_exp2f((v[1] - m) * LOG2E)) +
+               (__builtin_amdgcn_exp2f((v[2] - m) * LOG2E) + __builtin_amdgcn_exp2f((v[3] - m) * LOG2E));
+    };
+    if constexpr (NV > 0) {
+        f32x4 v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) v[u] = p[lane + 64 * u];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) m = vmax(m, v[u]);
+        m = wave_max(m);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) l += vsum(v[u]);
+    } else {
+        for (int f = lane; f < C / 4; f += 64) m = vmax(m, p[f]);
+        m = wave_max(m);
+        for (int f = lane; f < C / 4; f += 64) l += vsum(p[f]);
+    }
+    l = wave_sum(l);
+    if (lane == 0) { y[row * HW] = m; y[row * HW + 1] = l; }
+}
+
+template <int HW>
+__global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __restrict__ x, float* __restrict__ w,
+                                                                float* __restrict__ y, int C, int B) {
+    constexpr int RB = 32;                               // rows per workgroup
+    constexpr int CB = 64;                               // rows of X per column block
+    constexpr int BLK = CB * HW;                         // floats of one block of X (contiguous in memory)
+    constexpr int NPC = BLK / 256;                       // 1 KB LDS-DMA pieces of a block
+    constexpr int NPW = (NPC + 3) / 4;                   // pieces per wave and block (the same count in every wave: counted waits)
+    constexpr int PPG = (NPW + 6) / 7;                   // ... issued per MFMA group (seven of the eight groups of a step)
+    constexpr bool REMV = HW % 32 == 4;                  // 14 x 14 and 10 x 10 maps: the last FOUR columns of Y on the vector ALU (an
+                                                         // eighth 32-column tile of MFMAs for 4 of 196 columns is 12.5 % of the matrix work)
+    constexpr int NT2 = REMV ? HW / 32 : (HW + 31) / 32; // 32-column tiles of Y
+    static_assert(BLK % 256 == 0, "a block of X is a whole number of 1 KB pieces");
+    static_assert(3 * (NT2 * 16 * 64 + 256) <= 3 * BLK, "the partial Y tiles of three waves fit the stages");
+    __shared__ __attribute__((aligned(16))) float lds[3 * BLK + 32];
+
+    const int nrb = C / RB, ncb = C / CB;
+    // workgroup -> (sample, row block): XCD k (blockIdx % 8) takes the k-th EIGHTH of the sample-major list - neighbours in time
+    // walk the same X from the same L2 - rather than whole samples (xcd_map): 20 samples on 8 XCDs are 3 on four of them and
+    // 2 on the others, six rounds of the 32 CUs where the work is five
+    const int per = (B * nrb + NXCD - 1) / NXCD;
+    const int lin = (int)(blockIdx.x % NXCD) * per + (int)(blockIdx.x / NXCD);
+    if (lin >= B * nrb) return;
+    const int b = lin / nrb, I = lin % nrb;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float* xb = x + (long long)b * C * HW;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    // wave q: pieces q, q + 4, .. of the 64-row block - NPW requests whatever q is (the last piece of a block whose piece
+    // count is not a multiple of four is requested by several waves: the same bytes to the same place)
+    auto dma_blk = [&](int blk, float* dst) {
+        const float* src = xb + (long long)blk * BLK + 4 * lane;
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int pc = (q + 4 * u < NPC) ? q + 4 * u : NPC - 1;
+            glds16(src + 256 * pc, dst + 256 * pc);
+        }
+    };
+    const long long row = (long long)b * C + I * RB + l31;
+    float* wrow = w + row * C + 16 * q + 4 * lh;         // this lane's row of S / W: columns 16 q + 8 g + 4 lh .. + 3 of a block
+    const float m = y[row * HW], rl = 1.0f / y[row * HW + 1];          // (this row's Y is written at the very end)
+    auto load_s = [&](int blk, f32x4 (&d)[2]) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) HK_LOAD16_ASYNC(d[g], wrow + (long long)blk * CB + 8 * g);
+    };
+    auto softmax = [&](const f32x4 (&sv)[2], int r) { return __builtin_amdgcn_exp2f((sv[r >> 2][r & 3] - m) * LOG2E) * rl; };
+
+    // Pipeline.  In step J the MFMAs consume P(J) - registers - and X_J - stage J % 3 - while block J + 2 of X is on its way
+    // into the third stage, the piece of S for block J + 3 is on its way into registers (three sets in rotation: the loop is
+    // unrolled by three so that a set in flight is never copied), and P(J + 1) is formed from the piece that arrived during
+    // step J - 1, one exp per MFMA group.  The step ends with "everything older than this step's requests for X_{J+2} has
+    // arrived" (counted: those NPW requests and the two loads of S behind them are the last this wave issued) and a barrier.
+    if (tid < 32) lds[3 * BLK + tid] = 0.f;              // (read by the last tile's columns >= HW of a block's last row)
+    f32x4 sreg[3][2];
+    load_s(0, sreg[0]);
+    load_s(ncb > 1 ? 1 : 0, sreg[1]);
+    load_s(ncb > 2 ? 2 : ncb - 1, sreg[2]);
+    dma_blk(0, lds);
+    dma_blk(ncb > 1 ? 1 : 0, lds + BLK);
+    f32x16 yacc[NT2];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[n][r] = 0.f;
+    float pr[8], pn[8];
+    float yrem[4] = {0.f, 0.f, 0.f, 0.f};                // REMV: row l31, columns 32 NT2 .. + 3, this lane half's k
+    __builtin_amdgcn_s_waitcnt(HK_VMCNT_IMM(0));         // (the loads of S are not the compiler's to wait for: HK_LOAD16_ASYNC)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pr[r] = softmax(sreg[0], r);
+
+    auto step = [&](auto cur_tag, int J) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_tag)::value;    // J % 3: the stage of X_J, and the register set S(J + 3) goes into
+        f32x4 (&sa)[2] = sreg[(CUR + 1) % 3];            // S(J + 1)
+        const float* bj = lds + CUR * BLK + (16 * q + 4 * lh) * HW + l31;    // register r: row (r & 3) + 8 (r >> 2) of these
+        const int J2 = J + 2 < ncb ? J + 2 : ncb - 1;    // (past the end: the last block again, into a stage nobody reads)
+        const int J3 = J + 3 < ncb ? J + 3 : ncb - 1;
+        // Y_i += P X_j: A = P registers (i = lane & 31, k = lane half), B = x_j[column][n = lane & 31 (+ 32 n)].  The operands
+        // of step r + 1 are requested before the MFMAs of step r issue (one wave per SIMD: nobody else covers an LDS round
+        // trip); columns >= HW of the last tile read on into the next row (values of X, the next stage or the pad behind the
+        // stages) - unconditional reads keep the loop one basic block - and those columns of Y are never stored.
+        float bc[NT2], bn[NT2];
+        f32x4 xc = {0.f, 0.f, 0.f, 0.f}, xn = {0.f, 0.f, 0.f, 0.f};   // REMV: X[k][32 NT2 .. + 3], one address per lane half (broadcast)
+        const float* bj4 = lds + CUR * BLK + (16 * q + 4 * lh) * HW + 32 * NT2;
+#pragma unroll
+        for (int n = 0; n < NT2; ++n) bc[n] = bj[32 * n];
+        if (REMV) xc = *reinterpret_cast<const f32x4*>(bj4);
+        __builtin_amdgcn_sched_barrier(0);
+        // The step's vector-memory instructions - W(J) out, NPW pieces of X_{J+2}, the piece of S(J + 3), in that order - are
+        // dealt over the eight MFMA groups, two or three per group: issued in one burst at the top of the step they fill the
+        // CU's address queue and the wave sits in front of it instead of issuing MFMAs (measured: 367 us with the burst
+        // and neither S nor W, 273 at the matrix pipe's pace).
+        const float* xsrc = xb + (long long)J2 * BLK + 4 * lane;
+        float* xdst = lds + ((CUR + 2) % 3) * BLK;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r + 1 < 8) {
+#pragma unroll
+                for (int n = 0; n < NT2; ++n) bn[n] = bj[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * HW + 32 * n];
+                if (REMV) xn = *reinterpret_cast<const f32x4*>(bj4 + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * HW);
+            }
+            pn[r] = softmax(sa, r);
+            if (r == 0) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    *reinterpret_cast<f32x4*>(wrow + (long long)J * CB + 8 * g) = (f32x4){pr[4 * g], pr[4 * g + 1], pr[4 * g + 2], pr[4 * g + 3]};
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (r < 7) {
+#pragma unroll
+                for (int u = r * PPG; u < (r + 1) * PPG && u < NPW; ++u) {
+                    const int pc = (q + 4 * u < NPC) ? q + 4 * u : NPC - 1;
+                    glds16(xsrc + 256 * pc, xdst + 256 * pc);
+                }
+            } else {
+                load_s(J3, sreg[CUR]);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // the requests stay here, ahead of this step's MFMAs
+#pragma unroll
+            for (int n = 0; n < NT2; ++n) {
+                yacc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[r], bc[n], yacc[n], 0, 0, 0);
+                if (REMV && n == 0) {                                          // (in the shadow of the MFMA just issued)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) HK_FMAC_PINNED(yrem[c], pr[r], xc[c]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < NT2; ++n) bc[n] = bn[n];
+            xc = xn;
+        }
+        HK_VM_BARRIER(NPW + 2);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pr[r] = pn[r];
+    };
+    for (int J = 0; J < ncb; J += 3) {
+        step(std::integral_constant<int, 0>{}, J);
+        if (J + 1 < ncb) step(std::integral_constant<int, 1>{}, J + 1);
+        if (J + 2 < ncb) step(std::integral_constant<int, 2>{}, J + 2);
+    }
+    HK_VM_BARRIER(0);                                    // the stages are free - nothing is on its way into them, or into a register
+    // the partial Y of waves 1 .. 3 goes through LDS
+    constexpr int YB = NT2 * 16 * 64 + 256;              // floats per wave: the tiles, then the four remainder columns of its 32 rows
+    if (REMV) {                                          // the two lane halves hold disjoint k: lower + upper, the same in both
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float o = __shfl_xor(yrem[c], 32, 64);
+            yrem[c] = lh ? o + yrem[c] : yrem[c] + o;
+        }
+    }
+    if (q > 0) {
+        float* ybuf = lds + (q - 1) * YB;
+        if (REMV && lh == 0) *reinterpret_cast<f32x4*>(ybuf + NT2 * 16 * 64 + 4 * l31) = (f32x4){yrem[0], yrem[1], yrem[2], yrem[3]};
+#pragma unroll
+        for (int n = 0; n < NT2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ybuf[(n * 16 + r) * 64 + lane] = yacc[n][r];
+    }
+    __syncthreads();
+    if (q > 0) return;
+    // yacc[n]: standard layout - lane & 31 = column of tile n, registers = rows (r & 3) + 8 (r >> 2) + 4 lh of the 32
+    float* yb = y + ((long long)b * C + I * RB) * HW;
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+        const int col = 32 * n + l31;
+        if (col < HW) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = (n * 16 + r) * 64 + lane;
+                yb[((r & 3) + 8 * (r >> 2) + 4 * lh) * HW + col] =
+                    ((yacc[n][r] + lds[o]) + lds[YB + o]) + lds[2 * YB + o];
+            }
+        }
+    }
+    if (REMV && lh == 0) {
+        const float* rb = lds + NT2 * 16 * 64 + 4 * l31;
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = ((yrem[c] + rb[c]) + rb[YB + c]) + rb[2 * YB + c];
+        *reinterpret_cast<f32x4*>(yb + l31 * HW + 32 * NT2) = v;
+    }
+}
+
+// HK_ERR_UNSUPPORTED when the shape is not one the three kernels cover
+static int cin_sci_stored(const float* x, float* w, float* y, int B, int C, int HW, hipStream_t st) {
+    if (C % 64 != 0 || !aligned16(x) || !aligned16(w) || !aligned16(y)) return HK_ERR_UNSUPPORTED;
+    if (HW != 196 && HW != 144 && HW != 100) return HK_ERR_UNSUPPORTED;
+    const int rc = gram_fast_scaled(x, -1.0f / (float)HW, w, B, C, HW, st);                     // S = -X X^T / HW   :31-32
+    if (rc != HK_OK) return rc;
+    const long long rows = (long long)B * C;
+    const dim3 sgrid((unsigned)((rows + 3) / 4));
+    switch (C) {                                                                                // row max / sum of exp
+        case 2048: hipLaunchKernelGGL(cin_row_stats_kernel<8>, sgrid, dim3(256), 0, st, (const float*)w, y, C, HW, rows); break;
+        case 1024: hipLaunchKernelGGL(cin_row_stats_kernel<4>, sgrid, dim3(256), 0, st, (const float*)w, y, C, HW, rows); break;
+        case 512: hipLaunchKernelGGL(cin_row_stats_kernel<2>, sgrid, dim3(256), 0, st, (const float*)w, y, C, HW, rows); break;
+        default: hipLaunchKernelGGL(cin_row_stats_kernel<0>, sgrid, dim3(256), 0, st, (const float*)w, y, C, HW, rows); break;
+    }
+    const dim3 grid(NXCD * ((B * (C / 32) + NXCD - 1) / NXCD));
+    switch (HW) {
+        case 196: hipLaunchKernelGGL((cin_softmax_pv_kernel<196>), grid, dim3(256), 0, st, x, w, y, C, B); break;
+        case 144: hipLaunchKernelGGL((cin_softmax_pv_kernel<144>), grid, dim3(256), 0, st, x, w, y, C, B); break;
+        default: hipLaunchKernelGGL((cin_softmax_pv_kernel<100>), grid, dim3(256), 0, st, x, w, y, C, B); break;
+    }
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
 }  // namespace hk
 
 using namespace hk;
@@ -627,6 +896,8 @@ extern "C" int hk_cin_sci_fwd(const float* x, float* w, float* y, int B, int C, 
     if (tuning().bcnn_generic != 1) {                  // one kernel where the shape allows (C % 64 == 0, 7x7 / 8x8 / 6x6 maps)
         const int rc = cin_sci_flash(x, w, y, B, C, HW, st);
         if (rc != HK_ERR_UNSUPPORTED) return rc;
+        const int rc2 = cin_sci_stored(x, w, y, B, C, HW, st);        // 14x14 / 12x12 / 10x10 maps: Gram panel kernel, row statistics, softmax . X
+        if (rc2 != HK_ERR_UNSUPPORTED) return rc2;
     }
     const LdPlain lx = make_plain(x, (long long)C * HW, HW, C, HW);
     HK_TRY((bgemm_launch<true, true>(lx, lx, make_affine(w, (long long)C * C, C, -1.0f / (float)HW, nullptr, 0.f, 0.f), C, C,

@@ -88,6 +88,14 @@ __device__ __forceinline__ void buf_store4(buf_rsrc_t rs, unsigned byte_off, flo
 #define HK_PIN_LOADED(v) asm volatile("" : "+v"(v))
 #endif
 
+#ifndef HK_LOAD16_ASYNC  // a 16-byte global load the compiler does NOT keep books on: `dst` counts as written at once, and it is the
+                         // CALLER who guarantees - with a counted HK_VM_BARRIER between the request and the first use - that the
+                         // data has arrived.  For register prefetches several pipeline steps ahead next to LDS-DMA and stores:
+                         // with a tracked load the compiler's own s_waitcnt at the first use is vmcnt(0) as soon as stores are
+                         // pending too (it assumes loads and stores may return out of order), which drains the whole pipeline
+#define HK_LOAD16_ASYNC(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#endif
+
 // s_waitcnt vmcnt(n) + s_barrier: the workgroup barrier that ends a pipeline step of an LDS-DMA stream - waits for all but
 // the n most recent vector-memory operations of this wave (the pieces it has just issued), then publishes the stage
 #define HK_VMCNT_IMM(n) (((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))     /* gfx9 s_waitcnt: vmcnt only */

@@ -378,6 +378,9 @@ int hk_npairs_loss(const float* x, const int32_t* labels, float* loss, float* dx
  *   x, y, dy, dx [B,C,HW] ; w, dw [B,C,C] ; wt, dwt [B] ; B even for the CCI pair.
  *   hk_cin_sci_bwd: dwbuf [B,C,C] scratch; holds the gradient reaching W from the CCI
  *   branch on entry when has_extra != 0 (it is overwritten).
+ *   hk_cin_sci_fwd, C % 64 == 0: ONE kernel at 7x7 / 8x8 / 6x6 maps (scores recomputed on the matrix pipe, W written
+ *   once); at 14x14 / 12x12 / 10x10 maps three - Gram panel kernel, row statistics, softmax applied on the way into the
+ *   second product (W written once, in place of the scores); any other shape: Gram, row softmax, product on the generic tile.
  */
 int hk_cin_sci_fwd(const float* x, float* w, float* y, int B, int C, int HW, hk_stream_t stream);
 int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, float* dwbuf, int has_extra, float* dx, int B, int C,

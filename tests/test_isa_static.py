@@ -46,6 +46,29 @@ def test_streamed_cin_product_counts_its_requests(tmp_path):
     assert not any('s_cbranch' in l for l in loop[1:-1]), 'a branch inside the chunk loop'
 
 
+    # cin_softmax_pv_kernel<HW> (the 14 x 14 / 12 x 12 / 10 x 10 SCI forward): the pieces of S travel in registers the compiler
+    # keeps no books on (HK_LOAD16_ASYNC) and X_{J+2} by LDS-DMA; what makes that correct is the count at the end of every
+    # step - vmcnt(NPW + 2): everything older than this step's NPW pieces and two loads has landed - so: three steps in
+    # the unrolled loop, each ending in that wait, each issuing exactly its stores FIRST, then NPW LDS-DMA requests, then
+    # the two loads; no other vmcnt wait in the loop (a compiler-inserted vmcnt(0) would drain the pipeline), no scratch.
+    for hw, npw in ((196, 13), (144, 9), (100, 7)):
+        m = re.search(r'^(_ZN2hk21cin_softmax_pv_kernelILi%dE\w*):\s.*?\n(.*?)s_endpgm(.*?)\.end_amdhsa_kernel' % hw, txt, re.S | re.M)
+        assert m, f'cin_softmax_pv_kernel<{hw}> not found in the ISA'
+        assert re.search(r'\.amdhsa_private_segment_fixed_size 0\b', m.group(3)), f'<{hw}> uses scratch'
+        body = m.group(2).split('\n')
+        ends = [i for i, l in enumerate(body) if re.search(r's_waitcnt vmcnt\(%d\)' % (npw + 2), l)]
+        assert len(ends) == 3, (hw, ends)
+        first_store = next(i for i, l in enumerate(body) if 'global_store_dwordx4' in l)
+        starts = [first_store] + [e + 1 for e in ends[:2]]
+        for a, b in zip(starts, ends):
+            seg = body[a:b]
+            ops = [('S' if 'global_store_dwordx4' in l else 'D' if 'global_load_lds_dwordx4' in l else 'L')
+                   for l in seg if re.search(r'global_(store|load)', l)]
+            assert ''.join(ops) == 'SS' + 'D' * npw + 'LL', (hw, ''.join(ops))
+            assert not any(re.search(r's_waitcnt.*vmcnt', l) for l in seg), (hw, 'a second vmcnt wait inside a step')
+            assert sum('v_mfma' in l for l in seg) == 8 * (hw // 32 if hw % 32 == 4 else (hw + 31) // 32), hw
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='no hipcc')
 def test_gram_forward_leaves_in_16_byte_stores_and_never_spills(tmp_path):
     """bcnn_gram_panel_kernel (bcnn_fast.hip, hk_gram_tile.h): every element of y - direct and mirrored - leaves in a
