@@ -12,7 +12,9 @@
 // backward and dG X), cin_cci_dw_flash_kernel (the gradient reaching W from the contrastive branch); the C x C by C x HW
 // products that remain (W^T dY, dG^T X, |W - w W'| X and its transpose) stream their big operand once through the generic
 // tile with branch-free loaders (hk_bgemm.h: DEEP, LdPlainV / LdPlainN; LdAbsDiffV forms |W - w W'| on the way to LDS -
-// it is never stored).  Other shapes take the chains on the generic tile (bounds-checked loaders, row softmax and its
+// it is never stored).  14x14 / 12x12 / 10x10 maps (a 448^2 input) have their own forward - the scores materialised by the Gram
+// panel kernel of bcnn_fast.hip, row statistics, and cin_ax_kernel, which applies the softmax on the way into the second
+// product - and the same pipeline runs the backward's W^T dY and (dG + dG^T) X (see cin_ax_kernel).  Other shapes take the chains on the generic tile (bounds-checked loaders, row softmax and its
 // backward as one workgroup per row, fixed reduction order); knob bcnn_generic = 1 forces them (A/B, tests).
 #include "hk_bgemm.h"
 #include "../../include/hawkeye_hip.h"
@@ -621,7 +623,7 @@ static int cin_sci_flash(const float* x, float* w, float* y, int B, int C, int H
 // symmetric matrix once and writes it and its mirror image - and then
 //   cin_row_stats_kernel    one wave per row: m_i = max_j S_ij, l_i = sum_j exp(S_ij - m_i), the row held in registers between
 //                           the two sweeps, fixed order; parked in the first two floats of the row's own Y storage;
-//   cin_softmax_pv_kernel   a workgroup owns 32 rows of one sample and walks the 64-row blocks X_j (LDS-DMA, three stages);
+//   cin_ax_kernel   a workgroup owns 32 rows of one sample and walks the 64-row blocks X_j (LDS-DMA, three stages);
 //                           wave q takes columns 16 q .. + 15 of every block: it loads its 32 x 16 piece of S in the A-operand
 //                           layout of the 32x32x2 MFMA (lane = row, 16-byte loads), turns it into P = exp(S - m) / l in
 //                           registers, writes P over S - W is written ONCE and never read back - and issues Y += P X_j from
@@ -672,9 +674,16 @@ __global__ __launch_bounds__(256) void cin_row_stats_kernel(const float* __restr
     if (lane == 0) { y[row * HW] = m; y[row * HW + 1] = l; }
 }
 
-template <int HW>
-__global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __restrict__ x, float* __restrict__ w,
-                                                                float* __restrict__ y, int C, int B) {
+// MODE 0: the forward above (w: S in, W out; y: statistics in, Y out).
+// The same pipeline serves the two products of the backward whose big operand is a C x C matrix read ONCE (hk_cin_sci_bwd at
+// these map sizes; x = the C x HW operand that is staged, w = the matrix, read only):
+// MODE 1: y  = scale * w^T x          (W^T dY: the piece of w^T is a COLUMN piece of w - eight 4-byte loads per lane and block,
+//                                      32 lanes on 128 consecutive bytes of one row of w)
+// MODE 2: y += scale * (w + w^T) x    ((dG + dG^T) X / HW in ONE pass: row piece + column piece added in registers - one
+//                                      product on the matrix pipe where the chain on the generic tile ran two)
+template <int HW, int MODE>
+__global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict__ x, float* __restrict__ w, float* __restrict__ y,
+                                                        int C, int B, float scale) {
     constexpr int RB = 32;                               // rows per workgroup
     constexpr int CB = 64;                               // rows of X per column block
     constexpr int BLK = CB * HW;                         // floats of one block of X (contiguous in memory)
@@ -684,6 +693,8 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
     constexpr bool REMV = HW % 32 == 4;                  // 14 x 14 and 10 x 10 maps: the last FOUR columns of Y on the vector ALU (an
                                                          // eighth 32-column tile of MFMAs for 4 of 196 columns is 12.5 % of the matrix work)
     constexpr int NT2 = REMV ? HW / 32 : (HW + 31) / 32; // 32-column tiles of Y
+    constexpr bool ROWP = MODE != 1, COLP = MODE != 0;   // which pieces of w a step loads: 16-byte row pieces, 4-byte column pieces
+    constexpr int NL = (ROWP ? 2 : 0) + (COLP ? 8 : 0);  // loads per step and lane
     static_assert(BLK % 256 == 0, "a block of X is a whole number of 1 KB pieces");
     static_assert(3 * (NT2 * 16 * 64 + 256) <= 3 * BLK, "the partial Y tiles of three waves fit the stages");
     __shared__ __attribute__((aligned(16))) float lds[3 * BLK + 32];
@@ -713,23 +724,47 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
     };
     const long long row = (long long)b * C + I * RB + l31;
     float* wrow = w + row * C + 16 * q + 4 * lh;         // this lane's row of S / W: columns 16 q + 8 g + 4 lh .. + 3 of a block
-    const float m = y[row * HW], rl = 1.0f / y[row * HW + 1];          // (this row's Y is written at the very end)
+    // column piece: rows 64 blk + 16 q + 4 lh + (r & 3) + 8 (r >> 2) of w, column 32 I + l31 (= element [l31][k] of the transpose)
+    const float* wcol = w + ((long long)b * C + 16 * q + 4 * lh) * C + I * RB + l31;
+    float m = 0.f, rl = 1.f;
+    if (MODE == 0) { m = y[row * HW]; rl = 1.0f / y[row * HW + 1]; }   // (this row's Y is written at the very end)
     auto load_s = [&](int blk, f32x4 (&d)[2]) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) HK_LOAD16_ASYNC(d[g], wrow + (long long)blk * CB + 8 * g);
     };
-    auto softmax = [&](const f32x4 (&sv)[2], int r) { return __builtin_amdgcn_exp2f((sv[r >> 2][r & 3] - m) * LOG2E) * rl; };
+    auto load_t1 = [&](int blk, int r, float& d) { HK_LOAD4_ASYNC(d, wcol + ((long long)blk * CB + (r & 3) + 8 * (r >> 2)) * C); };
+    // element r of the A operand from the pieces that arrived: P = exp(S - m) / l, or w^T, or w + w^T
+    auto aval = [&](const f32x4 (&sv)[2], const float (&tv)[8], int r) {
+        if (MODE == 0) return __builtin_amdgcn_exp2f((sv[r >> 2][r & 3] - m) * LOG2E) * rl;
+        if (MODE == 1) return tv[r];
+        return sv[r >> 2][r & 3] + tv[r];
+    };
 
     // Pipeline.  In step J the MFMAs consume P(J) - registers - and X_J - stage J % 3 - while block J + 2 of X is on its way
-    // into the third stage, the piece of S for block J + 3 is on its way into registers (three sets in rotation: the loop is
-    // unrolled by three so that a set in flight is never copied), and P(J + 1) is formed from the piece that arrived during
-    // step J - 1, one exp per MFMA group.  The step ends with "everything older than this step's requests for X_{J+2} has
-    // arrived" (counted: those NPW requests and the two loads of S behind them are the last this wave issued) and a barrier.
+    // into the third stage and the A operand of step J + 1 is formed from the piece of w that has arrived, one element per
+    // MFMA group.  The pieces travel in registers the compiler keeps no books on (HK_LOAD16_ASYNC), so the rule that makes
+    // it correct is structural: the loop body is THREE steps; the pieces for the next body's three steps (cur -> nxt) are all
+    // requested in the first step, the counted wait at the end of the SECOND step (everything but that step's NPW LDS-DMA
+    // requests has landed) covers them, and only behind the third step are they copied nxt -> cur: no register in flight is
+    // ever read, moved or renamed (a set carried across the loop edge while in flight gets copied by the compiler at the
+    // edge - stale values, seen as 7e-3 errors on the GPU and never in the emulator; tests/test_isa_static.py now walks the
+    // ISA for any read of a register between its request and the wait that covers it).
     if (tid < 32) lds[3 * BLK + tid] = 0.f;              // (read by the last tile's columns >= HW of a block's last row)
-    f32x4 sreg[3][2];
-    load_s(0, sreg[0]);
-    load_s(ncb > 1 ? 1 : 0, sreg[1]);
-    load_s(ncb > 2 ? 2 : ncb - 1, sreg[2]);
+    f32x4 s0[2], scur[3][2], snxt[3][2];
+    float t0[8], tcur[3][8], tnxt[3][8];
+    auto load_set = [&](int blk, f32x4 (&sd)[2], float (&td)[8]) {
+        const int bc_ = blk < ncb ? blk : ncb - 1;       // (past the end: the last block again - loaded, never used)
+        if (ROWP) load_s(bc_, sd);
+        else sd[0] = sd[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (COLP) load_t1(bc_, r, td[r]);
+            else td[r] = 0.f;
+        }
+    };
+    load_set(0, s0, t0);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) load_set(u + 1, scur[u], tcur[u]);
     dma_blk(0, lds);
     dma_blk(ncb > 1 ? 1 : 0, lds + BLK);
     f32x16 yacc[NT2];
@@ -739,17 +774,18 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
         for (int r = 0; r < 16; ++r) yacc[n][r] = 0.f;
     float pr[8], pn[8];
     float yrem[4] = {0.f, 0.f, 0.f, 0.f};                // REMV: row l31, columns 32 NT2 .. + 3, this lane half's k
-    __builtin_amdgcn_s_waitcnt(HK_VMCNT_IMM(0));         // (the loads of S are not the compiler's to wait for: HK_LOAD16_ASYNC)
+    __builtin_amdgcn_s_waitcnt(HK_VMCNT_IMM(0));         // (the loads of the pieces are not the compiler's to wait for)
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) pr[r] = softmax(sreg[0], r);
+    for (int r = 0; r < 8; ++r) pr[r] = aval(s0, t0, r);
 
     auto step = [&](auto cur_tag, int J) __attribute__((always_inline)) {
-        constexpr int CUR = decltype(cur_tag)::value;    // J % 3: the stage of X_J, and the register set S(J + 3) goes into
-        f32x4 (&sa)[2] = sreg[(CUR + 1) % 3];            // S(J + 1)
+        constexpr int CUR = decltype(cur_tag)::value;    // J % 3: the stage of X_J; the piece of block J + 1 is set CUR of `cur`
+        f32x4 (&sa)[2] = scur[CUR];
+        float (&ta)[8] = tcur[CUR];
         const float* bj = lds + CUR * BLK + (16 * q + 4 * lh) * HW + l31;    // register r: row (r & 3) + 8 (r >> 2) of these
         const int J2 = J + 2 < ncb ? J + 2 : ncb - 1;    // (past the end: the last block again, into a stage nobody reads)
-        const int J3 = J + 3 < ncb ? J + 3 : ncb - 1;
         // Y_i += P X_j: A = P registers (i = lane & 31, k = lane half), B = x_j[column][n = lane & 31 (+ 32 n)].  The operands
         // of step r + 1 are requested before the MFMAs of step r issue (one wave per SIMD: nobody else covers an LDS round
         // trip); columns >= HW of the last tile read on into the next row (values of X, the next stage or the pad behind the
@@ -761,10 +797,10 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
         for (int n = 0; n < NT2; ++n) bc[n] = bj[32 * n];
         if (REMV) xc = *reinterpret_cast<const f32x4*>(bj4);
         __builtin_amdgcn_sched_barrier(0);
-        // The step's vector-memory instructions - W(J) out, NPW pieces of X_{J+2}, the piece of S(J + 3), in that order - are
-        // dealt over the eight MFMA groups, two or three per group: issued in one burst at the top of the step they fill the
-        // CU's address queue and the wave sits in front of it instead of issuing MFMAs (measured: 367 us with the burst
-        // and neither S nor W, 273 at the matrix pipe's pace).
+        // The step's vector-memory instructions - W(J) out first (MODE 0), then NPW pieces of X_{J+2} and, in the body's first
+        // step, the pieces of w for the next body - are dealt over the eight MFMA groups: issued in one burst at the top of
+        // the step they fill the CU's address queue and the wave sits in front of it instead of issuing MFMAs (measured:
+        // 367 us with the burst and neither S nor W, 273 at the matrix pipe's pace).
         const float* xsrc = xb + (long long)J2 * BLK + 4 * lane;
         float* xdst = lds + ((CUR + 2) % 3) * BLK;
 #pragma unroll
@@ -774,8 +810,8 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
                 for (int n = 0; n < NT2; ++n) bn[n] = bj[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * HW + 32 * n];
                 if (REMV) xn = *reinterpret_cast<const f32x4*>(bj4 + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * HW);
             }
-            pn[r] = softmax(sa, r);
-            if (r == 0) {
+            pn[r] = aval(sa, ta, r);
+            if (MODE == 0 && r == 0) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
                     *reinterpret_cast<f32x4*>(wrow + (long long)J * CB + 8 * g) = (f32x4){pr[4 * g], pr[4 * g + 1], pr[4 * g + 2], pr[4 * g + 3]};
@@ -787,8 +823,14 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
                     const int pc = (q + 4 * u < NPC) ? q + 4 * u : NPC - 1;
                     glds16(xsrc + 256 * pc, xdst + 256 * pc);
                 }
-            } else {
-                load_s(J3, sreg[CUR]);
+            }
+            if (CUR == 0) {                              // the next body's pieces: blocks J + 4, J + 5, J + 6
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int blk = J + 4 + u < ncb ? J + 4 + u : ncb - 1;
+                    if (COLP) load_t1(blk, r, tnxt[u][r]);
+                    if (ROWP && r == 2 * u + 1) load_s(blk, snxt[u]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);           // the requests stay here, ahead of this step's MFMAs
 #pragma unroll
@@ -804,7 +846,8 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
             for (int n = 0; n < NT2; ++n) bc[n] = bn[n];
             xc = xn;
         }
-        HK_VM_BARRIER(NPW + 2);
+        HK_VM_BARRIER(NPW + (CUR == 0 ? 3 * NL : 0));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 8; ++r) pr[r] = pn[r];
     };
@@ -812,8 +855,18 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
         step(std::integral_constant<int, 0>{}, J);
         if (J + 1 < ncb) step(std::integral_constant<int, 1>{}, J + 1);
         if (J + 2 < ncb) step(std::integral_constant<int, 2>{}, J + 2);
+        if (J + 3 < ncb) {                               // (another body follows: steps 1 and 2 ran, their waits covered nxt)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                scur[u][0] = snxt[u][0]; scur[u][1] = snxt[u][1];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) tcur[u][r] = tnxt[u][r];
+            }
+        }
     }
+    __builtin_amdgcn_sched_barrier(0);
     HK_VM_BARRIER(0);                                    // the stages are free - nothing is on its way into them, or into a register
+    __builtin_amdgcn_sched_barrier(0);
     // the partial Y of waves 1 .. 3 goes through LDS
     constexpr int YB = NT2 * 16 * 64 + 256;              // floats per wave: the tiles, then the four remainder columns of its 32 rows
     if (REMV) {                                          // the two lane halves hold disjoint k: lower + upper, the same in both
@@ -839,11 +892,15 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
     for (int n = 0; n < NT2; ++n) {
         const int col = 32 * n + l31;
         if (col < HW) {
+            float* dst = yb + 4 * lh * HW + col;           // register r: row (r & 3) + 8 (r >> 2) of these
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = MODE == 2 ? dst[((r & 3) + 8 * (r >> 2)) * HW] : 0.f;   // (all 16 in flight at once)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = (n * 16 + r) * 64 + lane;
-                yb[((r & 3) + 8 * (r >> 2) + 4 * lh) * HW + col] =
-                    ((yacc[n][r] + lds[o]) + lds[YB + o]) + lds[2 * YB + o];
+                const float t = ((yacc[n][r] + lds[o]) + lds[YB + o]) + lds[2 * YB + o];
+                dst[((r & 3) + 8 * (r >> 2)) * HW] = MODE == 0 ? t : MODE == 1 ? scale * t : fmaf(scale, t, old[r]);
             }
         }
     }
@@ -852,14 +909,36 @@ __global__ __launch_bounds__(256, 1) void cin_softmax_pv_kernel(const float* __r
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = ((yrem[c] + rb[c]) + rb[YB + c]) + rb[2 * YB + c];
-        *reinterpret_cast<f32x4*>(yb + l31 * HW + 32 * NT2) = v;
+        f32x4* dst = reinterpret_cast<f32x4*>(yb + l31 * HW + 32 * NT2);
+        if (MODE == 1) v = v * scale;
+        if (MODE == 2) {
+            const f32x4 old = *dst;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaf(scale, v[c], old[c]);
+        }
+        *dst = v;
     }
+}
+
+static bool cin_ax_covers(int C, int HW) { return C % 64 == 0 && (HW == 196 || HW == 144 || HW == 100); }
+
+template <int MODE>
+static int cin_ax_launch(const float* x, float* w, float* y, float scale, int B, int C, int HW, hipStream_t st) {
+    const dim3 grid(NXCD * ((B * (C / 32) + NXCD - 1) / NXCD));
+    switch (HW) {
+        case 196: hipLaunchKernelGGL((cin_ax_kernel<196, MODE>), grid, dim3(256), 0, st, x, w, y, C, B, scale); break;
+        case 144: hipLaunchKernelGGL((cin_ax_kernel<144, MODE>), grid, dim3(256), 0, st, x, w, y, C, B, scale); break;
+        case 100: hipLaunchKernelGGL((cin_ax_kernel<100, MODE>), grid, dim3(256), 0, st, x, w, y, C, B, scale); break;
+        default: return HK_ERR_UNSUPPORTED;
+    }
+    HK_LAUNCH_CHECK();
+    return HK_OK;
 }
 
 // HK_ERR_UNSUPPORTED when the shape is not one the three kernels cover
 static int cin_sci_stored(const float* x, float* w, float* y, int B, int C, int HW, hipStream_t st) {
     if (C % 64 != 0 || !aligned16(x) || !aligned16(w) || !aligned16(y)) return HK_ERR_UNSUPPORTED;
-    if (HW != 196 && HW != 144 && HW != 100) return HK_ERR_UNSUPPORTED;
+    if (!cin_ax_covers(C, HW)) return HK_ERR_UNSUPPORTED;
     const int rc = gram_fast_scaled(x, -1.0f / (float)HW, w, B, C, HW, st);                     // S = -X X^T / HW   :31-32
     if (rc != HK_OK) return rc;
     const long long rows = (long long)B * C;
@@ -870,14 +949,7 @@ static int cin_sci_stored(const float* x, float* w, float* y, int B, int C, int 
         case 512: hipLaunchKernelGGL(cin_row_stats_kernel<2>, sgrid, dim3(256), 0, st, (const float*)w, y, C, HW, rows); break;
         default: hipLaunchKernelGGL(cin_row_stats_kernel<0>, sgrid, dim3(256), 0, st, (const float*)w, y, C, HW, rows); break;
     }
-    const dim3 grid(NXCD * ((B * (C / 32) + NXCD - 1) / NXCD));
-    switch (HW) {
-        case 196: hipLaunchKernelGGL((cin_softmax_pv_kernel<196>), grid, dim3(256), 0, st, x, w, y, C, B); break;
-        case 144: hipLaunchKernelGGL((cin_softmax_pv_kernel<144>), grid, dim3(256), 0, st, x, w, y, C, B); break;
-        default: hipLaunchKernelGGL((cin_softmax_pv_kernel<100>), grid, dim3(256), 0, st, x, w, y, C, B); break;
-    }
-    HK_LAUNCH_CHECK();
-    return HK_OK;
+    return cin_ax_launch<0>(x, w, y, 1.f, B, C, HW, st);
 }
 
 }  // namespace hk
@@ -934,6 +1006,13 @@ extern "C" int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, f
     else HK_TRY((bgemm_launch<true, true>(ldy, lx, epw, C, C, HW, B, st)));
     hipLaunchKernelGGL(cin_softmax_bwd_rows_kernel, dim3((unsigned)B * C), dim3(256), 0, st, w, dwbuf, C);
     HK_LAUNCH_CHECK();
+    if (tuning().bcnn_generic != 1 && cin_ax_covers(C, HW) && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(w) &&
+        aligned16(dwbuf)) {
+        // 14x14 / 12x12 / 10x10 maps: each C x C matrix streamed once through the forward's pipeline (cin_ax_kernel) -
+        // dx = W^T dY, then dx += (dG + dG^T) X / HW as ONE product
+        HK_TRY((cin_ax_launch<1>(dy, const_cast<float*>(w), dx, 1.f, B, C, HW, st)));
+        return cin_ax_launch<2>(x, dwbuf, dx, 1.0f / (float)HW, B, C, HW, st);
+    }
     if (cin_inside(C, w) && aligned16(dwbuf)) {
         // (dG + dG^T) X as two products over dG - the transposed half of LdSym is a 4-byte gather with an 8 KB stride
         const LdPlainN cx = cin_cols(x, C, HW), cdy = cin_cols(dy, C, HW);

@@ -94,6 +94,7 @@ __device__ __forceinline__ void buf_store4(buf_rsrc_t rs, unsigned byte_off, flo
                          // with a tracked load the compiler's own s_waitcnt at the first use is vmcnt(0) as soon as stores are
                          // pending too (it assumes loads and stores may return out of order), which drains the whole pipeline
 #define HK_LOAD16_ASYNC(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define HK_LOAD4_ASYNC(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 #endif
 
 // s_waitcnt vmcnt(n) + s_barrier: the workgroup barrier that ends a pipeline step of an LDS-DMA stream - waits for all but

@@ -411,6 +411,7 @@ inline T __shfl(T v, int srclane, int = 64) {
 #define HK_FMAC_PINNED(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
 #define HK_PIN_LOADED(v) ((void)0)
 #define HK_LOAD16_ASYNC(dst, ptr) ((dst) = *reinterpret_cast<const hipemu::v4f*>(ptr))
+#define HK_LOAD4_ASYNC(dst, ptr) ((dst) = *(ptr))
 #define HK_BUF_RSRC 1      /* buffer-descriptor stores: bounds-checked like the hardware (lanes beyond the descriptor's size are dropped) */
 namespace hk {
 struct buf_rsrc_t { char* p; long long bytes; };

@@ -415,7 +415,7 @@ def test_mamc_npairs_loss_larger_batch(F):
 
 
 @pytest.mark.parametrize('b,c,hw', [(4, 24, 12), (2, 70, 5), (6, 130, 49), (4, 128, 49), (2, 192, 64), (10, 64, 36), (2, 128, 196),
-                                    (4, 192, 144), (10, 64, 100), (2, 320, 196)])
+                                    (4, 192, 144), (10, 64, 100), (2, 320, 196), (2, 448, 100)])
 def test_cin_channel_interaction_ops(F, b, c, hw, monkeypatch):
     """hk_cin_sci_* / hk_cin_cci_*  vs torch autograd of the reference's formulas (CIN.py:31-34, 51-54) in
     fp64: forward values, and the gradients through both branches including the one that reaches W_SCI from the

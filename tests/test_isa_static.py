@@ -46,27 +46,60 @@ def test_streamed_cin_product_counts_its_requests(tmp_path):
     assert not any('s_cbranch' in l for l in loop[1:-1]), 'a branch inside the chunk loop'
 
 
-    # cin_softmax_pv_kernel<HW> (the 14 x 14 / 12 x 12 / 10 x 10 SCI forward): the pieces of S travel in registers the compiler
-    # keeps no books on (HK_LOAD16_ASYNC) and X_{J+2} by LDS-DMA; what makes that correct is the count at the end of every
-    # step - vmcnt(NPW + 2): everything older than this step's NPW pieces and two loads has landed - so: three steps in
-    # the unrolled loop, each ending in that wait, each issuing exactly its stores FIRST, then NPW LDS-DMA requests, then
-    # the two loads; no other vmcnt wait in the loop (a compiler-inserted vmcnt(0) would drain the pipeline), no scratch.
+    # cin_ax_kernel<HW, MODE> (the 14 x 14 / 12 x 12 / 10 x 10 SCI forward and the backward's two big products): the pieces of
+    # the C x C matrix travel in registers the compiler keeps no books on (HK_LOAD16_ASYNC / HK_LOAD4_ASYNC) and X_{J+2} by
+    # LDS-DMA.  What makes that correct is (a) the counted wait at the end of every step - vmcnt(NPW) leaves only that step's
+    # NPW LDS-DMA requests in flight, vmcnt(NPW + 3 NL) behind the body's first step also the 3 NL piece loads it issued -
+    # (b) no compiler-inserted vmcnt wait inside the loop (a vmcnt(0) would drain the pipeline), and (c) NO instruction
+    # touching a register between its request and the wait that covers it: walked here, operand by operand.
     for hw, npw in ((196, 13), (144, 9), (100, 7)):
-        m = re.search(r'^(_ZN2hk21cin_softmax_pv_kernelILi%dE\w*):\s.*?\n(.*?)s_endpgm(.*?)\.end_amdhsa_kernel' % hw, txt, re.S | re.M)
-        assert m, f'cin_softmax_pv_kernel<{hw}> not found in the ISA'
-        assert re.search(r'\.amdhsa_private_segment_fixed_size 0\b', m.group(3)), f'<{hw}> uses scratch'
-        body = m.group(2).split('\n')
-        ends = [i for i, l in enumerate(body) if re.search(r's_waitcnt vmcnt\(%d\)' % (npw + 2), l)]
-        assert len(ends) == 3, (hw, ends)
-        first_store = next(i for i, l in enumerate(body) if 'global_store_dwordx4' in l)
-        starts = [first_store] + [e + 1 for e in ends[:2]]
-        for a, b in zip(starts, ends):
-            seg = body[a:b]
-            ops = [('S' if 'global_store_dwordx4' in l else 'D' if 'global_load_lds_dwordx4' in l else 'L')
-                   for l in seg if re.search(r'global_(store|load)', l)]
-            assert ''.join(ops) == 'SS' + 'D' * npw + 'LL', (hw, ''.join(ops))
-            assert not any(re.search(r's_waitcnt.*vmcnt', l) for l in seg), (hw, 'a second vmcnt wait inside a step')
-            assert sum('v_mfma' in l for l in seg) == 8 * (hw // 32 if hw % 32 == 4 else (hw + 31) // 32), hw
+        for mode, nl in ((0, 2), (1, 8), (2, 10)):
+            m = re.search(r'^(_ZN2hk13cin_ax_kernelILi%dELi%dE\w*):\s.*?\n(.*?)s_endpgm(.*?)\.end_amdhsa_kernel' % (hw, mode), txt, re.S | re.M)
+            assert m, f'cin_ax_kernel<{hw}, {mode}> not found in the ISA'
+            assert re.search(r'\.amdhsa_private_segment_fixed_size 0\b', m.group(3)), f'<{hw}, {mode}> uses scratch'
+            body = m.group(2).split('\n')
+            loop_start = next(i for i, l in enumerate(body) if re.search(r's_waitcnt vmcnt\(0\)', l))
+            loop_end = [i for i, l in enumerate(body) if i > loop_start and re.search(r's_waitcnt.*?vmcnt', l)][2]   # the body's third step ends here
+            waits = [int(k) for l in body[loop_start + 1:loop_end + 1] for k in re.findall(r's_waitcnt.*?vmcnt\((\d+)\)', l)]
+            assert sorted(waits) == [npw, npw, npw + 3 * nl], (hw, mode, waits)     # (the three steps, in whatever order the blocks are laid out)
+            nmfma = 8 * (hw // 32 if hw % 32 == 4 else (hw + 31) // 32)
+            segs, prev = [], loop_start + 1
+            for i in range(loop_start + 1, loop_end + 1):
+                w = re.search(r's_waitcnt.*?vmcnt\((\d+)\)', body[i])
+                if w:
+                    segs.append((int(w.group(1)), body[prev:i])); prev = i + 1
+            for cnt, seg in segs:
+                first = cnt != npw                                                  # the body's first step: it also requests the next body's pieces
+                ops = ''.join('S' if 'global_store_dwordx4' in l else 'D' if 'global_load_lds_dwordx4' in l else 'L'
+                              for l in seg if re.search(r'global_(store|load)', l))
+                assert ops.count('D') == npw and ops.count('L') == (3 * nl if first else 0), (hw, mode, cnt, ops)
+                assert ops.count('S') == (2 if mode == 0 else 0) and ops.startswith('SS' if mode == 0 else ''), (hw, mode, cnt, ops)
+                if not first: assert ops[-npw:] == 'D' * npw, (hw, mode, cnt, ops)  # vmcnt(NPW) leaves exactly the LDS-DMA requests
+                assert sum('v_mfma' in l for l in seg) == nmfma, (hw, mode, cnt)
+            # (c): registers in flight are never operands
+            flying, in_asm = set(), False
+
+            def regs(text):
+                out = set()
+                for lo, hi in re.findall(r'\bv\[(\d+):(\d+)\]', text): out.update(range(int(lo), int(hi) + 1))
+                out.update(int(v) for v in re.findall(r'\bv(\d+)\b', text))
+                return out
+            for l in body[:loop_end + 1]:
+                code = l.split(';')[0].strip()
+                if '#ASMSTART' in l: in_asm = True; continue
+                if '#ASMEND' in l: in_asm = False; continue
+                if not code or code.endswith(':'): continue
+                w = re.search(r's_waitcnt.*?vmcnt\((\d+)\)', code)
+                if w:
+                    if int(w.group(1)) <= npw: flying.clear()
+                    continue
+                if in_asm and code.startswith('global_load_dword'):
+                    dst, addr = code.split(',')[0], ','.join(code.split(',')[1:])
+                    assert not (regs(addr) & flying), (hw, mode, code)
+                    flying |= regs(dst)
+                    continue
+                assert not (regs(code) & flying), (hw, mode, 'reads or writes a register in flight', code)
+            assert not flying
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='no hipcc')
