@@ -623,7 +623,7 @@ static int cin_sci_flash(const float* x, float* w, float* y, int B, int C, int H
 // symmetric matrix once and writes it and its mirror image - and then
 //   cin_row_stats_kernel    one wave per row: m_i = max_j S_ij, l_i = sum_j exp(S_ij - m_i), the row held in registers between
 //                           the two sweeps, fixed order; parked in the first two floats of the row's own Y storage;
-//   cin_ax_kernel   a workgroup owns 32 rows of one sample and walks the 64-row blocks X_j (LDS-DMA, three stages);
+//   cin_ax_kernel<HW, 0>    a workgroup owns 32 rows of one sample and walks the 64-row blocks X_j (LDS-DMA, three stages);
 //                           wave q takes columns 16 q .. + 15 of every block: it loads its 32 x 16 piece of S in the A-operand
 //                           layout of the 32x32x2 MFMA (lane = row, 16-byte loads), turns it into P = exp(S - m) / l in
 //                           registers, writes P over S - W is written ONCE and never read back - and issues Y += P X_j from
@@ -635,7 +635,7 @@ static int cin_sci_flash(const float* x, float* w, float* y, int B, int C, int H
 // Measured at B = 20, C = 2048, 14 x 14 (rocprofv3, MI355X): Gram 196 us + statistics 81 us + this kernel 384 us; the chain on
 // the generic tile 588 + 225 + 549 us; rocBLAS bmm + softmax + bmm 940 us end to end (tools/cin_rows.py).  What each step of
 // the way to 384 us was worth: operands of MFMA group r + 1 requested before group r issues - nothing on its own (535 us);
-// eighths of the sample-major list per XCD instead of whole samples 535 -> 453; three stages and the piece of S three blocks
+// eighths of the sample-major list per XCD instead of whole samples 535 -> 453; three stages and the pieces of S several blocks
 // ahead in untracked registers 453 -> 460 (no gain: the wait was never latency); the step's 17 vector-memory instructions
 // dealt over the MFMA groups instead of issued in one burst 460 -> 407; the last four columns of Y on the vector ALU 407 ->
 // 384.  Without S and W traffic the same loop takes 330 us (= 0.62 of the matrix pipe's nominal peak, where the other fp32

@@ -381,6 +381,8 @@ int hk_npairs_loss(const float* x, const int32_t* labels, float* loss, float* dx
  *   hk_cin_sci_fwd, C % 64 == 0: ONE kernel at 7x7 / 8x8 / 6x6 maps (scores recomputed on the matrix pipe, W written
  *   once); at 14x14 / 12x12 / 10x10 maps three - Gram panel kernel, row statistics, softmax applied on the way into the
  *   second product (W written once, in place of the scores); any other shape: Gram, row softmax, product on the generic tile.
+ *   hk_cin_sci_bwd at those larger maps: W^T dY and (dG + dG^T) X / HW each stream their C x C operand once through the
+ *   forward's pipeline (the second as ONE product).
  */
 int hk_cin_sci_fwd(const float* x, float* w, float* y, int B, int C, int HW, hk_stream_t stream);
 int hk_cin_sci_bwd(const float* x, const float* w, const float* dy, float* dwbuf, int has_extra, float* dx, int B, int C,
