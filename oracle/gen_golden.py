@@ -360,6 +360,43 @@ def gen_cin_model():
          loss=loss)
 
 
+def gen_cin_448():
+    """CIN at a 448 x 448 input: 14 x 14 maps, the kernels of hk_cin_sci_fwd / bwd for the larger map sizes.
+    (a) the whole reference model in EVAL mode (its train mode is tied to 7 x 7 maps: CIN.py:22, the fc behind the
+    contrastive branch has 2 * 2048 * 49 inputs) -> model_cin_448.npz; (b) the reference ChannelInteractionModule built for
+    14 x 14 maps on 128 channels, train mode with the contrastive branch, outputs and every gradient -> cin_14x14.npz."""
+    from yacs.config import CfgNode as CN
+    from inputs import seeded_init
+    M_CIN = sys.modules['model.methods.CIN']
+    real_r50 = M_CIN.resnet50
+    M_CIN.resnet50 = lambda pretrained=True: real_r50(pretrained=False)
+    m = MODEL.get('CIN')(CN(dict(num_classes=200)))
+    M_CIN.resnet50 = real_r50
+    seeded_init(m, 930)
+    m.eval()
+    with torch.no_grad():
+        x = t(rs_randn(941, (2, 3, 448, 448)))
+        logits = m(x)
+        z = m.ChannelInteraction(m.backbone(x))
+    save('model_cin_448', logits_eval=logits, z_sub=sub(z, 97), z_sum=z.double().sum())
+
+    cim = M_CIN.ChannelInteractionModule(in_channel=128, spatial_size=(14, 14))
+    with torch.no_grad():
+        for i, p_ in enumerate(cim.parameters()):
+            p_.copy_(t(rs_randn(950 + i, tuple(p_.shape))) * (0.02 if p_.dim() > 1 else 0.01))
+    cim.train()
+    xm = t(rs_relu_randn(960, (4, 128, 14, 14))).requires_grad_(True)
+    z, zc = cim(xm)
+    ((z * t(rs_randn(961, tuple(z.shape)))).sum() + (zc * t(rs_randn(962, tuple(zc.shape)))).sum()).backward()
+    out = dict(z=sub(z, 7), z_cci=sub(zc, 7), dx=sub(xm.grad, 7), dx_norm=xm.grad.double().norm())
+    for k, v in cim.named_parameters():
+        out['g_' + k.replace('.', '__')] = sub(v.grad, 7)
+        out['gn_' + k.replace('.', '__')] = v.grad.double().norm()
+    cim.eval()
+    out['z_eval'] = sub(cim(t(rs_relu_randn(960, (4, 128, 14, 14)))), 7)
+    save('cin_14x14', **out)
+
+
 # ---------------------------------------------------------------- key contracts
 def gen_keys():
     from yacs.config import CfgNode as CN

@@ -467,6 +467,34 @@ def test_cin_module_matches_reference(F):
         assert rel(m(x.detach()), g['z_eval']) < 1e-5
 
 
+def test_cin_module_at_14x14_maps_matches_reference(F):
+    """The channel-interaction module built for 14 x 14 maps (a 448^2 input) on 128 channels vs the REFERENCE module
+    (tests/golden/cin_14x14.npz, oracle/gen_golden.py::gen_cin_448): train mode with the contrastive branch - Z, Z_CCI, dX and
+    every parameter gradient - and eval mode.  This is the path of hk_cin_sci_fwd / bwd for the larger maps: the scores
+    materialised by the Gram panel kernel, row statistics, cin_ax_kernel for softmax . X, W^T dY and (dG + dG^T) X."""
+    from hawkeye_amd.model.methods.CIN import ChannelInteractionModule
+    from inputs import rs_randn, rs_relu_randn, sub
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = _golden('cin_14x14')
+    m = ChannelInteractionModule(in_channel=128, spatial_size=(14, 14))
+    with torch.no_grad():
+        for i, p_ in enumerate(m.parameters()):
+            p_.copy_(tt(rs_randn(950 + i, tuple(p_.shape))) * (0.02 if p_.dim() > 1 else 0.01))
+    m = m.to(DEV).train()
+    x = tt(rs_relu_randn(960, (4, 128, 14, 14))).to(DEV).requires_grad_(True)
+    z, zc = m(x)
+    ((z * tt(rs_randn(961, tuple(z.shape))).to(DEV)).sum() + (zc * tt(rs_randn(962, tuple(zc.shape))).to(DEV)).sum()).backward()
+    assert rel(sub(z.cpu(), 7), g['z']) < 1e-5 and rel(sub(zc.cpu(), 7), g['z_cci']) < 1e-5
+    assert rel(sub(x.grad.cpu(), 7), g['dx']) < 1e-4 and abs(float(x.grad.double().norm()) / float(g['dx_norm']) - 1) < 1e-5
+    for k, p_ in m.named_parameters():
+        key = k.replace('.', '__')
+        assert rel(sub(p_.grad.cpu(), 7), g['g_' + key]) < 1e-4, k
+        assert abs(float(p_.grad.double().norm()) / float(g['gn_' + key]) - 1) < 1e-4, k
+    m.eval()
+    with torch.no_grad():
+        assert rel(sub(m(x.detach()).cpu(), 7), g['z_eval']) < 1e-5
+
+
 def test_cin_loss_matches_reference():
     from hawkeye_amd.config import CfgNode
     from hawkeye_amd.model.loss import CINLoss
@@ -862,6 +890,28 @@ def test_models_with_hip_classifier(F, name, monkeypatch):
         ey, ew, ef = rel(y_f, y_u), rel(cw_f, cw_u), rel(f_f, f_u)
         print(f'[fused pool + classifier] one node vs two: logits {ey:.2e}, classifier gradient {ew:.2e}, feature-map gradient {ef:.2e}')
         assert ey < 1e-6 and ew < 1e-5 and ef < 1e-4, (ey, ew, ef)
+
+
+def test_cin_model_at_448_input_matches_reference(F):
+    """The registered CIN plugin in eval mode on two 448 x 448 images (14 x 14 maps, C = 2048: the stored-score forward of
+    hk_cin_sci_fwd at its real width) vs the reference model (tests/golden/model_cin_448.npz): logits, argmax, and the
+    interaction module's output Z.  (The reference's TRAIN mode is tied to 7 x 7 maps - CIN.py:22 - so there is no
+    train-mode golden at this input size; the module itself is pinned at 14 x 14 by test_cin_module_at_14x14_maps_matches_reference.)"""
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.registry import MODEL
+    import hawkeye_amd.model  # noqa: F401
+    from inputs import rs_randn, seeded_init, sub
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = _golden('model_cin_448')
+    m = MODEL.get('CIN')(CfgNode(dict(name='CIN', num_classes=200)))
+    seeded_init(m, 930)
+    m = m.to(DEV).eval()
+    x = tt(rs_randn(941, (2, 3, 448, 448))).to(DEV)
+    with torch.no_grad():
+        le = m(x)
+        z = m.ChannelInteraction(m.backbone(x))
+    assert rel(le, g['logits_eval']) < 1e-4 and le.argmax(1).cpu().tolist() == g['logits_eval'].argmax(1).tolist()
+    assert rel(sub(z.cpu(), 97), g['z_sub']) < 1e-4 and abs(float(z.double().sum()) / float(g['z_sum']) - 1) < 1e-5
 
 
 def test_cin_model_matches_reference(F):
