@@ -31,7 +31,7 @@ SIGNATURES = {
     'hk_bcnn_ssqrt_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'hk_bcnn_ssqrt_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_ssqrt_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
-    'hk_bcnn_ssqrt_pool_fwd_parts': (c_i, [c_f, c_f, c_f, ctypes.POINTER(ctypes.c_int), c_i, c_i, c_i, c_f]),
+    'hk_bcnn_ssqrt_pool_fwd_parts': (c_i, [c_f, c_f, c_f, ctypes.c_void_p, c_i, c_i, c_i, c_f]),     # (4th: int* on the HOST - pass ctypes.byref)
     'hk_linear_fwd_ssq': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_ssqrt_pool_bwd_tdot': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_bcnn_ssqrt_pool_fwd_unscaled': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
