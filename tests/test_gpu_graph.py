@@ -18,7 +18,7 @@ def test_every_head_replays_bit_identically_from_a_graph():
                        timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     rows = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('[')][-1])
-    assert len(rows) == 5
+    assert len(rows) == 7                        # BCNN, CBCNN, MPN, AP-CNN, OSME, CIN at 7x7 and at 14x14 maps
     for r in rows:
         print(r)
         assert 'error' not in r, r

@@ -81,10 +81,23 @@ def head_osme(N=10):
     return [x, w1, w2, fc, fb], fn
 
 
+def head_cin(B=20, hw=7):
+    x = R(B, 2048, hw * hw, seed=29, relu=True, scale=0.5).requires_grad_(True)
+    wt = torch.rand(B, generator=torch.Generator().manual_seed(30)).to(dev).requires_grad_(True)
+    g1, g2 = R(B, 2048, hw * hw, seed=31), R(B, 2048, hw * hw, seed=32)
+
+    def fn():                                     # CIN.py:31-34 (SCI), :51-54 (CCI): both branches and the gradient that reaches W_SCI
+        y, w = F.cin_sci(x)
+        return ((y * g1).sum() + (F.cin_cci(w, x, wt) * g2).sum()) * 1e-3
+    return [x, wt], fn
+
+
 HEADS = {'BCNN (pool + classifier, B=64)': head_bcnn, 'CBCNN (compact pool + classifier, B=16)': head_cbcnn,
          'MPN (covariance + Newton-Schulz + triuvec + classifier, B=64)': head_mpn,
          'APCNN (attention pooling x 3 + ROI select + crop / resize, B=16)': head_apcnn,
-         'OSME (squeeze, gate, scale, part FC, N=10)': head_osme}
+         'OSME (squeeze, gate, scale, part FC, N=10)': head_osme,
+         'CIN (self- and contrastive channel interaction, B=20, 7x7 maps)': head_cin,
+         'CIN (the same at 14x14 maps: stored-score forward, cin_ax_kernel products)': lambda: head_cin(20, 14)}
 
 
 def time_loop(fn, iters):
@@ -145,14 +158,14 @@ def run_head(name, build, iters=20):
 if __name__ == '__main__':
     only = [a[7:] for a in sys.argv[1:] if a.startswith('--head=')]
     if only:                                        # child: one head
-        name = [n for n in HEADS if n.startswith(only[0])][0]
+        name = list(HEADS)[int(only[0])]
         print('ROW ' + json.dumps(run_head(name, HEADS[name], iters=5 if QUICK else 20)), flush=True)
         sys.exit(0)
     # parent: every head in a process of its own (a capture that fails must not take the others with it)
     import subprocess
     rows = []
-    for name in HEADS:
-        cmd = [sys.executable, '-X', 'faulthandler', os.path.abspath(__file__), '--head=' + name.split(' ')[0]] + (['--quick'] if QUICK else [])
+    for idx, name in enumerate(HEADS):
+        cmd = [sys.executable, '-X', 'faulthandler', os.path.abspath(__file__), '--head=%d' % idx] + (['--quick'] if QUICK else [])
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
         got = [ln for ln in p.stdout.splitlines() if ln.startswith('ROW ')]
         if p.returncode == 0 and got:
