@@ -743,15 +743,18 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
     // Pipeline.  In step J the MFMAs consume P(J) - registers - and X_J - stage J % 3 - while block J + 2 of X is on its way
     // into the third stage and the A operand of step J + 1 is formed from the piece of w that has arrived, one element per
     // MFMA group.  The pieces travel in registers the compiler keeps no books on (HK_LOAD16_ASYNC), so the rule that makes
-    // it correct is structural: the loop body is THREE steps; the pieces for the next body's three steps (cur -> nxt) are all
-    // requested in the first step, the counted wait at the end of the SECOND step (everything but that step's NPW LDS-DMA
-    // requests has landed) covers them, and only behind the third step are they copied nxt -> cur: no register in flight is
-    // ever read, moved or renamed (a set carried across the loop edge while in flight gets copied by the compiler at the
-    // edge - stale values, seen as 7e-3 errors on the GPU and never in the emulator; tests/test_isa_static.py now walks the
-    // ISA for any read of a register between its request and the wait that covers it).
+    // it correct is structural: the loop body is TWO steps of straight-line code (C % 128 == 0: an even number of blocks);
+    // the pieces for the next body's two steps (cur -> nxt) are requested in the first step, the counted wait at the end of
+    // the SECOND step (everything but that step's NPW LDS-DMA requests has landed) covers them, and only behind it are
+    // they copied nxt -> cur.  No register in flight is ever read, moved or renamed, and none is in flight when the loop is
+    // left.  (Learnt on the GPU, invisible in the emulator: a set carried across the loop edge while in flight gets copied
+    // by the compiler at the edge - stale values, 7e-3 errors; a conditional step makes the compiler rename registers at
+    // the join behind it, and behind the loop it moves the accumulators into whatever registers it considers free.
+    // tests/test_isa_static.py walks the ISA for any instruction that touches a register between its request and the
+    // wait that covers it.)
     if (tid < 32) lds[3 * BLK + tid] = 0.f;              // (read by the last tile's columns >= HW of a block's last row)
-    f32x4 s0[2], scur[3][2], snxt[3][2];
-    float t0[8], tcur[3][8], tnxt[3][8];
+    f32x4 s0[2], scur[2][2], snxt[2][2];
+    float t0[8], tcur[2][8], tnxt[2][8];
     auto load_set = [&](int blk, f32x4 (&sd)[2], float (&td)[8]) {
         const int bc_ = blk < ncb ? blk : ncb - 1;       // (past the end: the last block again - loaded, never used)
         if (ROWP) load_s(bc_, sd);
@@ -763,10 +766,10 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
         }
     };
     load_set(0, s0, t0);
-#pragma unroll
-    for (int u = 0; u < 3; ++u) load_set(u + 1, scur[u], tcur[u]);
+    load_set(1, scur[0], tcur[0]);
+    load_set(2, scur[1], tcur[1]);
     dma_blk(0, lds);
-    dma_blk(ncb > 1 ? 1 : 0, lds + BLK);
+    dma_blk(1, lds + BLK);
     f32x16 yacc[NT2];
 #pragma unroll
     for (int n = 0; n < NT2; ++n)
@@ -780,11 +783,12 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 8; ++r) pr[r] = aval(s0, t0, r);
 
-    auto step = [&](auto cur_tag, int J) __attribute__((always_inline)) {
-        constexpr int CUR = decltype(cur_tag)::value;    // J % 3: the stage of X_J; the piece of block J + 1 is set CUR of `cur`
-        f32x4 (&sa)[2] = scur[CUR];
-        float (&ta)[8] = tcur[CUR];
-        const float* bj = lds + CUR * BLK + (16 * q + 4 * lh) * HW + l31;    // register r: row (r & 3) + 8 (r >> 2) of these
+    int cur = 0;                                         // J % 3: the stage of X_J
+    auto step = [&](auto k_tag, int J) __attribute__((always_inline)) {
+        constexpr int K = decltype(k_tag)::value;        // step of the body: the piece of block J + 1 is set K of `cur`
+        f32x4 (&sa)[2] = scur[K];
+        float (&ta)[8] = tcur[K];
+        const float* bj = lds + cur * BLK + (16 * q + 4 * lh) * HW + l31;    // register r: row (r & 3) + 8 (r >> 2) of these
         const int J2 = J + 2 < ncb ? J + 2 : ncb - 1;    // (past the end: the last block again, into a stage nobody reads)
         // Y_i += P X_j: A = P registers (i = lane & 31, k = lane half), B = x_j[column][n = lane & 31 (+ 32 n)].  The operands
         // of step r + 1 are requested before the MFMAs of step r issue (one wave per SIMD: nobody else covers an LDS round
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
         // stages) - unconditional reads keep the loop one basic block - and those columns of Y are never stored.
         float bc[NT2], bn[NT2];
         f32x4 xc = {0.f, 0.f, 0.f, 0.f}, xn = {0.f, 0.f, 0.f, 0.f};   // REMV: X[k][32 NT2 .. + 3], one address per lane half (broadcast)
-        const float* bj4 = lds + CUR * BLK + (16 * q + 4 * lh) * HW + 32 * NT2;
+        const float* bj4 = lds + cur * BLK + (16 * q + 4 * lh) * HW + 32 * NT2;
 #pragma unroll
         for (int n = 0; n < NT2; ++n) bc[n] = bj[32 * n];
         if (REMV) xc = *reinterpret_cast<const f32x4*>(bj4);
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
         // the step they fill the CU's address queue and the wave sits in front of it instead of issuing MFMAs (measured:
         // 367 us with the burst and neither S nor W, 273 at the matrix pipe's pace).
         const float* xsrc = xb + (long long)J2 * BLK + 4 * lane;
-        float* xdst = lds + ((CUR + 2) % 3) * BLK;
+        float* xdst = lds + (cur == 0 ? 2 : cur - 1) * BLK;          // stage (J + 2) % 3
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (r + 1 < 8) {
@@ -824,10 +828,10 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
                     glds16(xsrc + 256 * pc, xdst + 256 * pc);
                 }
             }
-            if (CUR == 0) {                              // the next body's pieces: blocks J + 4, J + 5, J + 6
+            if (K == 0) {                                // the next body's pieces: blocks J + 3, J + 4
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int blk = J + 4 + u < ncb ? J + 4 + u : ncb - 1;
+                for (int u = 0; u < 2; ++u) {
+                    const int blk = J + 3 + u < ncb ? J + 3 + u : ncb - 1;
                     if (COLP) load_t1(blk, r, tnxt[u][r]);
                     if (ROWP && r == 2 * u + 1) load_s(blk, snxt[u]);
                 }
@@ -846,22 +850,20 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
             for (int n = 0; n < NT2; ++n) bc[n] = bn[n];
             xc = xn;
         }
-        HK_VM_BARRIER(NPW + (CUR == 0 ? 3 * NL : 0));
+        HK_VM_BARRIER(NPW + (K == 0 ? 2 * NL : 0));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 8; ++r) pr[r] = pn[r];
+        cur = cur == 2 ? 0 : cur + 1;
     };
-    for (int J = 0; J < ncb; J += 3) {
+    for (int J = 0; J < ncb; J += 2) {
         step(std::integral_constant<int, 0>{}, J);
-        if (J + 1 < ncb) step(std::integral_constant<int, 1>{}, J + 1);
-        if (J + 2 < ncb) step(std::integral_constant<int, 2>{}, J + 2);
-        if (J + 3 < ncb) {                               // (another body follows: steps 1 and 2 ran, their waits covered nxt)
+        step(std::integral_constant<int, 1>{}, J + 1);
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                scur[u][0] = snxt[u][0]; scur[u][1] = snxt[u][1];
+        for (int u = 0; u < 2; ++u) {
+            scur[u][0] = snxt[u][0]; scur[u][1] = snxt[u][1];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) tcur[u][r] = tnxt[u][r];
-            }
+            for (int r = 0; r < 8; ++r) tcur[u][r] = tnxt[u][r];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -920,7 +922,8 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
     }
 }
 
-static bool cin_ax_covers(int C, int HW) { return C % 64 == 0 && (HW == 196 || HW == 144 || HW == 100); }
+// (C % 128: the kernel's loop body is two 64-row blocks)
+static bool cin_ax_covers(int C, int HW) { return C % 128 == 0 && (HW == 196 || HW == 144 || HW == 100); }
 
 template <int MODE>
 static int cin_ax_launch(const float* x, float* w, float* y, float scale, int B, int C, int HW, hipStream_t st) {

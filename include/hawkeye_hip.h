@@ -379,7 +379,7 @@ int hk_npairs_loss(const float* x, const int32_t* labels, float* loss, float* dx
  *   hk_cin_sci_bwd: dwbuf [B,C,C] scratch; holds the gradient reaching W from the CCI
  *   branch on entry when has_extra != 0 (it is overwritten).
  *   hk_cin_sci_fwd, C % 64 == 0: ONE kernel at 7x7 / 8x8 / 6x6 maps (scores recomputed on the matrix pipe, W written
- *   once); at 14x14 / 12x12 / 10x10 maps three - Gram panel kernel, row statistics, softmax applied on the way into the
+ *   once); at 14x14 / 12x12 / 10x10 maps and C % 128 == 0 three - Gram panel kernel, row statistics, softmax applied on the way into the
  *   second product (W written once, in place of the scores); any other shape: Gram, row softmax, product on the generic tile.
  *   hk_cin_sci_bwd at those larger maps: W^T dY and (dG + dG^T) X / HW each stream their C x C operand once through the
  *   forward's pipeline (the second as ONE product).

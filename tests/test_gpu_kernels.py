@@ -415,12 +415,13 @@ def test_mamc_npairs_loss_larger_batch(F):
 
 
 @pytest.mark.parametrize('b,c,hw', [(4, 24, 12), (2, 70, 5), (6, 130, 49), (4, 128, 49), (2, 192, 64), (10, 64, 36), (2, 128, 196),
-                                    (4, 192, 144), (10, 64, 100), (2, 320, 196), (2, 448, 100)])
+                                    (4, 192, 144), (10, 64, 100), (2, 320, 196), (2, 256, 144), (4, 128, 100), (2, 384, 196)])
 def test_cin_channel_interaction_ops(F, b, c, hw, monkeypatch):
     """hk_cin_sci_* / hk_cin_cci_*  vs torch autograd of the reference's formulas (CIN.py:31-34, 51-54) in
     fp64: forward values, and the gradients through both branches including the one that reaches W_SCI from the
-    contrastive branch and the per-sample weights: the one-kernel forms at 7x7 / 8x8 / 6x6 maps and C % 64 == 0, the stored-S
-    forward (Gram panel kernel, row statistics, softmax . X) at 14x14 / 12x12 / 10x10 maps, the generic chains everywhere else."""
+    contrastive branch and the per-sample weights: the one-kernel forms at 7x7 / 8x8 / 6x6 maps and C % 64 == 0, the stored-score
+    forms (Gram panel kernel, row statistics, cin_ax_kernel for softmax . X, W^T dY and (dG + dG^T) X) at 14x14 / 12x12 / 10x10
+    maps and C % 128 == 0 - one, two and three loop bodies -, the generic chains everywhere else."""
     gen = torch.Generator().manual_seed(b * 100 + c)
     x = torch.relu(torch.randn(b, c, hw, generator=gen))
     wt = torch.randn(b, generator=gen) * 0.7
