@@ -159,6 +159,35 @@ __global__ __launch_bounds__(64) void cin_cci_dw_reduce_kernel(const float* __re
 }
 
 constexpr int CIN_DW_BLOCKS = 64;
+
+// A block of 64 rows x HW floats (contiguous in memory) on its way into LDS in two halves: blk_request issues all of a
+// thread's 16-byte loads at once (index-clamped: never behind a branch), blk_commit writes them to the stage - placed
+// BEHIND the column block's MFMAs, so that the loads have the whole tile to arrive.  (Rounds 3-4 staged these blocks with
+// `for (f = tid; f < BLK / 4; f += 256) dst[f] = src[f]` at the TOP of the column block, which the compiler kept as a
+// loop of load - s_waitcnt vmcnt(0) - ds_write: three to four memory round trips in a row before the first MFMA of every
+// block, draining the W / E prefetch with them.)
+template <int BLK>
+struct BlkRegs {
+    static constexpr int N = (BLK / 4 + 255) / 256;
+    f32x4 v[N];
+};
+template <int BLK>
+__device__ __forceinline__ void blk_request(const float* src, BlkRegs<BLK>& r, int tid) {
+#pragma unroll
+    for (int u = 0; u < BlkRegs<BLK>::N; ++u) {
+        const int f = tid + 256 * u;
+        r.v[u] = reinterpret_cast<const f32x4*>(src)[f < BLK / 4 ? f : BLK / 4 - 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);                   // (left to itself the scheduler sinks the loads to just above their use)
+}
+template <int BLK>
+__device__ __forceinline__ void blk_commit(float* dst, const BlkRegs<BLK>& r, int tid) {
+#pragma unroll
+    for (int u = 0; u < BlkRegs<BLK>::N; ++u) {
+        const int f = tid + 256 * u;
+        if (f < BLK / 4) reinterpret_cast<f32x4*>(dst)[f] = r.v[u];
+    }
+}
 constexpr int CIN_SETS = 2;            // chunks of a streamed C x C operand requested ahead per workgroup (hk_bgemm.h, DEEP; 4 measured no faster: 174 / 590 / 1022 us against 168 / 580 / 1003 - the products are then paced by the matrix pipe, 64-column tiles for 49 columns)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -186,12 +215,11 @@ __global__ __launch_bounds__(256, 3) void cin_sci_flash_kernel(const float* __re
                                                                float* __restrict__ y, int C, int B) {
     constexpr int RB = 64;                               // rows per workgroup and per column block
     constexpr int BLK = RB * HW;                         // floats of one 64-row block of X (contiguous in memory)
-    constexpr int BLK4 = BLK / 4;
     constexpr int KS = (HW + 1) / 2;                     // MFMA k-steps of the Gram (two k per step)
     constexpr int NT2 = (HW + 31) / 32;                  // 32-column tiles of Y
     static_assert(BLK % 4 == 0 && NT2 <= 2, "64 x HW block as float4; maps up to 8 x 8");
     static_assert(2 * NT2 * 16 * 64 <= 3 * BLK, "the partial Y tiles of two waves fit the block stages");
-    __shared__ __attribute__((aligned(16))) float lds[3 * BLK + 8];
+    __shared__ __attribute__((aligned(16))) float lds[3 * BLK + 32];
     __shared__ float comb[2][2][32][2];                  // [column half][row half][row]: (m, l) of pass 1
     float* sI = lds;
     float* sJ = lds + BLK;                               // two stages
@@ -206,11 +234,16 @@ __global__ __launch_bounds__(256, 3) void cin_sci_flash_kernel(const float* __re
     const float inv_hw = 1.0f / (float)HW;
     constexpr float LOG2E = 1.4426950408889634f;
 
-    auto load_blk = [&](int blk, float* dst) {           // 64 rows of X: BLK4 float4, coalesced
-        const f32x4* src = reinterpret_cast<const f32x4*>(xb + (long long)blk * BLK);
-        for (int f = tid; f < BLK4; f += 256) reinterpret_cast<f32x4*>(dst)[f] = src[f];
+    BlkRegs<BLK> nx;                                     // the next column block of X on its way in
+    auto load_blk = [&](int blk, float* dst) {           // 64 rows of X, at once (prologue)
+        BlkRegs<BLK> r;
+        blk_request<BLK>(xb + (long long)blk * BLK, r, tid);
+        blk_commit<BLK>(dst, r, tid);
     };
-    if (tid < 8) lds[3 * BLK + tid] = 0.f;               // (the last k-step of an odd HW reads one float past a block)
+    // block J + 1 (the last step: block J again, into the idle stage - requests are never behind a branch)
+    auto request_next = [&](int J) { blk_request<BLK>(xb + (long long)(J + 1 < nrb ? J + 1 : J) * BLK, nx, tid); };
+    auto commit_next = [&](int J) { blk_commit<BLK>(sJ + ((J + 1) & 1) * BLK, nx, tid); };
+    if (tid < 32) lds[3 * BLK + tid] = 0.f;              // (read past the last block: the last k-step of an odd HW, columns >= HW of Y's last tile)
     load_blk(I, sI);
     load_blk(0, sJ);
     __syncthreads();
@@ -234,7 +267,7 @@ __global__ __launch_bounds__(256, 3) void cin_sci_flash_kernel(const float* __re
     float m = -3.402823466e38f, l = 0.f;
     for (int J = 0; J < nrb; ++J) {
         const float* sj = sJ + (J & 1) * BLK;
-        if (J + 1 < nrb) load_blk(J + 1, sJ + ((J + 1) & 1) * BLK);          // (the other stage: free since the last barrier)
+        request_next(J);
         f32x16 acc;
         gram(sj, acc);
         float tm = m;
@@ -246,6 +279,7 @@ __global__ __launch_bounds__(256, 3) void cin_sci_flash_kernel(const float* __re
         for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f((acc[r] - tm) * LOG2E);
         l = l * __builtin_amdgcn_exp2f((m - tm) * LOG2E) + ps;
         m = tm;
+        commit_next(J);                                                      // (the other stage: free since the last barrier)
         __syncthreads();
     }
     l += __shfl_xor(l, 32, 64);                                              // the two lane halves hold disjoint columns
@@ -268,7 +302,7 @@ __global__ __launch_bounds__(256, 3) void cin_sci_flash_kernel(const float* __re
     float* wrow = w + ((long long)b * C + I * RB + rw * 32 + l31) * C + 32 * cw;   // this lane's row of W, this wave's columns
     for (int J = 0; J < nrb; ++J) {
         const float* sj = sJ + (J & 1) * BLK;
-        if (J + 1 < nrb) load_blk(J + 1, sJ + ((J + 1) & 1) * BLK);
+        request_next(J);
         f32x16 acc;
         gram(sj, acc);
 #pragma unroll
@@ -284,10 +318,12 @@ __global__ __launch_bounds__(256, 3) void cin_sci_flash_kernel(const float* __re
 #pragma unroll
             for (int n = 0; n < NT2; ++n) {
                 const int col = 32 * n + l31;
-                const float bv = col < HW ? sj[j * HW + col] : 0.f;
+                const float bv = sj[j * HW + col];       // (columns >= HW: whatever follows in LDS - unconditional reads keep the
+                                                         //  loop one basic block; those columns of the tile are never stored)
                 yacc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], bv, yacc[n], 0, 0, 0);
             }
         }
+        commit_next(J);
         __syncthreads();
     }
     // the partial Y of the upper column half goes through LDS (the stages are free: everybody passed the last barrier)
@@ -323,17 +359,16 @@ __global__ __launch_bounds__(256, 3) void cin_sci_flash_kernel(const float* __re
 // twice (16-byte requests issued ahead of the tile's MFMAs).  dx must hold W^T dY already; dG^T X is added afterwards by
 // the streamed product.
 template <int HW, bool EXTRA>
-__global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, EXTRA ? 2 : 3) void cin_sci_bwd_flash_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                    const float* __restrict__ dy, float* dg,
                                                                    float* __restrict__ dx, int C, int B) {
     constexpr int RB = 64;
     constexpr int BLK = RB * HW;
-    constexpr int BLK4 = BLK / 4;
     constexpr int KS = (HW + 1) / 2;
     constexpr int NT2 = (HW + 31) / 32;
     static_assert(BLK % 4 == 0 && NT2 <= 2, "64 x HW block as float4; maps up to 8 x 8");
     static_assert(2 * NT2 * 16 * 64 <= 3 * BLK, "the partial dx tiles of two waves fit the block stages");
-    __shared__ __attribute__((aligned(16))) float lds[3 * BLK + 8];
+    __shared__ __attribute__((aligned(16))) float lds[3 * BLK + 32];
     __shared__ float comb[2][2][32];
     float* sI = lds;
     float* sJ = lds + BLK;
@@ -346,11 +381,13 @@ __global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* 
     const int l31 = lane & 31, lh = lane >> 5;
     const float* xb = x + (long long)b * C * HW;
     const float inv_hw = 1.0f / (float)HW;
-    auto load_blk = [&](const float* src_, float* dst) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(src_);
-        for (int f = tid; f < BLK4; f += 256) reinterpret_cast<f32x4*>(dst)[f] = src[f];
+    BlkRegs<BLK> nx;                                     // the next column block of X on its way in
+    auto load_blk = [&](const float* src_, float* dst) {  // a block at once (prologue, between the passes)
+        BlkRegs<BLK> r;
+        blk_request<BLK>(src_, r, tid);
+        blk_commit<BLK>(dst, r, tid);
     };
-    if (tid < 8) lds[3 * BLK + tid] = 0.f;
+    if (tid < 32) lds[3 * BLK + tid] = 0.f;
     load_blk(dy + ((long long)b * C + I * RB) * HW, sI);
     load_blk(xb, sJ);
     __syncthreads();
@@ -380,8 +417,9 @@ __global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* 
     // request of the X block comes first - its wait would otherwise wait for these too - and is never behind a branch)
     auto next_x = [&](int J) {
         const int Jn = J + 1 < nrb ? J + 1 : J;                              // (last block: a redundant copy into the idle stage)
-        load_blk(xb + (long long)Jn * BLK, sJ + ((J + 1) & 1) * BLK);
+        blk_request<BLK>(xb + (long long)Jn * BLK, nx, tid);
     };
+    auto commit_x = [&](int J) { blk_commit<BLK>(sJ + ((J + 1) & 1) * BLK, nx, tid); };   // behind the block's MFMAs
     auto next_we = [&](int J, f32x4 (&wn)[4], f32x4 (&en)[4]) {
         const int Jn = J + 1 < nrb ? J + 1 : J;
         ldrow(wrow, Jn, wn);
@@ -401,6 +439,7 @@ __global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* 
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) t += wv[g][k] * (EXTRA ? acc[4 * g + k] + ev[g][k] : acc[4 * g + k]);
+        commit_x(J);
         __syncthreads();
     };
     ldrow(wrow, 0, wa);
@@ -443,10 +482,12 @@ __global__ __launch_bounds__(256, 3) void cin_sci_bwd_flash_kernel(const float* 
 #pragma unroll
             for (int n = 0; n < NT2; ++n) {
                 const int col = 32 * n + l31;
-                const float bv = col < HW ? sj[j * HW + col] : 0.f;
+                const float bv = sj[j * HW + col];       // (columns >= HW: whatever follows in LDS - unconditional reads keep the
+                                                         //  loop one basic block; those columns of the tile are never stored)
                 yacc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], bv, yacc[n], 0, 0, 0);
             }
         }
+        commit_x(J);
         __syncthreads();
     };
     ldrow(wrow, 0, wa);
@@ -511,10 +552,14 @@ __global__ __launch_bounds__(256, 2) void cin_cci_dw_flash_kernel(const float* _
                                                                   int B) {
     constexpr int RB = 64;
     constexpr int BLK = RB * HW;
-    constexpr int BLK4 = BLK / 4;
     constexpr int KS = (HW + 1) / 2;
     static_assert(BLK % 4 == 0, "64 x HW block as float4");
-    __shared__ __attribute__((aligned(16))) float lds[4 * BLK + 8];          // dY[b]_I, dY[pb]_I, X[b]_J, X[pb]_J
+    // dY[b]_I, dY[pb]_I, then the pair X[b]_J, X[pb]_J - in TWO stages where six blocks leave room for two workgroups per CU
+    // (7 x 7 and 6 x 6 maps: 75 / 55 KB): the next pair is requested before this one's tiles and written to the other stage
+    // behind them, one barrier per column block; 8 x 8 maps keep one stage (request, two barriers around the copy)
+    constexpr bool DB = 6 * BLK * 4 <= 80 * 1024;
+    constexpr int NXS = DB ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float lds[(2 + 2 * NXS) * BLK + 8];
     __shared__ float red[4];
 
     const int nrb = C / RB;
@@ -526,13 +571,29 @@ __global__ __launch_bounds__(256, 2) void cin_cci_dw_flash_kernel(const float* _
     const int l31 = lane & 31, lh = lane >> 5;
     const float wb = wt[b], wp = wt[pb];
     const long long sx = (long long)C * HW;
-    auto load_blk = [&](const float* src_, float* dst) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(src_);
-        for (int f = tid; f < BLK4; f += 256) reinterpret_cast<f32x4*>(dst)[f] = src[f];
+    BlkRegs<BLK> nxb, nxp;                               // the next pair of X blocks on its way in
+    auto load_blk = [&](const float* src_, float* dst) {  // a block at once (prologue)
+        BlkRegs<BLK> r;
+        blk_request<BLK>(src_, r, tid);
+        blk_commit<BLK>(dst, r, tid);
     };
-    if (tid < 8) lds[4 * BLK + tid] = 0.f;               // (the last k-step of an odd HW reads one float past a block)
+    auto request_x = [&](int J) {                        // (clamped: requests are never behind a branch)
+        const int Jc = J < nrb ? J : nrb - 1;
+        blk_request<BLK>(x + b * sx + (long long)Jc * BLK, nxb, tid);
+        blk_request<BLK>(x + pb * sx + (long long)Jc * BLK, nxp, tid);
+    };
+    auto commit_x = [&](int stage) {
+        blk_commit<BLK>(lds + (2 + 2 * stage) * BLK, nxb, tid);
+        blk_commit<BLK>(lds + (3 + 2 * stage) * BLK, nxp, tid);
+    };
+    if (tid < 8) lds[(2 + 2 * NXS) * BLK + tid] = 0.f;   // (the last k-step of an odd HW reads one float past a block)
     load_blk(dy + b * sx + (long long)I * BLK, lds);
     load_blk(dy + pb * sx + (long long)I * BLK, lds + BLK);
+    if (DB) {
+        request_x(0);
+        commit_x(0);
+        __syncthreads();
+    }
 
     auto gram = [&](const float* si, const float* sj, f32x16& acc) {          // transposed tile: lane = row i, registers = columns
 #pragma unroll
@@ -559,13 +620,18 @@ __global__ __launch_bounds__(256, 2) void cin_cci_dw_flash_kernel(const float* _
             wv[g] = *reinterpret_cast<const f32x4*>(wrow + J * RB + 8 * g);
             ov[g] = *reinterpret_cast<const f32x4*>(orow + J * RB + 8 * g);
         }
-        __syncthreads();                                                     // the previous block's tiles are done with
-        load_blk(x + b * sx + (long long)J * BLK, lds + 2 * BLK);
-        load_blk(x + pb * sx + (long long)J * BLK, lds + 3 * BLK);
-        __syncthreads();
+        const int stg = DB ? (J & 1) : 0;
+        if (DB) {
+            request_x(J + 1);
+        } else {
+            request_x(J);
+            __syncthreads();                                                 // the previous block's tiles are done with
+            commit_x(0);
+            __syncthreads();
+        }
         f32x16 ab, ap;
-        gram(lds, lds + 2 * BLK, ab);
-        gram(lds + BLK, lds + 3 * BLK, ap);
+        gram(lds, lds + (2 + 2 * stg) * BLK, ab);
+        gram(lds + BLK, lds + (3 + 2 * stg) * BLK, ap);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 v;
@@ -580,6 +646,10 @@ __global__ __launch_bounds__(256, 2) void cin_cci_dw_flash_kernel(const float* _
                 part += gb * o;
             }
             *reinterpret_cast<f32x4*>(drow + J * RB + 8 * g) = v;
+        }
+        if (DB) {
+            commit_x((J + 1) & 1);                                           // (the other stage: free since the last barrier)
+            __syncthreads();
         }
     }
     part = block_sum<4>(part, red);
