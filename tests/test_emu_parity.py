@@ -31,7 +31,9 @@ for _mod in _modules:
 
 # parameter sets that take 20 s .. 80 s each when emulated: run them with HK_EMU_FULL=1
 _HEAVY = {'test_cbp_rowsketch_equals_csr[512-6000-40]', 'test_models_with_hip_classifier[BCNN]',
-          'test_models_with_hip_classifier[MPN]', 'test_cin_model_matches_reference',
+          'test_models_with_hip_classifier[MPN]', 'test_cin_model_matches_reference', 'test_cin_model_at_448_input_matches_reference',
+          'test_bcnn_backward_in_one_launch[2-128-14-7-True]', 'test_signed_sqrt_norm_formed_in_the_classifier_reduce[5-512-14-7]',
+          'test_linear_bwd_single_products[33-16384-200]',
           'test_ns_grouped_products[2-256-2]', 'test_ns_grouped_products[3-200-3]',
           'test_cov_and_cbp_panel_kernels_vs_generic[70-256-8]', 'test_mpn_256_vs_golden',
           'test_linear_bwd_direct_at_classifier_shapes[3-262144-200]', 'test_bcnn_signed_sqrt_512_vs_golden',
