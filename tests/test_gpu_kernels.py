@@ -83,7 +83,7 @@ def test_backward_bwd3_kernel(F, b, c, hw, tune):
         assert rel(res[name][0], xo.grad) < 2e-5 and rel(res[name][1], xc.grad) < 1e-5, name
 
 
-@pytest.mark.parametrize('b,c,hw,k,bias', [(2, 128, 14, 7, True), (3, 256, 10, 20, True), (2, 64, 14, 70, False), (3, 192, 12, 5, True),
+@pytest.mark.parametrize('b,c,hw,k,bias', [(2, 128, 14, 7, True), (3, 256, 10, 20, True), (2, 64, 14, 70, False), (3, 192, 12, 5, True), (2, 64, 14, 5, True),
                                            (2, 256, 8, 13, True), (2, 512, 14, 200, True)])
 def test_bcnn_backward_in_one_launch(F, b, c, hw, k, bias, tune):
     """The BCNN backward with the rank-1 term folded into gram_bwd3_kernel (hk_bwd3.h, TK 1): hk_bcnn_pool_bwd_tdot
