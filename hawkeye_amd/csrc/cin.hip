@@ -184,8 +184,11 @@ template <int BLK>
 __device__ __forceinline__ void blk_commit(float* dst, const BlkRegs<BLK>& r, int tid) {
 #pragma unroll
     for (int u = 0; u < BlkRegs<BLK>::N; ++u) {
+        // (threads past the end write the block's last piece once more - the piece blk_request gave them: the same bytes to the
+        //  same place.  A store under `if (f < BLK / 4)` invites the compiler to sink the load into that branch - load, wait,
+        //  store, one memory round trip behind the block's MFMAs, with every other wave waiting at the barrier)
         const int f = tid + 256 * u;
-        if (f < BLK / 4) reinterpret_cast<f32x4*>(dst)[f] = r.v[u];
+        reinterpret_cast<f32x4*>(dst)[f < BLK / 4 ? f : BLK / 4 - 1] = r.v[u];
     }
 }
 constexpr int CIN_SETS = 2;            // chunks of a streamed C x C operand requested ahead per workgroup (hk_bgemm.h, DEEP; 4 measured no faster: 174 / 590 / 1022 us against 168 / 580 / 1003 - the products are then paced by the matrix pipe, 64-column tiles for 49 columns)

@@ -23,6 +23,19 @@ def _loops(lines):
             yield lines[labels[m.group(1)]:i]
 
 
+def _serialised_staging_loops(txt):
+    """Kernels whose ISA holds a small loop of  global_load - s_waitcnt vmcnt(0) - ds_write : a global -> LDS copy written as
+    `for (f = tid; f < n; f += 256) dst[f] = src[f]` that the compiler kept as a loop, one memory round trip per iteration.
+    (Rounds 3-4 shipped three CIN kernels with that at the top of every column block; found by reading the ISA in round 5.)"""
+    bad = []
+    for m in re.finditer(r'^(_ZN2hk\w+):[^\n]*\n(.*?)s_endpgm', txt, re.S | re.M):
+        for seg in _loops(m.group(2).split('\n')):
+            nested = re.search(r'Depth=([2-9])', ' '.join(seg[:3])) is not None   # inside another loop (a once-per-workgroup prologue copy is fine)
+            if nested and len(seg) <= 24 and any('global_load' in l for l in seg) and any('vmcnt(0)' in l for l in seg) and any('ds_write' in l for l in seg):
+                bad.append(m.group(1))
+    return bad
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='no hipcc')
 def test_streamed_cin_product_counts_its_requests(tmp_path):
     src = os.path.join(ROOT, 'hawkeye_amd', 'csrc', 'cin.hip')
@@ -30,6 +43,7 @@ def test_streamed_cin_product_counts_its_requests(tmp_path):
     subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-o', out, src],
                    check=True, capture_output=True, timeout=600)
     txt = open(out).read()
+    assert not _serialised_staging_loops(txt), _serialised_staging_loops(txt)
     # bgemm_kernel<true, false, LdPlainV, LdPlainN, EpAffine, 2, false>: W X with W streamed (hk_cin_sci_bwd, hk_cin_sci_fwd's chain)
     m = re.search(r'^(_ZN2hk12bgemm_kernelILb1ELb0ENS_8LdPlainVENS_8LdPlainNENS_8EpAffineELi2ELb0E\w*):\s.*?\n(.*?)s_endpgm', txt,
                   re.S | re.M)
@@ -118,6 +132,7 @@ def test_gram_forward_leaves_in_16_byte_stores_and_never_spills(tmp_path):
     subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-o', out, src],
                    check=True, capture_output=True, timeout=900)
     txt = open(out).read()
+    assert not _serialised_staging_loops(txt), _serialised_staging_loops(txt)
     seen = 0
     for m in re.finditer(r'^(_ZN2hk22bcnn_gram_panel_kernelILi(\d+)ELi(\d)ELb(\d)\w*):.*?\n(.*?)\.end_amdhsa_kernel', txt, re.S | re.M):
         body = m.group(5)
@@ -151,6 +166,7 @@ def test_classifier_kernels_keep_their_counted_waits(tmp_path):
     subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-o', out, src],
                    check=True, capture_output=True, timeout=900)
     txt = open(out).read()
+    assert not _serialised_staging_loops(txt), _serialised_staging_loops(txt)
     seen = 0
     for m in re.finditer(r'^_ZN2hk19linear_bwd64_kernelILi(\d+)ELi(\d)ELi0E\w*:.*?\n(.*?)\.end_amdhsa_kernel', txt, re.S | re.M):
         nks, mode, body = int(m.group(1)), int(m.group(2)), m.group(3)
