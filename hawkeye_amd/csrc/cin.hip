@@ -696,7 +696,8 @@ static int cin_sci_flash(const float* x, float* w, float* y, int B, int C, int H
 // symmetric matrix once and writes it and its mirror image - and then
 //   cin_row_stats_kernel    one wave per row: m_i = max_j S_ij, l_i = sum_j exp(S_ij - m_i), the row held in registers between
 //                           the two sweeps, fixed order; parked in the first two floats of the row's own Y storage;
-//   cin_ax_kernel<HW, 0>    a workgroup owns 32 rows of one sample and walks the 64-row blocks X_j (LDS-DMA, three stages);
+//   cin_ax_kernel<HW, 0>    a workgroup owns 32 rows of one sample and walks the 64-row blocks X_j (LDS-DMA, three stages, each
+//                           wave staging the quarter it reads: no workgroup barrier inside the loop);
 //                           wave q takes columns 16 q .. + 15 of every block: it loads its 32 x 16 piece of S in the A-operand
 //                           layout of the 32x32x2 MFMA (lane = row, 16-byte loads), turns it into P = exp(S - m) / l in
 //                           registers, writes P over S - W is written ONCE and never read back - and issues Y += P X_j from
@@ -760,8 +761,14 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
     constexpr int RB = 32;                               // rows per workgroup
     constexpr int CB = 64;                               // rows of X per column block
     constexpr int BLK = CB * HW;                         // floats of one block of X (contiguous in memory)
-    constexpr int NPC = BLK / 256;                       // 1 KB LDS-DMA pieces of a block
-    constexpr int NPW = (NPC + 3) / 4;                   // pieces per wave and block (the same count in every wave: counted waits)
+    // A wave reads only ITS quarter of a staged block (rows 16 q .. 16 q + 15: the k of its 16 columns of w), so it also
+    // requests exactly those rows - 16 HW floats = NP16 pieces of 1 KB and, for 14 x 14 and 10 x 10 maps, one of 256 bytes -
+    // and the four waves never meet inside the loop: a counted wait ends a step, not a workgroup barrier.
+    constexpr int QF = 16 * HW;                          // floats of a wave's quarter of a block
+    constexpr int NP16 = QF / 256;                       // its 1 KB pieces
+    constexpr int NP4 = (QF % 256) / 64;                 // ... and 256-byte pieces (4 bytes per lane)
+    constexpr int NPW = NP16 + NP4;                      // requests per wave and block
+    static_assert(QF % 64 == 0, "a quarter block is a whole number of 256-byte pieces");
     constexpr int PPG = (NPW + 6) / 7;                   // ... issued per MFMA group (seven of the eight groups of a step)
     constexpr bool REMV = HW % 32 == 4;                  // 14 x 14 and 10 x 10 maps: the last FOUR columns of Y on the vector ALU (an
                                                          // eighth 32-column tile of MFMAs for 4 of 196 columns is 12.5 % of the matrix work)
@@ -785,15 +792,15 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
     const float* xb = x + (long long)b * C * HW;
     constexpr float LOG2E = 1.4426950408889634f;
 
-    // wave q: pieces q, q + 4, .. of the 64-row block - NPW requests whatever q is (the last piece of a block whose piece
-    // count is not a multiple of four is requested by several waves: the same bytes to the same place)
+    // request u of this wave's quarter of a block (src / dst: the block in memory / its stage)
+    auto dma_piece = [&](const float* src, float* dst, int u) {
+        if (u < NP16) glds16(src + QF * q + 256 * u + 4 * lane, dst + QF * q + 256 * u);
+        else glds4(src + QF * q + 256 * NP16 + 64 * (u - NP16) + lane, dst + QF * q + 256 * NP16 + 64 * (u - NP16));
+    };
     auto dma_blk = [&](int blk, float* dst) {
-        const float* src = xb + (long long)blk * BLK + 4 * lane;
+        const float* src = xb + (long long)blk * BLK;
 #pragma unroll
-        for (int u = 0; u < NPW; ++u) {
-            const int pc = (q + 4 * u < NPC) ? q + 4 * u : NPC - 1;
-            glds16(src + 256 * pc, dst + 256 * pc);
-        }
+        for (int u = 0; u < NPW; ++u) dma_piece(src, dst, u);
     };
     const long long row = (long long)b * C + I * RB + l31;
     float* wrow = w + row * C + 16 * q + 4 * lh;         // this lane's row of S / W: columns 16 q + 8 g + 4 lh .. + 3 of a block
@@ -878,7 +885,7 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
         // step, the pieces of w for the next body - are dealt over the eight MFMA groups: issued in one burst at the top of
         // the step they fill the CU's address queue and the wave sits in front of it instead of issuing MFMAs (measured:
         // 367 us with the burst and neither S nor W, 273 at the matrix pipe's pace).
-        const float* xsrc = xb + (long long)J2 * BLK + 4 * lane;
+        const float* xsrc = xb + (long long)J2 * BLK;
         float* xdst = lds + (cur == 0 ? 2 : cur - 1) * BLK;          // stage (J + 2) % 3
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -896,10 +903,7 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
             }
             if (r < 7) {
 #pragma unroll
-                for (int u = r * PPG; u < (r + 1) * PPG && u < NPW; ++u) {
-                    const int pc = (q + 4 * u < NPC) ? q + 4 * u : NPC - 1;
-                    glds16(xsrc + 256 * pc, xdst + 256 * pc);
-                }
+                for (int u = r * PPG; u < (r + 1) * PPG && u < NPW; ++u) dma_piece(xsrc, xdst, u);
             }
             if (K == 0) {                                // the next body's pieces: blocks J + 3, J + 4
 #pragma unroll
@@ -923,7 +927,10 @@ __global__ __launch_bounds__(256, 1) void cin_ax_kernel(const float* __restrict_
             for (int n = 0; n < NT2; ++n) bc[n] = bn[n];
             xc = xn;
         }
-        HK_VM_BARRIER(NPW + (K == 0 ? 2 * NL : 0));
+        // (no workgroup barrier: the stage a wave refills next is the part of it that only this wave has read)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(HK_VMCNT_IMM(NPW + (K == 0 ? 2 * NL : 0)));
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 8; ++r) pr[r] = pn[r];

@@ -237,6 +237,13 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, AUX);
 }
 
+// ... and its 4-byte form (global_load_lds_dword): lane l copies 4 bytes to the wave-uniform LDS address l + 4 l - 256 bytes
+// per instruction, for the tail of a run that is not a whole number of 1 KB pieces
+__device__ __forceinline__ void glds4(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -87,7 +87,7 @@ def test_streamed_cin_product_counts_its_requests(tmp_path):
                     segs.append((int(w.group(1)), body[prev:i])); prev = i + 1
             for cnt, seg in segs:
                 first = cnt != npw                                                  # the body's first step: it also requests the next body's pieces
-                ops = ''.join('S' if 'global_store_dwordx4' in l else 'D' if 'global_load_lds_dwordx4' in l else 'L'
+                ops = ''.join('S' if 'global_store_dwordx4' in l else 'D' if 'global_load_lds_dword' in l else 'L'
                               for l in seg if re.search(r'global_(store|load)', l))
                 assert ops.count('D') == npw and ops.count('L') == (2 * nl if first else 0), (hw, mode, cnt, ops)
                 assert ops.count('S') == (2 if mode == 0 else 0) and ops.startswith('SS' if mode == 0 else ''), (hw, mode, cnt, ops)
