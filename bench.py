@@ -519,6 +519,11 @@ def main():
                                'frac': dom['frac'], 'traffic': tr_bytes, 'kernel': dom['kernel'][:96], 'us': dom['us'],
                                'flops_algorithmic': dom['flops_algorithmic'], 'flops_executed': dom['flops_executed'],
                                'bytes_algorithmic': dom['bytes_algorithmic'], 'traffic_source': tr_src}
+            # the path's own entry points beside the 8(f) classifier kernel above: kernel, us, frac
+            res['roofline']['also'] = [{'kernel': k['kernel'].split(',')[0].split(':')[0][:48], 'us': k['us'], 'frac': k['frac'],
+                                        'bound': k['bound']}
+                                       for k in ks if k['kernel'].startswith(('hk_bcnn_pool_fwd', 'hk_bcnn_pool_bwd_tdot',
+                                                                              'hk_linear_fwd'))]
             detail['kernels'] = ks
             if kernels_before is not None:
                 detail['kernels_before'] = kernels_before
@@ -536,6 +541,12 @@ def main():
                 ranks_seen=rank_devices['ranks_seen'], distinct_devices=rank_devices['distinct_devices'],
                 devices=rank_devices['devices'][:8], backend=torch.distributed.get_backend(),
                 comm_size=torch.distributed.get_world_size(), host_threads_per_rank=torch.get_num_threads())
+        if use_pg:                       # what RCCL built for this communicator (ddp._arm_rccl_log): channels, transports, algorithm
+            rs = ddp.rccl_summary(max_lines=2)
+            if rs is not None:
+                detail['rccl'] = ddp.rccl_summary(max_lines=40)
+                res.setdefault('ddp', {})['rccl'] = {k: rs[k] for k in ('version', 'channels', 'rings', 'trees', 'transports')} | \
+                    {'tuning': [t[:80] for t in rs['tuning']]}
         if world == 1 and not a.no_other_models and a.model == 'BCNN' and not a.force_pg:
             torch.cuda.empty_cache()
             detail['other_models'] = other_models()

@@ -44,8 +44,62 @@ def init_from_env(backend=None, force=False):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
             torch.cuda.set_device(local)
+            _arm_rccl_log(rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+_RCCL_LOG = None
+
+
+def _arm_rccl_log(rank):
+    """Before the communicator exists: have RCCL write its INIT / GRAPH / TUNING lines to a per-process file (the caller's
+    own NCCL_DEBUG* settings win), so that the first run on more than one GPU records by itself what RCCL built over the
+    xGMI mesh - channel count, rings / trees, transport per peer, the algorithm / protocol picked per message size - without
+    a code change (SURVEY section 5's ring-vs-direct arithmetic; replaces nothing in the reference, which has no log of
+    DataParallel's copies either).  HAWKEYE_RCCL_LOG=0 turns it off."""
+    global _RCCL_LOG
+    if os.environ.get('HAWKEYE_RCCL_LOG', '1') == '0' or 'NCCL_DEBUG' in os.environ or 'NCCL_DEBUG_FILE' in os.environ:
+        return
+    import tempfile
+    _RCCL_LOG = os.path.join(tempfile.gettempdir(), f'hk_rccl_{os.getpid()}_r{rank}.log')
+    os.environ['NCCL_DEBUG'] = 'INFO'
+    os.environ['NCCL_DEBUG_SUBSYS'] = 'INIT,GRAPH,TUNING,ENV'
+    os.environ['NCCL_DEBUG_FILE'] = _RCCL_LOG
+
+
+def rccl_summary(max_lines=6):
+    """What the armed log says about this rank's communicator, boiled down for a bench line: library version, channels,
+    how many peers are reached over which transport (P2P/IPC = xGMI or PCIe peer access, SHM, NET), the ring / tree lines'
+    count and the first `max_lines` tuning decisions.  None when the log was not armed or is empty."""
+    if _RCCL_LOG is None or not os.path.isfile(_RCCL_LOG):
+        return None
+    import re
+    out = {'version': None, 'channels': None, 'rings': 0, 'trees': 0, 'transports': {}, 'tuning': [], 'env': []}
+    with open(_RCCL_LOG, errors='replace') as f:
+        for line in f:
+            body = line.split('NCCL INFO', 1)[-1].strip()
+            m = re.search(r'(RCCL|NCCL) version ([^\s]+)', line)
+            if m and out['version'] is None:
+                out['version'] = f'{m.group(1)} {m.group(2)}'
+            m = re.search(r'Channel (\d+)/(\d+)\s*:', body)
+            if m:
+                out['channels'] = int(m.group(2))
+            m = re.search(r'(\d+) coll channels', body)
+            if m:
+                out['channels'] = int(m.group(1))
+            if re.match(r'Ring \d+', body):
+                out['rings'] += 1
+            if re.match(r'Trees? ', body):
+                out['trees'] += 1
+            m = re.search(r'\[(send|receive)\] via ([A-Za-z0-9/_]+)', body)
+            if m:
+                out['transports'][m.group(2)] = out['transports'].get(m.group(2), 0) + 1
+            if ('Algo' in body or 'algorithm' in body.lower()) and 'AllReduce' in body and len(out['tuning']) < max_lines:
+                out['tuning'].append(body[:120])
+            if body.startswith(('NCCL_', 'RCCL_')) and 'set by environment' in body and len(out['env']) < max_lines:
+                out['env'].append(body[:80])
+    return out if (out['version'] or out['channels'] or out['transports']) else None
 
 
 def _is_dense_permutation(t):
@@ -135,26 +189,37 @@ class GradientAllReducer:
 
     # ------------------------------------------------------------------ per step
     def zero_grad(self):
-        """Use instead of optimizer.zero_grad(): keeps `.grad` as views of the flat buffers."""
+        """Use instead of optimizer.zero_grad().  Nothing is cleared: `.grad` is dropped, so that the step's first
+        accumulation WRITES (autograd hands the fresh gradient over instead of adding it to zeros) and the post-accumulate
+        hook moves it into the flat buffer - one read + one write per gradient byte where a memset of the buffers followed by
+        autograd's read-modify-write cost a write + two reads + a write (BCNN: 268.6 MB of gradients per step).  A second
+        backward before the step accumulates in place into the views, as before."""
         for b in self.buckets:
-            b.flat.zero_()
             b.pending = len(b.params)
             b.work = None
             b.issued = None
-            for p, v in zip(b.params, b.views):
-                p.grad = v
+            for p in b.params:
+                p.grad = None
         if self.trace:
             self._t_start = torch.cuda.Event(enable_timing=True)
             self._t_start.record()
 
     def _hook(self, p):
         b, i = self._index[p]
-        if p.grad.data_ptr() != b.views[i].data_ptr():  # somebody reset .grad (zero_grad(set_to_none=True))
+        if p.grad.data_ptr() != b.views[i].data_ptr():  # the step's first gradient (or somebody reset .grad)
             b.views[i].copy_(p.grad)
             p.grad = b.views[i]
         b.pending -= 1
         if b.pending == 0 and self.collective:
             self._issue(b)
+
+    def _fill_missing(self, b):
+        """A parameter that produced no gradient this step: its slice of the flat buffer still holds the previous step's
+        values - clear it and hand it out as the gradient (what the memset gave), so that every rank reduces the same thing."""
+        for p, v in zip(b.params, b.views):
+            if p.grad is None:
+                v.zero_()
+                p.grad = v
 
     def _issue(self, b):
         if self.trace:
@@ -169,7 +234,8 @@ class GradientAllReducer:
             self._t_bwd_end.record()
         for b in self.buckets:
             if self.collective:
-                if b.pending != 0:                      # a parameter got no gradient this step: reduce what we have
+                if b.pending != 0:                      # a parameter got no gradient this step: reduce zeros for it
+                    self._fill_missing(b)
                     self._issue(b)
                 if b.work is not None:
                     b.work.wait()

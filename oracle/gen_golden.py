@@ -356,8 +356,30 @@ def gen_cin_model():
         crit.h.weight.copy_(t(rs_randn(932, tuple(crit.h.weight.shape))) * 1e-3)
         crit.h.bias.zero_()
         loss = crit((logits_train, z_cci), torch.tensor([5, 9, 5, 9]))
+    # a REAL backward through the plugin at its own width (C = 2048, 7 x 7): the trunk in eval mode (running statistics: no
+    # batch-of-4 BatchNorm amplification in front of the head), the interaction module in train mode, the criterion on
+    # (logits, Z_CCI) -> gradients of the classifier, the interaction module's conv / fc, and at the head's input.
+    m.eval()
+    m.ChannelInteraction.train()
+    feats = []
+    def keep(mod, inp, out):
+        out.retain_grad()
+        feats.append(out)
+    hook = m.backbone.register_forward_hook(keep)
+    m.zero_grad()
+    lg, zc = m(x)
+    hook.remove()
+    crit.train()
+    crit((lg, zc), torch.tensor([5, 9, 5, 9])).backward()
+    grads = dict(hy_logits=lg.detach(), hy_z_cci_sub=sub(zc, 97), hy_dfeat_sub=sub(feats[0].grad, 13),
+                 hy_dfeat_norm=feats[0].grad.double().norm())
+    for k, v in list(m.ChannelInteraction.named_parameters()) + list(m.classifier.named_parameters()):
+        key = k.replace('.', '__')
+        grads['hy_g_' + key] = sub(v.grad, 1009 if v.numel() > 500000 else 7)
+        grads['hy_gn_' + key] = v.grad.double().norm()
+    grads['hy_g_h'] = sub(crit.h.weight.grad, 97)
     save('model_cin', logits_eval=logits_eval, logits_train=logits_train, z_cci_sub=sub(z_cci, 97), z_cci_sum=z_cci.double().sum(),
-         loss=loss)
+         loss=loss, **grads)
 
 
 def gen_cin_448():
@@ -395,6 +417,30 @@ def gen_cin_448():
     cim.eval()
     out['z_eval'] = sub(cim(t(rs_relu_randn(960, (4, 128, 14, 14)))), 7)
     save('cin_14x14', **out)
+
+
+def gen_cin_2048():
+    """The reference ChannelInteractionModule exactly as the plugin builds it (CIN.py:99: 2048 channels, 7 x 7 maps =
+    configs/CIN.yaml:15), B = 4, train mode with the contrastive branch: Z, Z_CCI, dX and every parameter gradient
+    (subsampled + norms) -> cin_2048.npz.  The backward kernels this shape dispatches walk 32 column blocks."""
+    M_CIN = sys.modules['model.methods.CIN']
+    cim = M_CIN.ChannelInteractionModule(in_channel=2048, spatial_size=(7, 7))
+    with torch.no_grad():
+        for i, (k, p_) in enumerate(cim.named_parameters()):
+            scale = {'conv.weight': 0.005, 'fc.weight': 0.002}.get(k, 0.01)
+            p_.copy_(t(rs_randn(970 + i, tuple(p_.shape))) * scale)
+    cim.train()
+    xm = t(rs_relu_randn(980, (4, 2048, 7, 7))).requires_grad_(True)
+    z, zc = cim(xm)
+    ((z * t(rs_randn(981, tuple(z.shape)))).sum() + (zc * t(rs_randn(982, tuple(zc.shape)))).sum()).backward()
+    out = dict(z=sub(z, 7), z_cci=sub(zc, 7), dx=sub(xm.grad, 7), dx_norm=xm.grad.double().norm(),
+               z_norm=z.double().norm(), z_cci_norm=zc.double().norm())
+    for k, v in cim.named_parameters():
+        out['g_' + k.replace('.', '__')] = sub(v.grad, 1009 if v.numel() > 500000 else 7)
+        out['gn_' + k.replace('.', '__')] = v.grad.double().norm()
+    cim.eval()
+    out['z_eval'] = sub(cim(t(rs_relu_randn(980, (4, 2048, 7, 7)))), 7)
+    save('cin_2048', **out)
 
 
 # ---------------------------------------------------------------- key contracts

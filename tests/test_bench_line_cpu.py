@@ -33,7 +33,14 @@ def canned():
         'roofline': {'bound': dom['bound'], 'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
                      'frac': dom['frac'], 'traffic': 303269365, 'kernel': dom['kernel'][:96], 'us': dom['us'],
                      'flops_algorithmic': dom['flops_algorithmic'], 'flops_executed': dom['flops_executed'],
-                     'bytes_algorithmic': dom['bytes_algorithmic'], 'traffic_source': 'profiles/r5_pool_kernels_pmc.csv'},
+                     'bytes_algorithmic': dom['bytes_algorithmic'], 'traffic_source': 'profiles/r5_pool_kernels_pmc.csv',
+                     # the SURVEY 8(a) entry points beside the dominant kernel: kernel, us, frac (round 6)
+                     'also': [{'kernel': k['kernel'][:48], 'us': k['us'], 'frac': k['frac'], 'bound': k['bound']} for k in ks[:3]]},
+        'ddp': {'buckets_mib': [200.0] + [16.0] * 5, 'issued_ms': [0.3, 20.0, 40.0, 60.0, 80.0, 139.0], 'backward_end_ms': 140.0,
+                'joined_ms': 141.0, 'ranks_seen': list(range(8)), 'distinct_devices': 8, 'devices': ['0:5:0'] * 8, 'backend': 'nccl',
+                'comm_size': 8, 'host_threads_per_rank': 32,
+                'rccl': {'version': 'RCCL 2.22.3', 'channels': 32, 'rings': 32, 'trees': 32, 'transports': {'P2P/IPC': 448},
+                         'tuning': ['AllReduce: 209715200 Bytes -> Algo 1 proto 2 time 1234.5'[:80]] * 2}},
         'cpu_baseline': {'value': 2.35, 'unit': 'images/sec', 'cores': 32, 'kind': 'port',
                          'sample': 'BCNN stage-2 train step, batch 4, 448x448, best of 3 after 1 warm-up, torch CPU fp32, 32 '
                                    'threads of 256 host cores'},
@@ -54,6 +61,8 @@ def test_final_line_is_small_and_has_the_contract_keys():
     assert set(d) <= set(bench.LINE_KEYS)                      # nothing else rides on it
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in d['roofline'], k
+    assert all(set(r) == {'kernel', 'us', 'frac', 'bound'} and r['frac'] <= 1.0 for r in d['roofline']['also'])
+    assert d['ddp']['rccl']['channels'] == 32
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in d['cpu_baseline'], k
     assert 'workload' in d['config'] and 'model' not in d['config']

@@ -140,3 +140,40 @@ def test_tiny_parameter_joins_the_next_bucket():
     red2 = ddp.GradientAllReducer(net2, bucket_mb=0.03, broadcast=False)
     first = red2.describe()[0]
     assert first[0] == 2
+
+
+def test_zero_grad_clears_nothing_and_first_gradient_is_written():
+    """zero_grad() drops `.grad` instead of clearing the flat buffers: the step's first gradient is WRITTEN into its view
+    (no memset + read-modify-write), a second backward before the step accumulates in place, and a parameter that gets no
+    gradient in a step never hands the previous step's values to the optimiser."""
+    from hawkeye_amd import ddp
+    torch.manual_seed(1)
+    net = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 3))
+    extra = nn.Linear(4, 2)                                   # a branch that only some steps use
+    holder = nn.ModuleList([net, extra])
+    red = ddp.GradientAllReducer(holder, bucket_mb=0.0001, broadcast=False)
+    x, u = torch.randn(7, 6), torch.randn(7, 4)
+    red.zero_grad()
+    assert all(p.grad is None for p in holder.parameters())
+    (net(x).sum() + extra(u).sum()).backward()
+    red.finish()
+    views = {p: v for b in red.buckets for p, v in zip(b.params, b.views)}
+    for p in holder.parameters():
+        assert p.grad.data_ptr() == views[p].data_ptr()       # landed in the flat buffer
+    first = {p: p.grad.clone() for p in holder.parameters()}
+    # second step: `extra` unused -> the flat buffers still hold its old gradient, the optimiser must not see it
+    red.zero_grad()
+    net(x).sum().backward()
+    red.finish()
+    for p in extra.parameters():
+        assert p.grad is None                                 # (no process group: nothing reduced, the optimiser skips it)
+    for p in net.parameters():
+        torch.testing.assert_close(p.grad, first[p])
+    # two backwards before one step accumulate in place
+    red.zero_grad()
+    net(x).sum().backward()
+    net(x).sum().backward()
+    red.finish()
+    for p in net.parameters():
+        torch.testing.assert_close(p.grad, 2 * first[p])
+        assert p.grad.data_ptr() == views[p].data_ptr()

@@ -48,7 +48,10 @@ _HEAVY = {'test_cbp_rowsketch_equals_csr[512-6000-40]', 'test_models_with_hip_cl
           'test_linear_bwd_single_products[5-16448-208]', 'test_ns_two_queue_dispatch_bit_identical[16-64]',
           'test_linear_bwd_direct_at_classifier_shapes[16-20032-1000]', 'test_ns_symmetric_forward[2-200-3]',
           'test_signed_sqrt_pool_with_the_scale_folded_into_the_classifier[3-128-14-200]',
-          'test_linear_bwd_direct_at_classifier_shapes[2-32896-200]', 'test_linear_bwd_direct_at_classifier_shapes[4-32768-200]'}
+          'test_linear_bwd_direct_at_classifier_shapes[2-32896-200]', 'test_linear_bwd_direct_at_classifier_shapes[4-32768-200]',
+          'test_cin_channel_interaction_ops[2-2048-49]', 'test_cin_channel_interaction_ops[2-512-49]',
+          'test_cin_channel_interaction_ops[4-1024-64]', 'test_cin_channel_interaction_ops[2-2048-196]',
+          'test_cin_channel_interaction_ops[2-1024-144]', 'test_cin_module_at_plugin_width_matches_reference'}
 
 
 @pytest.fixture(autouse=True)

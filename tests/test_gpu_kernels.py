@@ -415,7 +415,10 @@ def test_mamc_npairs_loss_larger_batch(F):
 
 
 @pytest.mark.parametrize('b,c,hw', [(4, 24, 12), (2, 70, 5), (6, 130, 49), (4, 128, 49), (2, 192, 64), (10, 64, 36), (2, 128, 196),
-                                    (4, 192, 144), (10, 64, 100), (2, 320, 196), (2, 256, 144), (4, 128, 100), (2, 384, 196)])
+                                    (4, 192, 144), (10, 64, 100), (2, 320, 196), (2, 256, 144), (4, 128, 100), (2, 384, 196),
+                                    # the plugin's own width (CIN.py:99, configs/CIN.yaml:15): 32 column blocks, the two-stage
+                                    # rings of the backward kernels wrap many times
+                                    (2, 2048, 49), (2, 512, 49), (4, 1024, 64), (2, 2048, 196), (2, 1024, 144)])
 def test_cin_channel_interaction_ops(F, b, c, hw, monkeypatch):
     """hk_cin_sci_* / hk_cin_cci_*  vs torch autograd of the reference's formulas (CIN.py:31-34, 51-54) in
     fp64: forward values, and the gradients through both branches including the one that reaches W_SCI from the
@@ -490,6 +493,40 @@ def test_cin_module_at_14x14_maps_matches_reference(F):
     for k, p_ in m.named_parameters():
         key = k.replace('.', '__')
         assert rel(sub(p_.grad.cpu(), 7), g['g_' + key]) < 1e-4, k
+        assert abs(float(p_.grad.double().norm()) / float(g['gn_' + key]) - 1) < 1e-4, k
+    m.eval()
+    with torch.no_grad():
+        assert rel(sub(m(x.detach()).cpu(), 7), g['z_eval']) < 1e-5
+
+
+def test_cin_module_at_plugin_width_matches_reference(F):
+    """The channel-interaction module exactly as the plugin builds it - 2048 channels, 7 x 7 maps (CIN.py:99,
+    configs/CIN.yaml:15) - at B = 4 in train mode vs the REFERENCE module (tests/golden/cin_2048.npz,
+    oracle/gen_golden.py::gen_cin_2048): Z, Z_CCI, dX and every parameter gradient.  This is the shape whose backward
+    runs cin_sci_bwd_flash_kernel<49,*> / cin_cci_dw_flash_kernel<49> over 32 column blocks (their two-stage rings wrap)."""
+    from hawkeye_amd.model.methods.CIN import ChannelInteractionModule
+    from inputs import rs_randn, rs_relu_randn, sub
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = _golden('cin_2048')
+    m = ChannelInteractionModule(in_channel=2048, spatial_size=(7, 7))
+    with torch.no_grad():
+        for i, (k, p_) in enumerate(m.named_parameters()):
+            p_.copy_(tt(rs_randn(970 + i, tuple(p_.shape))) * {'conv.weight': 0.005, 'fc.weight': 0.002}.get(k, 0.01))
+    m = m.to(DEV).train()
+    x = tt(rs_relu_randn(980, (4, 2048, 7, 7))).to(DEV).requires_grad_(True)
+    z, zc = m(x)
+    ((z * tt(rs_randn(981, tuple(z.shape))).to(DEV)).sum() + (zc * tt(rs_randn(982, tuple(zc.shape))).to(DEV)).sum()).backward()
+    ez, ezc, edx = rel(sub(z.cpu(), 7), g['z']), rel(sub(zc.cpu(), 7), g['z_cci']), rel(sub(x.grad.cpu(), 7), g['dx'])
+    print(f'[CIN module 2048 x 7x7 vs reference] Z {ez:.2e}  Z_CCI {ezc:.2e}  dX {edx:.2e}')
+    assert ez < 1e-5 and ezc < 1e-5 and edx < 1e-4
+    assert abs(float(z.double().norm()) / float(g['z_norm']) - 1) < 1e-5
+    assert abs(float(zc.double().norm()) / float(g['z_cci_norm']) - 1) < 1e-5
+    assert abs(float(x.grad.double().norm()) / float(g['dx_norm']) - 1) < 1e-5
+    for k, p_ in m.named_parameters():
+        key = k.replace('.', '__')
+        e = rel(sub(p_.grad.cpu(), 1009 if p_.numel() > 500000 else 7), g['g_' + key])
+        print(f'    d {k}: {e:.2e}')
+        assert e < 1e-4, k
         assert abs(float(p_.grad.double().norm()) / float(g['gn_' + key]) - 1) < 1e-4, k
     m.eval()
     with torch.no_grad():
@@ -944,3 +981,29 @@ def test_cin_model_matches_reference(F):
         crit.h.bias.zero_()
         loss = crit.to(DEV)((lt, zc), torch.tensor([5, 9, 5, 9]).to(DEV))
     assert abs(float(loss) - float(g['loss'])) < 3e-3 * abs(float(g['loss']))
+    # a real backward through the head at the plugin's width: trunk in eval mode (running statistics), interaction module
+    # in train mode, the criterion on (logits, Z_CCI) - gradients vs the reference's autograd (gen_cin_model, 'hy_*')
+    m.eval()
+    m.ChannelInteraction.train()
+    crit.train()
+    feats = []
+
+    def keep(mod, inp, out):
+        out.retain_grad()
+        feats.append(out)
+    hook = m.backbone.register_forward_hook(keep)
+    m.zero_grad()
+    lg, zc = m(x)
+    hook.remove()
+    crit((lg, zc), torch.tensor([5, 9, 5, 9]).to(DEV)).backward()
+    e_l, e_z, e_f = rel(lg, g['hy_logits']), rel(sub(zc.cpu(), 97), g['hy_z_cci_sub']), rel(sub(feats[0].grad.cpu(), 13), g['hy_dfeat_sub'])
+    print(f'[CIN plugin, head backward in-model] logits {e_l:.2e}  Z_CCI {e_z:.2e}  d loss / d backbone(x) {e_f:.2e}')
+    assert e_l < 1e-4 and e_z < 1e-4 and e_f < 1e-4
+    assert abs(float(feats[0].grad.double().norm()) / float(g['hy_dfeat_norm']) - 1) < 1e-4
+    for k, p_ in list(m.ChannelInteraction.named_parameters()) + list(m.classifier.named_parameters()):
+        key = k.replace('.', '__')
+        e = rel(sub(p_.grad.cpu(), 1009 if p_.numel() > 500000 else 7), g['hy_g_' + key])
+        print(f'    d {k}: {e:.2e}')
+        assert e < 1e-4, k
+        assert abs(float(p_.grad.double().norm()) / float(g['hy_gn_' + key]) - 1) < 1e-4, k
+    assert rel(sub(crit.h.weight.grad.cpu(), 97), g['hy_g_h']) < 1e-4
