@@ -60,6 +60,12 @@ SIGNATURES = {
     'hk_cbp_unbin_matrix': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     'hk_cbp_loc_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'hk_cbp_loc_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'hk_cbp_rect_plan_bytes': (c_sz, [c_i, c_i, c_i]),
+    'hk_cbp_rect_plan_build': (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_f]),
+    'hk_cbp_rect_bin_matrix': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'hk_cbp_rect_unbin_matrix': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'hk_cbp_rect_loc_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    'hk_cbp_rect_loc_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     'hk_att_pool_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     'hk_att_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     'hk_att_pool3_fwd': (c_i, [c_f] * 8 + [c_i] * 5 + [c_f]),

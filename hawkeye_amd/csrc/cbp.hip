@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void cbp_bin_kernel(const float* __restrict__ 
 // per 4-B entry anywhere in a 1 MB matrix for the CSR gather above), every bin is summed in a fixed order, and the
 // 64-row partials are added in a fixed order by cbp_partsum_kernel: deterministic, no atomics.
 
+constexpr size_t CBP_LOC_LDS_MAX = 144 * 1024;   // dynamic LDS of cbp_loc_bwd_kernel (dc [D] + columns + hashes): of the CU's 160 KB
 constexpr int CBP_EMAX = 4;      // channels per non-empty h2 bin held in registers (plan build checks the hashes)
 constexpr int CBP_RB = 4;        // rows of G staged per LDS block
 
@@ -597,38 +598,36 @@ struct LdCbpDG {
 // Plain kernels (fixed summation orders, no atomics); the signed square root and F.normalize behind them are left to
 // the caller (hawkeye_amd/model/methods/CBCNN.py keeps the reference's own two lines for them).
 
-// dG[b,i,j] = s1_i s2_j dc[b, (h1_i + h2_j) mod D]
+// dG[b,i,j] = s1_i s2_j dc[b, (h1_i + h2_j) mod D]        dG [B, C1, C2]
 __global__ __launch_bounds__(256) void cbp_unbin_kernel(const float* __restrict__ dc, const int* __restrict__ h1,
                                                         const int* __restrict__ h2, const float* __restrict__ s1,
-                                                        const float* __restrict__ s2, float* __restrict__ dG, int C, int D) {
+                                                        const float* __restrict__ s2, float* __restrict__ dG, int C1, int C2, int D) {
     const int b = blockIdx.z, i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= C) return;
+    if (j >= C2) return;
     int k = h1[i] + h2[j];
     if (k >= D) k -= D;
-    dG[((long long)b * C + i) * C + j] = s1[i] * s2[j] * dc[(long long)b * D + k];
+    dG[((long long)b * C1 + i) * C2 + j] = s1[i] * s2[j] * dc[(long long)b * D + k];
 }
 
 // one workgroup per (location p, sample b): the two channel columns in LDS, thread t owns bins t, t + 256, ..; a bin's
-// entries in the plan's (i, j)-ascending order
+// entries (i * C2 + j) in the plan's (i, j)-ascending order
 __global__ __launch_bounds__(256) void cbp_loc_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                           const int* __restrict__ off, const unsigned* __restrict__ ent,
-                                                          float* __restrict__ c, int C, int HW, int D) {
-    HK_DYN_LDS(sm);                                    // [2][C]
+                                                          float* __restrict__ c, int C1, int C2, int HW, int D) {
+    HK_DYN_LDS(sm);                                    // x1 column [C1] | x2 column [C2]
     const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    for (int i = tid; i < C; i += 256) {
-        sm[i] = x1[((long long)b * C + i) * HW + p];
-        sm[C + i] = x2[((long long)b * C + i) * HW + p];
-    }
+    for (int i = tid; i < C1; i += 256) sm[i] = x1[((long long)b * C1 + i) * HW + p];
+    for (int j = tid; j < C2; j += 256) sm[C1 + j] = x2[((long long)b * C2 + j) * HW + p];
     __syncthreads();
-    const float rc = 1.0f / (float)C;
+    const float rc = 1.0f / (float)C2;
     float* cp = c + ((long long)b * HW + p) * D;
     for (int k = tid; k < D; k += 256) {
         float s = 0.f;
         for (int e = off[k]; e < off[k + 1]; ++e) {
             const unsigned u = ent[e];
             const int idx = (int)(u & 0x7fffffffu);
-            const int i = (int)(((float)idx + 0.5f) * rc);          // idx / C, exact for C <= 1024 (entry point checks)
-            const float v = sm[i] * sm[C + idx - i * C];
+            const int i = (int)(((float)idx + 0.5f) * rc);          // idx / C2, exact for C1, C2 <= 1024 (entry point checks)
+            const float v = sm[i] * sm[C1 + idx - i * C2];
             s += (u >> 31) ? -v : v;
         }
         cp[k] = s;
@@ -641,37 +640,75 @@ __global__ __launch_bounds__(256) void cbp_loc_bwd_kernel(const float* __restric
                                                           const float* __restrict__ dc, const int* __restrict__ h1,
                                                           const int* __restrict__ h2, const float* __restrict__ s1,
                                                           const float* __restrict__ s2, float* __restrict__ dx1,
-                                                          float* __restrict__ dx2, int C, int HW, int D) {
-    HK_DYN_LDS(sm);                                    // dc [D] | x1 s1 [C] | x2 s2 [C] | h1 [C] | h2 [C]
+                                                          float* __restrict__ dx2, int C1, int C2, int HW, int D) {
+    HK_DYN_LDS(sm);                                    // dc [D] | x1 s1 [C1] | x2 s2 [C2] | h1 [C1] | h2 [C2]
     const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     float* sd = sm;
     float* a1 = sm + D;
-    float* a2 = a1 + C;
-    int* g1 = reinterpret_cast<int*>(a2 + C);
-    int* g2 = g1 + C;
+    float* a2 = a1 + C1;
+    int* g1 = reinterpret_cast<int*>(a2 + C2);
+    int* g2 = g1 + C1;
     const float* dcp = dc + ((long long)b * HW + p) * D;
     for (int k = tid; k < D; k += 256) sd[k] = dcp[k];
-    for (int i = tid; i < C; i += 256) {
-        a1[i] = s1[i] * x1[((long long)b * C + i) * HW + p];
-        a2[i] = s2[i] * x2[((long long)b * C + i) * HW + p];
+    for (int i = tid; i < C1; i += 256) {
+        a1[i] = s1[i] * x1[((long long)b * C1 + i) * HW + p];
         g1[i] = h1[i];
-        g2[i] = h2[i];
+    }
+    for (int j = tid; j < C2; j += 256) {
+        a2[j] = s2[j] * x2[((long long)b * C2 + j) * HW + p];
+        g2[j] = h2[j];
     }
     __syncthreads();
-    for (int i = tid; i < C; i += 256) {
-        const int hi = g1[i], hj = g2[i];
-        float acc1 = 0.f, acc2 = 0.f;
-        for (int j = 0; j < C; ++j) {
-            int k1 = hi + g2[j];
-            if (k1 >= D) k1 -= D;
-            acc1 += sd[k1] * a2[j];                    // row i of dG against x2
-            int k2 = g1[j] + hj;
-            if (k2 >= D) k2 -= D;
-            acc2 += sd[k2] * a1[j];                    // column i of dG against x1
+    if (dx1)
+        for (int i = tid; i < C1; i += 256) {          // row i of dG against x2
+            const int hi = g1[i];
+            float acc = 0.f;
+            for (int j = 0; j < C2; ++j) {
+                int k = hi + g2[j];
+                if (k >= D) k -= D;
+                acc += sd[k] * a2[j];
+            }
+            dx1[((long long)b * C1 + i) * HW + p] = s1[i] * acc;
         }
-        if (dx1) dx1[((long long)b * C + i) * HW + p] = s1[i] * acc1;
-        if (dx2) dx2[((long long)b * C + i) * HW + p] = s2[i] * acc2;
-    }
+    if (dx2)
+        for (int j = tid; j < C2; j += 256) {          // column j of dG against x1
+            const int hj = g2[j];
+            float acc = 0.f;
+            for (int i = 0; i < C1; ++i) {
+                int k = g1[i] + hj;
+                if (k >= D) k -= D;
+                acc += sd[k] * a1[i];
+            }
+            dx2[((long long)b * C2 + j) * HW + p] = s2[j] * acc;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// input_dim1 != input_dim2 (CompactBilinearPooling(C1, C2, D), CBCNN.py:68-94): the same identity over a C1 x C2 cross
+// Gram.  A plan of its own - hashes, signs and the CSR table bin -> (i * C2 + j, sign) - and the plain kernels above; the
+// fused one-launch forms (hk_cbp_fwd / bwd) are for the square one-input case Hawkeye's CBCNN builds.
+struct CbpRectPlan {
+    const int* h1;       // [C1]
+    const int* h2;       // [C2]
+    const float* s1;
+    const float* s2;
+    const int* off;      // [D+1]
+    const unsigned* ent; // [C1*C2]
+};
+static inline size_t cbp_rect_bytes(int C1, int C2, int D) {
+    return 16 + 2 * cbp_align((size_t)C1 * 4) + 2 * cbp_align((size_t)C2 * 4) + cbp_align((size_t)(D + 1) * 4) +
+           cbp_align((size_t)C1 * C2 * 4);
+}
+static inline CbpRectPlan cbp_rect_view(const void* plan, int C1, int C2, int D) {
+    const char* p = (const char*)plan + 16;
+    CbpRectPlan v;
+    v.h1 = (const int*)p;            p += cbp_align((size_t)C1 * 4);
+    v.h2 = (const int*)p;            p += cbp_align((size_t)C2 * 4);
+    v.s1 = (const float*)p;          p += cbp_align((size_t)C1 * 4);
+    v.s2 = (const float*)p;          p += cbp_align((size_t)C2 * 4);
+    v.off = (const int*)p;           p += cbp_align((size_t)(D + 1) * 4);
+    v.ent = (const unsigned*)p;
+    return v;
 }
 
 }  // namespace hk
@@ -680,6 +717,7 @@ using namespace hk;
 
 extern "C" int hk_cbp_bin_matrix(const float* G, const void* plan, float* c_raw, int B, int C, int D, hk_stream_t stream) {
     if (!G || !plan || !c_raw || B <= 0 || C <= 0 || D <= 0) return HK_ERR_BAD_ARG;
+    if (B > 65535) return HK_ERR_UNSUPPORTED;
     const CbpPlan pl = cbp_view(plan, C, D);
     hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, G, pl.off, pl.ent, c_raw, C * C, D);
     HK_LAUNCH_CHECK();
@@ -691,7 +729,7 @@ extern "C" int hk_cbp_unbin_matrix(const float* dc, const void* plan, float* dG,
     if (B > 65535 || C > 65535) return HK_ERR_UNSUPPORTED;
     const CbpPlan pl = cbp_view(plan, C, D);
     hipLaunchKernelGGL(cbp_unbin_kernel, dim3((C + 255) / 256, C, B), dim3(256), 0, (hipStream_t)stream, dc, pl.h1, pl.h2, pl.s1,
-                       pl.s2, dG, C, D);
+                       pl.s2, dG, C, C, D);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
@@ -702,7 +740,7 @@ extern "C" int hk_cbp_loc_fwd(const float* x1, const float* x2, const void* plan
     if (C > 1024 || B > 65535) return HK_ERR_UNSUPPORTED;
     const CbpPlan pl = cbp_view(plan, C, D);
     hipLaunchKernelGGL(cbp_loc_fwd_kernel, dim3(HW, B), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream, x1, x2,
-                       pl.off, pl.ent, c, C, HW, D);
+                       pl.off, pl.ent, c, C, C, HW, D);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
@@ -711,10 +749,96 @@ extern "C" int hk_cbp_loc_bwd(const float* x1, const float* x2, const float* dc,
                               int C, int HW, int D, hk_stream_t stream) {
     if (!x1 || !x2 || !dc || !plan || (!dx1 && !dx2) || B <= 0 || C <= 0 || HW <= 0 || D <= 0) return HK_ERR_BAD_ARG;
     const size_t lds = ((size_t)D + 4 * (size_t)C) * sizeof(float);
-    if (lds > 64 * 1024 || B > 65535) return HK_ERR_UNSUPPORTED;
+    if (lds > CBP_LOC_LDS_MAX || B > 65535) return HK_ERR_UNSUPPORTED;
+    HK_ALLOW_BIG_LDS(cbp_loc_bwd_kernel, lds);          // D = 16000, C = 512 is 72 KB: above the default 64 KB, well inside 160
     const CbpPlan pl = cbp_view(plan, C, D);
     hipLaunchKernelGGL(cbp_loc_bwd_kernel, dim3(HW, B), dim3(256), lds, (hipStream_t)stream, x1, x2, dc, pl.h1, pl.h2, pl.s1, pl.s2,
-                       dx1, dx2, C, HW, D);
+                       dx1, dx2, C, C, HW, D);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+// ------------------------------------------------------------------ input_dim1 != input_dim2
+extern "C" size_t hk_cbp_rect_plan_bytes(int C1, int C2, int D) {
+    if (C1 <= 0 || C2 <= 0 || D <= 0) return 0;
+    return cbp_rect_bytes(C1, C2, D);
+}
+
+extern "C" int hk_cbp_rect_plan_build(const int32_t* h1, const float* s1, int C1, const int32_t* h2, const float* s2, int C2, int D,
+                                      void* plan, hk_stream_t stream) {
+    if (!h1 || !s1 || !h2 || !s2 || !plan || C1 <= 0 || C2 <= 0 || D <= 0 || (long long)C1 * C2 >= (1ll << 31)) return HK_ERR_BAD_ARG;
+    for (int i = 0; i < C1; ++i)
+        if (h1[i] < 0 || h1[i] >= D) return HK_ERR_BAD_ARG;                              // CBCNN.py:153
+    for (int j = 0; j < C2; ++j)
+        if (h2[j] < 0 || h2[j] >= D) return HK_ERR_BAD_ARG;
+    std::vector<char> blob(cbp_rect_bytes(C1, C2, D), 0);
+    ((int*)blob.data())[0] = C1;
+    ((int*)blob.data())[1] = C2;
+    ((int*)blob.data())[2] = D;
+    char* p = blob.data() + 16;
+    memcpy(p, h1, (size_t)C1 * 4); p += cbp_align((size_t)C1 * 4);
+    memcpy(p, h2, (size_t)C2 * 4); p += cbp_align((size_t)C2 * 4);
+    memcpy(p, s1, (size_t)C1 * 4); p += cbp_align((size_t)C1 * 4);
+    memcpy(p, s2, (size_t)C2 * 4); p += cbp_align((size_t)C2 * 4);
+    int* off = (int*)p; p += cbp_align((size_t)(D + 1) * 4);
+    unsigned* ent = (unsigned*)p;
+    std::vector<int> cnt(D, 0);
+    for (int i = 0; i < C1; ++i)
+        for (int j = 0; j < C2; ++j) cnt[(h1[i] + h2[j]) % D]++;
+    off[0] = 0;
+    for (int k = 0; k < D; ++k) off[k + 1] = off[k] + cnt[k];
+    std::vector<int> cur(off, off + D);
+    for (int i = 0; i < C1; ++i)       // (i,j) ascending inside each bin: fixed summation order
+        for (int j = 0; j < C2; ++j) {
+            const int k = (h1[i] + h2[j]) % D;
+            const unsigned neg = (s1[i] * s2[j] < 0.f) ? 0x80000000u : 0u;
+            ent[cur[k]++] = neg | (unsigned)(i * C2 + j);
+        }
+    hipError_t e = hipMemcpyAsync(plan, blob.data(), blob.size(), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize((hipStream_t)stream);   // one-time setup: the host blob dies at return
+    return e == hipSuccess ? HK_OK : (int)e;
+}
+
+extern "C" int hk_cbp_rect_bin_matrix(const float* G, const void* plan, float* c_raw, int B, int C1, int C2, int D, hk_stream_t stream) {
+    if (!G || !plan || !c_raw || B <= 0 || C1 <= 0 || C2 <= 0 || D <= 0) return HK_ERR_BAD_ARG;
+    if (B > 65535) return HK_ERR_UNSUPPORTED;
+    const CbpRectPlan pl = cbp_rect_view(plan, C1, C2, D);
+    hipLaunchKernelGGL(cbp_bin_kernel, dim3((D + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, G, pl.off, pl.ent, c_raw, C1 * C2, D);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_cbp_rect_unbin_matrix(const float* dc, const void* plan, float* dG, int B, int C1, int C2, int D, hk_stream_t stream) {
+    if (!dc || !plan || !dG || B <= 0 || C1 <= 0 || C2 <= 0 || D <= 0) return HK_ERR_BAD_ARG;
+    if (B > 65535 || C1 > 65535) return HK_ERR_UNSUPPORTED;
+    const CbpRectPlan pl = cbp_rect_view(plan, C1, C2, D);
+    hipLaunchKernelGGL(cbp_unbin_kernel, dim3((C2 + 255) / 256, C1, B), dim3(256), 0, (hipStream_t)stream, dc, pl.h1, pl.h2, pl.s1,
+                       pl.s2, dG, C1, C2, D);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_cbp_rect_loc_fwd(const float* x1, const float* x2, const void* plan, float* c, int B, int C1, int C2, int HW, int D,
+                                   hk_stream_t stream) {
+    if (!x1 || !x2 || !plan || !c || B <= 0 || C1 <= 0 || C2 <= 0 || HW <= 0 || D <= 0) return HK_ERR_BAD_ARG;
+    if (C1 > 1024 || C2 > 1024 || B > 65535) return HK_ERR_UNSUPPORTED;
+    const CbpRectPlan pl = cbp_rect_view(plan, C1, C2, D);
+    hipLaunchKernelGGL(cbp_loc_fwd_kernel, dim3(HW, B), dim3(256), (size_t)(C1 + C2) * sizeof(float), (hipStream_t)stream, x1, x2,
+                       pl.off, pl.ent, c, C1, C2, HW, D);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_cbp_rect_loc_bwd(const float* x1, const float* x2, const float* dc, const void* plan, float* dx1, float* dx2, int B,
+                                   int C1, int C2, int HW, int D, hk_stream_t stream) {
+    if (!x1 || !x2 || !dc || !plan || (!dx1 && !dx2) || B <= 0 || C1 <= 0 || C2 <= 0 || HW <= 0 || D <= 0) return HK_ERR_BAD_ARG;
+    const size_t lds = ((size_t)D + 2 * ((size_t)C1 + (size_t)C2)) * sizeof(float);
+    if (lds > CBP_LOC_LDS_MAX || B > 65535) return HK_ERR_UNSUPPORTED;
+    HK_ALLOW_BIG_LDS(cbp_loc_bwd_kernel, lds);
+    const CbpRectPlan pl = cbp_rect_view(plan, C1, C2, D);
+    hipLaunchKernelGGL(cbp_loc_bwd_kernel, dim3(HW, B), dim3(256), lds, (hipStream_t)stream, x1, x2, dc, pl.h1, pl.h2, pl.s1, pl.s2,
+                       dx1, dx2, C1, C2, HW, D);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

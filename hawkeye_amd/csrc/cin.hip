@@ -1032,6 +1032,7 @@ static int cin_sci_stored(const float* x, float* w, float* y, int B, int C, int 
         case 512: hipLaunchKernelGGL(cin_row_stats_kernel<2>, sgrid, dim3(256), 0, st, (const float*)w, y, C, HW, rows); break;
         default: hipLaunchKernelGGL(cin_row_stats_kernel<0>, sgrid, dim3(256), 0, st, (const float*)w, y, C, HW, rows); break;
     }
+    HK_LAUNCH_CHECK();
     return cin_ax_launch<0>(x, w, y, 1.f, B, C, HW, st);
 }
 

@@ -391,6 +391,14 @@ class _CbpCrossSum(torch.autograd.Function):
         return dx1, dx2, None
 
 
+def _loc_bwd_fits(ctx, c1, c2, d):
+    """hk_cbp_loc_bwd keeps dc[b,p,:], both channel columns and both hash tables of a location in LDS (144 KB of the CU's 160):
+    say so in the FORWARD of a pass that will need it, not in the middle of backward()."""
+    if any(ctx.needs_input_grad[:2]) and (d + 2 * (c1 + c2)) * 4 > 144 * 1024:
+        raise _lib.HawkeyeHipError(f'compact_bilinear_pool(sum_pool=False): the backward holds D + 2 (C1 + C2) = {d + 2 * (c1 + c2)} '
+                                   f'floats per location in LDS (limit {144 * 256}); run this shape under torch.no_grad() or reduce D')
+
+
 class _CbpPerLocation(torch.autograd.Function):
     """The tensor sketch of every location on its own (CompactBilinearPooling.forward with sum_pool = False, CBCNN.py:117-128
     before its signed sqrt): c[b,h,w,k] = sum_{(i,j) -> k} s1_i s2_j x1[b,i,h,w] x2[b,j,h,w]  ->  [B,H,W,D]."""
@@ -402,6 +410,7 @@ class _CbpPerLocation(torch.autograd.Function):
         b, c, h, w = x1.shape
         if tuple(x2.shape) != (b, c, h, w) or plan.C != c:
             raise _lib.HawkeyeHipError(f'compact_bilinear_pool: inputs {tuple(x1.shape)} / {tuple(x2.shape)}, plan for {plan.C} channels')
+        _loc_bwd_fits(ctx, c, c, plan.D)
         out = torch.empty(b, h, w, plan.D, dtype=torch.float32, device=x1.device)
         check(lib.hk_cbp_loc_fwd(ptr(x1), ptr(x2), ptr(plan.blob), ptr(out), b, c, h * w, plan.D, stream()), 'hk_cbp_loc_fwd')
         ctx.plan = plan
@@ -422,9 +431,107 @@ class _CbpPerLocation(torch.autograd.Function):
         return dx1, dx2, None
 
 
+class CbpRectPlan:
+    """Device-side plan for input_dim1 != input_dim2 (CompactBilinearPooling(C1, C2, D), CBCNN.py:68-94): hashes, signs and
+    the CSR table bin -> signed entries of the C1 x C2 cross Gram.  No host-side state in the library."""
+
+    def __init__(self, h1, s1, h2, s2, output_dim, device):
+        lib = _lib.load()
+        assert h1.ndim == 1 and s1.ndim == 1 and len(h1) == len(s1)            # CBCNN.py:151-152
+        assert h2.ndim == 1 and s2.ndim == 1 and len(h2) == len(s2)
+        assert np.all(h1 >= 0) and np.all(h1 < output_dim)                      # CBCNN.py:153
+        assert np.all(h2 >= 0) and np.all(h2 < output_dim)
+        self.C1, self.C2, self.D, self.device = len(h1), len(h2), int(output_dim), device
+        h1 = np.ascontiguousarray(h1, dtype=np.int32)
+        h2 = np.ascontiguousarray(h2, dtype=np.int32)
+        s1 = np.ascontiguousarray(s1, dtype=np.float32)
+        s2 = np.ascontiguousarray(s2, dtype=np.float32)
+        self.blob = torch.empty(lib.hk_cbp_rect_plan_bytes(self.C1, self.C2, self.D), dtype=torch.uint8, device=device)
+        with _on(device):
+            check(lib.hk_cbp_rect_plan_build(h1.ctypes.data, s1.ctypes.data, self.C1, h2.ctypes.data, s2.ctypes.data, self.C2,
+                                             self.D, ptr(self.blob), stream()), 'hk_cbp_rect_plan_build')
+
+
+def _rect_shapes(x1, x2, plan, what):
+    b, c1, h, w = x1.shape
+    if x2.shape[0] != b or tuple(x2.shape[2:]) != (h, w) or (c1, x2.shape[1]) != (plan.C1, plan.C2):
+        raise _lib.HawkeyeHipError(f'{what}: inputs {tuple(x1.shape)} / {tuple(x2.shape)}, plan for {plan.C1} x {plan.C2} channels')
+    return b, c1, x2.shape[1], h, w
+
+
+class _CbpRectSum(torch.autograd.Function):
+    """_CbpCrossSum for two inputs of DIFFERENT widths: the C1 x C2 cross Gram on the generic MFMA tiles, the rect plan's
+    gather over it; backward dG from dc, dX1 = dG X2, dX2 = dG^T X1."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, plan):
+        lib = _lib.load()
+        x1, x2 = _f32c(x1), _f32c(x2)
+        b, c1, c2, h, w = _rect_shapes(x1, x2, plan, 'compact_bilinear_pool')
+        hw, d = h * w, plan.D
+        g = torch.empty(b, c1, c2, dtype=torch.float32, device=x1.device)
+        _bgemm_raw(lib, x1.view(b, c1, hw), x2.view(b, c2, hw), g, False, True, c1, c2, hw, b)
+        c_raw = torch.empty(b, d, dtype=torch.float32, device=x1.device)
+        check(lib.hk_cbp_rect_bin_matrix(ptr(g), ptr(plan.blob), ptr(c_raw), b, c1, c2, d, stream()), 'hk_cbp_rect_bin_matrix')
+        ctx.plan = plan
+        ctx.save_for_backward(x1, x2)
+        return c_raw
+
+    @staticmethod
+    def backward(ctx, dc):
+        lib = _lib.load()
+        x1, x2 = ctx.saved_tensors
+        plan = ctx.plan
+        b, c1, h, w = x1.shape
+        c2, hw, d = x2.shape[1], h * w, plan.D
+        dc = _f32c(dc)
+        dg = torch.empty(b, c1, c2, dtype=torch.float32, device=x1.device)
+        check(lib.hk_cbp_rect_unbin_matrix(ptr(dc), ptr(plan.blob), ptr(dg), b, c1, c2, d, stream()), 'hk_cbp_rect_unbin_matrix')
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0]:
+            dx1 = torch.empty_like(x1)
+            _bgemm_raw(lib, dg, x2.view(b, c2, hw), dx1.view(b, c1, hw), False, False, c1, hw, c2, b)
+        if ctx.needs_input_grad[1]:
+            dx2 = torch.empty_like(x2)
+            _bgemm_raw(lib, dg, x1.view(b, c1, hw), dx2.view(b, c2, hw), True, False, c2, hw, c1, b)
+        return dx1, dx2, None
+
+
+class _CbpRectPerLocation(torch.autograd.Function):
+    """_CbpPerLocation for two inputs of different widths (sum_pool = False)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, plan):
+        lib = _lib.load()
+        x1, x2 = _f32c(x1), _f32c(x2)
+        b, c1, c2, h, w = _rect_shapes(x1, x2, plan, 'compact_bilinear_pool')
+        _loc_bwd_fits(ctx, c1, c2, plan.D)
+        out = torch.empty(b, h, w, plan.D, dtype=torch.float32, device=x1.device)
+        check(lib.hk_cbp_rect_loc_fwd(ptr(x1), ptr(x2), ptr(plan.blob), ptr(out), b, c1, c2, h * w, plan.D, stream()),
+              'hk_cbp_rect_loc_fwd')
+        ctx.plan = plan
+        ctx.save_for_backward(x1, x2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dc):
+        lib = _lib.load()
+        x1, x2 = ctx.saved_tensors
+        plan = ctx.plan
+        b, c1, h, w = x1.shape
+        dc = _f32c(dc)
+        dx1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
+        dx2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        check(lib.hk_cbp_rect_loc_bwd(ptr(x1), ptr(x2), ptr(dc), ptr(plan.blob), ptr(dx1), ptr(dx2), b, c1, x2.shape[1], h * w,
+                                      plan.D, stream()), 'hk_cbp_rect_loc_bwd')
+        return dx1, dx2, None
+
+
 def compact_bilinear_sketch(x1, x2, plan, sum_pool=True):
     """The count sketch BEFORE the signed square root, for the forms Hawkeye's own CBCNN does not take: two different inputs
-    ([B,D]) or no sum over the map ([B,H,W,D]); x2 may be x1."""
+    ([B,D]) or no sum over the map ([B,H,W,D]); x2 may be x1.  A CbpRectPlan (input_dim1 != input_dim2) takes the C1 x C2 forms."""
+    if isinstance(plan, CbpRectPlan):
+        return _CbpRectSum.apply(x1, x2, plan) if sum_pool else _CbpRectPerLocation.apply(x1, x2, plan)
     return _CbpCrossSum.apply(x1, x2, plan) if sum_pool else _CbpPerLocation.apply(x1, x2, plan)
 
 
@@ -844,8 +951,9 @@ class _SsqrtPoolLinear(torch.autograd.Function):
         inv_norm = torch.empty(b, dtype=torch.float32, device=x.device)
         nws = lib.hk_bcnn_ssqrt_ws_bytes(b, c, hw)
         ws = _ws(nws, x.device)
-        bias_c = _f32c(bias) if bias is not None else None
-        out = torch.empty(b, k, dtype=torch.float32, device=x.device)
+        # the kernels write the PRE-BIAS product `pre` = inv_norm (u W^T); it stays private to this node (the backward's
+        # <y, dy> = sum_k g_k pre_k needs it exact, whatever the bias is and whatever the caller does to the logits in place)
+        pre = torch.empty(b, k, dtype=torch.float32, device=x.device)
         nwl = lib.hk_linear_ws_bytes(b, j, k)
         wsl = _ws(nwl, x.device)
         # two launches + the classifier's reduce: the Gram kernel leaves partial sums of u^2 and the reduce launch forms 1 / |u|
@@ -853,23 +961,23 @@ class _SsqrtPoolLinear(torch.autograd.Function):
         nparts = ctypes.c_int(0)
         rc = lib.hk_bcnn_ssqrt_pool_fwd_parts(ptr(x), ptr(u), ptr(ws), ctypes.byref(nparts), b, c, hw, stream())
         if rc == _lib.HK_OK:
-            check(lib.hk_linear_fwd_ssq(ptr(u), ptr(weight), ptr(bias_c), ptr(ws), nparts.value, ptr(inv_norm), ptr(out), b, j, k,
+            check(lib.hk_linear_fwd_ssq(ptr(u), ptr(weight), None, ptr(ws), nparts.value, ptr(inv_norm), ptr(pre), b, j, k,
                                         ptr(wsl), nwl, stream()), 'hk_linear_fwd_ssq')
         else:
             if rc != _lib.HK_ERR_UNSUPPORTED:
                 check(rc, 'hk_bcnn_ssqrt_pool_fwd_parts')
             check(lib.hk_bcnn_ssqrt_pool_fwd_unscaled(ptr(x), ptr(u), ptr(inv_norm), b, c, hw, ptr(ws), nws, stream()),
                   'hk_bcnn_ssqrt_pool_fwd_unscaled')
-            check(lib.hk_linear_fwd_scaled(ptr(u), ptr(weight), ptr(bias_c), ptr(inv_norm), ptr(out), b, j, k, ptr(wsl), nwl,
+            check(lib.hk_linear_fwd_scaled(ptr(u), ptr(weight), None, ptr(inv_norm), ptr(pre), b, j, k, ptr(wsl), nwl,
                                            stream()), 'hk_linear_fwd_scaled')
-        ctx.save_for_backward(x, u, inv_norm, weight, bias_c if bias_c is not None else x.new_empty(0), out)
+        ctx.save_for_backward(x, u, inv_norm, weight, pre)
         ctx.has_bias = bias is not None
-        return out
+        return pre + _f32c(bias) if bias is not None else pre.clone()
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, u, inv_norm, weight, bias_c, out = ctx.saved_tensors
+        x, u, inv_norm, weight, pre = ctx.saved_tensors
         g = _f32c(g)
         b, c, h, w = x.shape
         hw, j, k = h * w, c * c, weight.shape[0]
@@ -890,10 +998,9 @@ class _SsqrtPoolLinear(torch.autograd.Function):
             dx = torch.empty_like(x)
             nws = lib.hk_bcnn_ssqrt_ws_bytes(b, c, hw)
             ws = _ws(nws, x.device)
-            # <y, dy> = sum_k g_k (logit_k - bias_k): the classifier's operands instead of a pass over u and dy
-            check(lib.hk_bcnn_ssqrt_pool_bwd_tdot(ptr(x), ptr(u), ptr(dy), ptr(inv_norm), ptr(g), ptr(out),
-                                                  ptr(bias_c) if ctx.has_bias else None, k, 1, ptr(dx), b, c, hw, ptr(ws), nws,
-                                                  stream()), 'hk_bcnn_ssqrt_pool_bwd_tdot')
+            # <y, dy> = sum_k g_k pre_k (the pre-bias product): the classifier's operands instead of a pass over u and dy
+            check(lib.hk_bcnn_ssqrt_pool_bwd_tdot(ptr(x), ptr(u), ptr(dy), ptr(inv_norm), ptr(g), ptr(pre), None, k, 1, ptr(dx),
+                                                  b, c, hw, ptr(ws), nws, stream()), 'hk_bcnn_ssqrt_pool_bwd_tdot')
         return dx, dw, db
 
 
@@ -901,7 +1008,7 @@ class _BilinearPoolLinear(torch.autograd.Function):
     """BilinearPooling + the classifier on it (model/methods/BCNN.py:13-27 + :54) as ONE autograd node.  Forward: the two
     entry points back to back (the l2 scale is already free in the Gram epilogue: nothing to fold).  Backward: because
     dy = g W is produced here, the inner product <y, dy> that F.normalize's backward needs is known in closed form,
-        t[b] = sum_j y[b,j] sum_k g[b,k] W[k,j] = sum_k g[b,k] (logits[b,k] - bias[k]),
+        t[b] = sum_j y[b,j] sum_k g[b,k] W[k,j] = sum_k g[b,k] (y W^T)[b,k]      (the pre-bias product, kept by this node),
     so hk_bcnn_pool_bwd_tdot runs the Gram backward as one launch with the rank-1 term applied while dX is written -
     no partial sums of y * dy, no second pass over dX."""
 
@@ -920,19 +1027,22 @@ class _BilinearPoolLinear(torch.autograd.Function):
         ws = _ws(nws, x.device)
         check(lib.hk_bcnn_pool_fwd(ptr(x), ptr(y), ptr(inv_norm), ptr(colsum), b, c, hw, ptr(ws), nws, stream()),
               'hk_bcnn_pool_fwd')
-        bias_c = _f32c(bias) if bias is not None else None
-        out = torch.empty(b, k, dtype=torch.float32, device=x.device)
+        # the kernel writes the PRE-BIAS product y W^T, which stays private to this node: the backward's closed form
+        # t = sum_k g_k (y W^T)_k then neither cancels against a large bias nor breaks when the caller modifies the logits in
+        # place (nn.Linear does not save its output either); the bias is added by one [B,K] elementwise op - the same bits
+        # as the kernel's own `sum + bias`
+        pre = torch.empty(b, k, dtype=torch.float32, device=x.device)
         nwl = lib.hk_linear_ws_bytes(b, j, k)
         wsl = _ws(nwl, x.device)
-        check(lib.hk_linear_fwd(ptr(y), ptr(weight), ptr(bias_c), ptr(out), b, j, k, ptr(wsl), nwl, stream()), 'hk_linear_fwd')
-        ctx.save_for_backward(x, y, inv_norm, colsum, weight, bias_c if bias_c is not None else x.new_empty(0), out)
+        check(lib.hk_linear_fwd(ptr(y), ptr(weight), None, ptr(pre), b, j, k, ptr(wsl), nwl, stream()), 'hk_linear_fwd')
+        ctx.save_for_backward(x, y, inv_norm, colsum, weight, pre)
         ctx.has_bias = bias is not None
-        return out
+        return pre + _f32c(bias) if bias is not None else pre.clone()
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, y, inv_norm, colsum, weight, bias_c, out = ctx.saved_tensors
+        x, y, inv_norm, colsum, weight, pre = ctx.saved_tensors
         g = _f32c(g)
         b, c, h, w = x.shape
         hw, j, k = h * w, c * c, weight.shape[0]
@@ -947,9 +1057,8 @@ class _BilinearPoolLinear(torch.autograd.Function):
             dx = torch.empty_like(x)
             nws = lib.hk_bcnn_pool_ws_bytes(b, c, hw)
             ws = _ws(nws, x.device)
-            check(lib.hk_bcnn_pool_bwd_tdot(ptr(x), ptr(y), ptr(dy), ptr(inv_norm), ptr(colsum), ptr(g), ptr(out),
-                                            ptr(bias_c) if ctx.has_bias else None, k, ptr(dx), b, c, hw, ptr(ws), nws,
-                                            stream()), 'hk_bcnn_pool_bwd_tdot')
+            check(lib.hk_bcnn_pool_bwd_tdot(ptr(x), ptr(y), ptr(dy), ptr(inv_norm), ptr(colsum), ptr(g), ptr(pre), None, k,
+                                            ptr(dx), b, c, hw, ptr(ws), nws, stream()), 'hk_bcnn_pool_bwd_tdot')
         return dx, dw, db
 
 

@@ -29,8 +29,9 @@ class CompactBilinearPooling(nn.Module):
     def _plan(self, device):
         key = (device.type, device.index)
         if key not in self._plans:
-            self._plans[key] = HF.CbpPlan(self.rand_h_1, self.rand_s_1, self.rand_h_2, self.rand_s_2,
-                                              self.output_dim, device)
+            # two widths (CBCNN.py:68-94 sizes each sketch matrix by its own input_dim): the plan over the C1 x C2 cross Gram
+            make = HF.CbpPlan if self.input_dim1 == self.input_dim2 else HF.CbpRectPlan
+            self._plans[key] = make(self.rand_h_1, self.rand_s_1, self.rand_h_2, self.rand_s_2, self.output_dim, device)
         return self._plans[key]
 
     def __deepcopy__(self, memo):          # plans hold device blobs: rebuild lazily in the copy
@@ -43,8 +44,6 @@ class CompactBilinearPooling(nn.Module):
         if bottom2 is None:
             bottom2 = bottom1                                                                # CBCNN.py:101-102 (a clone there)
         assert bottom1.size(1) == self.input_dim1 and bottom2.size(1) == self.input_dim2     # CBCNN.py:104-105
-        if self.input_dim1 != self.input_dim2:
-            raise NotImplementedError('input_dim1 != input_dim2: the plan (bin -> entries of a square Gram) is built per width')
         plan = self._plan(bottom1.device)
         if one_input and self.sum_pool:          # what Hawkeye's CBCNN calls (CBCNN.py:23,33): Gram + binning + finish on the kernels
             return HF.compact_bilinear_pool(bottom1, plan)

@@ -62,6 +62,30 @@ def pooled_classifier(model, feats):
     callable on its own, `classifier` an nn.Linear holding the parameters."""
     from .. import functional as F
     layer = model.classifier
+    if _hooked(model.bilinear_pooling) or _hooked(layer):
+        # somebody registered forward hooks on one of the two modules (feature extraction, CAM tooling): the fused node
+        # never goes through their __call__, so take the two-node composition - the same kernels, one launch more in the
+        # backward - with both modules called the way the reference calls them (BCNN.py:53-54)
+        return _call_on_kernels(layer, model.bilinear_pooling(feats))
     if model.bilinear_pooling.signed_sqrt:
         return F.ssqrt_pool_linear(feats, layer.weight, layer.bias)
     return F.bilinear_pool_linear(feats, layer.weight, layer.bias)
+
+
+def _hooked(module):
+    import torch.nn.modules.module as M
+    return bool(module._forward_hooks or module._forward_pre_hooks or M._global_forward_hooks or M._global_forward_pre_hooks)
+
+
+def _call_on_kernels(layer, x):
+    """`layer(x)` through nn.Module.__call__ (hooks fire) with the product computed by hk_linear_fwd / bwd instead of the
+    library GEMM: the instance's `forward` is pointed at wide_linear for the duration of the call."""
+    had = layer.__dict__.get('forward')
+    layer.forward = lambda inp: wide_linear(layer, inp)
+    try:
+        return layer(x)
+    finally:
+        if had is None:
+            del layer.forward
+        else:
+            layer.forward = had

@@ -245,6 +245,25 @@ int hk_cbp_loc_fwd(const float* x1, const float* x2, const void* plan, float* c,
 int hk_cbp_loc_bwd(const float* x1, const float* x2, const float* dc, const void* plan, float* dx1, float* dx2, int B,
                    int C, int HW, int D, hk_stream_t stream);
 
+/* input_dim1 != input_dim2: CompactBilinearPooling(C1, C2, D) (model/methods/CBCNN.py:68-94 builds one sketch matrix per
+ * input width; :104-105 asserts bottom1 has C1 and bottom2 C2 channels).  The same identity over the C1 x C2 cross Gram
+ * G = X1 X2^T (hk_bgemm_f32):   c[b,k] = sum_{(i,j) : (h1[i] + h2[j]) mod D = k} s1[i] s2[j] G[b,i,j].
+ *   hk_cbp_rect_plan_build   hashes h1 [C1], h2 [C2] in [0,D), signs s1 [C1], s2 [C2] (HOST pointers) -> `plan` (DEVICE memory,
+ *                            hk_cbp_rect_plan_bytes(C1, C2, D) bytes: the hashes, the signs and the CSR table bin -> (i*C2+j, sign))
+ *   hk_cbp_rect_bin_matrix   G [B,C1,C2] -> c_raw [B,D]            hk_cbp_rect_unbin_matrix   dc [B,D] -> dG [B,C1,C2]
+ *                            (then dX1 = dG X2, dX2 = dG^T X1)
+ *   hk_cbp_rect_loc_fwd/bwd  sum_pool = False: x1 [B,C1,HW], x2 [B,C2,HW] <-> c [B,HW,D]   (C1, C2 <= 1024; either gradient nullable)
+ * A rect plan holds no host-side state (nothing to destroy).  The signed square root and F.normalize stay the caller's. */
+size_t hk_cbp_rect_plan_bytes(int C1, int C2, int D);
+int hk_cbp_rect_plan_build(const int32_t* h1, const float* s1, int C1, const int32_t* h2, const float* s2, int C2, int D,
+                           void* plan, hk_stream_t stream);
+int hk_cbp_rect_bin_matrix(const float* G, const void* plan, float* c_raw, int B, int C1, int C2, int D, hk_stream_t stream);
+int hk_cbp_rect_unbin_matrix(const float* dc, const void* plan, float* dG, int B, int C1, int C2, int D, hk_stream_t stream);
+int hk_cbp_rect_loc_fwd(const float* x1, const float* x2, const void* plan, float* c, int B, int C1, int C2, int HW, int D,
+                        hk_stream_t stream);
+int hk_cbp_rect_loc_bwd(const float* x1, const float* x2, const float* dc, const void* plan, float* dx1, float* dx2, int B,
+                        int C1, int C2, int HW, int D, hk_stream_t stream);
+
 /* ------------------------------------------------------------------ AP-CNN ----
  * Attention pooling.  The reference materialises A = a_s*F + a_c*F and only ever
  * consumes its global average (cls3/4/5 start with AdaptiveAvgPool2d(1)), so

@@ -151,6 +151,68 @@ def gen_cbp():
          h1=h1, sgn1=s1[torch.arange(512), h1], h2=h2, sgn2=s2[torch.arange(512), h2])
 
 
+def gen_cbp_rect():
+    """CompactBilinearPooling with input_dim1 != input_dim2 (CBCNN.py:68-94: one sketch matrix per input width; :104-105 wants
+    bottom1 / bottom2 of those widths): (24, 16, 64) in full and (384, 512, 4096) subsampled, sum_pool True and False, outputs
+    and both input gradients - the reference in float32 and float64, the float32 run's own distance stored as the yardstick
+    (as gen_cbp's cbp_forms) -> cbp_rect.npz."""
+    res = {}
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for tag, (c1, c2, d), (b, h, w), stride in (('s', (24, 16, 64), (2, 3, 5), 1), ('L', (384, 512, 4096), (2, 7, 7), 13)):
+        for sp in (True, False):
+            runs = {}
+            for dt in (torch.float32, torch.float64):
+                cbp = M_CBCNN.CompactBilinearPooling(c1, c2, d, sum_pool=sp)
+                cbp.sparse_sketch_matrix1 = cbp.sparse_sketch_matrix1.to(dt)
+                cbp.sparse_sketch_matrix2 = cbp.sparse_sketch_matrix2.to(dt)
+                x1 = t(np.abs(rs_randn(1250, (b, c1, h, w))) + 0.1).to(dt).requires_grad_(True)
+                x2 = t(np.abs(rs_randn(1251, (b, c2, h, w))) + 0.1).to(dt).requires_grad_(True)
+                y = cbp(x1, x2)
+                (y * t(rs_randn(1252, tuple(y.shape))).to(dt)).sum().backward()
+                runs[dt] = (y.detach(), x1.grad.clone(), x2.grad.clone())
+            (y, d1, d2), (y64, d164, d264) = runs[torch.float32], runs[torch.float64]
+            k = f'{tag}_{"sum" if sp else "loc"}'
+            res[f'y_{k}'], res[f'y_shape_{k}'] = sub(y, stride), np.array(y.shape)
+            res[f'dx1_{k}'], res[f'dx2_{k}'] = sub(d1, stride), sub(d2, stride)
+            res[f'dx1_64_{k}'], res[f'dx2_64_{k}'] = sub(d164.float(), stride), sub(d264.float(), stride)
+            res[f'e32_{k}'] = np.array([rel(y, y64), rel(d1, d164), rel(d2, d264)])
+            print('cbp_rect', k, 'reference fp32 vs fp64: y %.2e dx1 %.2e dx2 %.2e' % tuple(res[f'e32_{k}']))
+            # the LINEAR part on its own - the sketch before the signed square root, CBCNN.py:113-130 with the module's own
+            # matrices, float64 - and its gradient under a linear functional: what the kernels compute, free of the
+            # conditioning of 1 / sqrt|c| at the bins that nearly cancel
+            x1 = t(np.abs(rs_randn(1250, (b, c1, h, w))) + 0.1).double().requires_grad_(True)
+            x2 = t(np.abs(rs_randn(1251, (b, c2, h, w))) + 0.1).double().requires_grad_(True)
+            sk1 = x1.permute(0, 2, 3, 1).contiguous().view(-1, c1).mm(cbp.sparse_sketch_matrix1)
+            sk2 = x2.permute(0, 2, 3, 1).contiguous().view(-1, c2).mm(cbp.sparse_sketch_matrix2)
+            c = torch.fft.ifft(torch.fft.fft(sk1) * torch.fft.fft(sk2)).real.view(b, h, w, d)
+            if sp:
+                c = c.sum(dim=1).sum(dim=1)
+            (c * t(rs_randn(1253, tuple(c.shape))).double()).sum().backward()
+            res[f'c_{k}'], res[f'dc1_{k}'], res[f'dc2_{k}'] = sub(c.float(), stride), sub(x1.grad.float(), stride), sub(x2.grad.float(), stride)
+            # and what ANY float32 evaluation of the identity by direct summation is away from float64 through the square
+            # root (the oracle's Gram-identity formula, bins filled by index_add): the yardstick beside the FFT route's own
+            h1, h2 = cbp.sparse_sketch_matrix1.abs().argmax(1), cbp.sparse_sketch_matrix2.abs().argmax(1)
+            sg1 = cbp.sparse_sketch_matrix1[torch.arange(c1), h1]
+            sg2 = cbp.sparse_sketch_matrix2[torch.arange(c2), h2]
+            kk = ((h1[:, None] + h2[None, :]) % d).reshape(-1)
+            dd = {}
+            for dt in (torch.float32, torch.float64):
+                a1 = t(np.abs(rs_randn(1250, (b, c1, h, w))) + 0.1).to(dt).requires_grad_(True)
+                a2 = t(np.abs(rs_randn(1251, (b, c2, h, w))) + 0.1).to(dt).requires_grad_(True)
+                f1 = a1.permute(0, 2, 3, 1).reshape(-1, c1) * sg1.to(dt)
+                f2 = a2.permute(0, 2, 3, 1).reshape(-1, c2) * sg2.to(dt)
+                prod = (f1[:, :, None] * f2[:, None, :]).reshape(f1.shape[0], -1)
+                cc = torch.zeros(f1.shape[0], d, dtype=dt).index_add(1, kk, prod).view(b, h, w, d)
+                if sp:
+                    cc = cc.sum(dim=1).sum(dim=1)
+                yy = torch.nn.functional.normalize(torch.sign(cc) * torch.sqrt(torch.abs(cc) + 1e-10))
+                (yy * t(rs_randn(1252, tuple(yy.shape))).to(dt)).sum().backward()
+                dd[dt] = (a1.grad.clone(), a2.grad.clone())
+            res[f'd32_{k}'] = np.array([rel(dd[torch.float32][0], dd[torch.float64][0]), rel(dd[torch.float32][1], dd[torch.float64][1])])
+            print('   direct float32 summation vs float64: dx1 %.2e dx2 %.2e' % tuple(res[f'd32_{k}']))
+    save('cbp_rect', **res)
+
+
 # ---------------------------------------------------------------- MPN-COV
 def gen_mpn():
     for tag, shape, iters in (('mpn_small', (2, 16, 4, 5), (5, 3, 2, 1)),

@@ -118,6 +118,58 @@ def test_bcnn_backward_in_one_launch(F, b, c, hw, k, bias, tune):
         assert rel(res['tdot'][1], xo.grad) < 2e-5 and rel(res['tdot_off'][1], xo.grad) < 2e-5, form
 
 
+@pytest.mark.parametrize('signed', [False, True])
+def test_fused_pool_classifier_keeps_nn_linear_semantics(F, signed):
+    """The fused pooling + classifier node behaves like the nn.Linear it replaces (BCNN.py:42,54) in the two respects the
+    round-5 advisor named: (1) the logits may be modified IN PLACE downstream (`logits /= T`): the node keeps the pre-bias
+    product privately instead of saving its output; (2) <y, dy> = sum_k g_k (y W^T)_k is formed from that pre-bias product,
+    so a bias thousands of times larger than the product costs no precision (it used to be rebuilt as logit - bias)."""
+    b, c, hw, k = 3, 128, 14, 24
+    gen = torch.Generator().manual_seed(17)
+    x = (torch.rand(b, c, hw, hw, generator=gen) + 0.05) * (torch.randint(0, 2, (1, c, 1, 1), generator=gen) * 2.0 - 1.0 if signed else 1.0)
+    w = torch.randn(k, c * c, generator=gen) * 0.05
+    bs = torch.randn(k, generator=gen) * 3000.0                    # |bias| >> |y W^T| ~ 0.05
+    tgt = torch.randint(0, k, (b,), generator=gen)
+    node = F.ssqrt_pool_linear if signed else F.bilinear_pool_linear
+    xg, wg, bg = (v.clone().to(DEV).requires_grad_(True) for v in (x, w, bs))
+    out = node(xg, wg, bg)
+    out /= 2.0                                                     # in place on the node's output
+    out.clamp_(-1e9, 1e9)
+    torch.nn.functional.cross_entropy(out, tgt.to(DEV)).backward()
+    xo, wo, bo = (v.clone().double().requires_grad_(True) for v in (x, w, bs))
+    pooled = (O.bilinear_pool_signed_sqrt if signed else O.bilinear_pool)(xo)
+    torch.nn.functional.cross_entropy(torch.nn.functional.linear(pooled, wo, bo) / 2.0, tgt).backward()
+    e = [rel(xg.grad, xo.grad), rel(wg.grad, wo.grad), rel(bg.grad, bo.grad)]
+    print(f'[fused node, signed={signed}, |bias| 3000 x the product, in-place logits] dX {e[0]:.2e}  dW {e[1]:.2e}  db {e[2]:.2e}')
+    assert e[0] < 2e-5 and e[1] < 1e-5 and e[2] < 1e-5, e
+
+
+def test_bcnn_forward_hooks_fire(F):
+    """Forward hooks on `bilinear_pooling` / `classifier` (feature extraction, CAM tooling written against the reference's
+    BCNN.forward, BCNN.py:53-54, which calls both modules) fire: with hooks present the plugin takes the two-node composition
+    through both modules' __call__ - same kernels, same logits as the fused node."""
+    from hawkeye_amd.config import CfgNode
+    from hawkeye_amd.model.registry import MODEL
+    import hawkeye_amd.model  # noqa: F401
+    from inputs import rs_randn, seeded_init
+    m = MODEL.get('BCNN')(CfgNode(dict(name='BCNN', stage=2, num_classes=10)))
+    seeded_init(m, 77)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(rs_randn(78, (2, 3, 64, 64))).to(DEV)
+    with torch.no_grad():
+        plain = m(x)
+    seen = {}
+    h1 = m.bilinear_pooling.register_forward_hook(lambda mod, i, o: seen.__setitem__('pool', tuple(o.shape)))
+    h2 = m.classifier.register_forward_hook(lambda mod, i, o: seen.__setitem__('cls', tuple(o.shape)))
+    with torch.no_grad():
+        hooked = m(x)
+    h1.remove()
+    h2.remove()
+    assert seen == {'pool': (2, 512 * 512), 'cls': (2, 10)}
+    assert 'forward' not in m.classifier.__dict__                  # the instance is left as it was
+    assert rel(hooked, plain) < 1e-6
+
+
 @pytest.mark.parametrize('b,c,hw,d', [(2, 128, 14, 2048), (3, 256, 10, 1000), (2, 64, 14, 96), (2, 256, 8, 6000), (3, 128, 12, 500)])
 def test_cbp_backward_bwd3c_kernel(F, b, c, hw, d, tune):
     """cbp_bwd3_kernel (hk_bwd3c.h) - the compact-bilinear backward GEMM with P generated from dc in LDS - in its three

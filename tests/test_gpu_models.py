@@ -311,10 +311,10 @@ def test_apcnn_at_config_shape_eval_vs_reference():
     assert out_mean.argmax(1).cpu().tolist() == g['out_mean'].reshape(2, -1).argmax(1).tolist()
 
 
-def test_apcnn_at_config_shape_train_vs_reference():
-    """The same model in TRAIN mode at batch 4 with the reference's python-`random` drop sequence (seed 5,
-    exact_random_stream): ROI cells, both stages' logits and gradients at five depths, pinned on the reference's float64
-    run with the reference's own float32 distance as the yardstick (as test_apcnn_train_mode_matches_reference)."""
+def _apcnn_448_train_distances():
+    """One train-mode forward + backward of the AP-CNN plugin as test_apcnn_at_config_shape_train_vs_reference runs it
+    (448 x 448, 8142 classes, batch 4, the reference's python-`random` drop sequence, seed 5) -> {tensor name: distance to the
+    reference's float64 run / the reference's own float32-vs-float64 distance}; ROI cells asserted bit-exact on the way."""
     import random
     g = load('model_apcnn_448')
     n = g['t_out_mean'].shape[0]
@@ -331,21 +331,83 @@ def test_apcnn_at_config_shape_train_vs_reference():
         got = got.cpu().numpy()
         assert got.shape == g[key].shape
         np.testing.assert_array_equal(got[:, :5], g[key][:, :5])
-    k = APCNN_TRAIN_K_448
-    worst = 0.0
+    dist = {}
     for i, o in enumerate(out_list):
-        r = float(rel(o, g['t_out_list'][i])) / max(float(g['t_e32_out_list'][i]), 1e-5)
-        worst = max(worst, r)
-        assert r < k, (i, r)
-    assert rel(out_mean, g['t_out_mean']) < k * max(float(g['t_e32_out_mean'][0]), 1e-5)
+        dist['out_list[%d]' % i] = float(rel(o, g['t_out_list'][i])) / max(float(g['t_e32_out_list'][i]), 1e-5)
+    dist['out_mean'] = float(rel(out_mean, g['t_out_mean'])) / max(float(g['t_e32_out_mean'][0]), 1e-5)
     grads = dict(m.named_parameters())
     for i, name in enumerate(g['t_grad_names']):
         gr = grads[str(name)].grad
-        r = float(rel(sub(gr.cpu(), max(7, gr.numel() // 2000 | 1)), g['t_g%d' % i])) / max(float(g['t_e32_g'][i]), 1e-5)
-        worst = max(worst, r)
-        assert r < k, (str(name), r)
-        assert abs(float(gr.double().norm()) / float(g['t_gn%d' % i][0]) - 1) < k * max(float(g['t_e32_g'][i]), 1e-5), str(name)
+        dist['d ' + str(name)] = float(rel(sub(gr.cpu(), max(7, gr.numel() // 2000 | 1)), g['t_g%d' % i])) / max(float(g['t_e32_g'][i]), 1e-5)
+        dist['|d ' + str(name) + '|'] = abs(float(gr.double().norm()) / float(g['t_gn%d' % i][0]) - 1) / max(float(g['t_e32_g'][i]), 1e-5)
+    return dist
+
+
+def test_apcnn_at_config_shape_train_vs_reference():
+    """The same model in TRAIN mode at batch 4 with the reference's python-`random` drop sequence (seed 5,
+    exact_random_stream): ROI cells, both stages' logits and gradients at five depths, pinned on the reference's float64
+    run with the reference's own float32 distance as the yardstick (as test_apcnn_train_mode_matches_reference)."""
+    dist = _apcnn_448_train_distances()
+    k = APCNN_TRAIN_K_448
+    worst = max(dist.values())
+    for name, r in dist.items():
+        assert r < k, (name, r)
     print(f'[apcnn 448 train] worst distance / reference fp32-vs-fp64 distance: {worst:.2f} (bound {k})')
+
+
+def _torch_heads(monkeypatch):
+    """Replace the hand-written kernels on AP-CNN's differentiable path by the reference's own torch formulas ON THE DEVICE
+    (APCNN.py:256-266 + the GAP of cls*, :478-531 with the boxes the plugin hands over) - a checker for the test below, not
+    a product path.  The ROI selection (no gradient, bit-exact against the reference cell for cell) stays on its kernel, so
+    both runs crop the same boxes."""
+    import hawkeye_amd.functional as HF
+
+    def att_pool(f, a_s=None):
+        return f.mean((2, 3)), (None if a_s is None else (a_s * f).mean((2, 3)))
+
+    def att_pool_levels(feats, atts):
+        return (torch.stack([f.mean((2, 3)) for f in feats]), torch.stack([(a * f).mean((2, 3)) for f, a in zip(feats, atts)]))
+
+    def roi_crop_resize(x, box, drop, training):
+        n, c, hh, ww = x.shape
+        bx, dr = box.cpu(), drop.cpu()
+        outs = []
+        for i in range(n):
+            x1, y1, x2, y2 = (int(v) for v in bx[i].long())                   # .long() truncation, :507
+            if training:
+                mask = torch.ones(c, hh, ww, dtype=x.dtype, device=x.device)
+                if float(dr[i, 2]) >= 0:                                       # a level-3 / level-4 ROI was drawn (:494-504)
+                    d = dr[i].long()
+                    mask[:, int(d[1]):int(d[3]), int(d[0]):int(d[2])] = 0
+                crop = (x[i] * mask)[:, y1:y2, x1:x2].contiguous().unsqueeze(0)
+                rate = c * (bx[i, 3] - bx[i, 1]) * (bx[i, 2] - bx[i, 0]) / mask[:, y1:y2, x1:x2].sum().cpu()   # :509-511
+                crop = crop * rate.to(x.device)
+            else:
+                crop = x[i, :, y1:y2, x1:x2].contiguous().unsqueeze(0)
+            outs.append(torch.nn.functional.interpolate(crop, (hh, ww), mode='bilinear', align_corners=False))
+        return torch.cat(outs, 0)
+
+    for name, fn in (('att_pool', att_pool), ('att_pool_levels', att_pool_levels), ('roi_crop_resize', roi_crop_resize)):
+        monkeypatch.setattr(HF, name, fn)
+
+
+def test_apcnn_train_distance_is_the_trunks_not_the_heads(monkeypatch):
+    """Where does the distance of test_apcnn_at_config_shape_train_vs_reference (5.4 x the reference's own fp32-vs-fp64
+    distance at 448 x 448 / 8142 classes, against 1.1 for torch on the CPU) come from?  The same plugin, weights, input and
+    drop sequence run twice on the MI355X: with the hk kernels, and with the attention pooling and the ROI crop / resize
+    replaced by the reference's torch formulas on the device (everything else - MIOpen trunk, FPN, gates, classifier heads -
+    identical).  If the two worst distances agree, the excess is the convolution library's summation order under train-mode
+    BatchNorm, not the hand-written heads; both are printed per tensor."""
+    d_hk = _apcnn_448_train_distances()
+    _torch_heads(monkeypatch)
+    d_th = _apcnn_448_train_distances()
+    print('[apcnn 448 train, distance / reference fp32-vs-fp64 distance]  tensor: hk heads | torch-op heads on the device')
+    for name in d_hk:
+        if not name.startswith('|'):
+            print(f'    {name:48s} {d_hk[name]:6.2f} | {d_th[name]:6.2f}')
+    w_hk, w_th = max(d_hk.values()), max(d_th.values())
+    print(f'[apcnn 448 train] worst: hk heads {w_hk:.2f}, torch-op heads {w_th:.2f} (ratio {w_hk / w_th:.2f})')
+    assert w_hk < 1.2 * w_th + 0.5, (w_hk, w_th)
 
 
 def test_apcnn_exact_random_stream_mode():

@@ -406,6 +406,46 @@ def test_cbp_two_inputs_and_per_location_vs_reference(F):
     assert rel(y2, y1) < 1e-5 and rel(xb.grad, xa.grad) < 1e-4
 
 
+def test_cbp_rectangular_vs_reference(F):
+    """CompactBilinearPooling(input_dim1 != input_dim2) - CBCNN.py:68-94 sizes each sketch matrix by its own width, :104-105
+    wants bottom1 / bottom2 of those widths - through the plugin module against the reference module on the same inputs
+    (tests/golden/cbp_rect.npz, gen_cbp_rect): (24, 16, 64) and (384, 512, 4096), sum_pool True (the C1 x C2 cross Gram binned by
+    the rect plan) and False (every location on its own).
+    (1) the LINEAR part - the sketch before the signed square root and its gradient under a linear functional - against
+        the reference's own lines 113-130 in float64: tight (1e-5), this is what the kernels compute;
+    (2) the module's output (1e-5) and both input gradients against the reference's float64 run, bounded by 1e-4 + twice what
+        a float32 evaluation is away from it - the larger of the reference's own float32 run (FFT route) and a float32 direct
+        summation of the identity: at (384, 512, 4096) per location 48 signed products share a bin, a few bins nearly cancel,
+        and 1 / sqrt|c| amplifies whatever rounding the route has there (5e-3 for the FFTs, 5e-2 for any direct sum)."""
+    from hawkeye_amd.model.methods.CBCNN import CompactBilinearPooling
+    g = load('cbp_rect')
+    for tag, (c1, c2, d), (b, h, w), stride in (('s', (24, 16, 64), (2, 3, 5), 1), ('L', (384, 512, 4096), (2, 7, 7), 13)):
+        for sp in (True, False):
+            k = f'{tag}_{"sum" if sp else "loc"}'
+            pool = CompactBilinearPooling(c1, c2, d, sum_pool=sp)
+            mk = lambda: (t(np.abs(rs_randn(1250, (b, c1, h, w))) + 0.1).to(DEV).requires_grad_(True),
+                          t(np.abs(rs_randn(1251, (b, c2, h, w))) + 0.1).to(DEV).requires_grad_(True))
+            x1, x2 = mk()
+            c = F.compact_bilinear_sketch(x1, x2, pool._plan(x1.device), sp)
+            (c * t(rs_randn(1253, tuple(c.shape))).to(DEV)).sum().backward()
+            ec, e1, e2 = rel(sub(c.cpu(), stride), g[f'c_{k}']), rel(sub(x1.grad.cpu(), stride), g[f'dc1_{k}']), rel(sub(x2.grad.cpu(), stride), g[f'dc2_{k}'])
+            print(f'[cbp rect {c1} x {c2} -> {d}, sum_pool={sp}] sketch {ec:.2e}  its gradients {e1:.2e} / {e2:.2e}')
+            assert ec < 1e-5 and e1 < 1e-5 and e2 < 1e-5, (k, ec, e1, e2)
+            x1, x2 = mk()
+            y = pool(x1, x2)
+            assert list(y.shape) == g[f'y_shape_{k}'].tolist()
+            (y * t(rs_randn(1252, tuple(y.shape))).to(DEV)).sum().backward()
+            yard = [max(float(g[f'e32_{k}'][1 + i]), float(g[f'd32_{k}'][i])) for i in (0, 1)]
+            ey = rel(sub(y.cpu(), stride), g[f'y_{k}'])
+            e1, e2 = rel(sub(x1.grad.cpu(), stride), g[f'dx1_64_{k}']), rel(sub(x2.grad.cpu(), stride), g[f'dx2_64_{k}'])
+            print(f'    module: y {ey:.2e}  dx1 {e1:.2e}  dx2 {e2:.2e} vs the reference in float64 (float32 yardsticks {yard[0]:.2e} / {yard[1]:.2e})')
+            assert ey < 1e-5, k
+            assert e1 < 1e-4 + 2 * yard[0] and e2 < 1e-4 + 2 * yard[1], (k, e1, e2)
+    # one input cannot satisfy two widths (the reference's assert, CBCNN.py:104-105)
+    with pytest.raises(AssertionError):
+        CompactBilinearPooling(24, 16, 64)(t(rs_randn(1, (2, 24, 3, 5))).to(DEV))
+
+
 @pytest.mark.parametrize('csr', ['0', '1', '2', '3', '4'])
 def test_cbp_512_both_binning_kernels(F, csr, tune):
     """hk_cbp_fwd has the fused Gram + binning kernel (3: the default) and three binning kernels behind a separate Gram

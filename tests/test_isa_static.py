@@ -13,6 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'hawkeye_amd', 'csrc')   # hk_common.h includes <hk_isa.h>
 
 
 def _loops(lines):
@@ -40,7 +41,7 @@ def _serialised_staging_loops(txt):
 def test_streamed_cin_product_counts_its_requests(tmp_path):
     src = os.path.join(ROOT, 'hawkeye_amd', 'csrc', 'cin.hip')
     out = str(tmp_path / 'cin.s')
-    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-o', out, src],
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + CSRC, '-S', '--cuda-device-only', '-o', out, src],
                    check=True, capture_output=True, timeout=600)
     txt = open(out).read()
     assert not _serialised_staging_loops(txt), _serialised_staging_loops(txt)
@@ -129,7 +130,7 @@ def test_gram_forward_leaves_in_16_byte_stores_and_never_spills(tmp_path):
     150 KB of panels + 8 KB of turn-tables fit the 160 KB of a CU."""
     src = os.path.join(ROOT, 'hawkeye_amd', 'csrc', 'bcnn_fast.hip')
     out = str(tmp_path / 'bcnn_fast.s')
-    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-o', out, src],
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + CSRC, '-S', '--cuda-device-only', '-o', out, src],
                    check=True, capture_output=True, timeout=900)
     txt = open(out).read()
     assert not _serialised_staging_loops(txt), _serialised_staging_loops(txt)
@@ -163,7 +164,7 @@ def test_classifier_kernels_keep_their_counted_waits(tmp_path):
         but it does not belong between two MFMA units."""
     src = os.path.join(ROOT, 'hawkeye_amd', 'csrc', 'linear.hip')
     out = str(tmp_path / 'linear.s')
-    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-o', out, src],
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + CSRC, '-S', '--cuda-device-only', '-o', out, src],
                    check=True, capture_output=True, timeout=900)
     txt = open(out).read()
     assert not _serialised_staging_loops(txt), _serialised_staging_loops(txt)
