@@ -368,7 +368,7 @@ def final_line(res):
     return line
 
 
-def emit(res, detail):
+def emit(res, detail, seal=False):
     """Detail -> gpurun_out/bench_detail.json + a short table on stderr; then the final line, last on stdout."""
     if detail:
         # (HAWKEYE_BENCH_DETAIL: where the tests' own bench runs put theirs - not over the record of the real one)
@@ -399,8 +399,37 @@ def emit(res, detail):
             else:
                 print(f'[bench] hipGraph {k}', file=sys.stderr)
         sys.stderr.flush()
+    if seal:         # the real run: nothing may follow the line on this process's stdout (seal_stdout)
+        seal_stdout(final_line(res))
+    else:
+        sys.stdout.flush()
+        print(final_line(res), flush=True)
+
+
+def flush_c_stdio():
+    """Native libraries in this process write to the C stdio buffers of stdout (RCCL's version banner sits there until exit):
+    push them out NOW, so that nothing of theirs can land behind the line the driver parses."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def seal_stdout(line=None):
+    """Print `line` (rank 0: the final JSON line; other ranks: nothing) as the LAST thing this process ever writes to stdout:
+    flush python's and C's buffers first, then point fd 1 at /dev/null - a banner flushed at exit, an atexit message of a
+    library or a late warning cannot follow the line any more."""
     sys.stdout.flush()
-    print(final_line(res), flush=True)
+    flush_c_stdio()
+    if line is not None:
+        os.write(1, (line + '\n').encode())
+    try:
+        null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null, 1)
+        os.close(null)
+    except OSError:
+        pass
 
 
 def main():
@@ -551,8 +580,13 @@ def main():
             torch.cuda.empty_cache()
             detail['other_models'] = other_models()
             detail['graph_rows'] = graph_rows()
-        emit(res, detail)
-    if world > 1:
+        if world > 1:               # every other rank has sealed its stdout before rank 0 writes the line (below)
+            torch.distributed.barrier()
+        emit(res, detail, seal=True)
+    elif world > 1:
+        seal_stdout()
+        torch.distributed.barrier()
+    if use_pg:
         torch.distributed.destroy_process_group()
 
 

@@ -57,9 +57,13 @@ def _arm_rccl_log(rank):
     own NCCL_DEBUG* settings win), so that the first run on more than one GPU records by itself what RCCL built over the
     xGMI mesh - channel count, rings / trees, transport per peer, the algorithm / protocol picked per message size - without
     a code change (SURVEY section 5's ring-vs-direct arithmetic; replaces nothing in the reference, which has no log of
-    DataParallel's copies either).  HAWKEYE_RCCL_LOG=0 turns it off."""
+    DataParallel's copies either).  HAWKEYE_RCCL_LOG=0 turns it off.  Side effect worth having: RCCL's version banner, which
+    it otherwise leaves in the C stdio buffer of STDOUT until the process exits (measured on the MI355X box: five lines BEHIND
+    everything python printed), goes to the file as well."""
     global _RCCL_LOG
-    if os.environ.get('HAWKEYE_RCCL_LOG', '1') == '0' or 'NCCL_DEBUG' in os.environ or 'NCCL_DEBUG_FILE' in os.environ:
+    # (an image-wide NCCL_DEBUG=VERSION / WARN is not a choice of the caller's: only INFO / TRACE or an explicit file are)
+    if os.environ.get('HAWKEYE_RCCL_LOG', '1') == '0' or os.environ.get('NCCL_DEBUG', '').upper() in ('INFO', 'TRACE') or \
+            'NCCL_DEBUG_FILE' in os.environ:
         return
     import tempfile
     _RCCL_LOG = os.path.join(tempfile.gettempdir(), f'hk_rccl_{os.getpid()}_r{rank}.log')

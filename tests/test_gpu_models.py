@@ -535,6 +535,33 @@ def test_bench_spawns_its_own_ranks(tmp_path, world):
     assert 1 <= d['host_threads_per_rank'] <= max(1, (os.cpu_count() or 1) // world)
 
 
+def test_bench_line_is_last_on_stdout_with_rccl(tmp_path):
+    """The driver parses bench.py's LAST stdout line.  With the `nccl` (RCCL) backend the library leaves its version banner
+    in the C stdio buffer of stdout until the process exits - behind everything python printed (observed on the MI355X box
+    with stdout on a pipe, which is how the driver reads it).  One rank over RCCL (--force-pg), stdout on a pipe: the JSON
+    line must still be the last one, and it carries what RCCL logged about the communicator (`ddp.rccl`)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'NCCL_DEBUG_FILE')}
+    env['HAWKEYE_BENCH_DETAIL'] = str(tmp_path / 'bench_detail.json')
+    env['MASTER_PORT'] = '29517'
+    for rccl_log in ('1', '0'):                # with the log armed (banner in the file) and without (banner on stdout at exit)
+        env['HAWKEYE_RCCL_LOG'] = rccl_log
+        p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--force-pg', '--steps', '2', '--warmup', '1', '--batch', '2',
+                            '--image', '64', '--no-cpu-baseline', '--no-kernels', '--no-other-models'],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        last = p.stdout.rstrip().splitlines()[-1]
+        assert last.startswith('{'), p.stdout[-600:]
+        out = json.loads(last)
+        assert out['n_gpus'] == 1 and out['value'] > 0 and 'issued_ms' in out['ddp']
+        if rccl_log == '1':
+            assert 'RCCL' in (out['ddp']['rccl']['version'] or ''), out['ddp']
+            print('[bench --force-pg] ddp.rccl =', out['ddp']['rccl'])
+
+
 def test_trainer_runs_one_synthetic_epoch(tmp_path):
     """The reference's Trainer flow (build from yaml -> train -> validate -> checkpoint) on the MI355X heads."""
     from hawkeye_amd.config import CfgNode
