@@ -1,0 +1,266 @@
+// Epilogues of the VGG trunk's convolutions (SURVEY 8a row A1': the BCNN / CBCNN module is `features` = 13 x [Conv2d 3x3 + bias,
+// ReLU] with five MaxPool2d(2, 2), model/backbone/vgg.py:24-57, and at 448 x 448 / batch 64 its activations are up to 3.3 GB
+// each).  The convolutions themselves stay MIOpen's; what PyTorch-ROCm runs AROUND them is one full-tensor pass per
+// elementwise op - bias add, ReLU, max-pool forward; pool backward, ReLU backward, bias-gradient reduction - 26.9 ms of the
+// 213.9 ms BCNN training step (profiles/r5_step_BCNN_kernel_stats.csv: 12.5 %, ninety times the whole pooling head).
+// These kernels make it ONE pass per convolution and direction, on the channels_last tensors the trunk runs in:
+//
+//   bias_relu_fwd        y = max(x + b, 0) in place on the convolution's output                  (read 1, write 1; was 2 + 2)
+//   bias_relu_bwd        dx = dy where y > 0, db = sum dx                                        (read 2, write 1; was 3 + 1 + 1)
+//   bias_relu_pool_fwd   p = maxpool2x2(max(x + b, 0)) + a 2-bit argmax per element              (read 1, write 1/4 + 1/64;
+//                        the full-resolution activation is never written: nobody needs it - the next convolution reads p,
+//                        this convolution's weight gradient reads its INPUT - was 2 + 2 + 1.75)
+//   bias_relu_pool_bwd   dx = dp at the argmax where p > 0, else 0; db = sum dx                  (read 1/2 + 1/64, write 1; was 5.75)
+//
+// All HBM-bound streams (16-byte accesses, NHWC: a pixel's channels are contiguous).  Same arithmetic as the ops they
+// replace: x + b then max(., 0) (torch.relu's clamp_min, NaN kept); the pooling window scanned row-major with "strictly
+// greater or NaN replaces" (ATen's max_pool2d: the FIRST maximum wins); the backward routes dp to that element and
+// applies ReLU's mask (y > 0  <=>  p > 0 at the argmax).  db is summed in a fixed order (per thread over its rows, threads of
+// a column quad in order, workgroups in order): deterministic, no atomics.
+#include "hk_common.h"
+#include "../../include/hawkeye_hip.h"
+
+namespace hk {
+
+constexpr int TRUNK_PART_BLOCKS = 2048;        // workgroups (= partial db rows) of the backward kernels, at most
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    f32x4 r;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r[t] = v[t] < 0.f ? 0.f : v[t];            // (NaN < 0 is false: NaN stays, as clamp_min)
+    return r;
+}
+
+// x [M][C] (M = N H W pixels), C % 4 == 0: in place.  n4 = M C / 4 float4, c4 = C / 4.
+__global__ __launch_bounds__(256) void bias_relu_fwd_kernel(float* __restrict__ x, const float* __restrict__ b, long long n4, int c4) {
+    f32x4* x4 = reinterpret_cast<f32x4*>(x);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n4) v[u] = x4[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long j = i + u * stride;
+            if (j < n4) x4[j] = relu4(v[u] + b4[(int)(j % c4)]);
+        }
+    }
+}
+
+// Shared tail of the two backward kernels: this thread's partial db of its column quad -> the workgroup's partial row.
+// Thread t owns column quad t % c4 (256 % c4 == 0: 256 / c4 threads per quad); their sums are added in thread order.
+__device__ __forceinline__ void trunk_db_partial(f32x4 acc, float* __restrict__ part, int c4) {
+    __shared__ f32x4 red[256];
+    const int tid = threadIdx.x;
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < c4) {
+        f32x4 s = red[tid];
+        for (int g = 1; g < 256 / c4; ++g) s += red[tid + g * c4];
+        reinterpret_cast<f32x4*>(part + (long long)blockIdx.x * 4 * c4)[tid] = s;
+    }
+}
+
+// dx = dy * (y > 0) ; part[block][C] = this workgroup's column sums of dx.  rows = M, workgroup b owns rows
+// [b rpb, (b + 1) rpb).  dx may alias dy.
+__global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* dy, const float* __restrict__ y, float* dx,
+                                                            float* __restrict__ part, long long rows, long long rpb, int c4) {
+    const int tid = threadIdx.x, q = tid % c4, r0 = tid / c4, rstep = 256 / c4;
+    const long long rbeg = (long long)blockIdx.x * rpb, rend = rbeg + rpb < rows ? rbeg + rpb : rows;
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (long long r = rbeg + r0; r < rend; r += 4 * rstep) {
+        f32x4 g[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long rr = r + u * rstep;
+            if (rr < rend) { g[u] = dy4[rr * c4 + q]; v[u] = y4[rr * c4 + q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long rr = r + u * rstep;
+            if (rr < rend) {
+                f32x4 d;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d[t] = v[u][t] > 0.f ? g[u][t] : 0.f;      // threshold_backward: y <= 0 -> 0
+                dx4[rr * c4 + q] = d;
+                acc += d;
+            }
+        }
+    }
+    trunk_db_partial(acc, part, c4);
+}
+
+// db[c] = sum over the nblk partial rows, in order: one workgroup per 16 channels, 16 groups of partial rows, then the groups
+__global__ __launch_bounds__(256) void trunk_db_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ db) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (int k = g; k < nblk; k += 16) s += part[(long long)k * C + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float t = red[0][cl];
+        for (int k = 1; k < 16; ++k) t += red[k][cl];
+        db[c] = t;
+    }
+}
+
+// x [N][H][W][C] -> p [N][H/2][W/2][C], am [N][H/2][W/2][C/4] (one byte per channel quad: 2 bits per channel, window position
+// 2 dh + dw of the first maximum).  One thread per pooled float4.
+__global__ __launch_bounds__(256) void bias_relu_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                                                 float* __restrict__ p, uint8_t* __restrict__ am, long long n4out,
+                                                                 int c4, int Wo, int Ho) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4out) return;
+    const int q = (int)(i % c4);
+    const long long pix = i / c4;                       // (n Ho + ho) Wo + wo
+    const int wo = (int)(pix % Wo);
+    const long long nh = pix / Wo;                      // n Ho + ho
+    const int ho = (int)(nh % Ho);
+    const long long n = nh / Ho;
+    const long long W = 2ll * Wo;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const long long base = ((n * 2 * Ho + 2 * ho) * W + 2 * wo) * c4 + q;       // float4 index of window element (0, 0)
+    f32x4 v[4];
+    v[0] = x4[base];
+    v[1] = x4[base + c4];
+    v[2] = x4[base + W * c4];
+    v[3] = x4[base + W * c4 + c4];
+    const f32x4 bb = reinterpret_cast<const f32x4*>(b)[q];
+    f32x4 m = relu4(v[0] + bb);
+    unsigned code = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const f32x4 a = relu4(v[k] + bb);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool take = (a[t] > m[t]) || (a[t] != a[t]);          // ATen max_pool2d: (val > max) || isnan(val)
+            m[t] = take ? a[t] : m[t];
+            code = take ? ((code & ~(3u << (2 * t))) | ((unsigned)k << (2 * t))) : code;
+        }
+    }
+    reinterpret_cast<f32x4*>(p)[i] = m;
+    am[i] = (uint8_t)code;
+}
+
+// dp, p [N][Ho][Wo][C], am -> dx [N][2 Ho][2 Wo][C] (every element written), part[block][C] = column sums of dx.
+// Workgroup b owns pooled pixels [b ppb, (b + 1) ppb).
+__global__ __launch_bounds__(256) void bias_relu_pool_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p,
+                                                                 const uint8_t* __restrict__ am, float* __restrict__ dx,
+                                                                 float* __restrict__ part, long long npix, long long ppb, int c4,
+                                                                 int Wo, int Ho) {
+    const int tid = threadIdx.x, q = tid % c4, r0 = tid / c4, rstep = 256 / c4;
+    const long long pbeg = (long long)blockIdx.x * ppb, pend = pbeg + ppb < npix ? pbeg + ppb : npix;
+    const f32x4* dp4 = reinterpret_cast<const f32x4*>(dp);
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(p);
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    const long long W = 2ll * Wo;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (long long pix = pbeg + r0; pix < pend; pix += 2 * rstep) {
+        f32x4 g[2], v[2];
+        unsigned code[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long pp = pix + u * rstep;
+            if (pp < pend) { g[u] = dp4[pp * c4 + q]; v[u] = p4[pp * c4 + q]; code[u] = am[pp * c4 + q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long pp = pix + u * rstep;
+            if (pp >= pend) continue;
+            const int wo = (int)(pp % Wo);
+            const long long nh = pp / Wo;
+            const int ho = (int)(nh % Ho);
+            const long long n = nh / Ho;
+            const long long base = ((n * 2 * Ho + 2 * ho) * W + 2 * wo) * c4 + q;
+            f32x4 d;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = v[u][t] > 0.f ? g[u][t] : 0.f;
+            acc += d;
+            f32x4 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[k][t] = ((code[u] >> (2 * t)) & 3u) == (unsigned)k ? d[t] : 0.f;
+            dx4[base] = o[0];
+            dx4[base + c4] = o[1];
+            dx4[base + W * c4] = o[2];
+            dx4[base + W * c4 + c4] = o[3];
+        }
+    }
+    trunk_db_partial(acc, part, c4);
+}
+
+static inline bool trunk_c_ok(int C) {              // 256 % (C / 4) == 0: a column quad per thread, whole rows per workgroup pass
+    return C >= 4 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0;
+}
+static inline int trunk_blocks(long long rows) {
+    long long b = (rows + 63) / 64;                  // at least 64 rows per workgroup
+    return (int)(b < 1 ? 1 : (b > TRUNK_PART_BLOCKS ? TRUNK_PART_BLOCKS : b));
+}
+
+}  // namespace hk
+
+using namespace hk;
+
+extern "C" size_t hk_trunk_ws_bytes(int C) { return C > 0 ? (size_t)TRUNK_PART_BLOCKS * C * sizeof(float) : 0; }
+
+extern "C" int hk_bias_relu_fwd(float* x, const float* bias, long long rows, int C, hk_stream_t stream) {
+    if (!x || !bias || rows <= 0 || C <= 0) return HK_ERR_BAD_ARG;
+    if (C % 4 != 0 || !aligned16(x) || !aligned16(bias)) return HK_ERR_UNSUPPORTED;
+    const long long n4 = rows * (C / 4);
+    long long blocks = (n4 + 1023) / 1024;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bias_relu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, n4, C / 4);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_bias_relu_bwd(const float* dy, const float* y, float* dx, float* dbias, long long rows, int C, void* ws,
+                                size_t ws_bytes, hk_stream_t stream) {
+    if (!dy || !y || !dx || !dbias || rows <= 0 || C <= 0) return HK_ERR_BAD_ARG;
+    if (!trunk_c_ok(C) || !aligned16(dy) || !aligned16(y) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < hk_trunk_ws_bytes(C)) return HK_ERR_WORKSPACE;
+    const int nblk = trunk_blocks(rows);
+    const long long rpb = (rows + nblk - 1) / nblk;
+    hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (float*)ws, rows, rpb, C / 4);
+    HK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(trunk_db_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, C, dbias);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_bias_relu_pool_fwd(const float* x, const float* bias, float* p, uint8_t* argmax, int N, int H, int W, int C,
+                                     hk_stream_t stream) {
+    if (!x || !bias || !p || !argmax || N <= 0 || H <= 0 || W <= 0 || C <= 0) return HK_ERR_BAD_ARG;
+    if (C % 4 != 0 || H % 2 != 0 || W % 2 != 0 || !aligned16(x) || !aligned16(bias) || !aligned16(p)) return HK_ERR_UNSUPPORTED;
+    const long long n4out = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    if ((n4out + 255) / 256 > 0x7fffffffll) return HK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bias_relu_pool_fwd_kernel, dim3((unsigned)((n4out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, bias, p,
+                       argmax, n4out, C / 4, W / 2, H / 2);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_bias_relu_pool_bwd(const float* dp, const float* p, const uint8_t* argmax, float* dx, float* dbias, int N, int H,
+                                     int W, int C, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    if (!dp || !p || !argmax || !dx || !dbias || N <= 0 || H <= 0 || W <= 0 || C <= 0) return HK_ERR_BAD_ARG;
+    if (!trunk_c_ok(C) || H % 2 != 0 || W % 2 != 0 || !aligned16(dp) || !aligned16(p) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < hk_trunk_ws_bytes(C)) return HK_ERR_WORKSPACE;
+    const long long npix = (long long)N * (H / 2) * (W / 2);
+    const int nblk = trunk_blocks(npix);
+    const long long ppb = (npix + nblk - 1) / nblk;
+    hipLaunchKernelGGL(bias_relu_pool_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dp, p, argmax, dx, (float*)ws, npix,
+                       ppb, C / 4, W / 2, H / 2);
+    HK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(trunk_db_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, C, dbias);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}

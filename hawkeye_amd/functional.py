@@ -1078,6 +1078,102 @@ def linear(y, weight, bias=None):
     return _Linear.apply(y, weight, bias)
 
 
+# --------------------------------------------------------------------- VGG trunk epilogues
+def _nhwc(t, what):
+    """A [N,C,H,W] fp32 tensor whose memory is NHWC (channels_last) - the layout the trunk runs in."""
+    if t.dtype != torch.float32:
+        raise _lib.HawkeyeHipError(f'{what}: fp32 only, got {t.dtype}')
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise _lib.HawkeyeHipError(f'{what}: needs a channels_last [N,C,H,W] tensor, got shape {tuple(t.shape)} strides {t.stride()}')
+    return t
+
+
+def trunk_epilogue_ok(x, pool=False):
+    """Whether hk_bias_relu_* serve this convolution output: an fp32 channels_last map on a HIP device, C / 4 a divisor of 256
+    (VGG: 64 .. 512), even H and W for the pooled form.  Anything else stays on the framework's own ops (model/backbone/vgg.py)."""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    n, c, h, w = x.shape
+    ok = n > 0 and c % 4 == 0 and c // 4 <= 256 and 256 % (c // 4) == 0 and x.is_contiguous(memory_format=torch.channels_last)
+    return ok and (not pool or (h % 2 == 0 and w % 2 == 0 and h > 0 and w > 0)) and x.data_ptr() % 16 == 0
+
+
+class _BiasReLU(torch.autograd.Function):
+    """y = relu(conv_out + bias) IN PLACE on the convolution's output; backward: dx = dy where y > 0, dbias = sum dx in one
+    pass.  replaces nn.Conv2d's bias add + nn.ReLU(inplace=True) of the VGG trunk (model/backbone/vgg.py:24-57)."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        lib = _lib.load()
+        _nhwc(x, 'bias_relu')
+        n, c, h, w = x.shape
+        b = _f32c(bias)
+        check(lib.hk_bias_relu_fwd(ptr(x), ptr(b), n * h * w, c, stream()), 'hk_bias_relu_fwd')
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        n, c, h, w = y.shape
+        if dy.dtype != torch.float32:
+            raise _lib.HawkeyeHipError(f'bias_relu backward: fp32 only, got {dy.dtype}')
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(dy, memory_format=torch.channels_last)
+        db = torch.empty(c, dtype=torch.float32, device=y.device)
+        nws = lib.hk_trunk_ws_bytes(c)
+        ws = _ws(nws, y.device)
+        check(lib.hk_bias_relu_bwd(ptr(dy), ptr(y), ptr(dx), ptr(db), n * h * w, c, ptr(ws), nws, stream()), 'hk_bias_relu_bwd')
+        return dx, db
+
+
+class _BiasReLUPool(torch.autograd.Function):
+    """p = maxpool2x2(relu(conv_out + bias)); the full-resolution activation is never written - a 2-bit argmax per element is
+    kept instead - and the backward routes dp through pool, ReLU and the bias sum in one pass.  replaces the bias add +
+    nn.ReLU + nn.MaxPool2d(2, 2) behind the last convolution of each VGG stage (model/backbone/vgg.py:24-57)."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        lib = _lib.load()
+        _nhwc(x, 'bias_relu_pool')
+        n, c, h, w = x.shape
+        b = _f32c(bias)
+        p = torch.empty(n, c, h // 2, w // 2, dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+        am = torch.empty(n, h // 2, w // 2, c // 4, dtype=torch.uint8, device=x.device)
+        check(lib.hk_bias_relu_pool_fwd(ptr(x), ptr(b), ptr(p), ptr(am), n, h, w, c, stream()), 'hk_bias_relu_pool_fwd')
+        ctx.save_for_backward(p, am)
+        ctx.in_shape = (n, c, h, w)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        lib = _lib.load()
+        p, am = ctx.saved_tensors
+        n, c, h, w = ctx.in_shape
+        if dp.dtype != torch.float32:
+            raise _lib.HawkeyeHipError(f'bias_relu_pool backward: fp32 only, got {dp.dtype}')
+        dp = dp.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty(n, c, h, w, dtype=torch.float32, device=p.device).contiguous(memory_format=torch.channels_last)
+        db = torch.empty(c, dtype=torch.float32, device=p.device)
+        nws = lib.hk_trunk_ws_bytes(c)
+        ws = _ws(nws, p.device)
+        check(lib.hk_bias_relu_pool_bwd(ptr(dp), ptr(p), ptr(am), ptr(dx), ptr(db), n, h, w, c, ptr(ws), nws, stream()),
+              'hk_bias_relu_pool_bwd')
+        return dx, db
+
+
+def bias_relu(x, bias):
+    """relu(x + bias[None,:,None,None]) in place on x (a channels_last convolution output); see _BiasReLU."""
+    return _BiasReLU.apply(x, bias)
+
+
+def bias_relu_pool(x, bias):
+    """max_pool2d(relu(x + bias[None,:,None,None]), 2, 2) for a channels_last convolution output; see _BiasReLUPool."""
+    return _BiasReLUPool.apply(x, bias)
+
+
 # --------------------------------------------------------------------- input finalisation
 def image_finalize(u8, erase=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), channels_last=False):
     """uint8 [B,H,W,3] on the device (+ int32 erase boxes [B,4] = top, left, h, w) -> normalised fp32 [B,3,H,W]

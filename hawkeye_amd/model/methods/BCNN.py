@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from ... import functional as HF
 from ..backbone import vgg16
+from ..backbone.vgg import ConvStack
 from ..registry import MODEL
 from ..utils import initialize_weights, pooled_classifier
 
@@ -48,7 +49,8 @@ class BCNN(nn.Module):
         super().__init__()
         self.stage = config.stage if 'stage' in config else 2
         trunk = vgg16(pretrained=True).features            # the whole `features` stack, final MaxPool included:
-        self.backbone = nn.Sequential(*trunk.children())    # 448x448 input -> [B,512,14,14]
+        self.backbone = ConvStack(*trunk.children())        # 448x448 input -> [B,512,14,14]; an nn.Sequential (same keys) whose
+                                                            # forward fuses the elementwise ops around each convolution
         self.bilinear_pooling = BilinearPooling()
         self.classifier = nn.Linear(FEATURE_CHANNELS * FEATURE_CHANNELS, config.num_classes)
         self.classifier.apply(initialize_weights)

@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from ... import functional as HF
 from ..backbone import vgg16
+from ..backbone.vgg import ConvStack
 from ..registry import MODEL
 from ..utils import initialize_weights, wide_linear
 
@@ -60,7 +61,7 @@ class CBCNN(nn.Module):
         super().__init__()
         self.config = config
         cin, cout = config.input_channel, config.output_channel
-        self.backbone = nn.Sequential(*list(vgg16(pretrained=True).features.children()))
+        self.backbone = ConvStack(*list(vgg16(pretrained=True).features.children()))    # an nn.Sequential: same keys
         self.bilinear_pooling = CompactBilinearPooling(cin, cin, cout)
         self.classifier = nn.Linear(cout, config.num_classes)
         self.classifier.apply(initialize_weights)

@@ -264,6 +264,29 @@ int hk_cbp_rect_loc_fwd(const float* x1, const float* x2, const void* plan, floa
 int hk_cbp_rect_loc_bwd(const float* x1, const float* x2, const float* dc, const void* plan, float* dx1, float* dx2, int B,
                         int C1, int C2, int HW, int D, hk_stream_t stream);
 
+/* ------------------------------------------------------- VGG trunk epilogues ----
+ * What PyTorch-ROCm runs around every convolution of the VGG-16 trunk (model/backbone/vgg.py:24-57: Conv2d + bias, ReLU,
+ * five MaxPool2d(2, 2); BCNN.py:38-39 / CBCNN.py:22 take all of `features`) as one full-tensor pass per elementwise op -
+ * bias add, ReLU, pool; pool backward, ReLU backward, bias-gradient reduction - fused to ONE pass per convolution and
+ * direction.  channels_last tensors: x [rows = N H W][C], C % 4 == 0.  Replaces, with the same arithmetic,
+ *   hk_bias_relu_fwd        x = max(x + bias, 0) IN PLACE                 (nn.Conv2d's bias add + nn.ReLU(inplace=True))
+ *   hk_bias_relu_bwd        dx = dy where y > 0 else 0 ; dbias = sum dx   (threshold_backward + the convolution's bias gradient;
+ *                           dx may alias dy)
+ *   hk_bias_relu_pool_fwd   p = maxpool2x2(max(x + bias, 0)), argmax [N][H/2][W/2][C/4] bytes (2 bits per channel: window position
+ *                           2 dh + dw of the FIRST maximum, ATen's tie rule); the full-resolution activation is not written
+ *   hk_bias_relu_pool_bwd   dx [N][H][W][C] = dp routed to the argmax where p > 0, zeros elsewhere ; dbias = sum dx
+ * The backward kernels need C / 4 to divide 256 (C = 64 .. 512 in VGG) and a workspace of hk_trunk_ws_bytes(C) bytes (partial
+ * column sums, added in a fixed order: deterministic).  HK_ERR_UNSUPPORTED (nothing launched) for other shapes / unaligned
+ * pointers: the caller keeps the framework's own ops for those. */
+size_t hk_trunk_ws_bytes(int C);
+int hk_bias_relu_fwd(float* x, const float* bias, long long rows, int C, hk_stream_t stream);
+int hk_bias_relu_bwd(const float* dy, const float* y, float* dx, float* dbias, long long rows, int C, void* ws, size_t ws_bytes,
+                     hk_stream_t stream);
+int hk_bias_relu_pool_fwd(const float* x, const float* bias, float* p, uint8_t* argmax, int N, int H, int W, int C,
+                          hk_stream_t stream);
+int hk_bias_relu_pool_bwd(const float* dp, const float* p, const uint8_t* argmax, float* dx, float* dbias, int N, int H, int W,
+                          int C, void* ws, size_t ws_bytes, hk_stream_t stream);
+
 /* ------------------------------------------------------------------ AP-CNN ----
  * Attention pooling.  The reference materialises A = a_s*F + a_c*F and only ever
  * consumes its global average (cls3/4/5 start with AdaptiveAvgPool2d(1)), so

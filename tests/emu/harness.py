@@ -6,6 +6,8 @@ hawkeye_amd.functional.  Outside the context the product behaviour (HIP tensors 
 """
 import contextlib
 import ctypes
+
+import torch
 import os
 
 
@@ -32,7 +34,7 @@ def load_emu():
 def _cpu_ptr(t):
     if t is None:
         return None
-    assert not t.is_cuda and t.is_contiguous()
+    assert not t.is_cuda and (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)))   # dense either way
     return ctypes.c_void_p(t.data_ptr())
 
 

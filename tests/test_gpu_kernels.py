@@ -118,6 +118,56 @@ def test_bcnn_backward_in_one_launch(F, b, c, hw, k, bias, tune):
         assert rel(res['tdot'][1], xo.grad) < 2e-5 and rel(res['tdot_off'][1], xo.grad) < 2e-5, form
 
 
+@pytest.mark.parametrize('n,c,h,w', [(2, 64, 8, 8), (1, 128, 6, 10), (3, 512, 4, 4), (2, 256, 14, 14), (1, 4, 2, 2), (5, 32, 2, 6)])
+def test_trunk_epilogues_equal_the_ops_they_replace(F, n, c, h, w):
+    """hk_bias_relu_fwd / bwd and hk_bias_relu_pool_fwd / bwd (csrc/trunk.hip: the VGG trunk's bias add + ReLU (+ 2 x 2 max-pool)
+    around each convolution, model/backbone/vgg.py:24-57, as one pass) against the framework ops they replace, on
+    channels_last maps: the forward values and the input gradient BIT FOR BIT (same arithmetic, ATen's first-maximum tie
+    rule - the maps are mostly <= 0 before the ReLU, so most pooling windows tie at 0), the bias gradient against a
+    float64 sum."""
+    gen = torch.Generator().manual_seed(n * 1000 + c + h)
+    x = (torch.randn(n, c, h, w, generator=gen) - 0.4).contiguous(memory_format=torch.channels_last)
+    x[0, :, 0, 0] = 0.25                                            # a window whose maxima tie at a POSITIVE value after the bias
+    x[0, :, 0, 1] = 0.25
+    b = torch.randn(c, generator=gen) * 0.3
+    dy = torch.randn(n, c, h, w, generator=gen).contiguous(memory_format=torch.channels_last)
+    dp = torch.randn(n, c, h // 2, w // 2, generator=gen).contiguous(memory_format=torch.channels_last)
+    # reference: the ops of nn.Conv2d's bias add, nn.ReLU, nn.MaxPool2d(2, 2)
+    xr, br = x.clone().requires_grad_(True), b.clone().double().requires_grad_(True)
+    yr = torch.relu(xr + br.float().view(1, -1, 1, 1))
+    yr.backward(dy)
+    xg, bg = x.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    y = F.bias_relu(xg * 1.0, bg)                                   # (* 1.0: the op works in place on a non-leaf, as on a conv output)
+    assert y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y.cpu(), yr.detach())
+    y.backward(dy.to(DEV))
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+    db64 = (dy.double() * (yr.detach() > 0)).sum((0, 2, 3))
+    assert rel(bg.grad, db64) < 1e-6
+    # pooled form
+    xr2 = x.clone().requires_grad_(True)
+    pr = torch.nn.functional.max_pool2d(torch.relu(xr2 + b.view(1, -1, 1, 1)), 2, 2)
+    pr.backward(dp)
+    xg2, bg2 = x.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    pg = F.bias_relu_pool(xg2 * 1.0, bg2)
+    assert pg.is_contiguous(memory_format=torch.channels_last) and torch.equal(pg.cpu(), pr.detach())
+    pg.backward(dp.to(DEV))
+    assert torch.equal(xg2.grad.cpu(), xr2.grad)
+    assert rel(bg2.grad, xr2.grad.double().sum((0, 2, 3))) < 1e-6
+    # run to run: the fixed summation order makes the bias gradient repeatable bit for bit
+    xg3, bg3 = x.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    F.bias_relu_pool(xg3 * 1.0, bg3).backward(dp.to(DEV))
+    assert torch.equal(bg3.grad, bg2.grad)
+
+
+def test_trunk_epilogues_refuse_what_they_do_not_cover(F):
+    x = torch.randn(2, 6, 4, 4).contiguous(memory_format=torch.channels_last).to(DEV)     # C = 6: not a multiple of 4
+    assert not F.trunk_epilogue_ok(x)
+    with pytest.raises(Exception):
+        F.bias_relu(torch.randn(2, 8, 4, 4).to(DEV), torch.zeros(8).to(DEV))              # NCHW memory
+    with pytest.raises(Exception):
+        F.bias_relu_pool(torch.randn(2, 8, 3, 4).contiguous(memory_format=torch.channels_last).to(DEV), torch.zeros(8).to(DEV))
+
+
 @pytest.mark.parametrize('signed', [False, True])
 def test_fused_pool_classifier_keeps_nn_linear_semantics(F, signed):
     """The fused pooling + classifier node behaves like the nn.Linear it replaces (BCNN.py:42,54) in the two respects the

@@ -535,6 +535,44 @@ def test_bench_spawns_its_own_ranks(tmp_path, world):
     assert 1 <= d['host_threads_per_rank'] <= max(1, (os.cpu_count() or 1) // world)
 
 
+def test_vgg_trunk_with_fused_epilogues_equals_the_plain_stack():
+    """ConvStack (model/backbone/vgg.py: nn.Sequential whose forward fuses bias + ReLU (+ 2 x 2 max-pool) behind each MIOpen
+    convolution, csrc/trunk.hip) against the SAME children run one by one as nn.Sequential does (= what the reference's
+    `features` executes, model/backbone/vgg.py:24-57) on a channels_last batch: the output, the input gradient and every
+    parameter gradient.  Not bit-identity: the convolution is called without its bias here, and MIOpen may pick another
+    algorithm for that problem; the epilogues themselves are bit-exact (test_trunk_epilogues_equal_the_ops_they_replace)."""
+    import copy
+    from hawkeye_amd.model.backbone import vgg16
+    from hawkeye_amd.model.backbone.vgg import ConvStack
+    torch.manual_seed(3)
+    fused = vgg16(pretrained=False).features.to(DEV).to(memory_format=torch.channels_last)
+    assert isinstance(fused, ConvStack) and isinstance(fused, torch.nn.Sequential)
+    plain = torch.nn.Sequential(*copy.deepcopy(fused).children())
+    assert list(plain.state_dict().keys()) == list(fused.state_dict().keys())
+    x = torch.randn(4, 3, 96, 64, device=DEV).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(4, 512, 3, 2, device=DEV)
+    outs = []
+    for net in (fused, plain):
+        xi = x.clone().requires_grad_(True)
+        y = net(xi)
+        (y * wt).sum().backward()
+        outs.append((y.detach(), xi.grad, [p_.grad for p_ in net.parameters()]))
+    (yf, gxf, gpf), (yp, gxp, gpp) = outs
+    ey, ex = rel(yf, yp), rel(gxf, gxp)
+    ep = max(rel(a, b) for a, b in zip(gpf, gpp))
+    print(f'[VGG trunk, fused epilogues vs plain stack] output {ey:.2e}  input gradient {ex:.2e}  worst parameter gradient {ep:.2e}')
+    assert ey < 1e-5 and ex < 1e-4 and ep < 1e-4
+    # NCHW memory, or a child with a forward hook: the children run one by one (hooks fire)
+    seen = []
+    h = fused[1].register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+    with torch.no_grad():
+        y2 = fused(x)
+    h.remove()
+    assert seen == [(4, 64, 96, 64)] and rel(y2, yp) < 1e-5
+    with torch.no_grad():
+        assert rel(fused(x.contiguous()), yp) < 1e-5
+
+
 def test_bench_line_is_last_on_stdout_with_rccl(tmp_path):
     """The driver parses bench.py's LAST stdout line.  With the `nccl` (RCCL) backend the library leaves its version banner
     in the C stdio buffer of stdout until the process exits - behind everything python printed (observed on the MI355X box
