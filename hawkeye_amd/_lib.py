@@ -141,7 +141,8 @@ def ptr(t):
     if not t.is_cuda:
         raise HawkeyeHipError('hawkeye_amd ops run on MI355X only: got a CPU tensor (no CPU fallback; '
                               'the CPU reference lives in oracle/ and is test infrastructure)')
-    if not t.is_contiguous():
+    # dense memory: row-major, or NHWC behind a [N,C,H,W] view (the trunk epilogues take channels_last maps as they lie)
+    if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
         raise HawkeyeHipError('internal error: non-contiguous tensor handed to the C ABI')
     if t.device.index != torch.cuda.current_device():
         # the library launches on the CURRENT device's stream (one process per GPU: Trainer / Tester / bench.py call

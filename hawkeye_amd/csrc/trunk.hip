@@ -22,7 +22,7 @@
 
 namespace hk {
 
-constexpr int TRUNK_PART_BLOCKS = 2048;        // workgroups (= partial db rows) of the backward kernels, at most
+constexpr int TRUNK_PART_BLOCKS = 1024;        // workgroups (= partial db rows) of the backward kernels, at most
 
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     f32x4 r;
@@ -101,8 +101,17 @@ __global__ __launch_bounds__(256) void trunk_db_final_kernel(const float* __rest
     const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    if (c < C)
-        for (int k = g; k < nblk; k += 16) s += part[(long long)k * C + c];
+    if (c < C) {
+        int k = g;
+        for (; k + 7 * 16 < nblk; k += 8 * 16) {        // eight independent loads in flight, added in order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + 16 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nblk; k += 16) s += part[(long long)k * C + c];
+    }
     red[g][cl] = s;
     __syncthreads();
     if (g == 0 && c < C) {

@@ -1140,7 +1140,7 @@ class _BiasReLUPool(torch.autograd.Function):
         _nhwc(x, 'bias_relu_pool')
         n, c, h, w = x.shape
         b = _f32c(bias)
-        p = torch.empty(n, c, h // 2, w // 2, dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+        p = torch.empty(n, c, h // 2, w // 2, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         am = torch.empty(n, h // 2, w // 2, c // 4, dtype=torch.uint8, device=x.device)
         check(lib.hk_bias_relu_pool_fwd(ptr(x), ptr(b), ptr(p), ptr(am), n, h, w, c, stream()), 'hk_bias_relu_pool_fwd')
         ctx.save_for_backward(p, am)
@@ -1155,7 +1155,7 @@ class _BiasReLUPool(torch.autograd.Function):
         if dp.dtype != torch.float32:
             raise _lib.HawkeyeHipError(f'bias_relu_pool backward: fp32 only, got {dp.dtype}')
         dp = dp.contiguous(memory_format=torch.channels_last)
-        dx = torch.empty(n, c, h, w, dtype=torch.float32, device=p.device).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty(n, c, h, w, dtype=torch.float32, device=p.device, memory_format=torch.channels_last)
         db = torch.empty(c, dtype=torch.float32, device=p.device)
         nws = lib.hk_trunk_ws_bytes(c)
         ws = _ws(nws, p.device)
