@@ -59,7 +59,8 @@ __global__ __launch_bounds__(512, 2) void linear_skinny_kernel(const float* __re
     int nch;
     if (walk) nch = slab < nchunk ? (nchunk - slab + S - 1) / S : 0;
     else {
-        const int nfeat = (J - f0) < KS ? (int)(J - f0) : KS;   // (a multiple of 32: J % 32 == 0, KS % 32 == 0)
+        const int nfeat = (J - f0) < KS ? (int)(J - f0) : KS;   // (KS % 32 == 0; J % 32 != 0: whole chunks only, the tail is
+                                                                //  linear_reduce_kernel's)
         nch = nfeat > 0 ? nfeat / CH : 0;
     }
 

@@ -53,7 +53,9 @@ struct LdSlab {
 __global__ __launch_bounds__(256) void linear_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                            const float* __restrict__ rs, float* __restrict__ out, int BK,
                                                            int K, int S, const float* __restrict__ ssq = nullptr, int nssq = 0,
-                                                           float* __restrict__ rs_out = nullptr) {
+                                                           float* __restrict__ rs_out = nullptr,
+                                                           const float* __restrict__ ty = nullptr,
+                                                           const float* __restrict__ tw = nullptr, int J = 0, int Jt0 = 0) {
     __shared__ float red[4][64];
     const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + l;
@@ -76,7 +78,16 @@ __global__ __launch_bounds__(256) void linear_reduce_kernel(const float* __restr
     red[g][l] = s;
     __syncthreads();
     if (g == 0 && e < BK) {
-        const float sum = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        float sum = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        // the features [Jt0, J) behind the last whole 32-feature chunk (J % 32 != 0: CBCNN's 6000 = 187 x 32 + 16), which the
+        // slab kernel does not touch: at most 31 products per output, added here in feature order
+        if (ty) {
+            const float* yr = ty + (long long)(e / K) * J;
+            const float* wr = tw + (long long)(e % K) * J;
+            float t = 0.f;
+            for (int j = Jt0; j < J; ++j) t += yr[j] * wr[j];
+            sum += t;
+        }
         float sc = rs ? rs[e / K] : 1.0f;
         if (ssq) {
             float t = 0.f;
@@ -100,10 +111,52 @@ __global__ __launch_bounds__(256) void linear_bias_grad_kernel(const float* __re
     if (lane == 0) db[k] = s;
 }
 
+// The features [J0, J) behind the last whole 64-feature chunk of linear_bwd64_kernel (J % 64 != 0: CBCNN's 6000 = 93 x 64 + 48):
+// one workgroup per output row - the B rows of dy, then the K rows of dW - thread (j, part): tail feature j, every 16th term of
+// the sum starting at `part` (all of a thread's loads in flight at once: a single thread walking 200 rows of W 24 KB apart
+// took 20 us), the 16 parts added in order.  At most 63 features, so that the whole classifier stays on the one-launch kernel.
+__global__ __launch_bounds__(1024) void linear_bwd_tail_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                               const float* __restrict__ y, float* __restrict__ dy,
+                                                               float* __restrict__ dw, const float* __restrict__ row_scale, int B,
+                                                               int J, int K, int J0) {
+    __shared__ float red[16][64];
+    const int r = blockIdx.x, jl = threadIdx.x & 63, part = threadIdx.x >> 6, j = J0 + jl;
+    const bool is_dy = r < B;
+    if ((is_dy && !dy) || (!is_dy && !dw)) return;                    // (uniform)
+    const int k = r - B;
+    const int n = is_dy ? K : B;                                       // terms of the sum
+    float s = 0.f;
+    if (j < J) {
+        for (int t0 = part; t0 < n; t0 += 16 * 8) {
+            float a[8], v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 16 * u;
+                const bool ok = t < n;
+                const int tc = ok ? t : 0;
+                if (is_dy) { a[u] = g[(long long)r * K + tc]; v[u] = w[(long long)tc * J + j]; }
+                else { a[u] = row_scale ? row_scale[tc] * g[(long long)tc * K + k] : g[(long long)tc * K + k]; v[u] = y[(long long)tc * J + j]; }
+                if (!ok) a[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += a[u] * v[u];
+        }
+    }
+    red[part][jl] = s;
+    __syncthreads();
+    if (part == 0 && j < J) {
+        float t = red[0][jl];
+        for (int q = 1; q < 16; ++q) t += red[q][jl];
+        if (is_dy) dy[(long long)r * J + j] = t;
+        else dw[(long long)k * J + j] = t;
+    }
+}
+
 // the wide-classifier plan: slabs of KS features for linear_skinny_kernel; false when the generic path serves the shape
 static inline bool skinny_plan(int B, int J, int K, int& KS, int& S, int& nt, int& ngrp, int& nrg) {
     if (tuning().linear_slabs < 0) return false;                 // knob: -1 forces the generic split-K path
-    if (J % 32 != 0) return false;
+    if (J % 4 != 0) return false;                                // (rows must start on 16 bytes for the LDS-DMA pieces; J % 32 != 0:
+                                                                 //  the whole chunks here, the tail in linear_reduce_kernel)
     // up to 16 samples (OSME, N = 10): one 16-row tile and 16 class tiles per workgroup (with the 64-row instance the
     // idle rows are matrix-pipe time: 273 us against 203 us on the generic path).  17-32 samples: generic path.
     const bool small = B <= 16;
@@ -111,14 +164,20 @@ static inline bool skinny_plan(int B, int J, int K, int& KS, int& S, int& nt, in
     ngrp = (K + nt * 16 - 1) / (nt * 16);
     nrg = small ? 1 : (B + 63) / 64;
     const long long chunks = (long long)(J / 32) * ngrp * nrg;   // chunk-tasks in all
-    // Not for: too little work to amortise a 4-stage pipeline per workgroup; 17-32 samples (fewer than half of the 64
-    // sample rows in use).  A forced slab count also forces this path (tests).
-    if ((chunks < 256 * 16 || (B > 16 && B < 33)) && tuning().linear_slabs <= 0) return false;
+    // Not for: fewer than 128 chunks (J < 4096: nothing to split); 17-32 samples (fewer than half of the 64 sample rows in
+    // use).  A forced slab count also forces this path (tests).
+    // Round 6: the lower limit was 4096 chunks - MPN's 64 x 32896 -> 200 (1028 chunks) ran the generic split-K tiles at
+    // 30.5 us; on this kernel with one slab per CU it is 21.4 us (tools/r6_lab.py lin_mpn_sweep: 86 slabs 29.6, 129: 24.0,
+    // 172: 21.8, 206: 21.4, 257 - a second wave of workgroups - 30.1), the yaml batch of 8: 26.0 -> 12.2 us, 64 x 8192 -> 200:
+    // 17.3 -> 13.0 us with two chunks per slab (one chunk per slab: 15.8 - the pipeline never starts).
+    if ((chunks < 128 || (B > 16 && B < 33)) && tuning().linear_slabs <= 0) return false;
     long long want = 256 / ((long long)ngrp * nrg);              // one workgroup per CU
     if (want < 1) want = 1;
-    if (tuning().linear_slabs > 0) want = tuning().linear_slabs;
-    KS = (int)(((J / 32 + want - 1) / want) * 32);
-    S = (J + KS - 1) / KS;
+    long long kc = (J / 32 + want - 1) / want;                   // chunks per slab
+    if (kc < 2) kc = 2;
+    if (tuning().linear_slabs > 0) kc = (J / 32 + tuning().linear_slabs - 1) / tuning().linear_slabs;
+    KS = (int)(kc * 32);
+    S = (int)((J / 32 + kc - 1) / kc);
     return true;
 }
 
@@ -173,7 +232,9 @@ static int linear_fwd_impl(const float* y, const float* w, const float* bias, co
             hipLaunchKernelGGL((linear_skinny_kernel<16, 1>), grid, dim3(512), lds, st, y, w, part, B, J, K, KS, S, ngrp, walk);
         HK_LAUNCH_CHECK();
         const int BK = B * K;
-        hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, row_scale, out, BK, K, S, ssq, nssq, rs_out);
+        const int Jt0 = (J / 32) * 32;                       // first feature of the tail (== J: none)
+        hipLaunchKernelGGL(linear_reduce_kernel, dim3((BK + 63) / 64), dim3(256), 0, st, (const float*)part, bias, row_scale, out, BK, K, S, ssq, nssq, rs_out,
+                           Jt0 < J ? y : (const float*)nullptr, w, J, Jt0);
         HK_LAUNCH_CHECK();
         return HK_OK;
     }
@@ -217,7 +278,10 @@ static int linear_bwd_impl(const float* y, const float* w, const float* g, const
     // linear_slabs = -1 keeps the generic tiles)
     // (the kernels address W / dW [K][J] and y / dy [B][J] through 32-bit byte offsets of buffer descriptors: both must
     //  stay below 2^30 elements - a wider problem takes the generic tiles)
-    if (B <= 64 && K <= 208 && J % 64 == 0 && (long long)J >= 16384 && (long long)K * J < (1ll << 30) &&
+    // (round 6: from 4096 features up - it was 16384 - and any J % 4 == 0: the features behind the last whole chunk are
+    //  linear_bwd_tail_kernel's.  CBCNN's 6000 -> 200 ran two generic-tile launches + the bias gradient: 19.3 / 24.0 us at
+    //  B = 16 / 64)
+    if (B <= 64 && K <= 208 && J % 4 == 0 && (long long)J >= 4096 && (long long)K * J < (1ll << 30) &&
         (long long)B * J < (1ll << 30) && (dy || dw) &&
         tuning().linear_slabs >= 0 && aligned16(y) && aligned16(w) && aligned16(dy) && aligned16(dw)) {
         const int nchunk = J / 64;
@@ -239,6 +303,10 @@ static int linear_bwd_impl(const float* y, const float* w, const float* g, const
         }
 #undef HK_LAUNCH_BWD64
         HK_LAUNCH_CHECK();
+        if (J % 64 != 0) {
+            hipLaunchKernelGGL(linear_bwd_tail_kernel, dim3(B + K), dim3(1024), 0, st, g, w, y, dy, dw, row_scale, B, J, K, nchunk * 64);
+            HK_LAUNCH_CHECK();
+        }
         if (db && !dw) {                                  // (db rides on the dW role)
             hipLaunchKernelGGL(linear_bias_grad_kernel, dim3((K + 3) / 4), dim3(256), 0, st, g, db, B, K);
             HK_LAUNCH_CHECK();

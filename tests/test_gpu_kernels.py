@@ -450,7 +450,10 @@ def test_linear_split_k(F, b, j, k, bias, tune):
 
 
 @pytest.mark.parametrize('b,j,k,slabs', [(70, 2048, 250, 4), (10, 3200, 500, 2), (64, 1024, 200, 1), (3, 640, 13, 5),
-                                         (64, 8192, 200, 0)])
+                                         (64, 8192, 200, 0),
+                                         # round 6: J % 32 != 0 (the tail in the reduce kernel) - CBCNN's 6000 -> 200 at the yaml
+                                         # batch and at 64, a 20-feature tail behind 128 chunks, MPN's width at the yaml batch
+                                         (16, 6000, 200, 0), (64, 6000, 200, 0), (8, 4116, 200, 0), (40, 6000, 420, 5), (8, 32896, 200, 0)])
 def test_linear_wide_classifier_kernel(F, b, j, k, slabs, tune):
     """linear_skinny_kernel (the forward of the wide classifiers: a workgroup owns a slab of features, all samples and a
     group of 13 / 15 class tiles; LDS-DMA staging, four stages, explicit vmcnt(n) barriers): more than 64 samples (two
@@ -868,7 +871,10 @@ _MODEL_CFG = {
 
 @pytest.mark.parametrize('b,j,k', [(2, 6000, 200), (2, 32896, 200), (3, 262144, 200), (16, 6000, 8142), (64, 65536, 200),
                                    (37, 65728, 130), (10, 100352, 1024), (7, 16448, 300), (16, 20032, 1000), (4, 32768, 200),
-                                   (3, 16384, 13), (17, 16384, 208)])
+                                   (3, 16384, 13), (17, 16384, 208),
+                                   # round 6: linear_bwd64_kernel from 4096 features up, the features behind the last whole 64-chunk
+                                   # in linear_bwd_tail_kernel (6000 = 93 x 64 + 48; 4100: a 4-feature tail; 4160: none)
+                                   (16, 6000, 200), (64, 6000, 200), (8, 32896, 200), (64, 4100, 200), (3, 4160, 208), (33, 6000, 130)])
 def test_linear_bwd_direct_at_classifier_shapes(F, b, j, k):
     """hk_linear_bwd on its own at the classifier widths of the plugins (CBCNN 6000: not a multiple of 64, so the
     48-column / 8-deep tails of the tile kernel are exercised; MPN 32896 and BCNN 262144: up to 64 samples and 208 classes
@@ -891,6 +897,7 @@ def test_linear_bwd_direct_at_classifier_shapes(F, b, j, k):
     assert rel(bg.grad, g.double().sum(0)) < 2e-6
     # element-wise as well: a wrong tail column hides in a norm
     assert float((yg.grad.double().cpu() - g.double() @ w.double()).abs().max()) < 1e-5 * float((g.double() @ w.double()).abs().max())
+    assert float((wg.grad.double().cpu() - g.double().t() @ y.double()).abs().max()) < 1e-5 * float((g.double().t() @ y.double()).abs().max())
 
 
 @pytest.mark.parametrize('b,j,k', [(33, 16384, 200), (5, 16448, 208), (9, 16384, 260), (64, 16384, 193)])

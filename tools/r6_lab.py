@@ -98,11 +98,18 @@ def g_lin_mpn():
     return [_lin_group('MPN 64 x 32896 -> 200', 64, 32896, 200, (-1, 64, 128, 257))]
 
 
+def g_lin_mpn_sweep():
+    return [_lin_group('MPN 64 x 32896 -> 200', 64, 32896, 200, (86, 103, 115, 129, 147, 172, 206)),
+            _lin_group('MPN yaml batch 8 x 32896 -> 200', 8, 32896, 200, (64, 103, 129, 172)),
+            _lin_group('CBCNN-sized 64 x 8192 -> 200', 64, 8192, 200, (32, 64, 128, 256))]
+
+
 def g_lin_cbcnn():
-    return [_lin_group('CBCNN 16 x 6000 -> 200', 16, 6000, 200, (-1,)), _lin_group('CBCNN 64 x 6000 -> 200', 64, 6000, 200, (-1,))]
+    return [_lin_group('CBCNN 16 x 6000 -> 200', 16, 6000, 200, (-1,)), _lin_group('CBCNN 64 x 6000 -> 200', 64, 6000, 200, (-1,)),
+            _lin_group('no tail: 16 x 5952 -> 200', 16, 5952, 200, (-1,)), _lin_group('64 x 16384 -> 200', 64, 16384, 200, (-1,))]
 
 
-GROUPS = {'ns': g_ns, 'cov': L5.g_cov, 'lin_mpn': g_lin_mpn, 'lin_cbcnn': g_lin_cbcnn, 'cbp': L5.g_cbp, 'linear': L5.g_linear,
+GROUPS = {'lin_mpn_sweep': g_lin_mpn_sweep, 'ns': g_ns, 'cov': L5.g_cov, 'lin_mpn': g_lin_mpn, 'lin_cbcnn': g_lin_cbcnn, 'cbp': L5.g_cbp, 'linear': L5.g_linear,
           'pool': L5.g_pool}
 
 if __name__ == '__main__':
