@@ -162,3 +162,23 @@ def test_example_trainers_keep_the_reference_optimizer_groups():
     sh.model = m
     opt = EM.MPNTrainer.get_optimizer(sh, CfgNode(dict(lr=8e-5, weight_decay=2e-5)))
     assert [g['lr'] for g in opt.param_groups] == [8e-5, 8e-5, pytest.approx(1.6e-5)]
+
+
+def test_vgg_conv_stack_is_a_sequential_with_the_reference_keys():
+    """ConvStack (the VGG trunk whose forward fuses the epilogues behind each convolution on an MI355X) is an nn.Sequential
+    with the reference's children under the reference's indices (model/backbone/vgg.py:24-57: keys `{0,2,5,...,28}.{weight,bias}`),
+    and off the GPU - CPU tensors here - it runs them one by one: the same values as a plain nn.Sequential of the same children."""
+    from hawkeye_amd.model.backbone import vgg16
+    from hawkeye_amd.model.backbone.vgg import ConvStack
+    torch.manual_seed(0)
+    feats = vgg16(pretrained=False).features
+    assert isinstance(feats, ConvStack) and isinstance(feats, torch.nn.Sequential) and len(feats) == 31
+    convs = [i for i, m in enumerate(feats) if isinstance(m, torch.nn.Conv2d)]
+    assert convs == [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]
+    assert list(feats.state_dict().keys()) == [f'{i}.{p}' for i in convs for p in ('weight', 'bias')]
+    plain = torch.nn.Sequential(*feats.children())
+    x = torch.randn(1, 3, 32, 32)
+    for inp in (x, x.contiguous(memory_format=torch.channels_last)):
+        assert torch.equal(feats(inp), plain(inp))
+    m = MODEL.get('BCNN')(CfgNode(CONFIGS['BCNN']))
+    assert isinstance(m.backbone, ConvStack) and isinstance(m.backbone[:7], torch.nn.Sequential)     # slicing keeps working
