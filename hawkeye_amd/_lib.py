@@ -65,6 +65,8 @@ SIGNATURES = {
     'hk_bias_relu_bwd': (c_i, [c_f, c_f, c_f, c_f, c_ll, c_i, c_f, c_sz, c_f]),
     'hk_bias_relu_pool_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'hk_bias_relu_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_add_relu_fwd': (c_i, [c_f, c_f, c_ll, c_f]),
+    'hk_relu_mask_bwd': (c_i, [c_f, c_f, c_f, c_ll, c_f]),
     'hk_cbp_rect_plan_bytes': (c_sz, [c_i, c_i, c_i]),
     'hk_cbp_rect_plan_build': (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_f]),
     'hk_cbp_rect_bin_matrix': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),

@@ -207,6 +207,47 @@ __global__ __launch_bounds__(256) void bias_relu_pool_bwd_kernel(const float* __
     trunk_db_partial(acc, part, c4);
 }
 
+// The end of a ResNet bottleneck (model/backbone/resnet.py:89-136: `out += identity; out = relu(out)`): y = max(a + b, 0) in place
+// on a - one pass (two reads, one write) where the framework runs add_ and relu_ (three reads, two writes).  Any dense layout:
+// the two operands only have to share it.
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(float* __restrict__ a, const float* __restrict__ b, long long n4) {
+    f32x4* a4 = reinterpret_cast<f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+        f32x4 u[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * stride < n4) { u[k] = a4[i + k * stride]; v[k] = b4[i + k * stride]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * stride < n4) a4[i + k * stride] = relu4(u[k] + v[k]);
+    }
+}
+
+// g = dy where y > 0 else 0 (the gradient of BOTH operands of add_relu)
+__global__ __launch_bounds__(256) void relu_mask_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            float* __restrict__ g, long long n4) {
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    f32x4* g4 = reinterpret_cast<f32x4*>(g);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+        f32x4 u[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * stride < n4) { u[k] = d4[i + k * stride]; v[k] = y4[i + k * stride]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * stride < n4) {
+                f32x4 r;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) r[t] = v[k][t] > 0.f ? u[k][t] : 0.f;
+                g4[i + k * stride] = r;
+            }
+    }
+}
+
 static inline bool trunk_c_ok(int C) {              // 256 % (C / 4) == 0: a column quad per thread, whole rows per workgroup pass
     return C >= 4 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0;
 }
@@ -270,6 +311,26 @@ extern "C" int hk_bias_relu_pool_bwd(const float* dp, const float* p, const uint
                        ppb, C / 4, W / 2, H / 2);
     HK_LAUNCH_CHECK();
     hipLaunchKernelGGL(trunk_db_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, C, dbias);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_add_relu_fwd(float* a, const float* b, long long n, hk_stream_t stream) {
+    if (!a || !b || n <= 0) return HK_ERR_BAD_ARG;
+    if (n % 4 != 0 || !aligned16(a) || !aligned16(b)) return HK_ERR_UNSUPPORTED;
+    long long blocks = (n / 4 + 1023) / 1024;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(add_relu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, n / 4);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_relu_mask_bwd(const float* dy, const float* y, float* g, long long n, hk_stream_t stream) {
+    if (!dy || !y || !g || n <= 0) return HK_ERR_BAD_ARG;
+    if (n % 4 != 0 || !aligned16(dy) || !aligned16(y) || !aligned16(g)) return HK_ERR_UNSUPPORTED;
+    long long blocks = (n / 4 + 1023) / 1024;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, g, n / 4);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }

@@ -1164,6 +1164,50 @@ class _BiasReLUPool(torch.autograd.Function):
         return dx, db
 
 
+def _same_dense_layout(a, b):
+    return (a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype == torch.float32 and a.numel() % 4 == 0 and a.numel() > 0
+            and (a.is_contiguous() or (a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last))))
+
+
+def add_relu_ok(a, b):
+    """Whether hk_add_relu_fwd serves `relu_(a.add_(b))`: two fp32 HIP tensors of one dense layout."""
+    return torch.is_tensor(a) and torch.is_tensor(b) and a.is_cuda and b.is_cuda and _same_dense_layout(a, b) and \
+        a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+
+
+class _AddReLU(torch.autograd.Function):
+    """a = relu(a + b) in place on a (the residual sum that ends a ResNet bottleneck, model/backbone/resnet.py:89-136):
+    one pass instead of add_ + relu_; backward: one masked copy that is the gradient of both operands."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        if not _same_dense_layout(a, b):
+            raise _lib.HawkeyeHipError(f'add_relu: operands must share one dense fp32 layout, got {tuple(a.shape)} {a.stride()} / '
+                                       f'{tuple(b.shape)} {b.stride()}')
+        check(lib.hk_add_relu_fwd(ptr(a), ptr(b), a.numel(), stream()), 'hk_add_relu_fwd')
+        ctx.mark_dirty(a)
+        ctx.save_for_backward(a)
+        return a
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        if dy.dtype != torch.float32:
+            raise _lib.HawkeyeHipError(f'add_relu backward: fp32 only, got {dy.dtype}')
+        if dy.stride() != y.stride():
+            dy = dy.contiguous(memory_format=torch.channels_last) if (y.dim() == 4 and not y.is_contiguous()) else dy.contiguous()
+        g = torch.empty_like(y)
+        check(lib.hk_relu_mask_bwd(ptr(dy), ptr(y), ptr(g), y.numel(), stream()), 'hk_relu_mask_bwd')
+        return g, g
+
+
+def add_relu(a, b):
+    """relu(a + b) in place on a; see _AddReLU."""
+    return _AddReLU.apply(a, b)
+
+
 def bias_relu(x, bias):
     """relu(x + bias[None,:,None,None]) in place on x (a channels_last convolution output); see _BiasReLU."""
     return _BiasReLU.apply(x, bias)

@@ -49,4 +49,38 @@ def use_in_tree_cache(base=None):
         os.environ.setdefault(k, '0')
     os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(base, 'cache'))
     os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(base, 'db'))
+    _warn_if_seed_is_for_another_miopen()
     return base
+
+
+def seed_miopen_version():
+    """(major, minor, patch) the in-tree find-db was written by, from its file name (`gfx950100.HIP.3_5_0_<build>.ufdb.txt`:
+    MIOpen names the user find-db after its own version and only ever opens the file of the running version)."""
+    import re
+    try:
+        for f in os.listdir(os.path.join(SEED, 'db')):
+            m = re.search(r'\.HIP\.(\d+)_(\d+)_(\d+)_', f)
+            if m:
+                return tuple(int(g) for g in m.groups())
+    except OSError:
+        pass
+    return None
+
+
+def _warn_if_seed_is_for_another_miopen():
+    """The seed goes stale silently on another ROCm: MIOpen looks for a find-db named after ITS version, does not find one,
+    and compiles / searches from scratch (minutes on the first step).  Say so once instead."""
+    try:
+        import torch
+        have = torch.backends.cudnn.version() if torch.cuda.is_available() else None     # MIOpen: major * 10^6 + minor * 10^3 + patch
+    except Exception:  # noqa: BLE001
+        have = None
+    seed = seed_miopen_version()
+    if have is None or seed is None:
+        return
+    running = (have // 1000000, (have // 1000) % 1000, have % 1000)
+    if running[:2] != seed[:2]:
+        import warnings
+        warnings.warn(f'hawkeye_amd/miopen_db was populated by MIOpen {seed[0]}.{seed[1]}.{seed[2]}, this process runs MIOpen '
+                      f'{running[0]}.{running[1]}.{running[2]}: the cached find results will not be used - the first training step '
+                      f'searches and compiles every convolution again (re-populate with tools/warm_miopen.sh)', stacklevel=2)

@@ -28,6 +28,12 @@ class Bottleneck(nn.Module):
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
+        # `y += idt; relu(y)` as one pass over the block's output on an MI355X (hk_add_relu_fwd, csrc/trunk.hip: two reads and a
+        # write where add_ + relu_ make three and two); the framework's ops for CPU tensors, other dtypes, a hooked ReLU
+        from ... import functional as HF
+        from ..utils import _hooked
+        if HF.add_relu_ok(y, idt) and not _hooked(self.relu):
+            return HF.add_relu(y, idt)
         y += idt
         return self.relu(y)
 

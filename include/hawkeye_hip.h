@@ -286,6 +286,11 @@ int hk_bias_relu_pool_fwd(const float* x, const float* bias, float* p, uint8_t* 
                           hk_stream_t stream);
 int hk_bias_relu_pool_bwd(const float* dp, const float* p, const uint8_t* argmax, float* dx, float* dbias, int N, int H, int W,
                           int C, void* ws, size_t ws_bytes, hk_stream_t stream);
+/* The end of a ResNet bottleneck, `out += identity; out = relu(out)` (model/backbone/resnet.py:89-136; the trunk of MPN, AP-CNN,
+ * OSMENet, CIN): hk_add_relu_fwd  a = max(a + b, 0) IN PLACE on a, n elements of any dense layout the two share, n % 4 == 0;
+ * hk_relu_mask_bwd  g = dy where y > 0 else 0 - the gradient of both operands. */
+int hk_add_relu_fwd(float* a, const float* b, long long n, hk_stream_t stream);
+int hk_relu_mask_bwd(const float* dy, const float* y, float* g, long long n, hk_stream_t stream);
 
 /* ------------------------------------------------------------------ AP-CNN ----
  * Attention pooling.  The reference materialises A = a_s*F + a_c*F and only ever

@@ -159,6 +159,26 @@ def test_trunk_epilogues_equal_the_ops_they_replace(F, n, c, h, w):
     assert torch.equal(bg3.grad, bg2.grad)
 
 
+@pytest.mark.parametrize('shape,cl', [((2, 64, 6, 6), True), ((3, 256, 7, 7), False), ((1, 8, 2, 2), True), ((5, 36), False)])
+def test_add_relu_equals_the_two_ops_it_replaces(F, shape, cl):
+    """hk_add_relu_fwd / hk_relu_mask_bwd (`out += identity; relu(out)` at the end of a ResNet bottleneck,
+    model/backbone/resnet.py:89-136) against add_ + relu_: values and both gradients bit for bit, channels_last and row-major."""
+    gen = torch.Generator().manual_seed(sum(shape))
+    a, b, dy = (torch.randn(*shape, generator=gen) for _ in range(3))
+    if cl:
+        a, b, dy = (v.contiguous(memory_format=torch.channels_last) for v in (a, b, dy))
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.relu(ar + br)
+    yr.backward(dy)
+    ag, bg = a.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    y = F.add_relu(ag * 1.0, bg)
+    assert torch.equal(y.cpu(), yr.detach()) and y.stride() == yr.stride()
+    y.backward(dy.to(DEV))
+    assert torch.equal(ag.grad.cpu(), ar.grad) and torch.equal(bg.grad.cpu(), br.grad)
+    with pytest.raises(Exception):
+        F.add_relu(torch.zeros(2, 8, 4, 4).to(DEV), torch.zeros(2, 8, 4, 4).contiguous(memory_format=torch.channels_last).to(DEV))
+
+
 def test_trunk_epilogues_refuse_what_they_do_not_cover(F):
     x = torch.randn(2, 6, 4, 4).contiguous(memory_format=torch.channels_last).to(DEV)     # C = 6: not a multiple of 4
     assert not F.trunk_epilogue_ok(x)

@@ -580,6 +580,30 @@ def test_vgg_trunk_with_fused_epilogues_equals_the_plain_stack():
         assert rel(fused(x.contiguous()), yp) < 1e-5
 
 
+def test_resnet_bottleneck_with_fused_residual_equals_the_plain_block():
+    """Bottleneck (model/backbone/resnet.py) ends in `out += identity; relu(out)`: on the MI355X one pass (hk_add_relu_fwd); a
+    forward hook on the block's ReLU switches the framework's two ops back in - same values, same gradients (the fused op is
+    bit-identical to add_ + relu_: test_add_relu_equals_the_two_ops_it_replaces; BatchNorm and the convolutions run the same
+    kernels either way)."""
+    import copy
+    from hawkeye_amd.model.backbone.resnet import Bottleneck
+    torch.manual_seed(5)
+    blk = Bottleneck(256, 64).to(DEV).to(memory_format=torch.channels_last).train()
+    ref = copy.deepcopy(blk)
+    h = ref.relu.register_forward_hook(lambda m, i, o: None)           # any hook: the plain path
+    x = torch.randn(4, 256, 14, 14, device=DEV).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(4, 256, 14, 14, device=DEV)
+    outs = []
+    for net in (blk, ref):
+        xi = x.clone().requires_grad_(True)
+        y = net(xi)
+        (y * wt).sum().backward()
+        outs.append((y.detach(), xi.grad, [p_.grad for p_ in net.parameters()]))
+    h.remove()
+    (y1, g1, p1), (y2, g2, p2) = outs
+    assert rel(y1, y2) < 1e-6 and rel(g1, g2) < 1e-5 and max(rel(a, b) for a, b in zip(p1, p2)) < 1e-5
+
+
 def test_bench_line_is_last_on_stdout_with_rccl(tmp_path):
     """The driver parses bench.py's LAST stdout line.  With the `nccl` (RCCL) backend the library leaves its version banner
     in the C stdio buffer of stdout until the process exits - behind everything python printed (observed on the MI355X box
