@@ -245,3 +245,44 @@ def test_classifier_backward_full_shape_is_reproducible_under_memory_pressure():
             assert rel(db, g.double().cpu().sum(0)) < 2e-6
         else:
             assert torch.equal(dy, ref[0]) and torch.equal(dw, ref[1]) and torch.equal(db, ref[2]), it
+
+
+def test_trunk_epilogues_at_the_metric_shape(F):
+    """hk_bias_relu_* at the first VGG stage of the metric's configuration - a 64 x 64 x 448 x 448 channels_last map, 3.29 GB: byte
+    offsets beyond 2^32, 205 M float4 per pass - against the framework's own ops ON THE DEVICE (the same fp32 arithmetic: the
+    values and the input gradients must be bit-identical, here too), the bias gradients against the device's float64 sum; and
+    run to run the same bits.  (tests/test_gpu_kernels.py pins the same kernels on small maps against torch on the CPU.)"""
+    n, c, h, w = 64, 64, 448, 448
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.empty(n, c, h, w, device=DEV, memory_format=torch.channels_last).normal_(-0.3, 1.0, generator=gen)
+    b = torch.randn(c, device=DEV, generator=gen) * 0.3
+    # plain form
+    dy = torch.empty_like(x).normal_(0.0, 1.0, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = torch.relu(xr + br.view(1, -1, 1, 1))
+    yr.backward(dy)
+    xg, bg = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.bias_relu(xg * 1.0, bg)
+    assert torch.equal(y, yr.detach())
+    y.backward(dy)
+    assert torch.equal(xg.grad, xr.grad)
+    db64 = xr.grad.double().sum((0, 2, 3))
+    assert rel(bg.grad, db64) < 1e-6 and rel(br.grad, db64) < 1e-4           # (ours: a fixed-order sum; ATen's own float32 reduction)
+    del yr, y, xr, xg, dy
+    torch.cuda.empty_cache()
+    # pooled form
+    dp = torch.empty(n, c, h // 2, w // 2, device=DEV, memory_format=torch.channels_last).normal_(0.0, 1.0, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    pr = torch.nn.functional.max_pool2d(torch.relu(xr + b.view(1, -1, 1, 1)), 2, 2)
+    pr.backward(dp)
+    grads = []
+    for _ in range(2):
+        xg, bg = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        p = F.bias_relu_pool(xg * 1.0, bg)
+        assert torch.equal(p, pr.detach())
+        p.backward(dp)
+        assert torch.equal(xg.grad, xr.grad)
+        grads.append(bg.grad.clone())
+        del p, xg
+    assert torch.equal(grads[0], grads[1]) and rel(grads[0], xr.grad.double().sum((0, 2, 3))) < 1e-6
