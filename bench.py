@@ -265,7 +265,7 @@ def pmc_traffic(row_name):
     import csv
     import re
     names = re.findall(r'[a-z][a-z0-9_]*_kernel', row_name)
-    for name in ('r5_pool_kernels_pmc.csv', 'r4_pool_kernels_pmc.csv'):
+    for name in ('r6_step_BCNN_pmc.csv', 'r5_pool_kernels_pmc.csv', 'r4_pool_kernels_pmc.csv'):    # newest first (r6: counted INSIDE the step)
         try:
             rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', name))))
             total = 0.0
