@@ -1,4 +1,4 @@
-"""What this RCCL build prints where (one rank on one GPU):  python tools/rccl_probe.py [inproc|shell]
+"""What this RCCL build prints where (one rank on one GPU):  python tools/probe/rccl_probe.py [inproc|shell]
 inproc: NCCL_DEBUG* set by os.environ after `import torch`, before init_process_group (what hawkeye_amd.ddp does)."""
 import os
 import sys
