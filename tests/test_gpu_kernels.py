@@ -1129,10 +1129,14 @@ def test_cin_model_matches_reference(F):
     print(f'[CIN plugin, head backward in-model] logits {e_l:.2e}  Z_CCI {e_z:.2e}  d loss / d backbone(x) {e_f:.2e}')
     assert e_l < 1e-4 and e_z < 1e-4 and e_f < 1e-4
     assert abs(float(feats[0].grad.double().norm()) / float(g['hy_dfeat_norm']) - 1) < 1e-4
+    # The gradients of the module's conv / fc (and of the criterion's h) come through the contrastive term - the squared distance
+    # of two embeddings of Z_CCI, and its square: a 1e-6 difference of the 50-layer MIOpen trunk's features (another summation
+    # order than the reference's CPU convolutions) arrives there at 3e-5 .. 1.1e-4 from run to run.  The module on its own,
+    # without a trunk in front, is pinned at 1e-6 (test_cin_module_at_plugin_width_matches_reference); here the bound is 5e-4.
     for k, p_ in list(m.ChannelInteraction.named_parameters()) + list(m.classifier.named_parameters()):
         key = k.replace('.', '__')
         e = rel(sub(p_.grad.cpu(), 1009 if p_.numel() > 500000 else 7), g['hy_g_' + key])
         print(f'    d {k}: {e:.2e}')
-        assert e < 1e-4, k
-        assert abs(float(p_.grad.double().norm()) / float(g['hy_gn_' + key]) - 1) < 1e-4, k
-    assert rel(sub(crit.h.weight.grad.cpu(), 97), g['hy_g_h']) < 1e-4
+        assert e < 5e-4, k
+        assert abs(float(p_.grad.double().norm()) / float(g['hy_gn_' + key]) - 1) < 5e-4, k
+    assert rel(sub(crit.h.weight.grad.cpu(), 97), g['hy_g_h']) < 5e-4
