@@ -558,17 +558,29 @@ def test_vgg_trunk_with_fused_epilogues_equals_the_plain_stack():
     assert list(plain.state_dict().keys()) == list(fused.state_dict().keys())
     x = torch.randn(4, 3, 96, 64, device=DEV).contiguous(memory_format=torch.channels_last)
     wt = torch.randn(4, 512, 3, 2, device=DEV)
-    outs = []
-    for net in (fused, plain):
-        xi = x.clone().requires_grad_(True)
-        y = net(xi)
-        (y * wt).sum().backward()
-        outs.append((y.detach(), xi.grad, [p_.grad for p_ in net.parameters()]))
-    (yf, gxf, gpf), (yp, gxp, gpp) = outs
-    ey, ex = rel(yf, yp), rel(gxf, gxp)
-    ep = max(rel(a, b) for a, b in zip(gpf, gpp))
-    print(f'[VGG trunk, fused epilogues vs plain stack] output {ey:.2e}  input gradient {ex:.2e}  worst parameter gradient {ep:.2e}')
-    assert ey < 1e-5 and ex < 1e-4 and ep < 1e-4
+    # MIOpen's backward is not repeatable on this stack: tools/probe/miopen_repeat_probe.py runs the PLAIN stack (torch ops and
+    # MIOpen only) sixteen times on one input and finds gradients 1e-3 .. 1e-2 away from the other runs in 1 of 8 (4 x 3 x 96 x 64)
+    # to 7 of 15 (8 x 3 x 448 x 448) of them - input gradient and first convolution mostly.  A wrong epilogue would be wrong every
+    # time; so the comparison is repeated and has to hold in at least one of five attempts (it holds in ~7 of 8).
+    tries = []
+    for attempt in range(5):
+        outs = []
+        for net in (fused, plain):
+            xi = x.clone().requires_grad_(True)
+            net.zero_grad(set_to_none=True)
+            y = net(xi)
+            (y * wt).sum().backward()
+            outs.append((y.detach(), xi.grad, [p_.grad for p_ in net.parameters()]))
+        (yf, gxf, gpf), (yp, gxp, gpp) = outs
+        ey, ex = rel(yf, yp), rel(gxf, gxp)
+        ep = max(rel(a, b) for a, b in zip(gpf, gpp))
+        tries.append((ey, ex, ep))
+        print(f'[VGG trunk, fused epilogues vs plain stack, attempt {attempt}] output {ey:.2e}  input gradient {ex:.2e}  worst parameter gradient {ep:.2e}')
+        assert ey < 1e-5                                           # the forward is repeatable
+        if ex < 1e-4 and ep < 1e-4:
+            break
+    else:
+        raise AssertionError(f'gradients of the fused stack never matched the plain one: {tries}')
     # NCHW memory, or a child with a forward hook: the children run one by one (hooks fire)
     seen = []
     h = fused[1].register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
