@@ -61,8 +61,8 @@ SIGNATURES = {
     'hk_cbp_loc_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'hk_cbp_loc_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'hk_trunk_ws_bytes': (c_sz, [c_i]),
-    'hk_bias_relu_fwd': (c_i, [c_f, c_f, c_ll, c_i, c_f]),
-    'hk_bias_relu_bwd': (c_i, [c_f, c_f, c_f, c_f, c_ll, c_i, c_f, c_sz, c_f]),
+    'hk_bias_relu_fwd': (c_i, [c_f, c_f, c_f, c_ll, c_i, c_f]),
+    'hk_bias_relu_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_f, c_sz, c_f]),
     'hk_bias_relu_pool_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'hk_bias_relu_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_add_relu_fwd': (c_i, [c_f, c_f, c_ll, c_f]),

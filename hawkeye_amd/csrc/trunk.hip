@@ -6,7 +6,8 @@
 // These kernels make it ONE pass per convolution and direction, on the channels_last tensors the trunk runs in:
 //
 //   bias_relu_fwd        y = max(x + b, 0) in place on the convolution's output                  (read 1, write 1; was 2 + 2)
-//   bias_relu_bwd        dx = dy where y > 0, db = sum dx                                        (read 2, write 1; was 3 + 1 + 1)
+//   bias_relu_bwd        dx = dy where y > 0, db = sum dx                                        (read 2 - or 1 1/16 with the forward's
+//                        sign mask -, write 1; was 3 + 1 + 1)
 //   bias_relu_pool_fwd   p = maxpool2x2(max(x + b, 0)) + a 2-bit argmax per element              (read 1, write 1/4 + 1/64;
 //                        the full-resolution activation is never written: nobody needs it - the next convolution reads p,
 //                        this convolution's weight gradient reads its INPUT - was 2 + 2 + 1.75)
@@ -32,7 +33,11 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 }
 
 // x [M][C] (M = N H W pixels), C % 4 == 0: in place.  n4 = M C / 4 float4, c4 = C / 4.
-__global__ __launch_bounds__(256) void bias_relu_fwd_kernel(float* __restrict__ x, const float* __restrict__ b, long long n4, int c4) {
+// MASK: also write one byte per float4 - bit t set where channel t of the quad came out positive - so that the backward reads
+// 1/16 of a map instead of the map (the activation itself stays: it is the next convolution's input)
+template <bool MASK>
+__global__ __launch_bounds__(256) void bias_relu_fwd_kernel(float* __restrict__ x, const float* __restrict__ b,
+                                                            uint8_t* __restrict__ mask, long long n4, int c4) {
     f32x4* x4 = reinterpret_cast<f32x4*>(x);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
     const long long stride = (long long)gridDim.x * 256;
@@ -44,7 +49,11 @@ __global__ __launch_bounds__(256) void bias_relu_fwd_kernel(float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long j = i + u * stride;
-            if (j < n4) x4[j] = relu4(v[u] + b4[(int)(j % c4)]);
+            if (j < n4) {
+                const f32x4 r = relu4(v[u] + b4[(int)(j % c4)]);
+                x4[j] = r;
+                if (MASK) mask[j] = (uint8_t)((r[0] > 0.f ? 1 : 0) | (r[1] > 0.f ? 2 : 0) | (r[2] > 0.f ? 4 : 0) | (r[3] > 0.f ? 8 : 0));
+            }
         }
     }
 }
@@ -65,7 +74,9 @@ __device__ __forceinline__ void trunk_db_partial(f32x4 acc, float* __restrict__ 
 
 // dx = dy * (y > 0) ; part[block][C] = this workgroup's column sums of dx.  rows = M, workgroup b owns rows
 // [b rpb, (b + 1) rpb).  dx may alias dy.
-__global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* dy, const float* __restrict__ y, float* dx,
+template <bool MASK>
+__global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* dy, const float* __restrict__ y,
+                                                            const uint8_t* __restrict__ mask, float* dx,
                                                             float* __restrict__ part, long long rows, long long rpb, int c4) {
     const int tid = threadIdx.x, q = tid % c4, r0 = tid / c4, rstep = 256 / c4;
     const long long rbeg = (long long)blockIdx.x * rpb, rend = rbeg + rpb < rows ? rbeg + rpb : rows;
@@ -75,10 +86,15 @@ __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* dy, con
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (long long r = rbeg + r0; r < rend; r += 4 * rstep) {
         f32x4 g[4], v[4];
+        unsigned mk[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long rr = r + u * rstep;
-            if (rr < rend) { g[u] = dy4[rr * c4 + q]; v[u] = y4[rr * c4 + q]; }
+            if (rr < rend) {
+                g[u] = dy4[rr * c4 + q];
+                if (MASK) mk[u] = mask[rr * c4 + q];
+                else v[u] = y4[rr * c4 + q];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -86,7 +102,8 @@ __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* dy, con
             if (rr < rend) {
                 f32x4 d;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) d[t] = v[u][t] > 0.f ? g[u][t] : 0.f;      // threshold_backward: y <= 0 -> 0
+                for (int t = 0; t < 4; ++t)                                            // threshold_backward: y <= 0 -> 0
+                    d[t] = (MASK ? ((mk[u] >> t) & 1u) != 0u : v[u][t] > 0.f) ? g[u][t] : 0.f;
                 dx4[rr * c4 + q] = d;
                 acc += d;
             }
@@ -262,25 +279,27 @@ using namespace hk;
 
 extern "C" size_t hk_trunk_ws_bytes(int C) { return C > 0 ? (size_t)TRUNK_PART_BLOCKS * C * sizeof(float) : 0; }
 
-extern "C" int hk_bias_relu_fwd(float* x, const float* bias, long long rows, int C, hk_stream_t stream) {
+extern "C" int hk_bias_relu_fwd(float* x, const float* bias, uint8_t* mask, long long rows, int C, hk_stream_t stream) {
     if (!x || !bias || rows <= 0 || C <= 0) return HK_ERR_BAD_ARG;
     if (C % 4 != 0 || !aligned16(x) || !aligned16(bias)) return HK_ERR_UNSUPPORTED;
     const long long n4 = rows * (C / 4);
     long long blocks = (n4 + 1023) / 1024;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bias_relu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, n4, C / 4);
+    if (mask) hipLaunchKernelGGL(bias_relu_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, mask, n4, C / 4);
+    else hipLaunchKernelGGL(bias_relu_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, mask, n4, C / 4);
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
 
-extern "C" int hk_bias_relu_bwd(const float* dy, const float* y, float* dx, float* dbias, long long rows, int C, void* ws,
-                                size_t ws_bytes, hk_stream_t stream) {
-    if (!dy || !y || !dx || !dbias || rows <= 0 || C <= 0) return HK_ERR_BAD_ARG;
-    if (!trunk_c_ok(C) || !aligned16(dy) || !aligned16(y) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
+extern "C" int hk_bias_relu_bwd(const float* dy, const float* y, const uint8_t* mask, float* dx, float* dbias, long long rows, int C,
+                                void* ws, size_t ws_bytes, hk_stream_t stream) {
+    if (!dy || (!y && !mask) || !dx || !dbias || rows <= 0 || C <= 0) return HK_ERR_BAD_ARG;
+    if (!trunk_c_ok(C) || !aligned16(dy) || (!mask && !aligned16(y)) || !aligned16(dx)) return HK_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < hk_trunk_ws_bytes(C)) return HK_ERR_WORKSPACE;
     const int nblk = trunk_blocks(rows);
     const long long rpb = (rows + nblk - 1) / nblk;
-    hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (float*)ws, rows, rpb, C / 4);
+    if (mask) hipLaunchKernelGGL(bias_relu_bwd_kernel<true>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, y, mask, dx, (float*)ws, rows, rpb, C / 4);
+    else hipLaunchKernelGGL(bias_relu_bwd_kernel<false>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, y, mask, dx, (float*)ws, rows, rpb, C / 4);
     HK_LAUNCH_CHECK();
     hipLaunchKernelGGL(trunk_db_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, C, dbias);
     HK_LAUNCH_CHECK();

@@ -1108,24 +1108,28 @@ class _BiasReLU(torch.autograd.Function):
         _nhwc(x, 'bias_relu')
         n, c, h, w = x.shape
         b = _f32c(bias)
-        check(lib.hk_bias_relu_fwd(ptr(x), ptr(b), n * h * w, c, stream()), 'hk_bias_relu_fwd')
+        # a pass that will run backward keeps the SIGN of the output as one byte per channel quad (1/16 of the map): the backward
+        # then reads that instead of the map (which stays alive anyway - it is the next convolution's input)
+        mask = torch.empty(n, h, w, c // 4, dtype=torch.uint8, device=x.device) if any(ctx.needs_input_grad) else None
+        check(lib.hk_bias_relu_fwd(ptr(x), ptr(b), ptr(mask), n * h * w, c, stream()), 'hk_bias_relu_fwd')
         ctx.mark_dirty(x)
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(mask)
+        ctx.in_shape = (n, c, h, w)
         return x
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        (y,) = ctx.saved_tensors
-        n, c, h, w = y.shape
+        (mask,) = ctx.saved_tensors
+        n, c, h, w = ctx.in_shape
         if dy.dtype != torch.float32:
             raise _lib.HawkeyeHipError(f'bias_relu backward: fp32 only, got {dy.dtype}')
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(dy, memory_format=torch.channels_last)
-        db = torch.empty(c, dtype=torch.float32, device=y.device)
+        db = torch.empty(c, dtype=torch.float32, device=dy.device)
         nws = lib.hk_trunk_ws_bytes(c)
-        ws = _ws(nws, y.device)
-        check(lib.hk_bias_relu_bwd(ptr(dy), ptr(y), ptr(dx), ptr(db), n * h * w, c, ptr(ws), nws, stream()), 'hk_bias_relu_bwd')
+        ws = _ws(nws, dy.device)
+        check(lib.hk_bias_relu_bwd(ptr(dy), None, ptr(mask), ptr(dx), ptr(db), n * h * w, c, ptr(ws), nws, stream()), 'hk_bias_relu_bwd')
         return dx, db
 
 

@@ -269,9 +269,10 @@ int hk_cbp_rect_loc_bwd(const float* x1, const float* x2, const float* dc, const
  * five MaxPool2d(2, 2); BCNN.py:38-39 / CBCNN.py:22 take all of `features`) as one full-tensor pass per elementwise op -
  * bias add, ReLU, pool; pool backward, ReLU backward, bias-gradient reduction - fused to ONE pass per convolution and
  * direction.  channels_last tensors: x [rows = N H W][C], C % 4 == 0.  Replaces, with the same arithmetic,
- *   hk_bias_relu_fwd        x = max(x + bias, 0) IN PLACE                 (nn.Conv2d's bias add + nn.ReLU(inplace=True))
+ *   hk_bias_relu_fwd        x = max(x + bias, 0) IN PLACE                 (nn.Conv2d's bias add + nn.ReLU(inplace=True)); `mask`
+ *                           (nullable, [rows][C/4] bytes): bit t of a byte = channel t of the quad came out positive
  *   hk_bias_relu_bwd        dx = dy where y > 0 else 0 ; dbias = sum dx   (threshold_backward + the convolution's bias gradient;
- *                           dx may alias dy)
+ *                           dx may alias dy); the sign from `mask` when given (1/16 of the bytes of y), else from y
  *   hk_bias_relu_pool_fwd   p = maxpool2x2(max(x + bias, 0)), argmax [N][H/2][W/2][C/4] bytes (2 bits per channel: window position
  *                           2 dh + dw of the FIRST maximum, ATen's tie rule); the full-resolution activation is not written
  *   hk_bias_relu_pool_bwd   dx [N][H][W][C] = dp routed to the argmax where p > 0, zeros elsewhere ; dbias = sum dx
@@ -279,9 +280,9 @@ int hk_cbp_rect_loc_bwd(const float* x1, const float* x2, const float* dc, const
  * column sums, added in a fixed order: deterministic).  HK_ERR_UNSUPPORTED (nothing launched) for other shapes / unaligned
  * pointers: the caller keeps the framework's own ops for those. */
 size_t hk_trunk_ws_bytes(int C);
-int hk_bias_relu_fwd(float* x, const float* bias, long long rows, int C, hk_stream_t stream);
-int hk_bias_relu_bwd(const float* dy, const float* y, float* dx, float* dbias, long long rows, int C, void* ws, size_t ws_bytes,
-                     hk_stream_t stream);
+int hk_bias_relu_fwd(float* x, const float* bias, uint8_t* mask, long long rows, int C, hk_stream_t stream);
+int hk_bias_relu_bwd(const float* dy, const float* y, const uint8_t* mask, float* dx, float* dbias, long long rows, int C, void* ws,
+                     size_t ws_bytes, hk_stream_t stream);
 int hk_bias_relu_pool_fwd(const float* x, const float* bias, float* p, uint8_t* argmax, int N, int H, int W, int C,
                           hk_stream_t stream);
 int hk_bias_relu_pool_bwd(const float* dp, const float* p, const uint8_t* argmax, float* dx, float* dbias, int N, int H, int W,

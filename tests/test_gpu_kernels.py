@@ -179,6 +179,36 @@ def test_add_relu_equals_the_two_ops_it_replaces(F, shape, cl):
         F.add_relu(torch.zeros(2, 8, 4, 4).to(DEV), torch.zeros(2, 8, 4, 4).contiguous(memory_format=torch.channels_last).to(DEV))
 
 
+def test_bias_relu_backward_from_the_sign_mask_equals_the_one_from_the_map(F):
+    """hk_bias_relu_bwd takes the sign of the forward's output either from the map itself or from the byte mask hk_bias_relu_fwd
+    writes (what the autograd node keeps: 1/16 of the bytes): the same dx and the same dbias, bit for bit."""
+    from hawkeye_amd import _lib
+    from hawkeye_amd.functional import ptr, stream
+    lib = _lib.load()
+    n, c, h, w = 3, 128, 6, 10
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.randn(n, h, w, c, generator=gen) - 0.2).to(DEV)                # NHWC rows as the kernels see them
+    b = (torch.randn(c, generator=gen) * 0.3).to(DEV)
+    dy = torch.randn(n, h, w, c, generator=gen).to(DEV)
+    y = x.clone()
+    mask = torch.empty(n, h, w, c // 4, dtype=torch.uint8, device=y.device)
+    assert lib.hk_bias_relu_fwd(ptr(y), ptr(b), ptr(mask), n * h * w, c, stream()) == 0
+    y2 = x.clone()
+    assert lib.hk_bias_relu_fwd(ptr(y2), ptr(b), None, n * h * w, c, stream()) == 0
+    assert torch.equal(y, y2) and torch.equal(y.cpu(), torch.relu(x.cpu() + b.cpu()))
+    bits = ((mask.cpu().unsqueeze(-1).int() >> torch.arange(4)) & 1).bool().reshape(n, h, w, c)
+    assert torch.equal(bits, y.cpu() > 0)
+    nws = lib.hk_trunk_ws_bytes(c)
+    ws = torch.empty(nws, dtype=torch.uint8, device=y.device)
+    res = []
+    for yy, mm in ((y, None), (None, mask)):
+        dx, db = torch.empty_like(dy), torch.empty(c, device=y.device)
+        assert lib.hk_bias_relu_bwd(ptr(dy), ptr(yy), ptr(mm), ptr(dx), ptr(db), n * h * w, c, ptr(ws), nws, stream()) == 0
+        res.append((dx.clone(), db.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][0].cpu(), dy.cpu() * (y.cpu() > 0))
+
+
 def test_trunk_epilogues_refuse_what_they_do_not_cover(F):
     x = torch.randn(2, 6, 4, 4).contiguous(memory_format=torch.channels_last).to(DEV)     # C = 6: not a multiple of 4
     assert not F.trunk_epilogue_ok(x)
