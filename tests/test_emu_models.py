@@ -25,7 +25,8 @@ for _name, _obj in list(vars(_mod).items()):
 
 
 # 10 - 25 s each when emulated (HK_EMU_FULL=1 runs them)
-_HEAVY = {'test_models_at_config_input_size_vs_reference[MPN]', 'test_train_step_runs_and_updates[MPN-128]', 'test_train_step_runs_and_updates[OSMENet-224]',
+_HEAVY = {'test_models_at_config_input_size_vs_reference[MPN]', 'test_models_at_config_input_size_vs_reference[BCNN-channels_last]',
+          'test_models_at_config_input_size_vs_reference[CBCNN-channels_last]', 'test_train_step_runs_and_updates[MPN-128]', 'test_train_step_runs_and_updates[OSMENet-224]',
           'test_osmenet_eval_matches_reference', 'test_apcnn_at_config_shape_train_vs_reference',
           'test_apcnn_at_config_shape_eval_vs_reference', 'test_bcnn_signed_sqrt_whole_model'}
 

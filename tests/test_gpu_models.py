@@ -66,7 +66,7 @@ def test_logits_match_reference(name):
     assert y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
 
 
-@pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN'])
+@pytest.mark.parametrize('name', ['BCNN', 'CBCNN', 'MPN', 'BCNN-channels_last', 'CBCNN-channels_last'])
 def test_models_at_config_input_size_vs_reference(name):
     """Whole plugins at the CONFIGS' input size (two 448 x 448 images -> 14 x 14 maps): here the heads dispatch what the
     benchmarked configs dispatch - bcnn_gram_panel_kernel<196> / gram_bwd3_kernel, cbp_fused_kernel<196> / cbp_bwd3_kernel,
@@ -79,14 +79,22 @@ def test_models_at_config_input_size_vs_reference(name):
     its float64 one there - sqrt'(|c|) of small bins - so its bound is 1e-4 + 2 e32).  The first convolution's gradient
     (behind MIOpen's whole backward) is printed and only bounded against gross disagreement."""
     g = load('model_logits_448')
+    # `-channels_last`: the memory format bench.py trains in - there the VGG trunk runs the fused epilogues behind its
+    # convolutions (csrc/trunk.hip, ConvStack), so this is the benchmarked path against the reference's numbers
+    name, _, fmt = name.partition('-')
     m = build(name, **CFG[name])
     seeded_init(m, 930)
     m = m.to(DEV).eval()
+    x = t(rs_randn(931, (2, 3, 448, 448))).to(DEV)
+    if fmt:
+        m, x = m.to(memory_format=torch.channels_last), x.contiguous(memory_format=torch.channels_last)
     keep = {}
     m.backbone.register_forward_hook(lambda _m, _i, o: (o.retain_grad(), keep.__setitem__('feat', o))[0])
     if name == 'MPN':
         m.pool.conv_dr_block.register_forward_hook(lambda _m, _i, o: (o.retain_grad(), keep.__setitem__('dr', o))[0])
-    y = m(t(rs_randn(931, (2, 3, 448, 448))).to(DEV))
+    y = m(x)
+    if fmt:
+        assert keep['feat'].is_contiguous(memory_format=torch.channels_last)
     assert rel(y, g[name]) < 1e-4, rel(y, g[name])
     assert y.argmax(1).cpu().tolist() == g[name].argmax(1).tolist()
     torch.nn.functional.cross_entropy(y, torch.tensor([3, 77], device=DEV)).backward()
@@ -98,7 +106,7 @@ def test_models_at_config_input_size_vs_reference(name):
     fg = keep['feat'].grad
     e32 = float(g[name + '_e32_feat_grad'][0])
     ef, ef64 = rel(sub(fg.cpu(), 7), g[name + '_feat_grad']), rel(sub(fg.cpu(), 7), g[name + '_feat_grad64'])
-    print(f'[448 {name}] head-input gradient vs reference: {ef:.2e} (vs its float64 run {ef64:.2e}; reference fp32 vs fp64 {e32:.2e})')
+    print(f'[448 {name} {fmt}] head-input gradient vs reference: {ef:.2e} (vs its float64 run {ef64:.2e}; reference fp32 vs fp64 {e32:.2e})')
     assert ef < (1e-4 + 2 * e32 if name == 'CBCNN' else 1e-4), ef
     assert abs(float(fg.double().abs().sum()) / float(g[name + '_feat_grad_abs'][0]) - 1) < 1e-4
     if name == 'MPN':
@@ -108,7 +116,7 @@ def test_models_at_config_input_size_vs_reference(name):
         assert abs(float(keep['dr'].grad.double().abs().sum()) / float(g['MPN_dr_grad_abs'][0]) - 1) < 1e-4
     w0 = next(m.backbone.parameters())
     e0 = rel(w0.grad, g[name + '_conv0_grad'])
-    print(f'[448 {name}] first-conv gradient vs reference: {e0:.2e}')
+    print(f'[448 {name} {fmt}] first-conv gradient vs reference: {e0:.2e}')
     assert e0 < 2e-2, e0
 
 
