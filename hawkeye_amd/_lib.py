@@ -65,6 +65,9 @@ SIGNATURES = {
     'hk_bias_relu_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_f, c_sz, c_f]),
     'hk_bias_relu_pool_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'hk_bias_relu_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    'hk_conv1_ws_bytes': (c_sz, [c_i]),
+    'hk_conv1_bias_relu_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    'hk_conv1_bias_relu_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
     'hk_add_relu_fwd': (c_i, [c_f, c_f, c_ll, c_f]),
     'hk_relu_mask_bwd': (c_i, [c_f, c_f, c_f, c_ll, c_f]),
     'hk_cbp_rect_plan_bytes': (c_sz, [c_i, c_i, c_i]),

@@ -353,3 +353,210 @@ extern "C" int hk_relu_mask_bwd(const float* dy, const float* y, float* g, long 
     HK_LAUNCH_CHECK();
     return HK_OK;
 }
+
+namespace hk {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The FIRST convolution of the trunk (model/backbone/vgg.py:24-57: Conv2d(3, 64, 3, padding=1) + ReLU; 64 x 3 x 448 x 448 in,
+// a 3.29 GB map out) as one kernel per direction.  27 multiply-adds per output are nothing for a matrix pipe to chew on - the
+// layer is the WRITE of its output (forward) and the READ of the output's gradient (backward) - yet the framework spends five
+// launches on it: the library's convolution (1.36 ms) + the bias / ReLU pass over the map (1.33 ms), and backwards the ReLU /
+// bias-gradient pass (1.17 ms, writes a second 3.29 GB map) + the library's weight gradient that reads it back (1.31 ms):
+// 5.2 ms of the 193 ms BCNN step (profiles/r6_step_BCNN_kernel_stats.csv).  Here:
+//   conv1_fwd   y = max(conv(x, w) + b, 0) and the sign mask, written once          (reads 0.15 GB, writes 3.29 + 0.21 GB)
+//   conv1_bwd   dW = sum_pix (dy o mask) (x) patch(x), db = sum_pix (dy o mask)      (reads 3.29 + 0.21 + 0.15 GB; the masked
+//               gradient map is never written - the images need no gradient)
+// VALU kernels: a thread owns a pixel (forward: 64 accumulators, the weights wave-uniform in scalar registers) or an output
+// channel (backward: 27 accumulators, the pixel's patch wave-uniform in scalar registers); no LDS on the operand side at all.
+// Weights are handed over TRANSPOSED, wt [27][64] with tap = (kh * 3 + kw) * Cin + c (a 7 KB permute of the layer's weight
+// per call, made by the caller); dW comes back in the same layout.  Cin <= 4 taps per position, Cout = 64, stride 1, pad 1.
+// Fixed summation orders (taps in order; pixels in row order per wave, waves and workgroups in order): deterministic.
+
+constexpr int C1_OUT = 64;
+
+// forward: thread = pixel (linear index over N H W), 256 pixels per workgroup
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        uint8_t* __restrict__ mask, long long npix, int H, int W) {
+    constexpr int NT = 9 * CIN;
+    __shared__ __attribute__((aligned(16))) float tile[4][64][68];      // per wave: 64 pixels x 64 channels, pitch 68 (output turn-table)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long p0 = (long long)blockIdx.x * 256;
+    const long long p = p0 + tid;
+    const bool live = p < npix;
+    const long long pc = live ? p : npix - 1;
+    const int w_ = (int)(pc % W);
+    const long long nh = pc / W;
+    const int h_ = (int)(nh % H);
+    // this pixel's patch, zero outside the image
+    float xv[NT];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hh = h_ + kh - 1;
+        const bool rok = hh >= 0 && hh < H;
+        const float* row = x + ((nh - h_ + (rok ? hh : h_)) * W) * CIN;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ww = w_ + kw - 1;
+            const bool ok = rok && ww >= 0 && ww < W;
+            const float* px = row + (long long)(ok ? ww : w_) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float v = px[c];
+                xv[(kh * 3 + kw) * CIN + c] = ok ? v : 0.f;
+            }
+        }
+    }
+    float acc[C1_OUT];
+#pragma unroll
+    for (int o = 0; o < C1_OUT; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int o = 0; o < C1_OUT; ++o) acc[o] = fmaf(xv[t], wt[t * C1_OUT + o], acc[o]);     // wt[..]: wave-uniform (scalar loads)
+    }
+    // bias, ReLU, the wave's 64 x 64 block turned through LDS so that it leaves as whole 256-byte pixel rows
+    float (*T)[68] = tile[wave];
+#pragma unroll
+    for (int o4 = 0; o4 < C1_OUT / 4; ++o4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = acc[4 * o4 + j] + bias[4 * o4 + j];
+            v[j] = s < 0.f ? 0.f : s;
+        }
+        *reinterpret_cast<f32x4*>(&T[lane][4 * o4]) = v;
+    }
+    HK_WAVE_SYNC();
+    const long long pw = p0 + 64 * wave;                              // first pixel of this wave
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int pl = 4 * i + (lane >> 4), q = lane & 15;           // pixel of the wave, channel quad
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&T[pl][4 * q]);
+        if (pw + pl < npix) {
+            reinterpret_cast<f32x4*>(y)[(pw + pl) * 16 + q] = v;
+            if (mask) mask[(pw + pl) * 16 + q] = (uint8_t)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0));
+        }
+    }
+}
+
+// backward: lane = output channel; a wave walks whole image rows (row = n H + h), pixel by pixel; part [workgroup][NT + 1][64]
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                        const float* __restrict__ x, float* __restrict__ part, long long nrows,
+                                                        int H, int W) {
+    constexpr int NT = 9 * CIN;
+    __shared__ float red[4][NT + 1][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float acc[NT], accb = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < nrows; r += nwaves) {        // (uniform per wave)
+        const int h_ = (int)(r % H);
+        const float* x0 = x + (r - 1) * (long long)W * CIN;             // image row h - 1 (same image: r - 1 = n H + h - 1)
+        const bool rok[3] = {h_ > 0, true, h_ + 1 < H};
+        const float* dyr = dy + r * (long long)W * C1_OUT;
+        const uint8_t* mr = mask + r * (long long)W * (C1_OUT / 4);
+        for (int w_ = 0; w_ < W; ++w_) {
+            float g = dyr[(long long)w_ * C1_OUT + lane];
+            const unsigned mb = mr[(long long)w_ * (C1_OUT / 4) + (lane >> 2)];
+            g = ((mb >> (lane & 3)) & 1u) ? g : 0.f;
+            accb += g;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                if (!rok[kh]) continue;                                  // (uniform)
+                const float* xr = x0 + (long long)kh * W * CIN;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ww = w_ + kw - 1;
+                    if (ww < 0 || ww >= W) continue;                     // (uniform)
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c)
+                        acc[(kh * 3 + kw) * CIN + c] = fmaf(g, xr[(long long)ww * CIN + c], acc[(kh * 3 + kw) * CIN + c]);   // xr[..]: wave-uniform
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) red[wave][t][lane] = acc[t];
+    red[wave][NT][lane] = accb;
+    __syncthreads();
+    float* pb = part + (long long)blockIdx.x * (NT + 1) * 64;
+    for (int e = threadIdx.x; e < (NT + 1) * 64; e += 256) {
+        const int t = e >> 6, o = e & 63;
+        pb[e] = (red[0][t][o] + red[1][t][o]) + (red[2][t][o] + red[3][t][o]);
+    }
+}
+
+// dwt [NT][64] and db [64] = the workgroup partials added in order (one thread per element, eight loads in flight)
+__global__ __launch_bounds__(256) void conv1_bwd_final_kernel(const float* __restrict__ part, int nblk, int nel, int nt64,
+                                                              float* __restrict__ dwt, float* __restrict__ db) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nel) return;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= nblk; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + u) * nel + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nblk; ++k) s += part[(long long)k * nel + e];
+    if (e < nt64) dwt[e] = s;
+    else db[e - nt64] = s;
+}
+
+constexpr int C1_BWD_BLOCKS = 1024;
+
+}  // namespace hk
+
+using namespace hk;
+
+extern "C" size_t hk_conv1_ws_bytes(int Cin) {           // (for any Cin > 0: the workspace check comes before the shape check)
+    return Cin > 0 ? (size_t)C1_BWD_BLOCKS * (9 * (Cin > 4 ? 4 : Cin) + 1) * 64 * sizeof(float) : 0;
+}
+
+extern "C" int hk_conv1_bias_relu_fwd(const float* x, const float* wt, const float* bias, float* y, uint8_t* mask, int N, int H, int W,
+                                      int Cin, int Cout, hk_stream_t stream) {
+    if (!x || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return HK_ERR_BAD_ARG;
+    if (Cin > 4 || Cout != C1_OUT || !aligned16(y)) return HK_ERR_UNSUPPORTED;
+    const long long npix = (long long)N * H * W;
+    const long long blocks = (npix + 255) / 256;
+    if (blocks > 0x7fffffffll) return HK_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)blocks);
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL(conv1_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, wt, bias, y, mask, npix, H, W); break;
+        case 2: hipLaunchKernelGGL(conv1_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, wt, bias, y, mask, npix, H, W); break;
+        case 3: hipLaunchKernelGGL(conv1_fwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, wt, bias, y, mask, npix, H, W); break;
+        default: hipLaunchKernelGGL(conv1_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, wt, bias, y, mask, npix, H, W); break;
+    }
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}
+
+extern "C" int hk_conv1_bias_relu_bwd(const float* dy, const uint8_t* mask, const float* x, float* dwt, float* dbias, int N, int H, int W,
+                                      int Cin, int Cout, void* ws, size_t ws_bytes, hk_stream_t stream) {
+    if (!dy || !mask || !x || !dwt || !dbias || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return HK_ERR_BAD_ARG;
+    if (!ws || ws_bytes < hk_conv1_ws_bytes(Cin)) return HK_ERR_WORKSPACE;
+    if (Cin > 4 || Cout != C1_OUT) return HK_ERR_UNSUPPORTED;
+    const long long nrows = (long long)N * H;
+    long long nblk = (nrows + 3) / 4;
+    if (nblk > C1_BWD_BLOCKS) nblk = C1_BWD_BLOCKS;
+    float* part = (float*)ws;
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL(conv1_bwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, x, part, nrows, H, W); break;
+        case 2: hipLaunchKernelGGL(conv1_bwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, x, part, nrows, H, W); break;
+        case 3: hipLaunchKernelGGL(conv1_bwd_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, x, part, nrows, H, W); break;
+        default: hipLaunchKernelGGL(conv1_bwd_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, x, part, nrows, H, W); break;
+    }
+    HK_LAUNCH_CHECK();
+    const int nel = (9 * Cin + 1) * 64;
+    hipLaunchKernelGGL(conv1_bwd_final_kernel, dim3((nel + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)nblk, nel,
+                       9 * Cin * 64, dwt, dbias);
+    HK_LAUNCH_CHECK();
+    return HK_OK;
+}

@@ -1212,6 +1212,64 @@ def add_relu(a, b):
     return _AddReLU.apply(a, b)
 
 
+def conv1_ok(x, conv):
+    """Whether hk_conv1_bias_relu_* serve this convolution: the trunk's first layer - Conv2d(Cin <= 4, 64, 3, stride 1, padding 1)
+    with a bias on an fp32 channels_last HIP batch that needs no gradient itself."""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not x.requires_grad):
+        return False
+    two = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+    return (x.shape[1] <= 4 and conv.in_channels == x.shape[1] and conv.out_channels == 64 and conv.bias is not None
+            and two(conv.kernel_size) == (3, 3) and two(conv.stride) == (1, 1) and two(conv.padding) == (1, 1)
+            and two(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and x.is_contiguous(memory_format=torch.channels_last) and x.numel() > 0)
+
+
+class _Conv1BiasReLU(torch.autograd.Function):
+    """relu(conv2d(x, weight, bias, padding=1)) for the trunk's first layer (Cin <= 4 -> 64 channels) in one kernel per
+    direction: the output map is written once (with its sign mask), and the backward forms dW and dbias straight from the
+    output's gradient without writing the masked gradient map.  replaces the library convolution + its bias / ReLU passes
+    (model/backbone/vgg.py:24-57, `features[0:2]`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        _nhwc(x, 'conv1_bias_relu')
+        n, cin, h, w = x.shape
+        if tuple(weight.shape) != (64, cin, 3, 3):
+            raise _lib.HawkeyeHipError(f'conv1_bias_relu: weight {tuple(weight.shape)} does not match [64, {cin}, 3, 3]')
+        wt = weight.detach().permute(2, 3, 1, 0).reshape(9 * cin, 64).contiguous()          # tap-major: (kh, kw, c) x out
+        b = _f32c(bias.detach())
+        y = torch.empty(n, 64, h, w, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        mask = torch.empty(n, h, w, 16, dtype=torch.uint8, device=x.device) if any(ctx.needs_input_grad[1:]) else None
+        check(lib.hk_conv1_bias_relu_fwd(ptr(x), ptr(wt), ptr(b), ptr(y), ptr(mask), n, h, w, cin, 64, stream()), 'hk_conv1_bias_relu_fwd')
+        ctx.save_for_backward(x, mask)
+        ctx.wfmt = weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous()
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, mask = ctx.saved_tensors
+        n, cin, h, w = x.shape
+        if dy.dtype != torch.float32:
+            raise _lib.HawkeyeHipError(f'conv1_bias_relu backward: fp32 only, got {dy.dtype}')
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dwt = torch.empty(9 * cin, 64, dtype=torch.float32, device=x.device)
+        db = torch.empty(64, dtype=torch.float32, device=x.device)
+        nws = lib.hk_conv1_ws_bytes(cin)
+        ws = _ws(nws, x.device)
+        check(lib.hk_conv1_bias_relu_bwd(ptr(dy), ptr(mask), ptr(x), ptr(dwt), ptr(db), n, h, w, cin, 64, ptr(ws), nws, stream()),
+              'hk_conv1_bias_relu_bwd')
+        dw = dwt.view(3, 3, cin, 64).permute(3, 2, 0, 1)                                     # [64, Cin, 3, 3]
+        dw = dw.contiguous(memory_format=torch.channels_last) if ctx.wfmt else dw.contiguous()
+        return None, dw, db
+
+
+def conv1_bias_relu(x, weight, bias):
+    """relu(conv2d(x, weight, bias, stride=1, padding=1)) for Cin <= 4 -> 64 channels; see _Conv1BiasReLU."""
+    return _Conv1BiasReLU.apply(x, weight, bias)
+
+
 def bias_relu(x, bias):
     """relu(x + bias[None,:,None,None]) in place on x (a channels_last convolution output); see _BiasReLU."""
     return _BiasReLU.apply(x, bias)

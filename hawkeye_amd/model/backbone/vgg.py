@@ -39,6 +39,11 @@ class ConvStack(nn.Sequential):
             m = mods[i]
             if (isinstance(m, nn.Conv2d) and m.bias is not None and m.padding_mode == 'zeros' and i + 1 < len(mods)
                     and isinstance(mods[i + 1], nn.ReLU)):
+                if not (i + 2 < len(mods) and _plain_pool(mods[i + 2])) and HF.conv1_ok(x, m):
+                    # the first layer (3 -> 64 channels): convolution, bias and ReLU in ONE kernel - it is the write of its output
+                    x = HF.conv1_bias_relu(x, m.weight, m.bias)
+                    i += 2
+                    continue
                 y = TF.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
                 pool = i + 2 < len(mods) and _plain_pool(mods[i + 2])
                 if pool and HF.trunk_epilogue_ok(y, pool=True):

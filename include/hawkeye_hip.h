@@ -290,6 +290,19 @@ int hk_bias_relu_pool_bwd(const float* dp, const float* p, const uint8_t* argmax
 /* The end of a ResNet bottleneck, `out += identity; out = relu(out)` (model/backbone/resnet.py:89-136; the trunk of MPN, AP-CNN,
  * OSMENet, CIN): hk_add_relu_fwd  a = max(a + b, 0) IN PLACE on a, n elements of any dense layout the two share, n % 4 == 0;
  * hk_relu_mask_bwd  g = dy where y > 0 else 0 - the gradient of both operands. */
+/* The trunk's FIRST convolution with its epilogue, Conv2d(Cin <= 4, 64, 3, padding=1) + bias + ReLU (model/backbone/vgg.py:24-57, layer 0
+ * of `features`), as one kernel per direction: the layer is the write of its 3.29 GB output / the read of that output's gradient.
+ *   hk_conv1_bias_relu_fwd   x [N][H][W][Cin] (channels_last), wt [9 Cin][64] = the layer's weight permuted to tap-major
+ *                            (tap = (kh * 3 + kw) * Cin + c), bias [64] -> y [N][H][W][64] = max(conv + bias, 0), mask (nullable,
+ *                            [N][H][W][16] bytes: the sign bits hk_bias_relu_fwd writes)
+ *   hk_conv1_bias_relu_bwd   dy, mask, x -> dwt [9 Cin][64] (same layout as wt), dbias [64]; no input gradient (images need none);
+ *                            workspace hk_conv1_ws_bytes(Cin) bytes; the masked gradient map is never written
+ * Replaces the library convolution + hk_bias_relu_fwd and hk_bias_relu_bwd + the library's weight gradient for that layer. */
+size_t hk_conv1_ws_bytes(int Cin);
+int hk_conv1_bias_relu_fwd(const float* x, const float* wt, const float* bias, float* y, uint8_t* mask, int N, int H, int W, int Cin,
+                           int Cout, hk_stream_t stream);
+int hk_conv1_bias_relu_bwd(const float* dy, const uint8_t* mask, const float* x, float* dwt, float* dbias, int N, int H, int W, int Cin,
+                           int Cout, void* ws, size_t ws_bytes, hk_stream_t stream);
 int hk_add_relu_fwd(float* a, const float* b, long long n, hk_stream_t stream);
 int hk_relu_mask_bwd(const float* dy, const float* y, float* g, long long n, hk_stream_t stream);
 

@@ -209,6 +209,32 @@ def test_bias_relu_backward_from_the_sign_mask_equals_the_one_from_the_map(F):
     assert torch.equal(res[0][0].cpu(), dy.cpu() * (y.cpu() > 0))
 
 
+@pytest.mark.parametrize('n,cin,h,w', [(2, 3, 9, 13), (1, 3, 64, 64), (2, 4, 5, 7), (3, 1, 4, 4), (1, 3, 1, 5), (2, 3, 20, 70)])
+def test_first_convolution_with_its_epilogue_in_one_kernel(F, n, cin, h, w):
+    """hk_conv1_bias_relu_fwd / bwd (the trunk's first layer, Conv2d(Cin <= 4, 64, 3, padding=1) + bias + ReLU of
+    model/backbone/vgg.py:24-57, one kernel per direction) against torch's conv2d + relu in float64: the output, the weight
+    and bias gradients; odd map sizes (every border case of the 3 x 3 window), one-pixel-high maps, more pixels than a
+    workgroup's 256, 1 / 3 / 4 input channels; the weight in both memory formats."""
+    gen = torch.Generator().manual_seed(n * 100 + cin * 10 + h)
+    x = torch.randn(n, cin, h, w, generator=gen).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(64, cin, 3, 3, generator=gen) * 0.3
+    b = torch.randn(64, generator=gen) * 0.2
+    dy = torch.randn(n, 64, h, w, generator=gen).contiguous(memory_format=torch.channels_last)
+    wr, br = wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.relu(torch.nn.functional.conv2d(x.double(), wr, br, padding=1))
+    yr.backward(dy.double())
+    for cl in (False, True):
+        wg = (wt.contiguous(memory_format=torch.channels_last) if cl else wt.clone()).to(DEV).requires_grad_(True)
+        bg = b.clone().to(DEV).requires_grad_(True)
+        y = F.conv1_bias_relu(x.to(DEV), wg, bg)
+        assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+        assert rel(y, yr) < 1e-6
+        assert bool(((y.cpu() > 0) == (yr > 1e-6)).logical_or(yr.abs() <= 1e-6).all())     # the same sign pattern (away from rounding)
+        y.backward(dy.to(DEV))
+        assert wg.grad.shape == wt.shape and rel(wg.grad, wr.grad) < 1e-5 and rel(bg.grad, br.grad) < 1e-5
+        assert wg.grad.is_contiguous(memory_format=torch.channels_last) or not cl
+
+
 def test_trunk_epilogues_refuse_what_they_do_not_cover(F):
     x = torch.randn(2, 6, 4, 4).contiguous(memory_format=torch.channels_last).to(DEV)     # C = 6: not a multiple of 4
     assert not F.trunk_epilogue_ok(x)
