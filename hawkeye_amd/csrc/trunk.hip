@@ -441,12 +441,15 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
-// backward: lane = output channel; a wave walks whole image rows (row = n H + h), pixel by pixel; part [workgroup][NT + 1][64]
+// backward: lane = output channel; a wave walks whole image rows (row = n H + h) eight pixels at a time - the eight gradient
+// loads, the mask bytes and the 3 x 10 x CIN patch values (wave-uniform: scalar loads) are all requested before the 8 x 27
+// multiply-adds (pixel by pixel the loop was one memory latency per pixel: 2.8 ms); part [workgroup][NT + 1][64]
 template <int CIN>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
                                                         const float* __restrict__ x, float* __restrict__ part, long long nrows,
                                                         int H, int W) {
     constexpr int NT = 9 * CIN;
+    constexpr int PB = 8;                                                // pixels per step
     __shared__ float red[4][NT + 1][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -456,27 +459,47 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     const long long nwaves = (long long)gridDim.x * 4;
     for (long long r = (long long)blockIdx.x * 4 + wave; r < nrows; r += nwaves) {        // (uniform per wave)
         const int h_ = (int)(r % H);
-        const float* x0 = x + (r - 1) * (long long)W * CIN;             // image row h - 1 (same image: r - 1 = n H + h - 1)
         const bool rok[3] = {h_ > 0, true, h_ + 1 < H};
         const float* dyr = dy + r * (long long)W * C1_OUT;
         const uint8_t* mr = mask + r * (long long)W * (C1_OUT / 4);
-        for (int w_ = 0; w_ < W; ++w_) {
-            float g = dyr[(long long)w_ * C1_OUT + lane];
-            const unsigned mb = mr[(long long)w_ * (C1_OUT / 4) + (lane >> 2)];
-            g = ((mb >> (lane & 3)) & 1u) ? g : 0.f;
-            accb += g;
+        for (int w0 = 0; w0 < W; w0 += PB) {
+            float g[PB];
+            unsigned mb[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int wc = w0 + u < W ? w0 + u : W - 1;
+                g[u] = dyr[(long long)wc * C1_OUT + lane];
+                mb[u] = mr[(long long)wc * (C1_OUT / 4) + (lane >> 2)];
+            }
+            // the patch values of the PB pixels: rows h - 1 .. h + 1, columns w0 - 1 .. w0 + PB, zero outside the image
+            float xs[3][(PB + 2) * CIN];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                if (!rok[kh]) continue;                                  // (uniform)
-                const float* xr = x0 + (long long)kh * W * CIN;
+                const float* xr = x + (r + (rok[kh] ? kh - 1 : 0)) * (long long)W * CIN;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ww = w_ + kw - 1;
-                    if (ww < 0 || ww >= W) continue;                     // (uniform)
+                for (int j = 0; j < PB + 2; ++j) {
+                    const int ww = w0 + j - 1;
+                    const bool ok = rok[kh] && ww >= 0 && ww < W;
+                    const int wc = ok ? ww : w0;
 #pragma unroll
-                    for (int c = 0; c < CIN; ++c)
-                        acc[(kh * 3 + kw) * CIN + c] = fmaf(g, xr[(long long)ww * CIN + c], acc[(kh * 3 + kw) * CIN + c]);   // xr[..]: wave-uniform
+                    for (int c = 0; c < CIN; ++c) {
+                        const float v = xr[(long long)wc * CIN + c];     // wave-uniform address
+                        xs[kh][j * CIN + c] = ok ? v : 0.f;
+                    }
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                float gv = ((mb[u] >> (lane & 3)) & 1u) ? g[u] : 0.f;
+                gv = w0 + u < W ? gv : 0.f;
+                accb += gv;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int c = 0; c < CIN; ++c)
+                            acc[(kh * 3 + kw) * CIN + c] = fmaf(gv, xs[kh][(u + kw) * CIN + c], acc[(kh * 3 + kw) * CIN + c]);
             }
         }
     }
@@ -491,26 +514,35 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     }
 }
 
-// dwt [NT][64] and db [64] = the workgroup partials added in order (one thread per element, eight loads in flight)
+// dwt [NT][64] and db [64] = the workgroup partials added in a fixed order: 64 elements per workgroup, four interleaved chains
+// per element (eight loads in flight each), combined in order
 __global__ __launch_bounds__(256) void conv1_bwd_final_kernel(const float* __restrict__ part, int nblk, int nel, int nt64,
                                                               float* __restrict__ dwt, float* __restrict__ db) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nel) return;
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + l;
     float s = 0.f;
-    int k = 0;
-    for (; k + 8 <= nblk; k += 8) {
-        float v[8];
+    if (e < nel) {
+        int k = q;
+        for (; k + 7 * 4 < nblk; k += 8 * 4) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + u) * nel + e];
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + 4 * u) * nel + e];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nblk; k += 4) s += part[(long long)k * nel + e];
     }
-    for (; k < nblk; ++k) s += part[(long long)k * nel + e];
-    if (e < nt64) dwt[e] = s;
-    else db[e - nt64] = s;
+    red[q][l] = s;
+    __syncthreads();
+    if (q == 0 && e < nel) {
+        const float t = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        if (e < nt64) dwt[e] = t;
+        else db[e - nt64] = t;
+    }
 }
 
-constexpr int C1_BWD_BLOCKS = 1024;
+constexpr int C1_BWD_BLOCKS = 512;           // two workgroups per CU
 
 }  // namespace hk
 
@@ -555,7 +587,7 @@ extern "C" int hk_conv1_bias_relu_bwd(const float* dy, const uint8_t* mask, cons
     }
     HK_LAUNCH_CHECK();
     const int nel = (9 * Cin + 1) * 64;
-    hipLaunchKernelGGL(conv1_bwd_final_kernel, dim3((nel + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)nblk, nel,
+    hipLaunchKernelGGL(conv1_bwd_final_kernel, dim3((nel + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)nblk, nel,
                        9 * Cin * 64, dwt, dbias);
     HK_LAUNCH_CHECK();
     return HK_OK;
