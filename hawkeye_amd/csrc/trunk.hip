@@ -366,10 +366,11 @@ namespace hk {
 //   conv1_fwd   y = max(conv(x, w) + b, 0) and the sign mask, written once          (reads 0.15 GB, writes 3.29 + 0.21 GB)
 //   conv1_bwd   dW = sum_pix (dy o mask) (x) patch(x), db = sum_pix (dy o mask)      (reads 3.29 + 0.21 + 0.15 GB; the masked
 //               gradient map is never written - the images need no gradient)
-// VALU kernels: a thread owns a pixel (forward: 64 accumulators, the weights wave-uniform in scalar registers) or an output
-// channel (backward: 27 accumulators, the pixel's patch wave-uniform in scalar registers); no LDS on the operand side at all.
+// Forward: a VALU kernel, a thread owns a pixel (64 accumulators, the weights wave-uniform in scalar registers, packed FMAs);
+// backward: a 64 x 28 x 12.8 M GEMM on the matrix pipe (see conv1_bwd_kernel).  No LDS on the operand side of either.
 // Weights are handed over TRANSPOSED, wt [27][64] with tap = (kh * 3 + kw) * Cin + c (a 7 KB permute of the layer's weight
-// per call, made by the caller); dW comes back in the same layout.  Cin <= 4 taps per position, Cout = 64, stride 1, pad 1.
+// per call, made by the caller); dW comes back in the same layout.  Cin <= 3 (27 taps + the ones column fit one 32-wide MFMA
+// tile), Cout = 64, stride 1, pad 1.
 // Fixed summation orders (taps in order; pixels in row order per wave, waves and workgroups in order): deterministic.
 
 constexpr int C1_OUT = 64;
@@ -441,71 +442,71 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
-// backward: lane = output channel; a wave walks whole image rows (row = n H + h) eight pixels at a time - the eight gradient
-// loads, the mask bytes and the 3 x 10 x CIN patch values (wave-uniform: scalar loads) are all requested before the 8 x 27
-// multiply-adds (pixel by pixel the loop was one memory latency per pixel: 2.8 ms); part [workgroup][NT + 1][64]
+// backward: dW^T [tap][o] = sum over pixels of patch[pix][tap] g[pix][o] is a GEMM with a 12.8 M-deep reduction and a 64 x 28
+// result - matrix-pipe work after all: v_mfma_f32_32x32x2f32 with A = g (rows = output channels of a 32-channel half, k = two
+// pixels), B = the two pixels' patches (columns = taps, column NT = 1.0: that column of the result is dbias).  A wave walks whole
+// image rows (row = n H + h), sixteen pixels per step with every load of the step in flight before its first MFMA: g as it
+// lies (a lane reads one float: 128-byte runs), the mask byte, and the patch value as a per-lane gather from the (cached,
+// 0.15 GB) input.  (The VALU form - lane = channel, 27 accumulators, patch values in scalar registers - stalled on its
+// scalar loads: 2.4 ms where this takes the time of the read.)  part [workgroup][NT + 1][64]
 template <int CIN>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
                                                         const float* __restrict__ x, float* __restrict__ part, long long nrows,
                                                         int H, int W) {
     constexpr int NT = 9 * CIN;
-    constexpr int PB = 8;                                                // pixels per step
+    static_assert(NT + 1 <= 32, "taps + the ones column fit one 32-wide MFMA tile");
+    constexpr int UN = 8;                                                // MFMA steps (pixel pairs) per loop iteration
     __shared__ float red[4][NT + 1][64];
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float acc[NT], accb = 0.f;
+    // this lane's column of B: tap l31 = (kh * 3 + kw) * CIN + c, or the ones column, or nothing
+    const bool is_tap = l31 < NT, is_one = l31 == NT;
+    const int kh = is_tap ? l31 / (3 * CIN) : 1, kw = is_tap ? (l31 / CIN) % 3 : 1, c = is_tap ? l31 % CIN : 0;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     const long long nwaves = (long long)gridDim.x * 4;
     for (long long r = (long long)blockIdx.x * 4 + wave; r < nrows; r += nwaves) {        // (uniform per wave)
         const int h_ = (int)(r % H);
-        const bool rok[3] = {h_ > 0, true, h_ + 1 < H};
-        const float* dyr = dy + r * (long long)W * C1_OUT;
-        const uint8_t* mr = mask + r * (long long)W * (C1_OUT / 4);
-        for (int w0 = 0; w0 < W; w0 += PB) {
-            float g[PB];
-            unsigned mb[PB];
+        const bool rowok = is_tap && (kh == 0 ? h_ > 0 : (kh == 2 ? h_ + 1 < H : true));
+        const float* xb = x + ((r + (rowok ? kh - 1 : 0)) * (long long)W) * CIN + c;     // + (w + kw - 1) CIN
+        const float* dyr = dy + r * (long long)W * C1_OUT + l31;
+        const uint8_t* mr = mask + r * (long long)W * (C1_OUT / 4) + (l31 >> 2);
+        for (int w0 = 0; w0 < W; w0 += 2 * UN) {
+            float a0[UN], a1[UN], b[UN];
+            unsigned m0[UN], m1[UN];
 #pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                const int wc = w0 + u < W ? w0 + u : W - 1;
-                g[u] = dyr[(long long)wc * C1_OUT + lane];
-                mb[u] = mr[(long long)wc * (C1_OUT / 4) + (lane >> 2)];
-            }
-            // the patch values of the PB pixels: rows h - 1 .. h + 1, columns w0 - 1 .. w0 + PB, zero outside the image
-            float xs[3][(PB + 2) * CIN];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const float* xr = x + (r + (rok[kh] ? kh - 1 : 0)) * (long long)W * CIN;
-#pragma unroll
-                for (int j = 0; j < PB + 2; ++j) {
-                    const int ww = w0 + j - 1;
-                    const bool ok = rok[kh] && ww >= 0 && ww < W;
-                    const int wc = ok ? ww : w0;
-#pragma unroll
-                    for (int c = 0; c < CIN; ++c) {
-                        const float v = xr[(long long)wc * CIN + c];     // wave-uniform address
-                        xs[kh][j * CIN + c] = ok ? v : 0.f;
-                    }
-                }
+            for (int u = 0; u < UN; ++u) {
+                const int w_ = w0 + 2 * u + hf;
+                const int wc = w_ < W ? w_ : W - 1;
+                a0[u] = dyr[(long long)wc * C1_OUT];
+                a1[u] = dyr[(long long)wc * C1_OUT + 32];
+                m0[u] = mr[(long long)wc * (C1_OUT / 4)];
+                m1[u] = mr[(long long)wc * (C1_OUT / 4) + 8];
+                const int ww = w_ + kw - 1;
+                const bool okb = rowok && w_ < W && ww >= 0 && ww < W;
+                const float v = xb[(long long)(okb ? ww : wc) * CIN];
+                b[u] = okb ? v : ((is_one && w_ < W) ? 1.0f : 0.f);
             }
 #pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                float gv = ((mb[u] >> (lane & 3)) & 1u) ? g[u] : 0.f;
-                gv = w0 + u < W ? gv : 0.f;
-                accb += gv;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                        for (int c = 0; c < CIN; ++c)
-                            acc[(kh * 3 + kw) * CIN + c] = fmaf(gv, xs[kh][(u + kw) * CIN + c], acc[(kh * 3 + kw) * CIN + c]);
+            for (int u = 0; u < UN; ++u) {
+                const bool in = w0 + 2 * u + hf < W;
+                const float g0 = (in && ((m0[u] >> (l31 & 3)) & 1u)) ? a0[u] : 0.f;
+                const float g1 = (in && ((m1[u] >> (l31 & 3)) & 1u)) ? a1[u] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, b[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, b[u], acc1, 0, 0, 0);
             }
         }
     }
+    // C layout of the 32 x 32 MFMA: column = lane & 31 (tap), row = 8 (i / 4) + 4 (lane >> 5) + i % 4 (channel of the half)
+    if (l31 <= NT) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) red[wave][t][lane] = acc[t];
-    red[wave][NT][lane] = accb;
+        for (int i = 0; i < 16; ++i) {
+            const int o = 8 * (i >> 2) + 4 * hf + (i & 3);
+            red[wave][l31][o] = acc0[i];
+            red[wave][l31][32 + o] = acc1[i];
+        }
+    }
     __syncthreads();
     float* pb = part + (long long)blockIdx.x * (NT + 1) * 64;
     for (int e = threadIdx.x; e < (NT + 1) * 64; e += 256) {
@@ -514,48 +515,49 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     }
 }
 
-// dwt [NT][64] and db [64] = the workgroup partials added in a fixed order: 64 elements per workgroup, four interleaved chains
+// dwt [NT][64] and db [64] = the workgroup partials added in a fixed order: 64 elements per workgroup, sixteen interleaved chains
 // per element (eight loads in flight each), combined in order
-__global__ __launch_bounds__(256) void conv1_bwd_final_kernel(const float* __restrict__ part, int nblk, int nel, int nt64,
-                                                              float* __restrict__ dwt, float* __restrict__ db) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void conv1_bwd_final_kernel(const float* __restrict__ part, int nblk, int nel, int nt64,
+                                                               float* __restrict__ dwt, float* __restrict__ db) {
+    __shared__ float red[16][64];
     const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + l;
     float s = 0.f;
     if (e < nel) {
         int k = q;
-        for (; k + 7 * 4 < nblk; k += 8 * 4) {
+        for (; k + 7 * 16 < nblk; k += 8 * 16) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + 4 * u) * nel + e];
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + 16 * u) * nel + e];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; k < nblk; k += 4) s += part[(long long)k * nel + e];
+        for (; k < nblk; k += 16) s += part[(long long)k * nel + e];
     }
     red[q][l] = s;
     __syncthreads();
     if (q == 0 && e < nel) {
-        const float t = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        float t = red[0][l];
+        for (int k = 1; k < 16; ++k) t += red[k][l];
         if (e < nt64) dwt[e] = t;
         else db[e - nt64] = t;
     }
 }
 
-constexpr int C1_BWD_BLOCKS = 512;           // two workgroups per CU
+constexpr int C1_BWD_BLOCKS = 1024;          // four workgroups per CU: sixteen waves to hide a step's load latency behind the others' FMAs
 
 }  // namespace hk
 
 using namespace hk;
 
 extern "C" size_t hk_conv1_ws_bytes(int Cin) {           // (for any Cin > 0: the workspace check comes before the shape check)
-    return Cin > 0 ? (size_t)C1_BWD_BLOCKS * (9 * (Cin > 4 ? 4 : Cin) + 1) * 64 * sizeof(float) : 0;
+    return Cin > 0 ? (size_t)C1_BWD_BLOCKS * (9 * (Cin > 3 ? 3 : Cin) + 1) * 64 * sizeof(float) : 0;
 }
 
 extern "C" int hk_conv1_bias_relu_fwd(const float* x, const float* wt, const float* bias, float* y, uint8_t* mask, int N, int H, int W,
                                       int Cin, int Cout, hk_stream_t stream) {
     if (!x || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return HK_ERR_BAD_ARG;
-    if (Cin > 4 || Cout != C1_OUT || !aligned16(y)) return HK_ERR_UNSUPPORTED;
+    if (Cin > 3 || Cout != C1_OUT || !aligned16(y)) return HK_ERR_UNSUPPORTED;
     const long long npix = (long long)N * H * W;
     const long long blocks = (npix + 255) / 256;
     if (blocks > 0x7fffffffll) return HK_ERR_UNSUPPORTED;
@@ -563,8 +565,7 @@ extern "C" int hk_conv1_bias_relu_fwd(const float* x, const float* wt, const flo
     switch (Cin) {
         case 1: hipLaunchKernelGGL(conv1_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, wt, bias, y, mask, npix, H, W); break;
         case 2: hipLaunchKernelGGL(conv1_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, wt, bias, y, mask, npix, H, W); break;
-        case 3: hipLaunchKernelGGL(conv1_fwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, wt, bias, y, mask, npix, H, W); break;
-        default: hipLaunchKernelGGL(conv1_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, wt, bias, y, mask, npix, H, W); break;
+        default: hipLaunchKernelGGL(conv1_fwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, wt, bias, y, mask, npix, H, W); break;
     }
     HK_LAUNCH_CHECK();
     return HK_OK;
@@ -574,7 +575,7 @@ extern "C" int hk_conv1_bias_relu_bwd(const float* dy, const uint8_t* mask, cons
                                       int Cin, int Cout, void* ws, size_t ws_bytes, hk_stream_t stream) {
     if (!dy || !mask || !x || !dwt || !dbias || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return HK_ERR_BAD_ARG;
     if (!ws || ws_bytes < hk_conv1_ws_bytes(Cin)) return HK_ERR_WORKSPACE;
-    if (Cin > 4 || Cout != C1_OUT) return HK_ERR_UNSUPPORTED;
+    if (Cin > 3 || Cout != C1_OUT) return HK_ERR_UNSUPPORTED;
     const long long nrows = (long long)N * H;
     long long nblk = (nrows + 3) / 4;
     if (nblk > C1_BWD_BLOCKS) nblk = C1_BWD_BLOCKS;
@@ -582,12 +583,11 @@ extern "C" int hk_conv1_bias_relu_bwd(const float* dy, const uint8_t* mask, cons
     switch (Cin) {
         case 1: hipLaunchKernelGGL(conv1_bwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, x, part, nrows, H, W); break;
         case 2: hipLaunchKernelGGL(conv1_bwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, x, part, nrows, H, W); break;
-        case 3: hipLaunchKernelGGL(conv1_bwd_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, x, part, nrows, H, W); break;
-        default: hipLaunchKernelGGL(conv1_bwd_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, x, part, nrows, H, W); break;
+        default: hipLaunchKernelGGL(conv1_bwd_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, x, part, nrows, H, W); break;
     }
     HK_LAUNCH_CHECK();
     const int nel = (9 * Cin + 1) * 64;
-    hipLaunchKernelGGL(conv1_bwd_final_kernel, dim3((nel + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)part, (int)nblk, nel,
+    hipLaunchKernelGGL(conv1_bwd_final_kernel, dim3((nel + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const float*)part, (int)nblk, nel,
                        9 * Cin * 64, dwt, dbias);
     HK_LAUNCH_CHECK();
     return HK_OK;

@@ -1213,20 +1213,20 @@ def add_relu(a, b):
 
 
 def conv1_ok(x, conv):
-    """Whether hk_conv1_bias_relu_* serve this convolution: the trunk's first layer - Conv2d(Cin <= 4, 64, 3, stride 1, padding 1)
+    """Whether hk_conv1_bias_relu_* serve this convolution: the trunk's first layer - Conv2d(Cin <= 3, 64, 3, stride 1, padding 1)
     with a bias on an fp32 channels_last HIP batch that needs no gradient itself."""
     if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not x.requires_grad):
         return False
     two = lambda v: (v, v) if isinstance(v, int) else tuple(v)
-    return (x.shape[1] <= 4 and conv.in_channels == x.shape[1] and conv.out_channels == 64 and conv.bias is not None
+    return (x.shape[1] <= 3 and conv.in_channels == x.shape[1] and conv.out_channels == 64 and conv.bias is not None
             and two(conv.kernel_size) == (3, 3) and two(conv.stride) == (1, 1) and two(conv.padding) == (1, 1)
             and two(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
             and x.is_contiguous(memory_format=torch.channels_last) and x.numel() > 0)
 
 
 class _Conv1BiasReLU(torch.autograd.Function):
-    """relu(conv2d(x, weight, bias, padding=1)) for the trunk's first layer (Cin <= 4 -> 64 channels) in one kernel per
-    direction: the output map is written once (with its sign mask), and the backward forms dW and dbias straight from the
+    """relu(conv2d(x, weight, bias, padding=1)) for the trunk's first layer (Cin <= 3 -> 64 channels) in one kernel per
+    direction (Cin <= 3): the output map is written once (with its sign mask), and the backward forms dW and dbias straight from the
     output's gradient without writing the masked gradient map.  replaces the library convolution + its bias / ReLU passes
     (model/backbone/vgg.py:24-57, `features[0:2]`)."""
 
@@ -1266,7 +1266,7 @@ class _Conv1BiasReLU(torch.autograd.Function):
 
 
 def conv1_bias_relu(x, weight, bias):
-    """relu(conv2d(x, weight, bias, stride=1, padding=1)) for Cin <= 4 -> 64 channels; see _Conv1BiasReLU."""
+    """relu(conv2d(x, weight, bias, stride=1, padding=1)) for Cin <= 3 -> 64 channels; see _Conv1BiasReLU."""
     return _Conv1BiasReLU.apply(x, weight, bias)
 
 

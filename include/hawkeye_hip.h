@@ -290,7 +290,7 @@ int hk_bias_relu_pool_bwd(const float* dp, const float* p, const uint8_t* argmax
 /* The end of a ResNet bottleneck, `out += identity; out = relu(out)` (model/backbone/resnet.py:89-136; the trunk of MPN, AP-CNN,
  * OSMENet, CIN): hk_add_relu_fwd  a = max(a + b, 0) IN PLACE on a, n elements of any dense layout the two share, n % 4 == 0;
  * hk_relu_mask_bwd  g = dy where y > 0 else 0 - the gradient of both operands. */
-/* The trunk's FIRST convolution with its epilogue, Conv2d(Cin <= 4, 64, 3, padding=1) + bias + ReLU (model/backbone/vgg.py:24-57, layer 0
+/* The trunk's FIRST convolution with its epilogue, Conv2d(Cin <= 3, 64, 3, padding=1) + bias + ReLU (model/backbone/vgg.py:24-57, layer 0
  * of `features`), as one kernel per direction: the layer is the write of its 3.29 GB output / the read of that output's gradient.
  *   hk_conv1_bias_relu_fwd   x [N][H][W][Cin] (channels_last), wt [9 Cin][64] = the layer's weight permuted to tap-major
  *                            (tap = (kh * 3 + kw) * Cin + c), bias [64] -> y [N][H][W][64] = max(conv + bias, 0), mask (nullable,
