@@ -286,3 +286,38 @@ def test_trunk_epilogues_at_the_metric_shape(F):
         grads.append(bg.grad.clone())
         del p, xg
     assert torch.equal(grads[0], grads[1]) and rel(grads[0], xr.grad.double().sum((0, 2, 3))) < 1e-6
+
+
+def test_first_convolution_kernels_at_the_metric_shape(F):
+    """hk_conv1_bias_relu_fwd / bwd at the metric's shape - 64 x 3 x 448 x 448 in, a 3.29 GB map out (byte offsets beyond 2^32):
+    the output against the library's convolution + ReLU on the device; the weight / bias gradients (a) of the first two images
+    against a float64 evaluation on the CPU, (b) of the whole batch against the SUM of the gradients of its four quarters
+    computed by the same kernels on their own - additivity ties the large-offset rows to the small-offset ones - and (c)
+    against the library's own float32 backward (loosely: its weight gradient is an atomic sum over 12.8 M pixels)."""
+    n, h, w = 64, 448, 448
+    gen = torch.Generator(device=DEV).manual_seed(23)
+    x = torch.empty(n, 3, h, w, device=DEV, memory_format=torch.channels_last).normal_(0.0, 1.0, generator=gen)
+    wt = (torch.randn(64, 3, 3, 3, device=DEV, generator=gen) * 0.3)
+    b = torch.randn(64, device=DEV, generator=gen) * 0.2
+    dy = torch.empty(n, 64, h, w, device=DEV, memory_format=torch.channels_last).normal_(0.0, 1.0, generator=gen)
+
+    def ours(xs, dys):
+        wg, bg = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = F.conv1_bias_relu(xs, wg, bg)
+        y.backward(dys)
+        return y.detach(), wg.grad, bg.grad
+    y, dw, db = ours(x, dy)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.relu(torch.nn.functional.conv2d(x, wr, br, padding=1))
+    assert rel(y, yr) < 1e-6
+    yr.backward(dy)
+    assert rel(dw, wr.grad) < 2e-3 and rel(db, br.grad) < 2e-3                     # (c)
+    del yr
+    parts = [ours(x[i:i + 16], dy[i:i + 16]) for i in range(0, n, 16)]
+    assert all(torch.equal(p[0], y[i:i + 16]) for p, i in zip(parts, range(0, n, 16)))
+    assert rel(dw, sum(p[1].double() for p in parts)) < 1e-5 and rel(db, sum(p[2].double() for p in parts)) < 1e-5    # (b)
+    _, dw2, db2 = ours(x[:2], dy[:2])
+    w64, b64 = wt.cpu().double().requires_grad_(True), b.cpu().double().requires_grad_(True)
+    torch.relu(torch.nn.functional.conv2d(x[:2].cpu().double(), w64, b64, padding=1)).backward(dy[:2].cpu().double())
+    assert rel(dw2, w64.grad) < 1e-5 and rel(db2, b64.grad) < 1e-5                 # (a)
+    assert torch.equal(ours(x, dy)[1], dw)                                          # run to run: the same bits
