@@ -316,8 +316,11 @@ def test_first_convolution_kernels_at_the_metric_shape(F):
     parts = [ours(x[i:i + 16], dy[i:i + 16]) for i in range(0, n, 16)]
     assert all(torch.equal(p[0], y[i:i + 16]) for p, i in zip(parts, range(0, n, 16)))
     assert rel(dw, sum(p[1].double() for p in parts)) < 1e-5 and rel(db, sum(p[2].double() for p in parts)) < 1e-5    # (b)
-    _, dw2, db2 = ours(x[:2], dy[:2])
+    y2, dw2, db2 = ours(x[:2], dy[:2])
     w64, b64 = wt.cpu().double().requires_grad_(True), b.cpu().double().requires_grad_(True)
-    torch.relu(torch.nn.functional.conv2d(x[:2].cpu().double(), w64, b64, padding=1)).backward(dy[:2].cpu().double())
+    # (the float64 evaluation takes the SIGN pattern of the float32 output: of 25.7 M outputs a dozen lie within rounding of the
+    #  ReLU's kink, and each one that flips moves the gradient by 1e-4 of its norm - that is the kink, not the kernel)
+    g64 = dy[:2].cpu().double() * (y2.cpu() > 0)
+    torch.nn.functional.conv2d(x[:2].cpu().double(), w64, b64, padding=1).backward(g64)
     assert rel(dw2, w64.grad) < 1e-5 and rel(db2, b64.grad) < 1e-5                 # (a)
     assert torch.equal(ours(x, dy)[1], dw)                                          # run to run: the same bits
