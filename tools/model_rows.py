@@ -36,13 +36,49 @@ def R(*shape):
     return torch.randn(*shape, device=dev)
 
 
-def kernel_row(model, name, fn, flops=0.0, bytes_=0.0, iters=30, flops_exec=None):
+_PMC = {}
+
+
+def pmc_traffic(model_csv, kernels):
+    """HBM bytes per launch sequence from the committed in-step counters of that config (profiles/r6_step_<cfg>_pmc.csv: FETCH_SIZE /
+    WRITE_SIZE in KiB, separate --pmc passes, FETCH_SIZE doubled per the guide) summed over the row's kernels - `kernels` = a list of
+    (kernel-name prefix, launches of it in the sequence).  None when a kernel is not in the file (counters cannot be sampled from
+    inside this process: this is the last profiled value, like bench.pmc_traffic)."""
+    import csv
+    path = os.path.join(ROOT, 'profiles', model_csv)
+    if path not in _PMC:
+        try:
+            _PMC[path] = list(csv.DictReader(open(path)))
+        except OSError:
+            _PMC[path] = []
+    total = 0.0
+    for prefix, count in kernels:
+        hit = [r for r in _PMC[path] if r['Kernel'].replace('void ', '').startswith('hk::' + prefix)]
+        by_kernel = {}
+        for r in hit:
+            if r['Counter'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+                by_kernel.setdefault(r['Kernel'], {})[r['Counter']] = float(r['MeanValue'])
+        vals = [v for v in by_kernel.values() if len(v) == 2]
+        if not vals:
+            return None
+        v = vals[0] if len(vals) == 1 else {k: sum(x[k] for x in vals) / len(vals) for k in ('FETCH_SIZE', 'WRITE_SIZE')}
+        total += count * (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0
+    return round(total)
+
+
+def kernel_row(model, name, fn, flops=0.0, bytes_=0.0, iters=30, flops_exec=None, pmc=None):
     """flops / bytes_: algorithmic work per call; flops_exec: what the kernels issue when that is less (symmetric
     Newton-Schulz forward: 6 of 8 tiles per product; backward: 34 of the reference's 38 products) - bench.roof_row prices
     `frac` on the smaller of the two."""
     us = bench.time_events(fn, iters, rounds=3)[0] * 1e3           # third back-to-back round: settled clocks (bench.py)
     r = bench.roof_row(name, us, flops, bytes_, flops_exec)
     r['model'] = model
+    if pmc is not None:                    # (csv of the config's in-step counters, [(kernel prefix, launches)])
+        r['traffic'] = pmc_traffic(*pmc)
+        if r['traffic'] is not None:
+            r['traffic_source'] = 'profiles/' + pmc[0]
+            if bytes_:
+                r['traffic_over_algorithmic'] = round(r['traffic'] / bytes_, 3)
     rows.append(r)
     if us < 12.0:     # back-to-back calls through python + ctypes cost ~8-9 us each: below that the row times the host
         r['note'] = 'host-call-bound row (python + ctypes ~ 9 us per call): rocprofv3 durations in profiles/r4_step_*_kernel_stats.csv'
@@ -84,9 +120,10 @@ def train_row(model_name, batch, classes, image=448, steps=6, warmup=3):
 def mpn_kernels(B=64, d=256, HW=196):
     x = torch.relu(R(B, d, HW)); cov = E(B, d, d); mu = E(B, d); g = R(B, d, d).triu(); dx = E(B, d, HW)
     kernel_row('MPN', 'cov_pool fwd (one kernel: means in LDS + centred Gram)', lambda: lib.hk_cov_pool_fwd(ptr(x), ptr(cov), ptr(mu), B, d, HW, stream()),
-               2.0 * B * d * d * HW, 4.0 * B * (d * HW + d * d), flops_exec=2.0 * B * d * d * HW * 10 / 16)
+               2.0 * B * d * d * HW, 4.0 * B * (d * HW + d * d), flops_exec=2.0 * B * d * d * HW * 10 / 16,
+               pmc=('r6_step_MPN_pmc.csv', [('bcnn_gram_panel_kernel<196, 1, true>', 1)]))
     kernel_row('MPN', 'cov_pool bwd', lambda: lib.hk_cov_pool_bwd(ptr(x), ptr(mu), ptr(g), ptr(dx), B, d, HW, stream()),
-               2.0 * B * d * d * HW, 4.0 * B * (2 * d * HW + d * d))
+               2.0 * B * d * d * HW, 4.0 * B * (2 * d * HW + d * d), pmc=('r6_step_MPN_pmc.csv', [('gram_bwd3_kernel<196, 1, 1', 1)]))
     out = E(B, d, d); na = E(B); ys = E(B, 4, d, d); zs = E(B, 4, d, d); da = E(B, d, d)
     nwf = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 0); nwb = lib.hk_ns_sqrtm_ws_bytes(B, d, 5, 1)
     wsf = E(nwf, dtype=torch.uint8); wsb = E(nwb, dtype=torch.uint8)
@@ -99,13 +136,18 @@ def mpn_kernels(B=64, d=256, HW=196):
     kernel_row('MPN', 'ns_sqrtm bwd chain (38 products of 256^3 per sample, 13 launches)',
                lambda: lib.hk_ns_sqrtm_bwd(ptr(cov), ptr(out), ptr(na), ptr(ys), ptr(zs), ptr(g), ptr(da), B, d, 5, ptr(wsb),
                                            nwb, stream()), 38 * 2.0 * B * d ** 3, 4.0 * B * d * d * 12,
-               flops_exec=34 * 2.0 * B * d ** 3)
+               flops_exec=34 * 2.0 * B * d ** 3,
+               # the backward per step: 2 queues x (8 launches of the general instance + the LAST launch)
+               pmc=('r6_step_MPN_pmc.csv', [('nsmm_kernel<64, false, false, false, false>', 16), ('nsmm_kernel<64, false, false, false, true>', 2)]))
     tv = E(B, d * (d + 1) // 2)
     kernel_row('MPN', 'ns_sqrtm fwd chain + triu_vec in its last product (hk_ns_sqrtm_triu_fwd, symmetric: what the MPN head calls)',
                lambda: lib.hk_ns_sqrtm_triu_fwd(ptr(cov), ptr(out), ptr(tv), ptr(na), ptr(ys), ptr(zs), B, d, 5, 1, ptr(wsf), nwf, stream()),
-               12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10, flops_exec=0.75 * 12 * 2.0 * B * d ** 3)
+               12 * 2.0 * B * d ** 3, 4.0 * B * d * d * 10, flops_exec=0.75 * 12 * 2.0 * B * d ** 3,
+               # the symmetric forward per step: 2 queues x (1 FIRST launch + 8 launches of the plain symmetric instance)
+               pmc=('r6_step_MPN_pmc.csv', [('nsmm_kernel<64, false, true, true, false>', 2), ('nsmm_kernel<64, false, true, false, false>', 16)]))
     kernel_row('MPN', 'triu_vec fwd', lambda: lib.hk_triu_vec_fwd(ptr(out), ptr(tv), B, d, stream()), 0, 4.0 * B * 32896 * 2)
-    kernel_row('MPN', 'triu_vec bwd', lambda: lib.hk_triu_vec_bwd(ptr(tv), ptr(da), B, d, stream()), 0, 4.0 * B * (32896 + 65536))
+    kernel_row('MPN', 'triu_vec bwd', lambda: lib.hk_triu_vec_bwd(ptr(tv), ptr(da), B, d, stream()), 0, 4.0 * B * (32896 + 65536),
+               pmc=('r6_step_MPN_pmc.csv', [('triu_bwd_kernel', 1)]))
 
 
 def cbp_kernels(C=512, HW=196, D=6000):
@@ -116,10 +158,12 @@ def cbp_kernels(C=512, HW=196, D=6000):
         fl = 2.0 * B * C * C * HW
         kernel_row('CBCNN', f'cbp fwd B={B} (fused Gram + binning, finish)',
                    lambda: lib.hk_cbp_fwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), B, C, HW, D, ptr(ws), nws, stream()),
-                   fl, 4.0 * B * (C * HW + D), flops_exec=fl * 36 / 64)     # Gram tiles J >= I only
+                   fl, 4.0 * B * (C * HW + D), flops_exec=fl * 36 / 64,     # Gram tiles J >= I only
+                   pmc=('r6_step_CBCNN_bs16_pmc.csv', [('cbp_fused_kernel<196, true>', 1), ('cbp_finish_kernel', 1)]) if B == 16 else None)
         kernel_row('CBCNN', f'cbp bwd B={B} (dc + P generation + GEMM in one kernel)',
                    lambda: lib.hk_cbp_bwd(ptr(x), ptr(plan.blob), ptr(y), ptr(craw), ptr(inv), ptr(dy), ptr(dx), B, C, HW, D,
-                                          ptr(ws), nws, stream()), fl, 4.0 * B * (2 * C * HW + 2 * D))
+                                          ptr(ws), nws, stream()), fl, 4.0 * B * (2 * C * HW + 2 * D),
+                   pmc=('r6_step_CBCNN_bs16_pmc.csv', [('cbp_bwd3_kernel<196, 1, true, 2>', 1)]) if B == 16 else None)
 
 
 def apcnn_kernels(B=16, classes=8142):
@@ -139,11 +183,13 @@ def apcnn_kernels(B=16, classes=8142):
     tot = sum(4.0 * B * 256 * s * s for s in (56, 28, 14))
     kernel_row('APCNN', 'att_pool3 fwd: the three levels in one launch (what PyramidAttentions calls)',
                lambda: lib.hk_att_pool3_fwd(ptr(ffs[0]), ptr(ffs[1]), ptr(ffs[2]), ptr(aas[0]), ptr(aas[1]), ptr(aas[2]), ptr(gp3), ptr(sg3),
-                                            B, 256, 3136, 784, 196, stream()), 0, tot)
+                                            B, 256, 3136, 784, 196, stream()), 0, tot,
+               pmc=('r6_step_APCNN_8142_pmc.csv', [('att_pool3_fwd_kernel', 1)]))
     kernel_row('APCNN', 'att_pool3 bwd: the three levels in one launch',
                lambda: lib.hk_att_pool3_bwd(ptr(ffs[0]), ptr(ffs[1]), ptr(ffs[2]), ptr(aas[0]), ptr(aas[1]), ptr(aas[2]), ptr(dgp3), ptr(dsg3),
                                             ptr(dfs[0]), ptr(dfs[1]), ptr(dfs[2]), ptr(das[0]), ptr(das[1]), ptr(das[2]),
-                                            B, 256, 3136, 784, 196, stream()), 0, 2 * tot)
+                                            B, 256, 3136, 784, 196, stream()), 0, 2 * tot,
+               pmc=('r6_step_APCNN_8142_pmc.csv', [('att_pool3_bwd_kernel', 1)]))
     masks = [torch.rand(B, 1, s, s, device=dev) for s in (56, 28, 14)]
     lv = [(8, 64., 5), (16, 128., 3), (32, 256., 1)]
     tabs = []
@@ -156,14 +202,15 @@ def apcnn_kernels(B=16, classes=8142):
 
     def roi_one():                                     # what the AP-CNN forward calls: one launch, grid B x 3
         tabs[:] = F.att_roi_select_levels(masks, lv, 448, 448, classes, 0.05)
-    kernel_row('APCNN', f'att_roi_select3: the three levels in one launch ({classes}-class border)', roi_one)
+    kernel_row('APCNN', f'att_roi_select3: the three levels in one launch ({classes}-class border)', roi_one,
+               pmc=('r6_step_APCNN_8142_pmc.csv', [('att_roi_select3_kernel', 1)]))
     u = torch.rand(B, 2, device=dev)
     box, drop = F.roi_boxes(tabs, u, 8.0)
     x2 = R(B, 512, 56, 56); y2 = E(B, 512, 56, 56)
     kernel_row('APCNN', 'roi_crop_resize fwd', lambda: lib.hk_roi_crop_resize_fwd(ptr(x2), ptr(box), ptr(drop), ptr(y2), B, 512, 56, 56, 1, stream()),
-               0, 8.0 * B * 512 * 3136)
+               0, 8.0 * B * 512 * 3136, pmc=('r6_step_APCNN_8142_pmc.csv', [('roi_crop_fwd_tab2_kernel', 1)]))
     kernel_row('APCNN', 'roi_crop_resize bwd', lambda: lib.hk_roi_crop_resize_bwd(ptr(y2), ptr(box), ptr(drop), ptr(x2), B, 512, 56, 56, 1, stream()),
-               0, 8.0 * B * 512 * 3136)
+               0, 8.0 * B * 512 * 3136, pmc=('r6_step_APCNN_8142_pmc.csv', [('roi_crop_bwd_tab3_kernel', 1)]))
 
 
 def ssqrt_kernels(B=64, C=512, HW=196):
