@@ -211,7 +211,8 @@ class Trainer:
 
     def to_device(self, m, parallel=False):
         """`experiment.channels_last: True` keeps images / conv weights in NHWC (MIOpen's fp32 kernels on gfx950 are
-        NHWC implicit-GEMMs: this removes its layout transposes, +10 % on the BCNN step - DESIGN.md section 5)."""
+        NHWC implicit-GEMMs: this removes its layout transposes, +10 % on the BCNN step - DESIGN.md section 5; it is also the
+        layout in which the VGG trunk runs its fused epilogues, csrc/trunk.hip: another +12 %)."""
         cl = 'channels_last' in self.config.experiment and self.config.experiment.channels_last
         if isinstance(m, dict) and 'u8' in m:              # uint8 crops from the workers (transformer.device_finalize)
             from . import functional as HF
